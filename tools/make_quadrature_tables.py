@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generate proximalgalerkin_amd/tables/quadrature.json — the ONE place quadrature tables live.
+
+Both the CPU oracle (oracle/) and the HIP path (proximalgalerkin_amd/) read the JSON this script
+writes, so their tables are bit-identical.
+
+Tables
+------
+tri_deg6_12 : fully symmetric 12-point, degree-6 rule on the reference triangle
+              {(x,y): x,y>=0, x+y<=1} (Dunavant 1985, Int. J. Numer. Meth. Engng 21:1129-1148,
+              rule p=6).  The 15-digit published values are used only as a starting guess: the
+              seven free parameters (w1,a1,w2,a2,w3,b3,c3) are re-solved here with mpmath from the
+              seven S3-invariant moment equations up to degree 6, to 40 digits, then rounded to
+              double.  So the table is *derivable* from this script alone.
+              Weights sum to 1/2 (reference-triangle area), matching the convention of
+              SURVEY.md App. A.2.
+
+The reference fixes quadrature_degree=6 for every integral of example 01
+(/root/reference/examples/01_obstacle_problem/obstacle_pg.py:106,115).  Basix's default table for
+that degree is not available offline => parity with a real FEniCSx run is
+"unpinned" until the table is confirmed; parity between oracle and HIP is exact by construction.
+"""
+import itertools
+import json
+import pathlib
+
+import mpmath as mp
+
+mp.mp.dps = 50
+
+
+def moments_exact(p, q):
+    """int_T x^p y^q dx dy on the reference triangle = p! q! / (p+q+2)!"""
+    return mp.factorial(p) * mp.factorial(q) / mp.factorial(p + q + 2)
+
+
+def orbit3(a):
+    """S3 orbit of barycentric point (a,a,1-2a) -> 3 points (x,y)."""
+    b = 1 - 2 * a
+    return [(a, a), (a, b), (b, a)]
+
+
+def orbit6(b, c):
+    a = 1 - b - c
+    pts = set(itertools.permutations((a, b, c)))
+    return [(p[0], p[1]) for p in sorted(pts)]
+
+
+def rule(params):
+    w1, a1, w2, a2, w3, b3, c3 = params
+    pts, wts = [], []
+    for w, a in ((w1, a1), (w2, a2)):
+        for p in orbit3(a):
+            pts.append(p)
+            wts.append(w)
+    for p in orbit6(b3, c3):
+        pts.append(p)
+        wts.append(w3)
+    return pts, wts
+
+
+# S3-invariant test polynomials spanning invariants up to degree 6 (7 of them):
+# use monomials x^p y^q with (p,q) chosen so the 7x7 system is non-singular.
+MONOS = [(0, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (3, 3)]
+
+
+def residual(*params):
+    pts, wts = rule(params)
+    out = []
+    for p, q in MONOS:
+        s = mp.mpf(0)
+        for (x, y), w in zip(pts, wts):
+            s += w * x**p * y**q
+        out.append(s - moments_exact(p, q))
+    return out
+
+
+def main():
+    # Dunavant p=6 published values (weights there sum to 1; halve for area 1/2)
+    guess = [
+        mp.mpf("0.116786275726379") / 2,
+        mp.mpf("0.249286745170910"),
+        mp.mpf("0.050844906370207") / 2,
+        mp.mpf("0.063089014491502"),
+        mp.mpf("0.082851075618374") / 2,
+        mp.mpf("0.310352451033784"),
+        mp.mpf("0.636502499121399"),
+    ]
+    sol = mp.findroot(residual, guess, tol=1e-40, maxsteps=50)
+    params = [sol[i] for i in range(7)]
+    pts, wts = rule(params)
+    # verify every monomial up to degree 6
+    worst = mp.mpf(0)
+    for p in range(7):
+        for q in range(7 - p):
+            s = sum(w * x**p * y**q for (x, y), w in zip(pts, wts))
+            worst = max(worst, abs(s - moments_exact(p, q)))
+    assert worst < mp.mpf(10) ** (-35), worst
+    for g, s in zip(guess, params):
+        assert abs(g - s) < 1e-13, (g, s)  # we converged to Dunavant's rule, not another root
+
+    table = {
+        "tri_deg6_12": {
+            "cell": "triangle",
+            "degree": 6,
+            "source": "Dunavant (1985) p=6, 12 points; re-solved to 40 digits by tools/make_quadrature_tables.py",
+            "points": [[float(x), float(y)] for (x, y) in pts],
+            "weights": [float(w) for w in wts],
+        }
+    }
+    out = pathlib.Path(__file__).resolve().parents[1] / "proximalgalerkin_amd" / "tables" / "quadrature.json"
+    out.write_text(json.dumps(table, indent=1) + "\n")
+    print("wrote", out, "max moment error", mp.nstr(worst, 3))
+
+
+if __name__ == "__main__":
+    main()
