@@ -1,0 +1,149 @@
+/*
+ * pgx.h - C ABI of libpgx.so: MI355X-native LVPP / proximal-Galerkin Newton inner loop.
+ *
+ * Drop-in boundary for ONE hot path of METHODS-Group/ProximalGalerkin: everything below
+ * `problem.solve()` in examples/01_obstacle_problem/obstacle_pg.py:190, i.e. what the reference
+ * delegates to DOLFINx assembly + PETSc SNES/KSP + MUMPS.  Plain pointers and sizes only; no torch
+ * or C++ types cross this boundary.  All reals are IEEE fp64, all indices int32.
+ *
+ * DOF layout of every state / residual vector of length 2*n_vertices:
+ *      x = [u_0 .. u_{n-1}, psi_0 .. psi_{n-1}]        (n = n_vertices, P1)
+ *
+ * Conventions:
+ *   - every function returns 0 on success, a negative PGX_E* code otherwise; pgx_last_error() gives text.
+ *   - the caller owns all host buffers passed in; they are never retained past the call.
+ *   - the handle owns all device memory; a handle is bound to one HIP device and is not thread-safe.
+ *   - calls are synchronous: the handle's stream is idle when a call returns.
+ *   - convergence is reported with PETSc's signed SNESConvergedReason values (>0 converged).
+ *
+ * Reference interface each entry point replaces (paths relative to the reference checkout):
+ *   pgx_create            dolfinx.fem.petsc.NonlinearProblem(F,u,bcs,J,petsc_options) construction
+ *                         (examples/01_obstacle_problem/obstacle_pg.py:140-142): form compilation,
+ *                         sparsity pattern, SNES creation; lvpp twin SNESProblem.__init__ +
+ *                         SNESSolver.create_data_structures (src/lvpp/problem.py:14-52,106-112)
+ *   pgx_set_state/get_state   sol.x.array[:] access (obstacle_pg.py:157,226)
+ *   pgx_set_prev / pgx_advance_prev   sol_k.x.array[:] = sol.x.array[:] (obstacle_pg.py:158,226)
+ *   pgx_set_alpha         alpha.value = ... (obstacle_pg.py:175-186)
+ *   pgx_residual          SNESProblem.F(snes, x, F) (src/lvpp/problem.py:54-67)
+ *   pgx_jacobian_fill     SNESProblem.J(snes, x, J, P) (src/lvpp/problem.py:69-77)
+ *   pgx_csr_export        the PETSc Mat `A` of SNESSolver (src/lvpp/problem.py:110), for inspection
+ *   pgx_spmv              MatMult on that Mat (inside KSP; the reference uses LU instead:
+ *                         obstacle_pg.py:129-131)
+ *   pgx_newton_solve      problem.solve() / SNESSolver.solve() (obstacle_pg.py:190;
+ *                         src/lvpp/problem.py:114-124) incl. "copy back only if converged"
+ *   pgx_observables       the six assemble_scalar + allreduce calls (obstacle_pg.py:145-152,196-201)
+ *   pgx_destroy           SNESSolver.__del__ (src/lvpp/problem.py:126-127)
+ */
+#ifndef PGX_H
+#define PGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGX_OK 0
+#define PGX_EINVAL (-1)   /* bad argument / inconsistent sizes */
+#define PGX_EHIP (-2)     /* HIP runtime error (text in pgx_last_error) */
+#define PGX_ENODEV (-3)   /* no usable GPU */
+#define PGX_ENOMEM (-4)
+#define PGX_ESTATE (-5)   /* call order violated (e.g. spmv before jacobian_fill) */
+
+/* PETSc SNESConvergedReason values mirrored by pgx_newton_solve */
+#define PGX_SNES_CONVERGED_FNORM_ABS 2
+#define PGX_SNES_CONVERGED_FNORM_RELATIVE 3
+#define PGX_SNES_CONVERGED_SNORM_RELATIVE 4
+#define PGX_SNES_DIVERGED_LINEAR_SOLVE (-3)
+#define PGX_SNES_DIVERGED_FNORM_NAN (-4)
+#define PGX_SNES_DIVERGED_MAX_IT (-5)
+#define PGX_SNES_DIVERGED_DTOL (-9)
+
+typedef struct pgx_handle pgx_handle;
+
+typedef struct {
+  int32_t n_vertices;
+  int32_t n_cells;
+  const double* coords;   /* [n_vertices][2] */
+  const int32_t* cells;   /* [n_cells][3], vertex ids */
+  /* >0 only for the right-diagonal structured triangulation with vertex v = j*(nx+1)+i and cells
+   * (2q, 2q+1) = [v0,v1,v3],[v0,v2,v3] of square q = j*nx+i (dolfinx create_rectangle default).
+   * Enables the geometric multigrid preconditioner; 0 = general mesh (single-level smoother). */
+  int32_t structured_nx;
+  int32_t structured_ny;
+} pgx_mesh;
+
+typedef struct {
+  int32_t degree;          /* Lagrange degree of both fields; 1 supported */
+  int32_t nq;              /* quadrature points per cell (<= 16) */
+  const double* qpts;      /* [nq][2] on the reference triangle */
+  const double* qwts;      /* [nq], summing to 1/2 */
+  const double* phi_q;     /* [n_cells][nq] obstacle at physical quadrature points (obstacle_pg.py:107-111) */
+  double f;                /* constant forcing (obstacle_pg.py:74) */
+  int32_t n_bc;            /* Dirichlet dofs of the u block (obstacle_pg.py:76-83) */
+  const int32_t* bc_dofs;  /* [n_bc] vertex ids */
+  const double* bc_vals;   /* [n_bc] or NULL for homogeneous */
+} pgx_problem;
+
+/* Subset of the PETSc option dictionary the reference passes (obstacle_pg.py:128-139). */
+typedef struct {
+  double snes_rtol;   /* default 1e-8; ex 01 sets 1e-6 */
+  double snes_atol;   /* 1e-50 */
+  double snes_stol;   /* 1e-8 */
+  double snes_divtol; /* 1e4 */
+  int32_t snes_max_it;/* 50; ex 01 sets 100 */
+  /* Newton linear solve (replaces ksp preonly + pc lu/mumps): FGMRES + multigrid V-cycle */
+  double ksp_rtol;    /* relative residual target, default 1e-10 (LU-level accuracy) */
+  int32_t ksp_max_it; /* default 200 */
+  int32_t ksp_restart;/* default 50 */
+  int32_t mg_nu;      /* pre/post smoothing sweeps, default 2 */
+  double mg_omega;    /* collective-Jacobi damping, default 0.8 */
+  int32_t monitor;    /* 1 = print per-Newton-step residuals (snes_monitor/ksp_monitor) */
+} pgx_snes_opts;
+
+void pgx_default_opts(pgx_snes_opts* o);
+
+int pgx_create(const pgx_mesh* mesh, const pgx_problem* prob, int device, pgx_handle** out);
+void pgx_destroy(pgx_handle* h);
+const char* pgx_last_error(const pgx_handle* h); /* h may be NULL: error of the last failed pgx_create */
+
+int pgx_num_dofs(const pgx_handle* h, int64_t* ndofs);          /* 2*n_vertices */
+int pgx_set_state(pgx_handle* h, const double* x);               /* host -> device `sol` */
+int pgx_get_state(pgx_handle* h, double* x);
+int pgx_set_prev(pgx_handle* h, const double* xk);               /* host -> device `sol_k` */
+int pgx_get_prev(pgx_handle* h, double* xk);
+int pgx_advance_prev(pgx_handle* h);                             /* sol_k <- sol on device */
+int pgx_set_alpha(pgx_handle* h, double alpha);
+
+/* F(x) with the callback contract of problem.py:54-67. x==NULL -> use device `sol`. F may be NULL. */
+int pgx_residual(pgx_handle* h, const double* x, double* F, double* fnorm);
+/* Fill the Jacobian values at x (x==NULL -> device `sol`) into the fixed pattern. */
+int pgx_jacobian_fill(pgx_handle* h, const double* x);
+
+/* Scalar pattern shared by the four blocks [[alpha*K, M],[M, -D]]:
+ * call once with arrays NULL to get sizes, then with host buffers to receive copies.
+ * K, M are the unconstrained blocks; bc rows/cols are applied by the operator. */
+int pgx_csr_export(pgx_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col,
+                   double* K, double* M, double* D);
+
+/* y = J x with J = Jacobian of the last pgx_jacobian_fill, incl. BC rows/cols (identity). */
+int pgx_spmv(pgx_handle* h, const double* x, double* y);
+/* Time `reps` back-to-back SpMV launches on device-resident data with HIP events on the handle's
+ * stream; returns average ms per launch and the algorithmic bytes one launch moves. */
+int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+
+/* One nonlinear solve from device `sol` with proximal centre `sol_k`; on reason>0 `sol` is replaced. */
+int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its);
+/* energy, |complementarity|, feasibility, dual feasibility, H1 increment, latent L2 increment */
+int pgx_observables(pgx_handle* h, double out[6]);
+
+/* Accumulated device-time per phase since the last reset, ms (HIP events; only when enabled):
+ * [0] residual [1] jacobian fill [2] mg setup [3] spmv (outer Krylov) [4] v-cycle [5] orthogonalisation
+ * [6] observables [7] total newton_solve wall */
+int pgx_profile_enable(pgx_handle* h, int on);
+int pgx_profile_get(pgx_handle* h, double ms[8], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

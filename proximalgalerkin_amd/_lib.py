@@ -1,0 +1,129 @@
+"""ctypes binding of libpgx.so (C ABI: include/pgx.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no GPU is visible the
+calls raise.  (The numpy oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libpgx.so"
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class PgxError(RuntimeError):
+    pass
+
+
+class pgx_mesh(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_int32),
+        ("n_cells", C.c_int32),
+        ("coords", c_double_p),
+        ("cells", c_int32_p),
+        ("structured_nx", C.c_int32),
+        ("structured_ny", C.c_int32),
+    ]
+
+
+class pgx_problem(C.Structure):
+    _fields_ = [
+        ("degree", C.c_int32),
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("phi_q", c_double_p),
+        ("f", C.c_double),
+        ("n_bc", C.c_int32),
+        ("bc_dofs", c_int32_p),
+        ("bc_vals", c_double_p),
+    ]
+
+
+class pgx_snes_opts(C.Structure):
+    _fields_ = [
+        ("snes_rtol", C.c_double),
+        ("snes_atol", C.c_double),
+        ("snes_stol", C.c_double),
+        ("snes_divtol", C.c_double),
+        ("snes_max_it", C.c_int32),
+        ("ksp_rtol", C.c_double),
+        ("ksp_max_it", C.c_int32),
+        ("ksp_restart", C.c_int32),
+        ("mg_nu", C.c_int32),
+        ("mg_omega", C.c_double),
+        ("monitor", C.c_int32),
+    ]
+
+
+# every symbol include/pgx.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("pgx_default_opts", None, [C.POINTER(pgx_snes_opts)]),
+    ("pgx_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_destroy", None, [_H]),
+    ("pgx_last_error", C.c_char_p, [_H]),
+    ("pgx_num_dofs", C.c_int, [_H, C.POINTER(C.c_int64)]),
+    ("pgx_set_state", C.c_int, [_H, c_double_p]),
+    ("pgx_get_state", C.c_int, [_H, c_double_p]),
+    ("pgx_set_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_get_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_advance_prev", C.c_int, [_H]),
+    ("pgx_set_alpha", C.c_int, [_H, C.c_double]),
+    ("pgx_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("pgx_jacobian_fill", C.c_int, [_H, c_double_p]),
+    ("pgx_csr_export", C.c_int,
+     [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
+    ("pgx_spmv", C.c_int, [_H, c_double_p, c_double_p]),
+    ("pgx_spmv_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_newton_solve", C.c_int,
+     [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pgx_observables", C.c_int, [_H, c_double_p]),
+    ("pgx_profile_enable", C.c_int, [_H, C.c_int]),
+    ("pgx_profile_get", C.c_int, [_H, c_double_p, C.c_int]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libpgx.so (built by `make -C proximalgalerkin_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PgxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_int32_p)
+
+
+def check(lib, handle, rc: int, what: str):
+    if rc != 0:
+        msg = lib.pgx_last_error(handle)
+        raise PgxError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

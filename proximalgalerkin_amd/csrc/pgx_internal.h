@@ -1,0 +1,75 @@
+// Internal declarations shared by pgx_kernels.hip (device code + launch wrappers) and pgx_api.hip
+// (host-side plan building, Newton / FGMRES / multigrid drivers, C ABI).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PGX_MAX_NQ 16
+#define PGX_BLOCK 256
+
+// Quadrature + P1 reference-element tables, passed BY VALUE as a kernel argument: they land in the
+// kernarg segment and are read with scalar loads (wave-uniform), no constant-memory symbol to manage.
+struct QuadTab {
+  double N[PGX_MAX_NQ][3];  // P1 basis at quadrature points
+  double w[PGX_MAX_NQ];     // weights (sum 1/2)
+  double Mref[3][3];        // sum_q w_q N_a N_b
+  double mref[3];           // sum_q w_q N_a
+  int nq;
+};
+
+// 7-point stencil slots on a right-diagonal structured grid with row stride sx = nx+1:
+//   0:(0,0) 1:(+1,0) 2:(-1,0) 3:(0,+1) 4:(0,-1) 5:(+1,+1) 6:(-1,-1)
+// coefficient arrays are SoA: S[slot*n + v].  Links leaving the grid hold 0.
+struct GridLevel {
+  int nx, ny, n;             // cells per direction, vertices
+  double *K, *M, *D;         // [7*n] unmasked symmetric stencils (K,M fixed at create; D per Newton step)
+  uint8_t* mask;             // [n] 1 = Dirichlet dof of the u block
+  double *xu, *xp, *xu2, *xp2;  // solution ping-pong
+  double *bu, *bp;           // right-hand side
+  double *ru, *rp;           // residual scratch
+};
+
+// ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
+void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
+               QuadTab q, double* bphi);
+void pgxk_residual(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const uint8_t* mask,
+                   const double* gbc, const double* bphi, const double* x, const double* xk, double alpha, double f,
+                   QuadTab q, double* F);
+// mode 0: K, 1: M, 2: D(psi)
+void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
+                    const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
+                    const double* psi, QuadTab q, double* out);
+// mode 0: y = J x ; 1: y = b - J x ; 2: y = x + omega*Binv*(b - J x) (collective Jacobi; first!=0: x taken as 0)
+void pgxk_bspmv(hipStream_t st, int mode, int n, const int32_t* rowptr, const int32_t* colm, const double* K,
+                const double* M, const double* D, double alpha, const double* xu, const double* xp, const double* bu,
+                const double* bp, double omega, int first, double* yu, double* yp);
+void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
+                      const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks, double* out6);
+int pgxk_observables_blocks(int nc);
+
+// vectors (length len)
+void pgxk_axpy(hipStream_t st, size_t len, double a, const double* x, double* y);          // y += a x
+void pgxk_scale_copy(hipStream_t st, size_t len, double a, const double* x, double* y);    // y = a x
+void pgxk_set(hipStream_t st, size_t len, double a, double* y);
+// out[i] = V_i . w, i<nv (V_i = V + i*ldv).  partials: [PGX_RED_BLOCKS * nv] scratch
+#define PGX_RED_BLOCKS 1024
+void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* w, double* partials,
+                   double* out);
+// w -= sum_i h[i] V_i   (h is a DEVICE pointer to nv doubles)
+void pgxk_multiaxpy(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w);
+// x = sum_i y[i] Z_i  (y device pointer); accumulate!=0 -> x += ...
+void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ldz, const double* y, double* x,
+                  int accumulate);
+
+// multigrid on stencil levels
+void pgxk_csr_to_stencil(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm, const double* vals,
+                         double* S);
+void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridLevel& c, double* Sc);
+void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                   const double* bu, const double* bp, double omega, int first, double* yu, double* yp);
+void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const double* rp, const GridLevel& c,
+                   double* bu, double* bp);
+void pgxk_prolong_add(hipStream_t st, const GridLevel& c, const double* cu, const double* cp, const GridLevel& f,
+                      double* xu, double* xp);
+void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const GridLevel& f);

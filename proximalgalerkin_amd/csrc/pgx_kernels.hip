@@ -1,0 +1,819 @@
+// HIP kernels for gfx950 (MI355X / CDNA4).  Everything here is fp64, HBM-bandwidth-bound work:
+// no MFMA.  64-wide wavefronts are assumed throughout (shuffle widths, reductions).
+//
+// Kernel inventory (DESIGN.md holds the byte counts and rooflines):
+//   k_bphi, k_residual_p1          cell-parallel element evaluation, fp64 atomics
+//   k_fill_rows<MODE>              row-parallel (owner-computes) fill of the K / M / D(psi) CSR blocks,
+//                                  LDS-staged so the CSR value stream is written fully coalesced
+//   k_bspmv<MODE,LPR>              block-CSR SpMV for J=[[aK,M],[M,-D]] sharing ONE pattern (28 B/nnz
+//                                  instead of 4x12 B/nnz), also the level-0 collective-Jacobi smoother
+//   k_st_apply<MODE>, k_rap7, k_restrict, k_prolong_add, k_csr_to_stencil   7-point stencil multigrid
+//   k_multidot<NV>, k_multiaxpy<NV>, ...                                     Krylov vector kernels
+#include "pgx_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// sum over the block; result valid in thread 0. `sm` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  __syncthreads();
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < (int)(blockDim.x / WAVE); ++k) r += sm[k];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1 element geometry: J=[x1-x0, x2-x0], G = grad_ref(N) * J^-1
+// ------------------------------------------------------------------------------------------------
+struct P1Geom {
+  double adet;     // |det J|
+  double G[3][2];  // physical gradients of the three hat functions
+};
+
+__device__ __forceinline__ P1Geom p1_geom(double x0, double y0, double x1, double y1, double x2, double y2) {
+  P1Geom g;
+  const double J00 = x1 - x0, J01 = x2 - x0, J10 = y1 - y0, J11 = y2 - y0;
+  const double det = J00 * J11 - J01 * J10;
+  const double inv = 1.0 / det;
+  g.adet = fabs(det);
+  g.G[1][0] = J11 * inv;
+  g.G[1][1] = -J01 * inv;
+  g.G[2][0] = -J10 * inv;
+  g.G[2][1] = J00 * inv;
+  g.G[0][0] = -(g.G[1][0] + g.G[2][0]);
+  g.G[0][1] = -(g.G[1][1] + g.G[2][1]);
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// b_phi = int phi w_i  (obstacle_pg.py:122 "- phi * w * dx"), assembled once at create
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PGX_BLOCK) k_bphi(int nc, const int32_t* __restrict__ cells,
+                                                    const double* __restrict__ coords,
+                                                    const double* __restrict__ phi_q, QuadTab q,
+                                                    double* __restrict__ bphi) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int v0 = cells[3 * c], v1 = cells[3 * c + 1], v2 = cells[3 * c + 2];
+  const P1Geom g = p1_geom(coords[2 * v0], coords[2 * v0 + 1], coords[2 * v1], coords[2 * v1 + 1], coords[2 * v2],
+                           coords[2 * v2 + 1]);
+  double b0 = 0, b1 = 0, b2 = 0;
+  for (int k = 0; k < q.nq; ++k) {
+    const double wp = q.w[k] * phi_q[(size_t)c * q.nq + k];
+    b0 += wp * q.N[k][0];
+    b1 += wp * q.N[k][1];
+    b2 += wp * q.N[k][2];
+  }
+  atomicAdd(&bphi[v0], g.adet * b0);
+  atomicAdd(&bphi[v1], g.adet * b1);
+  atomicAdd(&bphi[v2], g.adet * b2);
+}
+
+void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
+               QuadTab q, double* bphi) {
+  hipMemsetAsync(bphi, 0, sizeof(double) * n, st);
+  hipLaunchKernelGGL(k_bphi, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cells, coords, phi_q,
+                     q, bphi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual F(x) (obstacle_pg.py:116-124) with the BC contract of lvpp/problem.py:54-67
+//   cell pass : F_u += a K_e u~ + M_e (psi-psi_k) - a f m_e ;  F_psi += M_e u~ - b_exp(psi)
+//               with u~ = u on free dofs, g on Dirichlet dofs (== apply_lifting with scale -1)
+//   final pass: F_psi -= b_phi ;  F_u[bc] = u[bc] - g (set_bc(F,bcs,x,-1))
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PGX_BLOCK) k_residual_p1(int nc, int n, const int32_t* __restrict__ cells,
+                                                           const double* __restrict__ coords,
+                                                           const uint8_t* __restrict__ mask,
+                                                           const double* __restrict__ gbc,
+                                                           const double* __restrict__ x,
+                                                           const double* __restrict__ xk, double alpha, double f,
+                                                           QuadTab q, double* __restrict__ F) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
+  double u[3], p[3], dp[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    u[a] = mask[v[a]] ? gbc[v[a]] : x[v[a]];
+    p[a] = x[n + v[a]];
+    dp[a] = p[a] - xk[n + v[a]];
+  }
+  const P1Geom g = p1_geom(coords[2 * v[0]], coords[2 * v[0] + 1], coords[2 * v[1]], coords[2 * v[1] + 1],
+                           coords[2 * v[2]], coords[2 * v[2] + 1]);
+  double be[3] = {0, 0, 0};
+  for (int k = 0; k < q.nq; ++k) {
+    const double pq = p[0] * q.N[k][0] + p[1] * q.N[k][1] + p[2] * q.N[k][2];
+    const double we = q.w[k] * exp(pq);
+    be[0] += we * q.N[k][0];
+    be[1] += we * q.N[k][1];
+    be[2] += we * q.N[k][2];
+  }
+  // grad u~ (constant on the cell)
+  const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
+  const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
+  const double half = 0.5 * g.adet;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double Ku = half * (g.G[a][0] * gx + g.G[a][1] * gy);
+    const double Mdp = g.adet * (q.Mref[a][0] * dp[0] + q.Mref[a][1] * dp[1] + q.Mref[a][2] * dp[2]);
+    const double Mu = g.adet * (q.Mref[a][0] * u[0] + q.Mref[a][1] * u[1] + q.Mref[a][2] * u[2]);
+    atomicAdd(&F[v[a]], alpha * Ku + Mdp - alpha * f * g.adet * q.mref[a]);
+    atomicAdd(&F[n + v[a]], Mu - g.adet * be[a]);
+  }
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_residual_final(int n, const uint8_t* __restrict__ mask,
+                                                              const double* __restrict__ gbc,
+                                                              const double* __restrict__ bphi,
+                                                              const double* __restrict__ x, double* __restrict__ F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F[n + i] -= bphi[i];
+  if (mask[i]) F[i] = x[i] - gbc[i];
+}
+
+void pgxk_residual(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const uint8_t* mask,
+                   const double* gbc, const double* bphi, const double* x, const double* xk, double alpha, double f,
+                   QuadTab q, double* F) {
+  hipMemsetAsync(F, 0, sizeof(double) * 2 * (size_t)n, st);
+  hipLaunchKernelGGL(k_residual_p1, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, n, cells,
+                     coords, mask, gbc, x, xk, alpha, f, q, F);
+  hipLaunchKernelGGL(k_residual_final, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, mask, gbc,
+                     bphi, x, F);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-parallel ("owner computes") fill of one scalar CSR block.  A block owns 256 consecutive rows,
+// whose CSR value range [rowptr[i0], rowptr[i0+256]) is contiguous: contributions are summed in an
+// LDS image of that range (each thread only touches its own row segment -> no atomics, bitwise
+// reproducible), then the image is streamed out with fully coalesced stores.
+//   MODE 0: K_ij = int grad phi_i . grad phi_j      MODE 1: M_ij      MODE 2: D_ij = int e^psi phi_i phi_j
+// v2c_ent[k] = cell*4 + local index a of the row vertex in that cell
+// v2c_pos[k] = positions (within the row's sorted column list) of the cell's 3 vertices, 8 bits each
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows(int n, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ v2c_ptr,
+                                                         const int32_t* __restrict__ v2c_ent,
+                                                         const int32_t* __restrict__ v2c_pos,
+                                                         const int32_t* __restrict__ cells,
+                                                         const double* __restrict__ coords,
+                                                         const double* __restrict__ psi, QuadTab q,
+                                                         double* __restrict__ out) {
+  extern __shared__ double acc[];
+  const int i0 = blockIdx.x * PGX_BLOCK;
+  const int i = i0 + threadIdx.x;
+  const int iend = min(i0 + PGX_BLOCK, n);
+  const int base = rowptr[i0];
+  const int len = rowptr[iend] - base;
+  for (int k = threadIdx.x; k < len; k += PGX_BLOCK) acc[k] = 0.0;
+  __syncthreads();
+  if (i < n) {
+    double* row = acc + (rowptr[i] - base);
+    const int ke = v2c_ptr[i + 1];
+    for (int k = v2c_ptr[i]; k < ke; ++k) {
+      const int e = v2c_ent[k];
+      const int c = e >> 2, a = e & 3;
+      const int pos = v2c_pos[k];
+      const int v0 = cells[3 * c], v1 = cells[3 * c + 1], v2 = cells[3 * c + 2];
+      const P1Geom g = p1_geom(coords[2 * v0], coords[2 * v0 + 1], coords[2 * v1], coords[2 * v1 + 1],
+                               coords[2 * v2], coords[2 * v2 + 1]);
+      double d[3];
+      if (MODE == 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) d[b] = 0.5 * g.adet * (g.G[a][0] * g.G[b][0] + g.G[a][1] * g.G[b][1]);
+      } else if (MODE == 1) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) d[b] = g.adet * q.Mref[a][b];
+      } else {
+        const double p0 = psi[v0], p1 = psi[v1], p2 = psi[v2];
+        d[0] = d[1] = d[2] = 0.0;
+        for (int k2 = 0; k2 < q.nq; ++k2) {
+          const double pq = p0 * q.N[k2][0] + p1 * q.N[k2][1] + p2 * q.N[k2][2];
+          const double wa = q.w[k2] * exp(pq) * q.N[k2][a];
+          d[0] += wa * q.N[k2][0];
+          d[1] += wa * q.N[k2][1];
+          d[2] += wa * q.N[k2][2];
+        }
+        d[0] *= g.adet;
+        d[1] *= g.adet;
+        d[2] *= g.adet;
+      }
+      row[pos & 0xff] += d[0];
+      row[(pos >> 8) & 0xff] += d[1];
+      row[(pos >> 16) & 0xff] += d[2];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < len; k += PGX_BLOCK) out[base + k] = acc[k];
+}
+
+void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
+                    const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
+                    const double* psi, QuadTab q, double* out) {
+  dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_fill_rows<0>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, coords,
+                       psi, q, out);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_fill_rows<1>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, coords,
+                       psi, q, out);
+  else
+    hipLaunchKernelGGL(k_fill_rows<2>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, coords,
+                       psi, q, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-CSR SpMV for the Newton matrix  J = [[aK, M],[M, -D]]  with ONE shared scalar pattern.
+// colm[k] = column | (column is a Dirichlet dof of u) << 31.  Dirichlet rows/cols of the u block act
+// as identity (lvpp/problem.py:69-77 + dolfinx assemble_matrix(bcs) semantics):
+//   y_u[i]   = bc_i ? x_u[i] : sum_j aK_ij x~_u[j] + M_ij x_psi[j]        x~_u = x_u with bc entries zeroed
+//   y_psi[i] =                 sum_j  M_ij x~_u[j] - D_ij x_psi[j]
+// LPR lanes cooperate on a row (P1: ~7 nnz/row); consecutive lanes read consecutive CSR entries, so
+// the three value streams + the column stream are read coalesced.
+// MODE 0: y = Jx   MODE 1: y = b - Jx   MODE 2: y = x + omega * Binv (b - Jx)   (collective Jacobi:
+//   Binv = inverse of the vertex 2x2 block [[a,b],[b,-d]], det = -ad-b^2 < 0; bc rows use omega=1)
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int LPR>
+__global__ void __launch_bounds__(PGX_BLOCK) k_bspmv(int n, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ colm,
+                                                     const double* __restrict__ K, const double* __restrict__ M,
+                                                     const double* __restrict__ D, double alpha,
+                                                     const double* __restrict__ xu, const double* __restrict__ xp,
+                                                     const double* __restrict__ bu, const double* __restrict__ bp,
+                                                     double omega, int first, double* __restrict__ yu,
+                                                     double* __restrict__ yp) {
+  const int t = blockIdx.x * PGX_BLOCK + threadIdx.x;
+  const int row = t / LPR, lane = t % LPR;
+  const bool live = row < n;
+  int s = 0, e = 0;
+  if (live) {
+    s = rowptr[row];
+    e = rowptr[row + 1];
+  }
+  double au = 0.0, ap = 0.0, da = 0.0, dm = 0.0, dd = 0.0;
+  int rowbc = 0;
+  const bool skip = (MODE == 2) && first;
+  for (int k = s + lane; k < e; k += LPR) {
+    const int cm = colm[k];
+    const int c = cm & 0x7fffffff;
+    const double kv = K[k], mv = M[k], dv = D[k];
+    if (c == row) {
+      rowbc = cm < 0;
+      da = alpha * kv;
+      dm = mv;
+      dd = dv;
+    }
+    if (!skip) {
+      const double xuv = (cm < 0) ? 0.0 : xu[c];
+      const double xpv = xp[c];
+      au += alpha * kv * xuv + mv * xpv;
+      ap += mv * xuv - dv * xpv;
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) {
+    au += __shfl_xor(au, o, LPR);
+    ap += __shfl_xor(ap, o, LPR);
+    if (MODE == 2) {
+      da += __shfl_xor(da, o, LPR);
+      dm += __shfl_xor(dm, o, LPR);
+      dd += __shfl_xor(dd, o, LPR);
+    }
+    rowbc |= __shfl_xor(rowbc, o, LPR);
+  }
+  if (!live || lane != 0) return;
+  const double xur = skip ? 0.0 : xu[row];
+  if (rowbc) au = xur;
+  if (MODE == 0) {
+    yu[row] = au;
+    yp[row] = ap;
+  } else if (MODE == 1) {
+    yu[row] = bu[row] - au;
+    yp[row] = bp[row] - ap;
+  } else {
+    const double su = bu[row] - au, sp = bp[row] - ap;
+    const double xpr = skip ? 0.0 : xp[row];
+    double a = da, b = dm;
+    double om_u = omega;
+    if (rowbc) {
+      a = 1.0;
+      b = 0.0;
+      om_u = 1.0;
+    }
+    const double det = -a * dd - b * b;
+    double du = 0.0, dpsi = 0.0;
+    if (det != 0.0) {
+      du = (-dd * su - b * sp) / det;
+      dpsi = (-b * su + a * sp) / det;
+    } else if (rowbc) {
+      du = su;
+    }
+    yu[row] = xur + om_u * du;
+    yp[row] = xpr + omega * dpsi;
+  }
+}
+
+void pgxk_bspmv(hipStream_t st, int mode, int n, const int32_t* rowptr, const int32_t* colm, const double* K,
+                const double* M, const double* D, double alpha, const double* xu, const double* xp, const double* bu,
+                const double* bp, double omega, int first, double* yu, double* yp) {
+  constexpr int LPR = 8;
+  const size_t threads = (size_t)n * LPR;
+  dim3 grid((unsigned)((threads + PGX_BLOCK - 1) / PGX_BLOCK)), block(PGX_BLOCK);
+  if (mode == 0)
+    hipLaunchKernelGGL((k_bspmv<0, LPR>), grid, block, 0, st, n, rowptr, colm, K, M, D, alpha, xu, xp, bu, bp, omega,
+                       first, yu, yp);
+  else if (mode == 1)
+    hipLaunchKernelGGL((k_bspmv<1, LPR>), grid, block, 0, st, n, rowptr, colm, K, M, D, alpha, xu, xp, bu, bp, omega,
+                       first, yu, yp);
+  else
+    hipLaunchKernelGGL((k_bspmv<2, LPR>), grid, block, 0, st, n, rowptr, colm, K, M, D, alpha, xu, xp, bu, bp, omega,
+                       first, yu, yp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// six observables of obstacle_pg.py:145-152 in ONE pass over the cells (the reference makes six)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PGX_BLOCK) k_observables(int nc, int n, const int32_t* __restrict__ cells,
+                                                           const double* __restrict__ coords,
+                                                           const double* __restrict__ x,
+                                                           const double* __restrict__ xk, double alpha, double f,
+                                                           QuadTab q, double* __restrict__ partials) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    const int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
+    double u[3], p[3], uk[3], pk[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[a] = x[v[a]];
+      p[a] = x[n + v[a]];
+      uk[a] = xk[v[a]];
+      pk[a] = xk[n + v[a]];
+    }
+    const P1Geom g = p1_geom(coords[2 * v[0]], coords[2 * v[0] + 1], coords[2 * v[1]], coords[2 * v[1] + 1],
+                             coords[2 * v[2]], coords[2 * v[2] + 1]);
+    const double area = 0.5 * g.adet;
+    const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
+    const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
+    const double hx = gx - (uk[0] * g.G[0][0] + uk[1] * g.G[1][0] + uk[2] * g.G[2][0]);
+    const double hy = gy - (uk[0] * g.G[0][1] + uk[1] * g.G[1][1] + uk[2] * g.G[2][1]);
+    s[0] += 0.5 * area * (gx * gx + gy * gy);
+    s[4] += area * (hx * hx + hy * hy);
+    for (int k = 0; k < q.nq; ++k) {
+      const double wd = g.adet * q.w[k];
+      const double uq = u[0] * q.N[k][0] + u[1] * q.N[k][1] + u[2] * q.N[k][2];
+      const double pq = p[0] * q.N[k][0] + p[1] * q.N[k][1] + p[2] * q.N[k][2];
+      const double ukq = uk[0] * q.N[k][0] + uk[1] * q.N[k][1] + uk[2] * q.N[k][2];
+      const double pkq = pk[0] * q.N[k][0] + pk[1] * q.N[k][1] + pk[2] * q.N[k][2];
+      s[0] -= f * wd * uq;
+      s[1] += wd * (pkq - pq) / alpha * uq;
+      s[2] += wd * (uq < 0.0 ? -uq : 0.0);
+      s[3] += wd * (pkq < pq ? (pq - pkq) / alpha : 0.0);
+      const double du = uq - ukq;
+      s[4] += wd * du * du;
+      const double de = exp(pq) - exp(pkq);
+      s[5] += wd * de * de;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double r = block_sum(s[k], sm);
+    if (threadIdx.x == 0) partials[blockIdx.x * 6 + k] = r;
+  }
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_observables_final(int nblocks, const double* __restrict__ partials,
+                                                                 double* __restrict__ out6) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  for (int k = 0; k < 6; ++k) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[b * 6 + k];
+    const double r = block_sum(s, sm);
+    if (threadIdx.x == 0) {
+      double v = r;
+      if (k == 1) v = fabs(v);
+      if (k >= 4) v = sqrt(v);
+      out6[k] = v;
+    }
+  }
+}
+
+int pgxk_observables_blocks(int nc) {
+  int b = (nc + PGX_BLOCK - 1) / PGX_BLOCK;
+  return b < 2048 ? b : 2048;
+}
+
+void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
+                      const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks,
+                      double* out6) {
+  hipLaunchKernelGGL(k_observables, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cells, coords, x, xk, alpha, f, q,
+                     partials);
+  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector kernels (16 B / lane accesses; len is even and all bases 16-B aligned by construction)
+// ------------------------------------------------------------------------------------------------
+static inline dim3 stream_grid(size_t len2) {
+  size_t b = (len2 + PGX_BLOCK - 1) / PGX_BLOCK;
+  if (b > 4096) b = 4096;
+  if (b == 0) b = 1;
+  return dim3((unsigned)b);
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_axpy(size_t len2, double a, const double2* __restrict__ x,
+                                                    double2* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 xv = x[i], yv = y[i];
+    yv.x += a * xv.x;
+    yv.y += a * xv.y;
+    y[i] = yv;
+  }
+}
+void pgxk_axpy(hipStream_t st, size_t len, double a, const double* x, double* y) {
+  hipLaunchKernelGGL(k_axpy, stream_grid(len / 2), dim3(PGX_BLOCK), 0, st, len / 2, a, (const double2*)x,
+                     (double2*)y);
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_scale_copy(size_t len2, double a, const double2* __restrict__ x,
+                                                          double2* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 xv = x[i];
+    xv.x *= a;
+    xv.y *= a;
+    y[i] = xv;
+  }
+}
+void pgxk_scale_copy(hipStream_t st, size_t len, double a, const double* x, double* y) {
+  hipLaunchKernelGGL(k_scale_copy, stream_grid(len / 2), dim3(PGX_BLOCK), 0, st, len / 2, a, (const double2*)x,
+                     (double2*)y);
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_set(size_t len, double a, double* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a;
+}
+void pgxk_set(hipStream_t st, size_t len, double a, double* y) {
+  hipLaunchKernelGGL(k_set, stream_grid(len), dim3(PGX_BLOCK), 0, st, len, a, y);
+}
+
+// out[i] = V_i . w : each block streams a slice of w ONCE for NV vectors (Gram-Schmidt is the
+// second-largest HBM consumer of the Newton solve; batching cuts its traffic from 2 to 1+1/NV
+// vector reads per dot product).  Two-stage, fixed grid -> bitwise reproducible.
+template <int NV>
+__global__ void __launch_bounds__(PGX_BLOCK) k_multidot(size_t len2, const double2* __restrict__ V, size_t ldv2,
+                                                        const double2* __restrict__ w,
+                                                        double* __restrict__ partials, int pstride, int poff) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 wv = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double2 a = V[v * ldv2 + i];
+      acc[v] += a.x * wv.x + a.y * wv.y;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double r = block_sum(acc[v], sm);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * pstride + poff + v] = r;
+  }
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_reduce_partials(int nblocks, int nv, const double* __restrict__ p,
+                                                               double* __restrict__ out) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  const int v = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += p[(size_t)b * nv + v];
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) out[v] = r;
+}
+
+void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* w, double* partials,
+                   double* out) {
+  const size_t len2 = len / 2, ldv2 = ldv / 2;
+  size_t nb = (len2 + PGX_BLOCK - 1) / PGX_BLOCK;
+  if (nb > PGX_RED_BLOCKS) nb = PGX_RED_BLOCKS;
+  if (nb == 0) nb = 1;
+  dim3 grid((unsigned)nb), block(PGX_BLOCK);
+  int done = 0;
+  while (done < nv) {
+    const int rem = nv - done;
+    const double2* Vp = (const double2*)(V + (size_t)done * ldv);
+    if (rem >= 8) {
+      hipLaunchKernelGGL(k_multidot<8>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
+      done += 8;
+    } else if (rem >= 4) {
+      hipLaunchKernelGGL(k_multidot<4>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
+      done += 4;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL(k_multidot<2>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
+      done += 2;
+    } else {
+      hipLaunchKernelGGL(k_multidot<1>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
+      done += 1;
+    }
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nv), block, 0, st, (int)nb, nv, partials, out);
+}
+
+template <int NV>
+__global__ void __launch_bounds__(PGX_BLOCK) k_multiaxpy(size_t len2, const double2* __restrict__ V, size_t ldv2,
+                                                         const double* __restrict__ h, double2* __restrict__ w) {
+  double hv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) hv[v] = h[v];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 wv = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double2 a = V[v * ldv2 + i];
+      wv.x -= hv[v] * a.x;
+      wv.y -= hv[v] * a.y;
+    }
+    w[i] = wv;
+  }
+}
+
+void pgxk_multiaxpy(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w) {
+  const size_t len2 = len / 2, ldv2 = ldv / 2;
+  dim3 grid = stream_grid(len2), block(PGX_BLOCK);
+  int done = 0;
+  while (done < nv) {
+    const int rem = nv - done;
+    const double2* Vp = (const double2*)(V + (size_t)done * ldv);
+    if (rem >= 8) {
+      hipLaunchKernelGGL(k_multiaxpy<8>, grid, block, 0, st, len2, Vp, ldv2, h + done, (double2*)w);
+      done += 8;
+    } else if (rem >= 4) {
+      hipLaunchKernelGGL(k_multiaxpy<4>, grid, block, 0, st, len2, Vp, ldv2, h + done, (double2*)w);
+      done += 4;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL(k_multiaxpy<2>, grid, block, 0, st, len2, Vp, ldv2, h + done, (double2*)w);
+      done += 2;
+    } else {
+      hipLaunchKernelGGL(k_multiaxpy<1>, grid, block, 0, st, len2, Vp, ldv2, h + done, (double2*)w);
+      done += 1;
+    }
+  }
+}
+
+// x (+)= sum_i y[i] Z_i
+__global__ void __launch_bounds__(PGX_BLOCK) k_lincomb(size_t len2, int nv, const double2* __restrict__ Z,
+                                                       size_t ldz2, const double* __restrict__ y,
+                                                       double2* __restrict__ x, int accumulate) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 s = accumulate ? x[i] : make_double2(0.0, 0.0);
+    for (int v = 0; v < nv; ++v) {
+      const double2 a = Z[v * ldz2 + i];
+      const double yv = y[v];
+      s.x += yv * a.x;
+      s.y += yv * a.y;
+    }
+    x[i] = s;
+  }
+}
+void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ldz, const double* y, double* x,
+                  int accumulate) {
+  hipLaunchKernelGGL(k_lincomb, stream_grid(len / 2), dim3(PGX_BLOCK), 0, st, len / 2, nv, (const double2*)Z,
+                     ldz / 2, y, (double2*)x, accumulate);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7-point stencil multigrid (structured right-diagonal meshes, nested by vertex coarsening)
+// ------------------------------------------------------------------------------------------------
+__device__ __constant__ int c_OX[7] = {0, 1, -1, 0, 0, 1, -1};
+__device__ __constant__ int c_OY[7] = {0, 0, 0, 1, -1, 1, -1};
+
+// P1 prolongation weight of the fine vertex at offset (dx,dy) from a coarse vertex
+__device__ __forceinline__ constexpr double pw(int dx, int dy) {
+  return (dx == 0 && dy == 0) ? 1.0
+         : ((dx == 1 && dy == 0) || (dx == -1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 0 && dy == -1) ||
+            (dx == 1 && dy == 1) || (dx == -1 && dy == -1))
+             ? 0.5
+             : 0.0;
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil(int n, int sx, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ colm,
+                                                              const double* __restrict__ vals,
+                                                              double* __restrict__ S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int o = (colm[k] & 0x7fffffff) - i;
+    const double v = vals[k];
+    if (o == 0) s[0] = v;
+    else if (o == 1) s[1] = v;
+    else if (o == -1) s[2] = v;
+    else if (o == sx) s[3] = v;
+    else if (o == -sx) s[4] = v;
+    else if (o == sx + 1) s[5] = v;
+    else if (o == -sx - 1) s[6] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) S[(size_t)k * n + i] = s[k];
+}
+void pgxk_csr_to_stencil(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm, const double* vals,
+                         double* S) {
+  hipLaunchKernelGGL(k_csr_to_stencil, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, sx, rowptr,
+                     colm, vals, S);
+}
+
+// Galerkin coarse operator S_c = P^T S_f P for a 7-point stencil; stays 7-point because the P1 spaces
+// are nested.  One thread per coarse vertex; all 7x7x7 index combinations are resolved at compile time.
+__global__ void __launch_bounds__(PGX_BLOCK) k_rap7(int nxf, int nyf, int nf, const double* __restrict__ Sf, int nxc,
+                                                    int nyc, int ncv, double* __restrict__ Sc) {
+  const int C = blockIdx.x * blockDim.x + threadIdx.x;
+  if (C >= ncv) return;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  const int sxc = nxc + 1, sxf = nxf + 1;
+  const int I = C % sxc, Jc = C / sxc;
+  double out[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int oa = 0; oa < 7; ++oa) {
+    const int ax = 2 * I + OX[oa], ay = 2 * Jc + OY[oa];
+    if (ax < 0 || ax > nxf || ay < 0 || ay > nyf) continue;
+    const double wa = pw(OX[oa], OY[oa]);
+    const size_t a = (size_t)ay * sxf + ax;
+#pragma unroll
+    for (int os = 0; os < 7; ++os) {
+      const double coef = wa * Sf[(size_t)os * nf + a];
+      const int dx = OX[oa] + OX[os], dy = OY[oa] + OY[os];
+#pragma unroll
+      for (int oc = 0; oc < 7; ++oc) {
+        const double w2 = pw(dx - 2 * OX[oc], dy - 2 * OY[oc]);
+        if (w2 != 0.0) out[oc] += coef * w2;
+      }
+    }
+  }
+#pragma unroll
+  for (int oc = 0; oc < 7; ++oc) {
+    const int nx_ = I + OX[oc], ny_ = Jc + OY[oc];
+    const bool ok = nx_ >= 0 && nx_ <= nxc && ny_ >= 0 && ny_ <= nyc;
+    Sc[(size_t)oc * ncv + C] = ok ? out[oc] : 0.0;
+  }
+}
+void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridLevel& c, double* Sc) {
+  hipLaunchKernelGGL(k_rap7, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, f.nx, f.ny, f.n, Sf, c.nx,
+                     c.ny, c.n, Sc);
+}
+
+__global__ void k_coarse_mask(int nxc, int nyc, int ncv, int nxf, const uint8_t* __restrict__ mf,
+                              uint8_t* __restrict__ mc) {
+  const int C = blockIdx.x * blockDim.x + threadIdx.x;
+  if (C >= ncv) return;
+  const int I = C % (nxc + 1), J = C / (nxc + 1);
+  mc[C] = mf[(size_t)(2 * J) * (nxf + 1) + 2 * I];
+}
+void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const GridLevel& f) {
+  hipLaunchKernelGGL(k_coarse_mask, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, c.nx, c.ny, c.n,
+                     f.nx, f.mask, mask_c);
+}
+
+// same three modes as k_bspmv, on stencil storage
+template <int MODE>
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, const double* __restrict__ K,
+                                                        const double* __restrict__ M, const double* __restrict__ D,
+                                                        const uint8_t* __restrict__ mask, double alpha,
+                                                        const double* __restrict__ xu, const double* __restrict__ xp,
+                                                        const double* __restrict__ bu, const double* __restrict__ bp,
+                                                        double omega, int first, double* __restrict__ yu,
+                                                        double* __restrict__ yp) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int sx = nx + 1;
+  const int i = v % sx, j = v / sx;
+  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+  const bool ok[7] = {true, i < nx, i > 0, j < ny, j > 0, i < nx && j < ny, i > 0 && j > 0};
+  const int rowbc = mask[v];
+  double au = 0.0, ap = 0.0;
+  const bool skip = (MODE == 2) && first;
+  if (!skip) {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      if (!ok[s]) continue;
+      const int nb = v + off[s];
+      const double kv = K[(size_t)s * n + v], mv = M[(size_t)s * n + v], dv = D[(size_t)s * n + v];
+      const double xuv = mask[nb] ? 0.0 : xu[nb];
+      const double xpv = xp[nb];
+      au += alpha * kv * xuv + mv * xpv;
+      ap += mv * xuv - dv * xpv;
+    }
+  }
+  const double xur = skip ? 0.0 : xu[v];
+  if (rowbc) au = xur;
+  if (MODE == 0) {
+    yu[v] = au;
+    yp[v] = ap;
+  } else if (MODE == 1) {
+    yu[v] = bu[v] - au;
+    yp[v] = bp[v] - ap;
+  } else {
+    const double su = bu[v] - au, sp = bp[v] - ap;
+    const double xpr = skip ? 0.0 : xp[v];
+    double a = alpha * K[v], b = M[v];
+    const double dd = D[v];
+    double om_u = omega;
+    if (rowbc) {
+      a = 1.0;
+      b = 0.0;
+      om_u = 1.0;
+    }
+    const double det = -a * dd - b * b;
+    double du = 0.0, dpsi = 0.0;
+    if (det != 0.0) {
+      du = (-dd * su - b * sp) / det;
+      dpsi = (-b * su + a * sp) / det;
+    } else if (rowbc) {
+      du = su;
+    }
+    yu[v] = xur + om_u * du;
+    yp[v] = xpr + omega * dpsi;
+  }
+}
+void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                   const double* bu, const double* bp, double omega, int first, double* yu, double* yp) {
+  dim3 grid((L.n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_st_apply<0>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
+                       bp, omega, first, yu, yp);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_st_apply<1>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
+                       bp, omega, first, yu, yp);
+  else
+    hipLaunchKernelGGL(k_st_apply<2>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
+                       bp, omega, first, yu, yp);
+}
+
+// b_c = P^T r_f  (u rows of coarse Dirichlet vertices get 0: they are not unknowns of the coarse problem)
+__global__ void __launch_bounds__(PGX_BLOCK) k_restrict(int nxf, int nyf, const double* __restrict__ ru,
+                                                        const double* __restrict__ rp, int nxc, int nyc, int ncv,
+                                                        const uint8_t* __restrict__ mask_c, double* __restrict__ bu,
+                                                        double* __restrict__ bp) {
+  const int C = blockIdx.x * blockDim.x + threadIdx.x;
+  if (C >= ncv) return;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  const int sxc = nxc + 1, sxf = nxf + 1;
+  const int I = C % sxc, J = C / sxc;
+  double su = 0.0, sp = 0.0;
+#pragma unroll
+  for (int o = 0; o < 7; ++o) {
+    const int ax = 2 * I + OX[o], ay = 2 * J + OY[o];
+    if (ax < 0 || ax > nxf || ay < 0 || ay > nyf) continue;
+    const size_t a = (size_t)ay * sxf + ax;
+    const double w = pw(OX[o], OY[o]);
+    su += w * ru[a];
+    sp += w * rp[a];
+  }
+  bu[C] = mask_c[C] ? 0.0 : su;
+  bp[C] = sp;
+}
+void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const double* rp, const GridLevel& c,
+                   double* bu, double* bp) {
+  hipLaunchKernelGGL(k_restrict, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, f.nx, f.ny, ru, rp,
+                     c.nx, c.ny, c.n, c.mask, bu, bp);
+}
+
+// x_f += P x_c
+__global__ void __launch_bounds__(PGX_BLOCK) k_prolong_add(int nxc, const double* __restrict__ cu,
+                                                           const double* __restrict__ cp, int nxf, int nf,
+                                                           double* __restrict__ xu, double* __restrict__ xp) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nf) return;
+  const int sxf = nxf + 1, sxc = nxc + 1;
+  const int i = v % sxf, j = v / sxf;
+  const int i0 = i >> 1, j0 = j >> 1;
+  const int io = i & 1, jo = j & 1;
+  // (i,j) lies between coarse vertices (i0,j0) and (i0+io, j0+jo): identical, x-edge, y-edge or diagonal midpoint
+  const int c0 = j0 * sxc + i0, c1 = (j0 + jo) * sxc + (i0 + io);
+  xu[v] += 0.5 * (cu[c0] + cu[c1]);
+  xp[v] += 0.5 * (cp[c0] + cp[c1]);
+}
+void pgxk_prolong_add(hipStream_t st, const GridLevel& c, const double* cu, const double* cp, const GridLevel& f,
+                      double* xu, double* xp) {
+  hipLaunchKernelGGL(k_prolong_add, dim3((f.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, c.nx, cu, cp,
+                     f.nx, f.n, xu, xp);
+}

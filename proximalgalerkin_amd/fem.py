@@ -1,0 +1,223 @@
+"""Host-side problem description: the small part of the DOLFINx surface that
+/root/reference/examples/01_obstacle_problem/obstacle_pg.py uses, re-stated
+declaratively because UFL/DOLFINx cannot ship.  Pure numpy, setup-time only; nothing here is on the
+hot path.
+
+Names follow the reference call sites:
+    mesh.create_rectangle / create_unit_square     gradient_constraint_dolfinx.py:36
+    functionspace(mesh, ("Lagrange", k), mixed)     obstacle_pg.py:68-70
+    Function(V).x.array                             obstacle_pg.py:157-158,226
+    Constant(mesh, value).value                     obstacle_pg.py:73-74,175-186
+    exterior_boundary_dofs / dirichletbc            obstacle_pg.py:76-83
+    QuadratureFunction.interpolate(phi_set)         obstacle_pg.py:106-111
+"""
+from __future__ import annotations
+
+import json
+import pathlib
+from dataclasses import dataclass
+
+import numpy as np
+
+_TABLES = pathlib.Path(__file__).resolve().parent / "tables" / "quadrature.json"
+
+
+def quadrature_rule(cell: str, degree: int):
+    """(points (nq,2), weights (nq,)) on the reference triangle. Tables live in ONE file shared with
+    the oracle (tools/make_quadrature_tables.py)."""
+    tabs = json.loads(_TABLES.read_text())
+    for t in tabs.values():
+        if t["cell"] == cell and t["degree"] == degree:
+            return (np.ascontiguousarray(t["points"], dtype=np.float64),
+                    np.ascontiguousarray(t["weights"], dtype=np.float64))
+    raise NotImplementedError(f"no quadrature table for {cell} degree {degree} (available: "
+                              f"{[(t['cell'], t['degree']) for t in tabs.values()]})")
+
+
+# ------------------------------------------------------------------------------------------------
+class Mesh:
+    """Simplicial mesh. `structured=(nx, ny)` marks the right-diagonal triangulation with vertex
+    v=j*(nx+1)+i (enables the geometric-multigrid preconditioner)."""
+
+    def __init__(self, coords, cells, structured=None):
+        self.geometry = np.ascontiguousarray(coords, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        if self.geometry.ndim != 2 or self.geometry.shape[1] != 2 or self.cells.ndim != 2 or self.cells.shape[1] != 3:
+            raise ValueError("expected coords (nv,2) and triangle cells (nc,3)")
+        self.structured = tuple(int(s) for s in structured) if structured else None
+
+    @property
+    def num_vertices(self):
+        return self.geometry.shape[0]
+
+    @property
+    def num_cells(self):
+        return self.cells.shape[0]
+
+    def cell_name(self):
+        return "triangle"
+
+    def exterior_vertices(self):
+        """Vertices on exterior facets (edges that belong to exactly one cell):
+        mesh.exterior_facet_indices + locate_dofs_topological of obstacle_pg.py:76-79 for P1."""
+        if self.structured:
+            nx, ny = self.structured
+            i, j = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+            return np.flatnonzero(((i == 0) | (i == nx) | (j == 0) | (j == ny)).ravel()).astype(np.int32)
+        c = self.cells.astype(np.int64)
+        e = np.concatenate([c[:, [0, 1]], c[:, [1, 2]], c[:, [2, 0]]])
+        e.sort(axis=1)
+        key = e[:, 0] * self.num_vertices + e[:, 1]
+        uk, cnt = np.unique(key, return_counts=True)
+        b = uk[cnt == 1]
+        return np.unique(np.concatenate([b // self.num_vertices, b % self.num_vertices])).astype(np.int32)
+
+
+def create_rectangle(points, n, diagonal="right"):
+    """dolfinx.mesh.create_rectangle(comm, points, n) for triangles, default (right) diagonal."""
+    if diagonal != "right":
+        raise NotImplementedError("only the default 'right' diagonal is implemented")
+    (x0, y0), (x1, y1) = points
+    nx, ny = int(n[0]), int(n[1])
+    xs = np.linspace(x0, x1, nx + 1)
+    ys = np.linspace(y0, y1, ny + 1)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+    i, j = np.meshgrid(np.arange(nx, dtype=np.int64), np.arange(ny, dtype=np.int64), indexing="xy")
+    v0 = (j * (nx + 1) + i).ravel()
+    v1, v2 = v0 + 1, v0 + nx + 1
+    v3 = v2 + 1
+    cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
+    cells[0::2] = np.stack([v0, v1, v3], axis=1)
+    cells[1::2] = np.stack([v0, v2, v3], axis=1)
+    return Mesh(coords, cells, structured=(nx, ny))
+
+
+def create_unit_square(nx, ny):
+    return create_rectangle(((0.0, 0.0), (1.0, 1.0)), (nx, ny))
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class FunctionSpace:
+    """Equal-order mixed Lagrange space [P_k]^ncomp on `mesh` (basix mixed_element([P,P]),
+    obstacle_pg.py:68-70).  Dofs are blocked: [comp0 | comp1 | ...], vertex-numbered within a block."""
+    mesh: Mesh
+    degree: int = 1
+    ncomp: int = 2
+
+    @property
+    def block_size(self):
+        if self.degree != 1:
+            raise NotImplementedError("P1 only in this round (P2 is the next section-8 row)")
+        return self.mesh.num_vertices
+
+    @property
+    def num_dofs(self):
+        return self.ncomp * self.block_size
+
+    def sub(self, i):
+        return SubSpace(self, i)
+
+
+@dataclass(frozen=True)
+class SubSpace:
+    parent: FunctionSpace
+    index: int
+
+
+def functionspace(mesh, element=("Lagrange", 1), ncomp=2):
+    family, degree = element
+    if family != "Lagrange":
+        raise NotImplementedError(family)
+    return FunctionSpace(mesh, int(degree), ncomp)
+
+
+class _Vector:
+    """`.array` is the host numpy view. When bound to a device slot of a solver handle the two copies
+    are synchronised lazily: reading `.array` pulls if the device copy is newer and (because the
+    caller may write through the view) marks the device copy stale."""
+
+    def __init__(self, n):
+        self._a = np.zeros(n, dtype=np.float64)
+        self._binding = None  # (NonlinearProblem, "state"|"prev")
+        self._host_valid = True
+        self._dev_valid = False
+
+    @property
+    def array(self):
+        if not self._host_valid:
+            self._binding[0]._pull(self._binding[1], self._a)
+            self._host_valid = True
+        self._dev_valid = False
+        return self._a
+
+    def assign_from(self, other: "_Vector"):
+        """self <- other without a host round trip when both live on the same handle
+        (the device-resident form of `sol_k.x.array[:] = sol.x.array[:]`, obstacle_pg.py:226)."""
+        b, ob = self._binding, other._binding
+        if (b and ob and b[0] is ob[0] and b[1] == "prev" and ob[1] == "state" and other._dev_valid):
+            b[0]._advance_prev()
+            self._dev_valid, self._host_valid = True, False
+        else:
+            self.array[:] = other.array
+
+
+class Function:
+    def __init__(self, V: FunctionSpace, name="f"):
+        self.function_space = V
+        self.name = name
+        self.x = _Vector(V.num_dofs)
+
+    def sub_array(self, i):
+        n = self.function_space.block_size
+        return self.x.array[i * n:(i + 1) * n]
+
+
+class Constant:
+    def __init__(self, mesh, value):
+        self.value = float(value)
+
+
+class QuadratureFunction:
+    """Function in a quadrature space of the given degree: one value per (cell, point), dof =
+    cell*nq + q (basix.ufl.quadrature_element + fem.functionspace, obstacle_pg.py:107-110)."""
+
+    def __init__(self, mesh: Mesh, degree: int, name="phi"):
+        self.mesh, self.degree, self.name = mesh, degree, name
+        self.points, self.weights = quadrature_rule(mesh.cell_name(), degree)
+        self.values = np.zeros((mesh.num_cells, len(self.weights)))
+
+    def physical_points(self):
+        X, Y = self.points[:, 0], self.points[:, 1]
+        N = np.stack([1.0 - X - Y, X, Y], axis=1)
+        x = self.mesh.geometry[self.mesh.cells]  # (nc,3,2)
+        return np.einsum("qa,cad->cqd", N, x)
+
+    def interpolate(self, fn, chunk=1 << 20):
+        """fn takes x of shape (2, npts) like a dolfinx interpolation callable."""
+        nc, nq = self.values.shape
+        X, Y = self.points[:, 0], self.points[:, 1]
+        N = np.stack([1.0 - X - Y, X, Y], axis=1)
+        for s in range(0, nc, chunk):
+            x = self.mesh.geometry[self.mesh.cells[s:s + chunk]]
+            xq = np.einsum("qa,cad->cqd", N, x).reshape(-1, 2).T
+            self.values[s:s + chunk] = np.asarray(fn(np.ascontiguousarray(xq))).reshape(-1, nq)
+
+
+@dataclass
+class DirichletBC:
+    dofs: np.ndarray     # dofs within the sub-space block
+    values: np.ndarray
+    sub: int             # which component of the mixed space
+
+
+def dirichletbc(value, dofs, V):
+    """fem.dirichletbc(value=u_bc, dofs=dofs, V=V.sub(0)) (obstacle_pg.py:83)."""
+    sub = V.index if isinstance(V, SubSpace) else 0
+    dofs = np.ascontiguousarray(dofs, dtype=np.int32)
+    if isinstance(value, Function):
+        vals = np.ascontiguousarray(value.x.array[:value.function_space.block_size][dofs])
+    else:
+        vals = np.full(len(dofs), float(value))
+    return DirichletBC(dofs, vals, sub)

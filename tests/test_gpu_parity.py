@@ -1,0 +1,199 @@
+"""HIP path vs CPU oracle, through the C ABI (libpgx.so), on seeded / deterministic inputs.
+
+Tolerances (fp64 path):
+  * kernels (residual, Jacobian blocks, SpMV, observables): 1e-12 relative - different summation
+    orders and fp64 atomics only
+  * full LVPP solve: identical Newton/outer iteration counts, final primal field <= 1e-10 relative L2
+    (BASELINE.json north_star)
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DOMAIN = ((-1.0, -1.0), (1.0, 1.0))
+
+
+def _setup(N, M=None):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import setup_problem
+
+    M = N if M is None else M
+    msh = fem.create_rectangle(DOMAIN, (N, M))
+    problem, sol, sol_k, alpha = setup_problem(msh)
+    coords, cells = O.create_rectangle(N, M)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, M))
+    return problem, sol, sol_k, alpha, prob
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _iterates(prob, n2, seed):
+    """a smooth + a rough state, with psi spanning the range met in real runs (H4: down to -700)"""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n2) * 0.1
+    xk = rng.standard_normal(n2) * 0.1
+    n = n2 // 2
+    x[n:] = -np.abs(rng.standard_normal(n)) * np.where(rng.random(n) < 0.3, 300.0, 2.0)
+    return x, xk
+
+
+@pytest.mark.parametrize("N,M", [(8, 8), (33, 17), (64, 64)])
+def test_residual_matches_oracle(require_gpu, N, M):
+    problem, sol, sol_k, alpha, prob = _setup(N, M)
+    x, xk = _iterates(prob, 2 * prob.n, 1)
+    for a in (1.0, 37.5):
+        alpha.value = a
+        sol_k.x.array[:] = xk
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, a)
+        assert _rel(F, Fr) < 1e-12
+        assert abs(fn - np.linalg.norm(Fr)) <= 1e-12 * np.linalg.norm(Fr)
+    # zero state, the first residual of a real run
+    z = np.zeros(2 * prob.n)
+    sol_k.x.array[:] = 0.0
+    alpha.value = 1.0
+    F, _ = problem.residual(z)
+    assert _rel(F, prob.residual(z, z, 1.0)) < 1e-12
+    problem.close()
+
+
+@pytest.mark.parametrize("N,M", [(8, 8), (33, 17), (64, 64)])
+def test_jacobian_blocks_and_spmv_match_oracle(require_gpu, N, M):
+    problem, sol, sol_k, alpha, prob = _setup(N, M)
+    x, xk = _iterates(prob, 2 * prob.n, 2)
+    alpha.value = 2.5
+    problem.assemble_jacobian(x)
+    rowptr, col, K, Mv, D = problem.export_blocks()
+    assert np.array_equal(rowptr, prob.indptr_s.astype(np.int32))
+    assert np.array_equal(col, prob.indices_s)
+    assert _rel(K, prob.K.data) < 1e-13
+    assert _rel(Mv, prob.M.data) < 1e-13
+    Dr = prob.jacobian_blocks(x)
+    assert _rel(D, Dr) < 1e-12
+    # entries that underflow to exactly 0 in the oracle must do so here as well (H4)
+    assert np.array_equal(D == 0.0, Dr == 0.0)
+    J = prob.jacobian(x, 2.5)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        v = rng.standard_normal(2 * prob.n)
+        assert _rel(problem.spmv(v), J @ v) < 1e-12
+    problem.close()
+
+
+def test_observables_match_oracle(require_gpu):
+    problem, sol, sol_k, alpha, prob = _setup(48)
+    x, xk = _iterates(prob, 2 * prob.n, 4)
+    x[prob.n:] = np.clip(x[prob.n:], -50, None)
+    alpha.value = 3.0
+    sol.x.array[:] = x
+    sol_k.x.array[:] = xk
+    got = problem.observables()
+    want = prob.observables(x, xk, 3.0)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+    problem.close()
+
+
+@pytest.mark.parametrize("scheme,alpha_max,tol,N", [("double_exponential", 1e2, 1e-4, 64), ("constant", 1e5, 1e-6, 32),
+                                                    ("geometric", 1e5, 1e-5, 32)])
+def test_full_lvpp_run_matches_oracle(require_gpu, scheme, alpha_max, tol, N):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import COLUMNS, solve_problem
+
+    msh = fem.create_rectangle(DOMAIN, (N, N))
+    sol, newton, hist = solve_problem(msh, 1, 100, scheme, alpha_max, tol, verbose=False, return_history=True)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    x_ref, h_ref = O.solve_problem(prob, 100, scheme, alpha_max, tol)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert newton == sum(h_ref["Newton steps"])
+    n = prob.n
+    assert _rel(sol.x.array[:n], x_ref[:n]) < 1e-10
+    for c in COLUMNS:
+        assert np.allclose(hist[c], h_ref[c], rtol=1e-7, atol=1e-11), c
+
+
+def test_host_and_device_resident_loops_agree(require_gpu):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import solve_problem
+
+    msh = fem.create_rectangle(DOMAIN, (32, 32))
+    a, na = solve_problem(msh, 1, 100, "double_exponential", 1e2, 1e-4, verbose=False, device_resident=True)
+    b, nb = solve_problem(msh, 1, 100, "double_exponential", 1e2, 1e-4, verbose=False, device_resident=False)
+    assert na == nb
+    assert _rel(a.x.array, b.x.array) < 1e-9
+
+
+def test_lvpp_snes_solver_api(require_gpu):
+    """lvpp.SNESProblem / SNESSolver call shapes (src/lvpp/problem.py:14-127)."""
+    from proximalgalerkin_amd import SNESProblem, SNESSolver, fem
+    from proximalgalerkin_amd.obstacle import phi_set
+    from proximalgalerkin_amd.problem import ObstacleResidual
+
+    N = 16
+    msh = fem.create_rectangle(DOMAIN, (N, N))
+    V = fem.functionspace(msh, ("Lagrange", 1))
+    sol, sol_k = fem.Function(V), fem.Function(V)
+    alpha, f = fem.Constant(msh, 1.0), fem.Constant(msh, 0.0)
+    phi = fem.QuadratureFunction(msh, 6)
+    phi.interpolate(phi_set)
+    bc = fem.dirichletbc(0.0, msh.exterior_vertices(), V.sub(0))
+    F = ObstacleResidual(sol, sol_k, alpha, f, phi, 6)
+    problem = SNESProblem(F, sol, bcs=[bc])
+    solver = SNESSolver(problem, {"snes_rtol": 1e-6, "snes_max_it": 100, "snes_linesearch_type": "none"})
+    reason, its = solver.solve()
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    z = np.zeros(2 * prob.n)
+    x_ref, r_ref, its_ref = O.newton_solve(prob, z, z, 1.0, O.SnesOptions(rtol=1e-6, max_it=100))
+    assert (reason, its) == (r_ref, its_ref)
+    assert _rel(sol.x.array, x_ref) < 1e-9
+    # callbacks
+    Fout = np.empty(2 * prob.n)
+    problem.F(None, x_ref, Fout)
+    assert _rel(Fout, prob.residual(x_ref, z, 1.0)) < 1e-9
+    problem.J(None, x_ref, None, None)
+    # not converged -> solution is NOT copied back (problem.py:121-123)
+    before = sol.x.array.copy()
+    sol_k.x.array[:] = 0.0
+    sol.x.array[:] = 0.0
+    solver2 = SNESSolver(problem, {"snes_rtol": 1e-14, "snes_max_it": 1, "snes_linesearch_type": "none"})
+    reason2, its2 = solver2.solve()
+    assert reason2 == -5 and its2 == 1
+    assert np.all(sol.x.array == 0.0) and before is not None
+
+
+def test_unstructured_vertex_numbering_single_level(require_gpu):
+    """A permuted (hence 'general') mesh: assembly kernels must not depend on structure; the Newton
+    solve then runs with the single-level smoother as preconditioner."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import setup_problem
+
+    N = 12
+    coords, cells = O.create_rectangle(N, N)
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(len(coords))  # new id of old vertex v is perm[v]
+    inv = np.argsort(perm)
+    msh = fem.Mesh(coords[inv], perm[cells].astype(np.int32)[rng.permutation(len(cells))])
+    problem, sol, sol_k, alpha = setup_problem(msh)
+    prob = O.ObstacleP1(msh.geometry, msh.cells, msh.exterior_vertices())
+    x, xk = _iterates(prob, 2 * prob.n, 5)
+    sol_k.x.array[:] = xk
+    F, _ = problem.residual(x)
+    assert _rel(F, prob.residual(x, xk, 1.0)) < 1e-12
+    problem.assemble_jacobian(x)
+    v = rng.standard_normal(2 * prob.n)
+    assert _rel(problem.spmv(v), prob.jacobian(x, 1.0) @ v) < 1e-12
+    sol.x.array[:] = 0.0
+    sol_k.x.array[:] = 0.0
+    problem.solve()
+    z = np.zeros(2 * prob.n)
+    x_ref, r_ref, its_ref = O.newton_solve(prob, z, z, 1.0, O.SnesOptions(rtol=1e-6, max_it=100))
+    assert problem.solver.getIterationNumber() == its_ref
+    assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-9
+    problem.close()
