@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py - LVPP / proximal-Galerkin Newton loop on the 2048x2048 P1 obstacle problem.
+
+    python bench.py --gpus 1 --steps K --warmup W
+
+A "step" is ONE complete proximal-point solve of the obstacle problem (the loop of
+/root/reference/examples/01_obstacle_problem/obstacle_pg.py:173-227: every proximal iteration, each
+with its Newton iterations, observables and stopping test) from the zero state, on a mesh that is
+already resident in HBM.  `value` = Newton iterations per second over the timed K steps
+(BASELINE.json metric "proximal-Newton iterations/sec"); proximal iterations/s is reported beside it.
+
+N>1: one process per GPU under torch.distributed.run; see DESIGN.md section "multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+SETTINGS = {
+    # script defaults of obstacle_pg.py:295,304,320
+    "A": dict(alpha_scheme="constant", alpha_max=1e5, tol_exit=1e-6, max_outer=100),
+    # what the reference's CI runs: compare_all.py:80-87
+    "B": dict(alpha_scheme="double_exponential", alpha_max=1e2, tol_exit=1e-4, max_outer=500),
+}
+
+
+def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
+    """Oracle (numpy assembly + SuperLU exact Newton, 1 thread) timed on this host: the SAME LVPP run at a
+    reduced mesh size n_sample, cut off after ~budget_s of CPU work.  Timed region = the loop of
+    obstacle_pg.py:173-227 (residual + Jacobian assembly, factorisation, solves, observables)."""
+    import scipy.sparse.linalg as spla
+
+    from oracle import pg_oracle as O  # CPU baseline leg only
+
+    coords, cells = O.create_rectangle(n_sample, n_sample)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(n_sample, n_sample))
+    x = np.zeros(2 * prob.n)
+    xk = x.copy()
+    sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
+    steps, t0 = 0, time.perf_counter()
+    over = lambda: time.perf_counter() - t0 > budget_s  # noqa: E731
+    for k in range(settings["max_outer"]):
+        alpha = sched.update(k)
+        F = prob.residual(x, xk, alpha)
+        f0 = np.linalg.norm(F)
+        for _ in range(100):
+            lu = spla.splu(prob.jacobian(x, alpha).tocsc())
+            x = x + lu.solve(-F)
+            steps += 1
+            F = prob.residual(x, xk, alpha)
+            if np.linalg.norm(F) <= 1e-6 * f0 or over():
+                break
+        if over() or prob.observables(x, xk, alpha)[4] < settings["tol_exit"]:
+            break
+        xk = x.copy()
+    dt = time.perf_counter() - t0
+    return steps / dt, steps, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2048, help="cells per side (BASELINE config: 2048)")
+    ap.add_argument("--settings", choices=["A", "B"], default="B")
+    ap.add_argument("--cpu-n", type=int, default=384, help="mesh size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    S = SETTINGS[args.settings]
+    N = args.n
+    # ---- setup (untimed): mesh, obstacle at quadrature points, plan, constant blocks, MG hierarchy ----
+    t_setup = time.perf_counter()
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+    problem, sol, sol_k, alpha = setup_problem(msh, 1, device=local_rank)
+    t_setup = time.perf_counter() - t_setup
+    if args.profile:
+        problem.profile(enable=True, reset=True)
+
+    def one_step():
+        return run_outer_loop(problem, sol, sol_k, alpha, S["max_outer"], S["alpha_scheme"], S["alpha_max"],
+                              S["tol_exit"], device_resident=True, verbose=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hist = one_step()
+    if args.profile:
+        problem.profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    newton_total, outer_total = 0, 0
+    for _ in range(args.steps):
+        hist = one_step()
+        newton_total += int(sum(hist["Newton steps"]))
+        outer_total += hist["outer_iterations"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([newton_total, outer_total], device="cuda", dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        newton_total, outer_total = int(c[0].item()), int(c[1].item())
+    lin_its = problem.solver.getLinearSolveIterations()
+
+    # ---- roofline of the dominant kernel (k_bspmv): HIP events on the library's own stream ----
+    problem.assemble_jacobian()  # Jacobian at the final iterate
+    spmv_ms, spmv_bytes = problem.spmv_bench(reps=50)
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    n = msh.num_vertices
+    rowptr_nnz = None
+    prof = problem.profile() if args.profile else None
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "proximal-Newton iterations/sec, 2048^2 P1 obstacle (LVPP Newton inner loop)",
+            "value": newton_total / dt,
+            "unit": "Newton iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N}x{N} right-diagonal P1 obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
+                            f"settings {args.settings}: alpha {S['alpha_scheme']}, alpha_max {S['alpha_max']:g}, "
+                            f"tol {S['tol_exit']:g}; snes_rtol 1e-6, ksp_rtol 1e-10",
+                "mixed_unknowns": 2 * n,
+                "step": "one full LVPP solve from the zero state",
+                "newton_iterations_per_step": newton_total / args.steps / world,
+                "proximal_iterations_per_step": outer_total / args.steps / world,
+                "parallelism": "replicas" if world > 1 else "single",
+            },
+            "proximal_iterations_per_s": outer_total / dt,
+            "last_newton_linear_iterations": lin_its,
+            "setup_s": t_setup,
+            "roofline": {
+                "kernel": "k_bspmv (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": spmv_bytes,
+                "avg_launch_ms": spmv_ms,
+                "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)
+                                            / (spmv_ms * 1e-3) / 1e9,
+            },
+        }
+        if prof:
+            out["phase_ms"] = prof
+        if not args.no_cpu_baseline and world == 1:
+            v, steps, secs = cpu_baseline(args.cpu_n, S)
+            out["cpu_baseline"] = {
+                "value": v,
+                "unit": "Newton iterations/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"{steps} Newton steps ({secs:.1f} s) of the same LVPP run on a {args.cpu_n}x{args.cpu_n} mesh "
+                          f"(numpy assembly + SuperLU(COLAMD) exact Newton, 1 thread); the 2048^2 factorisation "
+                          f"does not fit a bounded sample - see DESIGN.md for the measured scaling",
+            }
+    problem.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,7 @@
  *                         SNESSolver.create_data_structures (src/lvpp/problem.py:14-52,106-112)
  *   pgx_set_state/get_state   sol.x.array[:] access (obstacle_pg.py:157,226)
  *   pgx_set_prev / pgx_advance_prev   sol_k.x.array[:] = sol.x.array[:] (obstacle_pg.py:158,226)
+ *   pgx_zero_state        sol.x.array[:] = 0.0; sol_k.x.array[:] = sol.x.array[:] (obstacle_pg.py:157-158)
  *   pgx_set_alpha         alpha.value = ... (obstacle_pg.py:175-186)
  *   pgx_residual          SNESProblem.F(snes, x, F) (src/lvpp/problem.py:54-67)
  *   pgx_jacobian_fill     SNESProblem.J(snes, x, J, P) (src/lvpp/problem.py:69-77)
@@ -113,6 +114,7 @@ int pgx_get_state(pgx_handle* h, double* x);
 int pgx_set_prev(pgx_handle* h, const double* xk);               /* host -> device `sol_k` */
 int pgx_get_prev(pgx_handle* h, double* xk);
 int pgx_advance_prev(pgx_handle* h);                             /* sol_k <- sol on device */
+int pgx_zero_state(pgx_handle* h);                               /* sol = sol_k = 0 on device (obstacle_pg.py:157-158) */
 int pgx_set_alpha(pgx_handle* h, double alpha);
 
 /* F(x) with the callback contract of problem.py:54-67. x==NULL -> use device `sol`. F may be NULL. */

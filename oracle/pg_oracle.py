@@ -307,7 +307,7 @@ def newton_solve(prob: ObstacleP1, x0, xk, alpha, opts: SnesOptions, linear_solv
             log.t_jacobian += time.perf_counter() - t
         if linear_solve is None:
             t = time.perf_counter()
-            lu = spla.splu(J.tocsc(), permc_spec="MMD_AT_PLUS_A")  # symmetric pattern: 2x less fill than COLAMD
+            lu = spla.splu(J.tocsc())  # COLAMD: MMD_AT_PLUS_A explodes (100x fill) once partial pivoting leaves the diagonal
             t1 = time.perf_counter()
             dx = lu.solve(-F)
             if log is not None:

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("pgx_set_prev", C.c_int, [_H, c_double_p]),
     ("pgx_get_prev", C.c_int, [_H, c_double_p]),
     ("pgx_advance_prev", C.c_int, [_H]),
+    ("pgx_zero_state", C.c_int, [_H]),
     ("pgx_set_alpha", C.c_int, [_H, C.c_double]),
     ("pgx_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
     ("pgx_jacobian_fill", C.c_int, [_H, c_double_p]),

@@ -462,6 +462,13 @@ extern "C" int pgx_advance_prev(pgx_handle* h) {
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
+extern "C" int pgx_zero_state(pgx_handle* h) {
+  NEED(h);
+  HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * 2 * (size_t)h->n, h->st));
+  HIPCHK(hipMemsetAsync(h->xk, 0, sizeof(double) * 2 * (size_t)h->n, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
 extern "C" int pgx_set_alpha(pgx_handle* h, double a) {
   if (!h || !(a > 0.0)) return PGX_EINVAL;
   h->alpha = a;

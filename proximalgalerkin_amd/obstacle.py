@@ -85,8 +85,11 @@ def run_outer_loop(problem, sol, sol_k, alpha, maximum_number_of_outer_loop_iter
     """obstacle_pg.py:154-227. With device_resident=False the iterate update is the reference's literal
     `sol_k.x.array[:] = sol.x.array[:]` (a PCIe round trip); True does the same copy on the device."""
     hist = {c: [] for c in COLUMNS}
-    sol.x.array[:] = 0.0  # :157
-    sol_k.x.array[:] = sol.x.array[:]  # :158
+    if device_resident:
+        problem.zero_state()  # :157-158 on the device
+    else:
+        sol.x.array[:] = 0.0  # :157
+        sol_k.x.array[:] = sol.x.array[:]  # :158
     alpha_k = 1
     increment_k = 0.0
     k = -1

@@ -201,6 +201,12 @@ class NonlinearProblem:
     def _advance_prev(self):
         _lib.check(self._lib, self._h, self._lib.pgx_advance_prev(self._h), "pgx_advance_prev")
 
+    def zero_state(self):
+        """sol = sol_k = 0 on the device, no PCIe traffic (obstacle_pg.py:157-158)."""
+        _lib.check(self._lib, self._h, self._lib.pgx_zero_state(self._h), "pgx_zero_state")
+        for v in (self.F_form.sol.x, self.F_form.sol_k.x):
+            v._dev_valid, v._host_valid = True, False
+
     def _sync_inputs(self):
         self._push("state", self.F_form.sol.x)
         self._push("prev", self.F_form.sol_k.x)
