@@ -40,7 +40,11 @@ struct pgx_handle {
   // multigrid
   std::vector<GridLevel> lev;
   double *tmp_u = nullptr, *tmp_p = nullptr, *res_u = nullptr, *res_p = nullptr;  // level-0 scratch (each n)
-  int coarse_sweeps = 60;
+  int coarse_sweeps = 4;  // prototype (oracle/krylov_proto.py): 2..60 sweeps give identical Krylov counts
+  int tail_start = -1;  // first level handled by the fused k_mg_tail launch (-1: none)
+  int xcd_remap = 2;    // bit 1 of the `first` kernel argument; PGX_XCD_REMAP=0 disables (A/B: +1..3 %)
+  int tail_verts = 1100;
+  TailArgs tail{};
   // observables
   double *obs_partials = nullptr, *d_out6 = nullptr;
   int obs_blocks = 0;
@@ -210,6 +214,39 @@ static int build_plan(pgx_handle* h, const pgx_mesh* m, const std::vector<uint8_
   return PGX_OK;
 }
 
+// Is the stencil the same at every interior vertex (uniform grid)?  Then interior rows take their K and M
+// coefficients from kernel arguments.  Setup-time host check on a downloaded copy.
+static int detect_uniform(pgx_handle* h, GridLevel& L) {
+  L.uniform = 0;
+  if (L.nx < 2 || L.ny < 2) return PGX_OK;
+  std::vector<double> K((size_t)7 * L.n), M((size_t)7 * L.n);
+  HIPCHK(hipMemcpyAsync(K.data(), L.K, K.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipMemcpyAsync(M.data(), L.M, M.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  const int sx = L.nx + 1;
+  const int v0 = sx + 1;
+  double kmax = 0, mmax = 0;
+  for (int s = 0; s < 7; ++s) {
+    L.Kc[s] = K[(size_t)s * L.n + v0];
+    L.Mc[s] = M[(size_t)s * L.n + v0];
+    kmax = std::max(kmax, std::fabs(L.Kc[s]));
+    mmax = std::max(mmax, std::fabs(L.Mc[s]));
+  }
+  bool same = true;
+  for (int j = 1; j < L.ny && same; ++j)
+    for (int i = 1; i < L.nx && same; ++i) {
+      const size_t v = (size_t)j * sx + i;
+      for (int s = 0; s < 7; ++s)
+        if (std::fabs(K[(size_t)s * L.n + v] - L.Kc[s]) > 1e-11 * kmax ||
+            std::fabs(M[(size_t)s * L.n + v] - L.Mc[s]) > 1e-11 * mmax) {
+          same = false;
+          break;
+        }
+    }
+  L.uniform = same ? 1 : 0;
+  return PGX_OK;
+}
+
 static int build_multigrid(pgx_handle* h) {
   GridLevel L0{};
   L0.nx = h->nx;
@@ -218,12 +255,13 @@ static int build_multigrid(pgx_handle* h) {
   L0.mask = h->mask;
   h->lev.push_back(L0);
   if (!h->structured) return PGX_OK;
-  // level-0 stencils of K and M (only needed to coarsen), D buffer refreshed every Newton step
   DALLOC(h->lev[0].K, (size_t)7 * h->n);
   DALLOC(h->lev[0].M, (size_t)7 * h->n);
-  DALLOC(h->lev[0].D, (size_t)7 * h->n);
+  DALLOC(h->lev[0].Dh, (size_t)4 * h->n);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Kv, h->lev[0].K);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Mv, h->lev[0].M);
+  int rc = detect_uniform(h, h->lev[0]);
+  if (rc) return rc;
   int nx = h->nx, ny = h->ny;
   while (nx % 2 == 0 && ny % 2 == 0 && nx > 2 && ny > 2) {
     nx /= 2;
@@ -234,7 +272,7 @@ static int build_multigrid(pgx_handle* h) {
     L.n = (nx + 1) * (ny + 1);
     DALLOC(L.K, (size_t)7 * L.n);
     DALLOC(L.M, (size_t)7 * L.n);
-    DALLOC(L.D, (size_t)7 * L.n);
+    DALLOC(L.Dh, (size_t)4 * L.n);
     DALLOC(L.mask, L.n);
     DALLOC(L.xu, L.n);
     DALLOC(L.xp, L.n);
@@ -248,7 +286,43 @@ static int build_multigrid(pgx_handle* h) {
     pgxk_coarse_mask(h->st, L, L.mask, Fl);
     pgxk_rap7(h->st, Fl, Fl.K, L, L.K);
     pgxk_rap7(h->st, Fl, Fl.M, L, L.M);
+    rc = detect_uniform(h, L);
+    if (rc) return rc;
     h->lev.push_back(L);
+  }
+  // fused tail: every level with at most PGX_TAIL_VERTS vertices (and at most PGX_TAIL_MAX of them)
+  const int nl = (int)h->lev.size();
+  for (int l = 1; l < nl; ++l)
+    if (h->lev[l].n <= h->tail_verts && nl - l <= PGX_TAIL_MAX) {
+      h->tail_start = l;
+      break;
+    }
+  if (h->tail_start > 0) {
+    h->tail.nlev = nl - h->tail_start;
+    for (int l = h->tail_start; l < nl; ++l) {
+      const GridLevel& L = h->lev[l];
+      TailLevel& T = h->tail.L[l - h->tail_start];
+      T.nx = L.nx;
+      T.ny = L.ny;
+      T.n = L.n;
+      T.K = L.K;
+      T.M = L.M;
+      T.Dh = L.Dh;
+      for (int s = 0; s < 7; ++s) {
+        T.sc.K[s] = L.Kc[s];
+        T.sc.M[s] = L.Mc[s];
+      }
+      T.sc.uniform = L.uniform;
+      T.mask = L.mask;
+      T.xu = L.xu;
+      T.xp = L.xp;
+      T.xu2 = L.xu2;
+      T.xp2 = L.xp2;
+      T.bu = L.bu;
+      T.bp = L.bp;
+      T.ru = L.ru;
+      T.rp = L.rp;
+    }
   }
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
@@ -271,6 +345,8 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     return PGX_EINVAL;
   }
   pgx_handle* h = new pgx_handle();
+  if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
+  if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
     pgx_destroy(h);
@@ -497,33 +573,42 @@ static void jacobian_dev(pgx_handle* h, const double* x) {
     pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
                    x + h->n, h->q, h->Dv);
   }
-  if (h->structured && h->lev.size() > 1) {
+  if (h->structured) {
     PhaseTimer t(h, 2);
-    pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].D);
-    for (size_t l = 1; l < h->lev.size(); ++l) pgxk_rap7(h->st, h->lev[l - 1], h->lev[l - 1].D, h->lev[l], h->lev[l].D);
+    pgxk_csr_to_stencil_h(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].Dh);
+    for (size_t l = 1; l < h->lev.size(); ++l)
+      pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, h->lev[l], h->lev[l].Dh);
   }
   h->jac_valid = true;
 }
 
 // y = J x on device vectors of length 2n
 static void spmv_dev(pgx_handle* h, const double* x, double* y) {
-  pgxk_bspmv(h->st, 0, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, x, x + h->n, nullptr, nullptr, 0.0, 0,
-             y, y + h->n);
+  pgxk_bspmv(h->st, 0, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, x, x + h->n, nullptr, nullptr, 0.0,
+             h->xcd_remap, y, y + h->n);
 }
 
 static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const double* xp, const double* bu,
                         const double* bp, double omega, int first, double* yu, double* yp) {
-  if (l == 0)
-    pgxk_bspmv(h->st, mode, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, xu, xp, bu, bp, omega, first, yu,
-               yp);
+  if (l == 0 && !h->structured)  // general mesh: the block-CSR kernel is also the (single-level) smoother
+    pgxk_bspmv(h->st, mode, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, xu, xp, bu, bp, omega,
+               first | h->xcd_remap, yu, yp);
   else
-    pgxk_st_apply(h->st, mode, h->lev[l], h->alpha, xu, xp, bu, bp, omega, first, yu, yp);
+    pgxk_st_apply(h->st, mode, h->lev[l], h->alpha, xu, xp, bu, bp, omega, first | h->xcd_remap, yu, yp);
 }
 
 // one V(nu,nu) cycle for J_l x = b, zero initial guess, result in (outu,outp)
 static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu,
                    double omega) {
   GridLevel& L = h->lev[l];
+  if (l > 0 && l == h->tail_start) {  // all remaining levels in ONE launch (k_mg_tail); result in L.xu/L.xp
+    h->tail.nu = nu;
+    h->tail.omega = omega;
+    h->tail.alpha = h->alpha;
+    h->tail.coarse_sweeps = h->coarse_sweeps;
+    pgxk_mg_tail(h->st, h->tail);
+    return;
+  }
   const bool last = (l + 1 == (int)h->lev.size());
   double* Au = outu;
   double* Ap = outp;
@@ -578,8 +663,9 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
   double res = bnorm;
   double prev_cycle_res = bnorm;
   bool first_cycle = true;
-  while (its < o->ksp_max_it) {
+  while (true) {
     double beta;
+    if (first_cycle && its >= o->ksp_max_it) break;
     if (first_cycle) {
       beta = bnorm;
       pgxk_scale_copy(h->st, n2, 1.0 / beta, b, h->V);
@@ -592,9 +678,11 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       rc = dev_norm(h, h->w, &beta);
       if (rc) return rc;
       res = beta;
+      if (o->monitor > 1) printf("      ksp true residual after cycle: %.6e (rel %.3e)\n", beta, beta / bnorm);
       if (beta <= target) break;
       // attainable-accuracy exit: a full restart cycle that gains < 10x once we are at LU-level residuals
       if (beta > 0.1 * prev_cycle_res && beta <= 1e-7 * bnorm) break;
+      if (its >= o->ksp_max_it) break;
       prev_cycle_res = beta;
       pgxk_scale_copy(h->st, n2, 1.0 / beta, h->w, h->V);
     }
@@ -611,24 +699,33 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       }
       {
         PhaseTimer t(h, 3);
-        spmv_dev(h, zj, h->w);
+        spmv_dev(h, zj, h->V + (size_t)(j + 1) * n2);
       }
-      double* d_h1 = h->d_small;
-      double* d_h2 = h->d_small + (m + 1);
-      double* d_nn = h->d_small + 2 * (m + 1);
+      // w = J z_j was written straight into the V_{j+1} slot.  CGS2 (classical Gram-Schmidt, always two
+      // passes: one pass loses orthogonality on these ill-conditioned systems and the true residual stalls).
+      // Each pass is ONE batched dot kernel [h; ww] = [V_0..V_j, w]^T w plus one batched axpy; the norm of the
+      // result comes from Pythagoras on the second pass (|w''|^2 = ww' - |h2|^2, cancellation-free because
+      // the second pass removes almost nothing), so no separate norm kernel.
+      double* wj = h->V + (size_t)(j + 1) * n2;
+      double hn = 0.0;
       {
         PhaseTimer t(h, 5);
-        pgxk_multidot(h->st, n2, j + 1, h->V, n2, h->w, h->partials, d_h1);
-        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h1, h->w);
-        pgxk_multidot(h->st, n2, j + 1, h->V, n2, h->w, h->partials, d_h2);
-        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h2, h->w);
-        pgxk_multidot(h->st, n2, 1, h->w, 0, h->w, h->partials, d_nn);
-        HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 1) + 1), hipMemcpyDeviceToHost,
-                              h->st));
+        double* d_h1 = h->d_small;
+        double* d_h2 = h->d_small + (m + 2);
+        pgxk_multidot(h->st, n2, j + 1, h->V, n2, wj, h->partials, d_h1);
+        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h1, wj);
+        pgxk_multidot(h->st, n2, j + 2, h->V, n2, wj, h->partials, d_h2);
+        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h2, wj);
+        HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
+        double hh = 0.0;
+        for (int i = 0; i <= j; ++i) {
+          const double h2 = h->h_small[(m + 2) + i];
+          H[(size_t)i * m + j] = h->h_small[i] + h2;
+          hh += h2 * h2;
+        }
+        hn = std::sqrt(std::max(h->h_small[(m + 2) + j + 1] - hh, 0.0));
       }
-      for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h->h_small[i] + h->h_small[(m + 1) + i];
-      const double hn = std::sqrt(h->h_small[2 * (m + 1)]);
       H[(size_t)(j + 1) * m + j] = hn;
       for (int i = 0; i < j; ++i) {
         const double t1 = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
@@ -655,7 +752,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         ++j;
         break;
       }
-      pgxk_scale_copy(h->st, n2, 1.0 / hn, h->w, h->V + (size_t)(j + 1) * n2);
+      pgxk_scale_copy(h->st, n2, 1.0 / hn, wj, wj);
     }
     // y = H^-1 g (upper triangular), x += Z y
     for (int i = j - 1; i >= 0; --i) {
@@ -667,7 +764,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     HIPCHK(hipMemcpyAsync(h->d_small, h->h_small, sizeof(double) * j, hipMemcpyHostToDevice, h->st));
     pgxk_lincomb(h->st, n2, j, h->Z, n2, h->d_small, x, 1);
     HIPCHK(hipStreamSynchronize(h->st));
-    if (res <= target) break;
+    // the loop head recomputes the TRUE residual b - Jx: it decides convergence, not the Arnoldi estimate
   }
   *its_out = its;
   *relres = res / bnorm;

@@ -23,12 +23,41 @@ struct QuadTab {
 // coefficient arrays are SoA: S[slot*n + v].  Links leaving the grid hold 0.
 struct GridLevel {
   int nx, ny, n;             // cells per direction, vertices
-  double *K, *M, *D;         // [7*n] unmasked symmetric stencils (K,M fixed at create; D per Newton step)
+  double *K, *M;             // [7*n] unmasked symmetric stencils, fixed at create
+  // D(psi), refreshed every Newton step, symmetric-half storage [4*n]: slots 0:(0,0) 1:(+1,0) 2:(0,+1) 3:(+1,+1);
+  // the three negative-direction links are the neighbours' positive ones (D is symmetric).
+  double* Dh;
+  // On a uniform grid every interior vertex has the same K and M stencil: passed in the kernarg segment
+  // instead of streaming 14 coefficient arrays. Verified on the host at create; 0 -> explicit arrays.
+  int uniform;
+  double Kc[7], Mc[7];
   uint8_t* mask;             // [n] 1 = Dirichlet dof of the u block
   double *xu, *xp, *xu2, *xp2;  // solution ping-pong
   double *bu, *bp;           // right-hand side
   double *ru, *rp;           // residual scratch
 };
+
+struct StConst {
+  double K[7], M[7];
+  int uniform;
+};
+
+// fused multigrid tail (k_mg_tail): level descriptors travel in the kernarg segment
+#define PGX_TAIL_MAX 8
+#define PGX_TAIL_VERTS 17000  // 129x129 vertices and below
+struct TailLevel {
+  int nx, ny, n;
+  const double *K, *M, *Dh;
+  StConst sc;
+  const uint8_t* mask;
+  double *xu, *xp, *xu2, *xp2, *bu, *bp, *ru, *rp;
+};
+struct TailArgs {
+  int nlev, nu, coarse_sweeps;
+  double alpha, omega;
+  TailLevel L[PGX_TAIL_MAX];
+};
+void pgxk_mg_tail(hipStream_t st, const TailArgs& A);
 
 // ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
@@ -65,7 +94,10 @@ void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ld
 // multigrid on stencil levels
 void pgxk_csr_to_stencil(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm, const double* vals,
                          double* S);
+void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
+                           const double* vals, double* Sh);
 void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridLevel& c, double* Sc);
+void pgxk_rap7h(hipStream_t st, const GridLevel& f, const double* Sfh, const GridLevel& c, double* Sch);
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
                    const double* bu, const double* bp, double omega, int first, double* yu, double* yp);
 void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const double* rp, const GridLevel& c,

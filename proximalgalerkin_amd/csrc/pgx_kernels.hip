@@ -22,6 +22,17 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// XCD-aware block remap (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin,
+// so blocks b and b+8 share an XCD).  Logical block = the b-th block of a CONTIGUOUS range owned by one
+// XCD: neighbouring rows (which re-read the same x / stencil lines) then hit the same L2 instead of
+// pulling every line into up to 8 L2s.  Bijective for any grid size; speed only, never correctness.
+__device__ __forceinline__ int xcd_block(int b, int nb, int enable) {
+  if (!enable) return b;
+  const int xcd = b & 7, k = b >> 3;
+  const int q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // sum over the block; result valid in thread 0. `sm` must hold blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* sm) {
   v = wave_sum(v);
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv(int n, const int32_t* __res
                                                      const double* __restrict__ bu, const double* __restrict__ bp,
                                                      double omega, int first, double* __restrict__ yu,
                                                      double* __restrict__ yp) {
-  const int t = blockIdx.x * PGX_BLOCK + threadIdx.x;
+  const int t = xcd_block(blockIdx.x, gridDim.x, first >> 1) * PGX_BLOCK + threadIdx.x;
   const int row = t / LPR, lane = t % LPR;
   const bool live = row < n;
   int s = 0, e = 0;
@@ -267,7 +278,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv(int n, const int32_t* __res
   }
   double au = 0.0, ap = 0.0, da = 0.0, dm = 0.0, dd = 0.0;
   int rowbc = 0;
-  const bool skip = (MODE == 2) && first;
+  const bool skip = (MODE == 2) && (first & 1);
   for (int k = s + lane; k < e; k += LPR) {
     const int cm = colm[k];
     const int c = cm & 0x7fffffff;
@@ -601,9 +612,6 @@ void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ld
 // ------------------------------------------------------------------------------------------------
 // 7-point stencil multigrid (structured right-diagonal meshes, nested by vertex coarsening)
 // ------------------------------------------------------------------------------------------------
-__device__ __constant__ int c_OX[7] = {0, 1, -1, 0, 0, 1, -1};
-__device__ __constant__ int c_OY[7] = {0, 0, 0, 1, -1, 1, -1};
-
 // P1 prolongation weight of the fine vertex at offset (dx,dy) from a coarse vertex
 __device__ __forceinline__ constexpr double pw(int dx, int dy) {
   return (dx == 0 && dy == 0) ? 1.0
@@ -680,6 +688,85 @@ void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridL
                      c.ny, c.n, Sc);
 }
 
+// Load the 7 coefficients of a symmetric-half stencil at vertex v=(i,j): the negative-direction links
+// are the neighbours' positive ones.  Sh slots: 0:(0,0) 1:(+1,0) 2:(0,+1) 3:(+1,+1).
+__device__ __forceinline__ void ld7h(const double* __restrict__ Sh, int n, int sx, int v, int i, int j, int nx,
+                                     int ny, double d[7]) {
+  d[0] = Sh[v];
+  d[1] = (i < nx) ? Sh[(size_t)n + v] : 0.0;
+  d[2] = (i > 0) ? Sh[(size_t)n + v - 1] : 0.0;
+  d[3] = (j < ny) ? Sh[(size_t)2 * n + v] : 0.0;
+  d[4] = (j > 0) ? Sh[(size_t)2 * n + v - sx] : 0.0;
+  d[5] = (i < nx && j < ny) ? Sh[(size_t)3 * n + v] : 0.0;
+  d[6] = (i > 0 && j > 0) ? Sh[(size_t)3 * n + v - sx - 1] : 0.0;
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil_h(int n, int sx, const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ colm,
+                                                                const double* __restrict__ vals,
+                                                                double* __restrict__ Sh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int o = (colm[k] & 0x7fffffff) - i;
+    const double v = vals[k];
+    if (o == 0) s[0] = v;
+    else if (o == 1) s[1] = v;
+    else if (o == sx) s[2] = v;
+    else if (o == sx + 1) s[3] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) Sh[(size_t)k * n + i] = s[k];
+}
+void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
+                           const double* vals, double* Sh) {
+  hipLaunchKernelGGL(k_csr_to_stencil_h, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, sx, rowptr,
+                     colm, vals, Sh);
+}
+
+// Galerkin coarsening on symmetric-half storage: only the 4 stored coarse slots are produced.
+__global__ void __launch_bounds__(PGX_BLOCK) k_rap7h(int nxf, int nyf, int nf, const double* __restrict__ Sfh, int nxc,
+                                                     int nyc, int ncv, double* __restrict__ Sch) {
+  const int C = blockIdx.x * blockDim.x + threadIdx.x;
+  if (C >= ncv) return;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  constexpr int KEEP[4] = {0, 1, 3, 5};  // full-stencil slots stored in the half format
+  const int sxc = nxc + 1, sxf = nxf + 1;
+  const int I = C % sxc, Jc = C / sxc;
+  double out[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int oa = 0; oa < 7; ++oa) {
+    const int ax = 2 * I + OX[oa], ay = 2 * Jc + OY[oa];
+    if (ax < 0 || ax > nxf || ay < 0 || ay > nyf) continue;
+    const double wa = pw(OX[oa], OY[oa]);
+    const int a = ay * sxf + ax;
+    double cf[7];
+    ld7h(Sfh, nf, sxf, a, ax, ay, nxf, nyf, cf);
+#pragma unroll
+    for (int os = 0; os < 7; ++os) {
+      const double coef = wa * cf[os];
+      const int dx = OX[oa] + OX[os], dy = OY[oa] + OY[os];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double w2 = pw(dx - 2 * OX[KEEP[q]], dy - 2 * OY[KEEP[q]]);
+        if (w2 != 0.0) out[q] += coef * w2;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int nx_ = I + OX[KEEP[q]], ny_ = Jc + OY[KEEP[q]];
+    const bool ok = nx_ >= 0 && nx_ <= nxc && ny_ >= 0 && ny_ <= nyc;
+    Sch[(size_t)q * ncv + C] = ok ? out[q] : 0.0;
+  }
+}
+void pgxk_rap7h(hipStream_t st, const GridLevel& f, const double* Sfh, const GridLevel& c, double* Sch) {
+  hipLaunchKernelGGL(k_rap7h, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, f.nx, f.ny, f.n, Sfh,
+                     c.nx, c.ny, c.n, Sch);
+}
+
 __global__ void k_coarse_mask(int nxc, int nyc, int ncv, int nxf, const uint8_t* __restrict__ mf,
                               uint8_t* __restrict__ mc) {
   const int C = blockIdx.x * blockDim.x + threadIdx.x;
@@ -692,34 +779,48 @@ void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const
                      f.nx, f.mask, mask_c);
 }
 
-// same three modes as k_bspmv, on stencil storage
+// One vertex of the collective operator / smoother on stencil storage (same three modes as k_bspmv).
+// Per vertex this streams 4 D coefficients + the vectors (~80 B) instead of a CSR row (~250 B): on a
+// uniform grid the K and M stencils of interior vertices are kernel-argument constants, only boundary
+// vertices read arrays.
 template <int MODE>
-__global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, const double* __restrict__ K,
-                                                        const double* __restrict__ M, const double* __restrict__ D,
-                                                        const uint8_t* __restrict__ mask, double alpha,
-                                                        const double* __restrict__ xu, const double* __restrict__ xp,
-                                                        const double* __restrict__ bu, const double* __restrict__ bp,
-                                                        double omega, int first, double* __restrict__ yu,
-                                                        double* __restrict__ yp) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
+__device__ __forceinline__ void st_vertex(int v, int nx, int ny, int n, const double* __restrict__ K,
+                                          const double* __restrict__ M, const double* __restrict__ Dh,
+                                          const StConst& sc, const uint8_t* __restrict__ mask, double alpha,
+                                          const double* xu, const double* xp, const double* bu, const double* bp,
+                                          double omega, int first, double* yu, double* yp) {
   const int sx = nx + 1;
   const int i = v % sx, j = v / sx;
   const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
   const bool ok[7] = {true, i < nx, i > 0, j < ny, j > 0, i < nx && j < ny, i > 0 && j > 0};
+  const bool interior = sc.uniform && i > 0 && i < nx && j > 0 && j < ny;
+  double kv[7], mv[7], dv[7];
+  if (interior) {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      kv[s] = sc.K[s];
+      mv[s] = sc.M[s];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      kv[s] = K[(size_t)s * n + v];
+      mv[s] = M[(size_t)s * n + v];
+    }
+  }
+  ld7h(Dh, n, sx, v, i, j, nx, ny, dv);
   const int rowbc = mask[v];
   double au = 0.0, ap = 0.0;
-  const bool skip = (MODE == 2) && first;
+  const bool skip = (MODE == 2) && (first & 1);
   if (!skip) {
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
       if (!ok[s]) continue;
       const int nb = v + off[s];
-      const double kv = K[(size_t)s * n + v], mv = M[(size_t)s * n + v], dv = D[(size_t)s * n + v];
       const double xuv = mask[nb] ? 0.0 : xu[nb];
       const double xpv = xp[nb];
-      au += alpha * kv * xuv + mv * xpv;
-      ap += mv * xuv - dv * xpv;
+      au += alpha * kv[s] * xuv + mv[s] * xpv;
+      ap += mv[s] * xuv - dv[s] * xpv;
     }
   }
   const double xur = skip ? 0.0 : xu[v];
@@ -733,8 +834,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, c
   } else {
     const double su = bu[v] - au, sp = bp[v] - ap;
     const double xpr = skip ? 0.0 : xp[v];
-    double a = alpha * K[v], b = M[v];
-    const double dd = D[v];
+    double a = alpha * kv[0], b = mv[0];
+    const double dd = dv[0];
     double om_u = omega;
     if (rowbc) {
       a = 1.0;
@@ -753,18 +854,38 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, c
     yp[v] = xpr + omega * dpsi;
   }
 }
+
+template <int MODE>
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, const double* __restrict__ K,
+                                                        const double* __restrict__ M,
+                                                        const double* __restrict__ Dh, StConst sc,
+                                                        const uint8_t* __restrict__ mask, double alpha,
+                                                        const double* __restrict__ xu, const double* __restrict__ xp,
+                                                        const double* __restrict__ bu, const double* __restrict__ bp,
+                                                        double omega, int first, double* __restrict__ yu,
+                                                        double* __restrict__ yp) {
+  const int v = xcd_block(blockIdx.x, gridDim.x, first >> 1) * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  st_vertex<MODE>(v, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, bu, bp, omega, first, yu, yp);
+}
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
                    const double* bu, const double* bp, double omega, int first, double* yu, double* yp) {
   dim3 grid((L.n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  StConst sc;
+  for (int s = 0; s < 7; ++s) {
+    sc.K[s] = L.Kc[s];
+    sc.M[s] = L.Mc[s];
+  }
+  sc.uniform = L.uniform;
   if (mode == 0)
-    hipLaunchKernelGGL(k_st_apply<0>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
-                       bp, omega, first, yu, yp);
+    hipLaunchKernelGGL(k_st_apply<0>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask, alpha, xu, xp,
+                       bu, bp, omega, first, yu, yp);
   else if (mode == 1)
-    hipLaunchKernelGGL(k_st_apply<1>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
-                       bp, omega, first, yu, yp);
+    hipLaunchKernelGGL(k_st_apply<1>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask, alpha, xu, xp,
+                       bu, bp, omega, first, yu, yp);
   else
-    hipLaunchKernelGGL(k_st_apply<2>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.D, L.mask, alpha, xu, xp, bu,
-                       bp, omega, first, yu, yp);
+    hipLaunchKernelGGL(k_st_apply<2>, grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask, alpha, xu, xp,
+                       bu, bp, omega, first, yu, yp);
 }
 
 // b_c = P^T r_f  (u rows of coarse Dirichlet vertices get 0: they are not unknowns of the coarse problem)
@@ -816,4 +937,104 @@ void pgxk_prolong_add(hipStream_t st, const GridLevel& c, const double* cu, cons
                       double* xu, double* xp) {
   hipLaunchKernelGGL(k_prolong_add, dim3((f.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, c.nx, cu, cp,
                      f.nx, f.n, xu, xp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused multigrid tail: ONE launch, ONE workgroup runs the complete V-cycle over all levels small enough
+// that a kernel per sweep is pure launch latency (rocprof: 68 launches of ~3.4 us + ~3.7 us gaps per cycle
+// before fusion).  Phases are separated by __syncthreads(); all data is L2/L1 resident.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void restrict_vertex(int C, int nxf, int nyf, const double* ru, const double* rp, int nxc,
+                                                const uint8_t* __restrict__ mask_c, double* bu, double* bp) {
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  const int sxc = nxc + 1, sxf = nxf + 1;
+  const int I = C % sxc, J = C / sxc;
+  double su = 0.0, sp = 0.0;
+#pragma unroll
+  for (int o = 0; o < 7; ++o) {
+    const int ax = 2 * I + OX[o], ay = 2 * J + OY[o];
+    if (ax < 0 || ax > nxf || ay < 0 || ay > nyf) continue;
+    const size_t a = (size_t)ay * sxf + ax;
+    const double w = pw(OX[o], OY[o]);
+    su += w * ru[a];
+    sp += w * rp[a];
+  }
+  bu[C] = mask_c[C] ? 0.0 : su;
+  bp[C] = sp;
+}
+
+__device__ __forceinline__ void prolong_vertex(int v, int nxc, const double* cu, const double* cp, int nxf, double* xu,
+                                               double* xp) {
+  const int sxf = nxf + 1, sxc = nxc + 1;
+  const int i = v % sxf, j = v / sxf;
+  const int i0 = i >> 1, j0 = j >> 1;
+  const int c0 = j0 * sxc + i0, c1 = (j0 + (j & 1)) * sxc + (i0 + (i & 1));
+  xu[v] += 0.5 * (cu[c0] + cu[c1]);
+  xp[v] += 0.5 * (cp[c0] + cp[c1]);
+}
+
+__global__ void __launch_bounds__(1024) k_mg_tail(TailArgs A) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* cu[PGX_TAIL_MAX];
+  const double* cp[PGX_TAIL_MAX];
+  // ---- down leg ----
+  for (int l = 0; l < A.nlev; ++l) {
+    const TailLevel& L = A.L[l];
+    const bool last = (l + 1 == A.nlev);
+    const int total = last ? A.coarse_sweeps : 2 * A.nu;
+    const int now = last ? A.coarse_sweeps : A.nu;
+    bool toA = (total % 2) == 1;
+    const double *xu = nullptr, *xp = nullptr;
+    for (int s = 0; s < now; ++s) {
+      double* tu = toA ? L.xu : L.xu2;
+      double* tp = toA ? L.xp : L.xp2;
+      for (int v = tid; v < L.n; v += nt)
+        st_vertex<2>(v, L.nx, L.ny, L.n, L.K, L.M, L.Dh, L.sc, L.mask, A.alpha, xu, xp, L.bu, L.bp, A.omega, s == 0, tu,
+                     tp);
+      __syncthreads();
+      xu = tu;
+      xp = tp;
+      toA = !toA;
+    }
+    cu[l] = xu;
+    cp[l] = xp;
+    if (!last) {
+      for (int v = tid; v < L.n; v += nt)
+        st_vertex<1>(v, L.nx, L.ny, L.n, L.K, L.M, L.Dh, L.sc, L.mask, A.alpha, xu, xp, L.bu, L.bp, 0.0, 0, L.ru, L.rp);
+      __syncthreads();
+      const TailLevel& C = A.L[l + 1];
+      for (int c = tid; c < C.n; c += nt) restrict_vertex(c, L.nx, L.ny, L.ru, L.rp, C.nx, C.mask, C.bu, C.bp);
+      __syncthreads();
+    }
+  }
+  // ---- up leg ----
+  for (int l = A.nlev - 2; l >= 0; --l) {
+    const TailLevel& L = A.L[l];
+    const TailLevel& C = A.L[l + 1];
+    double* xu = (double*)cu[l];
+    double* xp = (double*)cp[l];
+    for (int v = tid; v < L.n; v += nt) prolong_vertex(v, C.nx, cu[l + 1], cp[l + 1], L.nx, xu, xp);
+    __syncthreads();
+    // after nu sweeps of 2*nu the current buffer is A if nu is even, B if odd; keep alternating so the
+    // final sweep lands in A (= L.xu / L.xp), exactly like the host-driven cycle
+    bool toA = (xu != L.xu);
+    const double *su = xu, *sp = xp;
+    for (int s = 0; s < A.nu; ++s) {
+      double* tu = toA ? L.xu : L.xu2;
+      double* tp = toA ? L.xp : L.xp2;
+      for (int v = tid; v < L.n; v += nt)
+        st_vertex<2>(v, L.nx, L.ny, L.n, L.K, L.M, L.Dh, L.sc, L.mask, A.alpha, su, sp, L.bu, L.bp, A.omega, 0, tu, tp);
+      __syncthreads();
+      su = tu;
+      sp = tp;
+      toA = !toA;
+    }
+    cu[l] = su;
+    cp[l] = sp;
+  }
+}
+
+void pgxk_mg_tail(hipStream_t st, const TailArgs& A) {
+  hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, st, A);
 }
