@@ -1,0 +1,35 @@
+"""Obstacle problem (experiment 4 of Keith & Surowiec, Proximal Galerkin, FoCM 2024) on the HIP backend.
+
+Counterpart of /root/reference/examples/01_obstacle_problem/obstacle_pg.py: same CLI flags, same proximal
+loop, same CSV columns and return value.  The XDMF mesh argument (-f) is replaced by -N cells per side of a
+right-diagonal triangulation of [-1,1]^2 (the reference's own square-domain variant,
+obstacle_finite_difference.jl:46); mesh file I/O is outside the hot path.
+"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+
+from proximalgalerkin_amd import fem  # noqa: E402
+from proximalgalerkin_amd.obstacle import solve_problem  # noqa: E402
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="Run examples from paper",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("-N", dest="N", type=int, default=64, help="cells per side of the square mesh")
+    parser.add_argument("--polynomial_order", "-p", dest="polynomial_order", type=int, default=1, choices=[1],
+                        help="Polynomial order of primal space (2 is the next scope row)")
+    parser.add_argument("--alpha-scheme", dest="alpha_scheme", type=str, default="constant",
+                        choices=["constant", "double_exponential", "geometric"], help="Step size rule")
+    parser.add_argument("--max-iter", "-i", dest="maximum_number_of_outer_loop_iterations", type=int, default=100,
+                        help="Maximum number of outer loop iterations")
+    parser.add_argument("--alpha-max", "-a", dest="alpha_max", type=float, default=1e5, help="Maximum alpha")
+    parser.add_argument("--tol", "-t", dest="tol_exit", type=float, default=1e-6,
+                        help="Tolerance for exiting Newton iteration")
+    args = parser.parse_args()
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N))
+    sol, newton_steps = solve_problem(msh, args.polynomial_order, args.maximum_number_of_outer_loop_iterations,
+                                      args.alpha_scheme, args.alpha_max, args.tol_exit,
+                                      output_dir=Path.cwd() / "output")
+    print(f"total Newton steps: {newton_steps}")
