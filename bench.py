@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=384, help="mesh size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
+    ap.add_argument("--opts", default="", help="extra solver options key=val,key=val (e.g. ksp_gmres_restart=20)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +100,14 @@ def main():
     # ---- setup (untimed): mesh, obstacle at quadrature points, plan, constant blocks, MG hierarchy ----
     t_setup = time.perf_counter()
     msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
-    problem, sol, sol_k, alpha = setup_problem(msh, 1, device=local_rank)
+    petsc_options = None
+    if args.opts:
+        petsc_options = {"snes_error_if_not_converged": True, "snes_linesearch_type": "none", "snes_rtol": 1e-6,
+                         "snes_max_it": 100}  # obstacle_pg.py:128-139
+        for kv in args.opts.split(","):
+            k, v = kv.split("=")
+            petsc_options[k] = float(v) if any(c in v for c in ".e") else int(v)
+    problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options=petsc_options, device=local_rank)
     t_setup = time.perf_counter() - t_setup
     if args.profile:
         problem.profile(enable=True, reset=True)

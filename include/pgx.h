@@ -94,9 +94,9 @@ typedef struct {
   double snes_divtol; /* 1e4 */
   int32_t snes_max_it;/* 50; ex 01 sets 100 */
   /* Newton linear solve (replaces ksp preonly + pc lu/mumps): FGMRES + multigrid V-cycle */
-  double ksp_rtol;    /* relative residual target, default 1e-10 (LU-level accuracy) */
+  double ksp_rtol;    /* relative TRUE residual target, default 1e-9 (measured effect on u: DESIGN.md section 3) */
   int32_t ksp_max_it; /* default 200 */
-  int32_t ksp_restart;/* default 50 */
+  int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */
   int32_t mg_nu;      /* pre/post smoothing sweeps, default 2 */
   double mg_omega;    /* collective-Jacobi damping, default 0.8 */
   int32_t monitor;    /* 1 = print per-Newton-step residuals (snes_monitor/ksp_monitor) */

@@ -44,6 +44,8 @@ struct pgx_handle {
   int tail_start = -1;  // first level handled by the fused k_mg_tail launch (-1: none)
   int xcd_remap = 2;    // bit 1 of the `first` kernel argument; PGX_XCD_REMAP=0 disables (A/B: +1..3 %)
   int tail_verts = 1100;
+  int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
+  int fused_min = 500000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
   // observables
   double *obs_partials = nullptr, *d_out6 = nullptr;
@@ -105,9 +107,9 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->snes_stol = 1e-8;
   o->snes_divtol = 1e4;
   o->snes_max_it = 50;
-  o->ksp_rtol = 1e-10;
+  o->ksp_rtol = 1e-9;  // final u moves 9e-14 (bar 1e-10) vs a 1e-13 solve at 2048^2: DESIGN.md section 3
   o->ksp_max_it = 200;
-  o->ksp_restart = 50;
+  o->ksp_restart = 30;
   o->mg_nu = 2;
   o->mg_omega = 0.8;
   o->monitor = 0;
@@ -347,6 +349,8 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   pgx_handle* h = new pgx_handle();
   if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
   if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
+  if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
+  if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
     pgx_destroy(h);
@@ -616,6 +620,16 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
   double* Bp = (l == 0) ? h->tmp_p : L.xp2;
   double* ru = (l == 0) ? h->res_u : L.ru;
   double* rp = (l == 0) ? h->res_p : L.rp;
+  if (h->structured && !last && nu == 2 && h->fused_legs && L.n >= h->fused_min) {
+    // 3 launches per level: S(S(0)) | P^T(b - Jx) | S(S(x + P x_c))   (pgx_kernels.hip, "Fused V-cycle legs")
+    GridLevel& C = h->lev[l + 1];
+    const int remap = h->xcd_remap ? 1 : 0;
+    pgxk_st_smooth2(h->st, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, Bu, Bp);
+    pgxk_st_resid_restrict(h->st, L, h->alpha, Bu, Bp, bu, bp, C, remap, C.bu, C.bp);
+    vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
+    pgxk_st_smooth2(h->st, 1, L, h->alpha, Bu, Bp, &C, C.xu, C.xp, bu, bp, omega, remap, Au, Ap);
+    return;
+  }
   const int total = last ? (h->lev.size() == 1 ? 2 * nu : h->coarse_sweeps) : 2 * nu;
   bool toA = (total % 2) == 1;  // alternate targets so that the final sweep lands in A
   const double *cu = nullptr, *cp = nullptr;

@@ -105,3 +105,10 @@ void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const d
 void pgxk_prolong_add(hipStream_t st, const GridLevel& c, const double* cu, const double* cp, const GridLevel& f,
                       double* xu, double* xp);
 void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const GridLevel& f);
+// fused V-cycle legs (nu = 2): two Jacobi sweeps per launch on LDS tiles, residual+restriction in one launch
+void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                     const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,
+                     double omega, int remap, double* yu, double* yp);
+void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                            const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
+                            double* cbp);

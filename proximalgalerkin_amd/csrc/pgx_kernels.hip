@@ -868,6 +868,327 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, c
   if (v >= n) return;
   st_vertex<MODE>(v, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, bu, bp, omega, first, yu, yp);
 }
+// ------------------------------------------------------------------------------------------------
+// Fused V-cycle legs (nu = 2).  rocprof showed the cycle bound by (a) four full passes over the level
+// for the four Jacobi sweeps and (b) ~8 dependent launches per level.  Here a level costs 3 launches:
+//   k_st_smooth2<PRE>   x1 = S(S(0))                      (S = one collective damped-Jacobi sweep)
+//   k_st_resid_restrict b_c = P^T (b - J x1)              (no residual round trip through HBM)
+//   k_st_smooth2<POST>  x2 = S(S(x1 + P x_c))             (prolongation folded in)
+// smooth2 works on 2-D tiles: sweep 1 is evaluated on the tile plus a one-vertex halo into LDS (redundant
+// work (TX+2)(TY+2)/(TX*TY) = 1.16 for 64x16), sweep 2 reads it from LDS, so both sweeps cost ONE pass over
+// D, b and x instead of two.
+// ------------------------------------------------------------------------------------------------
+struct StCoef {
+  double kv[7], mv[7], dv[7];
+  bool ok[7];
+  int rowbc;
+};
+
+__device__ __forceinline__ void st_load_coef(int v, int i, int j, int nx, int ny, int n, const double* __restrict__ K,
+                                             const double* __restrict__ M, const double* __restrict__ Dh,
+                                             const StConst& sc, const uint8_t* __restrict__ mask, StCoef& c) {
+  const int sx = nx + 1;
+  c.ok[0] = true;
+  c.ok[1] = i < nx;
+  c.ok[2] = i > 0;
+  c.ok[3] = j < ny;
+  c.ok[4] = j > 0;
+  c.ok[5] = i < nx && j < ny;
+  c.ok[6] = i > 0 && j > 0;
+  if (sc.uniform && i > 0 && i < nx && j > 0 && j < ny) {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      c.kv[s] = sc.K[s];
+      c.mv[s] = sc.M[s];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      c.kv[s] = K[(size_t)s * n + v];
+      c.mv[s] = M[(size_t)s * n + v];
+    }
+  }
+  ld7h(Dh, n, sx, v, i, j, nx, ny, c.dv);
+  c.rowbc = mask[v];
+}
+
+// (au, ap) = rows of J applied to neighbour values (xun must already be 0 at Dirichlet columns)
+__device__ __forceinline__ void st_rows(const StCoef& c, double alpha, const double xun[7], const double xpn[7],
+                                        double& au, double& ap) {
+  au = 0.0;
+  ap = 0.0;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    if (!c.ok[s]) continue;
+    au += alpha * c.kv[s] * xun[s] + c.mv[s] * xpn[s];
+    ap += c.mv[s] * xun[s] - c.dv[s] * xpn[s];
+  }
+}
+
+__device__ __forceinline__ void st_jacobi(const StCoef& c, double alpha, double omega, double au, double ap,
+                                          double xur, double xpr, double buv, double bpv, double& yu, double& yp) {
+  if (c.rowbc) au = xur;
+  const double su = buv - au, sp = bpv - ap;
+  double a = alpha * c.kv[0], b = c.mv[0];
+  const double dd = c.dv[0];
+  double om_u = omega;
+  if (c.rowbc) {
+    a = 1.0;
+    b = 0.0;
+    om_u = 1.0;
+  }
+  const double det = -a * dd - b * b;
+  double du = 0.0, dpsi = 0.0;
+  if (det != 0.0) {
+    du = (-dd * su - b * sp) / det;
+    dpsi = (-b * su + a * sp) / det;
+  } else if (c.rowbc) {
+    du = su;
+  }
+  yu = xur + om_u * du;
+  yp = xpr + omega * dpsi;
+}
+
+template <int TX, int TY, bool POST>
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n, const double* __restrict__ K,
+                                                          const double* __restrict__ M,
+                                                          const double* __restrict__ Dh, StConst sc,
+                                                          const uint8_t* __restrict__ mask, double alpha,
+                                                          const double* __restrict__ xu, const double* __restrict__ xp,
+                                                          const double* __restrict__ cu, const double* __restrict__ cp,
+                                                          int nxc, const double* __restrict__ bu,
+                                                          const double* __restrict__ bp, double omega, int remap,
+                                                          double* __restrict__ yu, double* __restrict__ yp) {
+  constexpr int W2 = TX + 4, H2 = TY + 4, W1 = TX + 2, H1 = TY + 2;
+  __shared__ double s0u[POST ? W2 * H2 : 1], s0p[POST ? W2 * H2 : 1];
+  __shared__ double s1u[W1 * H1], s1p[W1 * H1];
+  __shared__ uint8_t smk[W2 * H2];
+  const int sx = nx + 1;
+  const int ntx = (nx + TX) / TX;  // ceil((nx+1)/TX)
+  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
+  const int i0 = (b % ntx) * TX, j0 = (b / ntx) * TY;
+  const int tid = threadIdx.x;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  // phase 0: Dirichlet mask (and, POST, the corrected iterate x + P x_c) on the tile + 2-halo
+  for (int p = tid; p < W2 * H2; p += PGX_BLOCK) {
+    const int gi = i0 - 2 + p % W2, gj = j0 - 2 + p / W2;
+    const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+    const int v = gj * sx + gi;
+    smk[p] = in ? mask[v] : 1;
+    if (POST) {
+      double a = 0.0, c2 = 0.0;
+      if (in) {
+        const int sxc = nxc + 1;
+        const int ic = gi >> 1, jc = gj >> 1;
+        const int c0 = jc * sxc + ic, c1 = (jc + (gj & 1)) * sxc + (ic + (gi & 1));
+        a = xu[v] + 0.5 * (cu[c0] + cu[c1]);
+        c2 = xp[v] + 0.5 * (cp[c0] + cp[c1]);
+      }
+      s0u[p] = a;
+      s0p[p] = c2;
+    }
+  }
+  __syncthreads();
+  // phase 1: sweep 1 on the tile + 1-halo -> LDS
+  for (int p = tid; p < W1 * H1; p += PGX_BLOCK) {
+    const int li = p % W1, lj = p / W1;
+    const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
+    double r1u = 0.0, r1p = 0.0;
+    if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+      const int v = gj * sx + gi;
+      StCoef c;
+      st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+      double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+      if (POST) {
+        double xun[7], xpn[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+          const int q = (lj + 1 + OY[s]) * W2 + (li + 1 + OX[s]);
+          xun[s] = smk[q] ? 0.0 : s0u[q];
+          xpn[s] = s0p[q];
+        }
+        st_rows(c, alpha, xun, xpn, au, ap);
+        const int q0 = (lj + 1) * W2 + (li + 1);
+        xur = s0u[q0];
+        xpr = s0p[q0];
+      }
+      st_jacobi(c, alpha, omega, au, ap, xur, xpr, bu[v], bp[v], r1u, r1p);
+    }
+    s1u[p] = r1u;
+    s1p[p] = r1p;
+  }
+  __syncthreads();
+  // phase 2: sweep 2 on the tile, neighbours from LDS
+  for (int p = tid; p < TX * TY; p += PGX_BLOCK) {
+    const int li = p % TX, lj = p / TX;
+    const int gi = i0 + li, gj = j0 + lj;
+    if (gi > nx || gj > ny) continue;
+    const int v = gj * sx + gi;
+    StCoef c;
+    st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+    double xun[7], xpn[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int q1 = (lj + 1 + OY[s]) * W1 + (li + 1 + OX[s]);
+      const int q2 = (lj + 2 + OY[s]) * W2 + (li + 2 + OX[s]);
+      xun[s] = smk[q2] ? 0.0 : s1u[q1];
+      xpn[s] = s1p[q1];
+    }
+    double au, ap, ou, op;
+    st_rows(c, alpha, xun, xpn, au, ap);
+    const int q0 = (lj + 1) * W1 + (li + 1);
+    st_jacobi(c, alpha, omega, au, ap, s1u[q0], s1p[q0], bu[v], bp[v], ou, op);
+    yu[v] = ou;
+    yp[v] = op;
+  }
+}
+
+static inline StConst make_stconst(const GridLevel& L) {
+  StConst sc;
+  for (int s = 0; s < 7; ++s) {
+    sc.K[s] = L.Kc[s];
+    sc.M[s] = L.Mc[s];
+  }
+  sc.uniform = L.uniform;
+  return sc;
+}
+
+// post=0: (yu,yp) = S(S(0));  post=1: (yu,yp) = S(S((xu,xp) + P (cu,cp)))   -- out of place
+void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                     const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,
+                     double omega, int remap, double* yu, double* yp) {
+  constexpr int TX = 64, TY = 16;
+  const int ntx = (L.nx + TX) / TX, nty = (L.ny + TY) / TY;
+  dim3 grid(ntx * nty), block(PGX_BLOCK);
+  const StConst sc = make_stconst(L);
+  if (post)
+    hipLaunchKernelGGL((k_st_smooth2<TX, TY, true>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
+                       alpha, xu, xp, cu, cp, C->nx, bu, bp, omega, remap, yu, yp);
+  else
+    hipLaunchKernelGGL((k_st_smooth2<TX, TY, false>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
+                       alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
+}
+
+// b_c = P^T (b - J x): one thread per COARSE vertex evaluates the (up to) 7 fine residuals it needs; the
+// fine residual vector never exists in memory.
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict(int nx, int ny, int n, const double* __restrict__ K,
+                                                                 const double* __restrict__ M,
+                                                                 const double* __restrict__ Dh, StConst sc,
+                                                                 const uint8_t* __restrict__ mask, double alpha,
+                                                                 const double* __restrict__ xu,
+                                                                 const double* __restrict__ xp,
+                                                                 const double* __restrict__ bu,
+                                                                 const double* __restrict__ bp, int nxc, int nyc,
+                                                                 int ncv, const uint8_t* __restrict__ mask_c, int remap,
+                                                                 double* __restrict__ cbu, double* __restrict__ cbp) {
+  const int C = xcd_block(blockIdx.x, gridDim.x, remap) * blockDim.x + threadIdx.x;
+  if (C >= ncv) return;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  const int sxc = nxc + 1, sx = nx + 1;
+  const int I = C % sxc, J = C / sxc;
+  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+  double su = 0.0, sp = 0.0;
+#pragma unroll
+  for (int o = 0; o < 7; ++o) {
+    const int gi = 2 * I + OX[o], gj = 2 * J + OY[o];
+    if (gi < 0 || gi > nx || gj < 0 || gj > ny) continue;
+    const int v = gj * sx + gi;
+    StCoef c;
+    st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+    double xun[7], xpn[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int nb = c.ok[s] ? v + off[s] : v;
+      xun[s] = mask[nb] ? 0.0 : xu[nb];
+      xpn[s] = xp[nb];
+    }
+    double au, ap;
+    st_rows(c, alpha, xun, xpn, au, ap);
+    if (c.rowbc) au = xu[v];
+    const double w = pw(OX[o], OY[o]);
+    su += w * (bu[v] - au);
+    sp += w * (bp[v] - ap);
+  }
+  cbu[C] = mask_c[C] ? 0.0 : su;
+  cbp[C] = sp;
+}
+// Tile version (the one used): a block owns a CXxCY tile of COARSE vertices; the fine residual is
+// evaluated ONCE per fine vertex of the (2CX+1)x(2CY+1) footprint with row-contiguous (coalesced) accesses
+// into LDS, then each thread restricts one coarse vertex from LDS.  The strided coarse-thread kernel above
+// measured 189 us on level 0 against 121 us for separate residual + restriction launches.
+template <int CX, int CY>
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict_t(int nx, int ny, int n, const double* __restrict__ K,
+                                                                   const double* __restrict__ M,
+                                                                   const double* __restrict__ Dh, StConst sc,
+                                                                   const uint8_t* __restrict__ mask, double alpha,
+                                                                   const double* __restrict__ xu,
+                                                                   const double* __restrict__ xp,
+                                                                   const double* __restrict__ bu,
+                                                                   const double* __restrict__ bp, int nxc, int nyc,
+                                                                   const uint8_t* __restrict__ mask_c, int remap,
+                                                                   double* __restrict__ cbu, double* __restrict__ cbp) {
+  static_assert(CX * CY == PGX_BLOCK, "one coarse vertex per thread");
+  constexpr int W = 2 * CX + 1, H = 2 * CY + 1;
+  __shared__ double sru[W * H], srp[W * H];
+  const int sx = nx + 1, sxc = nxc + 1;
+  const int ntx = (nxc + CX) / CX;
+  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
+  const int I0 = (b % ntx) * CX, J0 = (b / ntx) * CY;
+  const int tid = threadIdx.x;
+  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+  for (int p = tid; p < W * H; p += PGX_BLOCK) {
+    const int gi = 2 * I0 - 1 + p % W, gj = 2 * J0 - 1 + p / W;
+    double ru = 0.0, rp = 0.0;
+    if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+      const int v = gj * sx + gi;
+      StCoef c;
+      st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+      double xun[7], xpn[7];
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        const int nb = c.ok[s] ? v + off[s] : v;
+        xun[s] = mask[nb] ? 0.0 : xu[nb];
+        xpn[s] = xp[nb];
+      }
+      double au, ap;
+      st_rows(c, alpha, xun, xpn, au, ap);
+      if (c.rowbc) au = xu[v];
+      ru = bu[v] - au;
+      rp = bp[v] - ap;
+    }
+    sru[p] = ru;
+    srp[p] = rp;
+  }
+  __syncthreads();
+  const int I = I0 + tid % CX, J = J0 + tid / CX;
+  if (I > nxc || J > nyc) return;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  const int li = 2 * (tid % CX) + 1, lj = 2 * (tid / CX) + 1;  // position of fine vertex (2I,2J) in the LDS image
+  double su = 0.0, sp = 0.0;
+#pragma unroll
+  for (int o = 0; o < 7; ++o) {  // out-of-grid fine vertices hold 0 in the image
+    const int q = (lj + OY[o]) * W + (li + OX[o]);
+    const double w = pw(OX[o], OY[o]);
+    su += w * sru[q];
+    sp += w * srp[q];
+  }
+  const int C = J * sxc + I;
+  cbu[C] = mask_c[C] ? 0.0 : su;
+  cbp[C] = sp;
+}
+
+void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
+                            const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
+                            double* cbp) {
+  constexpr int CX = 32, CY = 8;
+  const int ntx = (C.nx + CX) / CX, nty = (C.ny + CY) / CY;
+  hipLaunchKernelGGL((k_st_resid_restrict_t<CX, CY>), dim3(ntx * nty), dim3(PGX_BLOCK), 0, st, L.nx, L.ny, L.n, L.K,
+                     L.M, L.Dh, make_stconst(L), L.mask, alpha, xu, xp, bu, bp, C.nx, C.ny, C.mask, remap, cbu, cbp);
+}
+
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
                    const double* bu, const double* bp, double omega, int first, double* yu, double* yp) {
   dim3 grid((L.n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
@@ -1035,6 +1356,148 @@ __global__ void __launch_bounds__(1024) k_mg_tail(TailArgs A) {
   }
 }
 
+// LDS-resident tail (the one used when the top tail level has <= 2048 vertices): k_mg_tail above spends
+// ~3 us per phase on L2 round trips (rocprof: 100 us per call).  Here every vector of every tail level
+// lives in LDS (8 arrays x sum(n_l) doubles <= 96 KB) and each thread keeps the stencil coefficients of its
+// (at most two) vertices in registers for all sweeps of a level visit, so a phase is LDS traffic + barrier.
+__device__ __forceinline__ void tail_load(const TailLevel& L, int v, StCoef& c, unsigned& nbm) {
+  const int sx = L.nx + 1;
+  const int i = v % sx, j = v / sx;
+  st_load_coef(v, i, j, L.nx, L.ny, L.n, L.K, L.M, L.Dh, L.sc, L.mask, c);
+  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+  nbm = 0;
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+    if (c.ok[s] && L.mask[v + off[s]]) nbm |= 1u << s;
+}
+
+__device__ __forceinline__ void tail_gather(const StCoef& c, unsigned nbm, int v, int sx, const double* xu,
+                                            const double* xp, double xun[7], double xpn[7]) {
+  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int nb = c.ok[s] ? v + off[s] : v;
+    xun[s] = ((nbm >> s) & 1u) ? 0.0 : xu[nb];
+    xpn[s] = xp[nb];
+  }
+}
+
+__global__ void __launch_bounds__(512) k_mg_tail_lds(TailArgs A) {
+  extern __shared__ double lds[];
+  constexpr int NT = 512, VPT = 3;  // 8 waves -> 256-VGPR budget: 3 vertices x 21 coefficients stay in registers
+  const int tid = threadIdx.x;
+  int base[PGX_TAIL_MAX];
+  {
+    int acc = 0;
+    for (int l = 0; l < A.nlev; ++l) {
+      base[l] = acc;
+      acc += 8 * A.L[l].n;
+    }
+  }
+  // array k of level l:  0,1: x (buffer 0)   2,3: x (buffer 1)   4,5: b   6,7: r
+#define TL(l, k) (lds + base[l] + (k) * A.L[l].n)
+  int cur[PGX_TAIL_MAX];
+  for (int v = tid; v < A.L[0].n; v += NT) {
+    TL(0, 4)[v] = A.L[0].bu[v];
+    TL(0, 5)[v] = A.L[0].bp[v];
+  }
+  __syncthreads();
+  StCoef c[VPT];
+  unsigned nbm[VPT];
+  auto sweeps = [&](int l, int count, bool from_zero, int& buf) {
+    const TailLevel& L = A.L[l];
+    const int sx = L.nx + 1;
+    for (int s = 0; s < count; ++s) {
+      const int src = buf, dst = buf ^ 1;
+      const double *xu = TL(l, 2 * src), *xp = TL(l, 2 * src + 1);
+      double *yu = TL(l, 2 * dst), *yp = TL(l, 2 * dst + 1);
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        const int v = tid + k * NT;
+        if (v < L.n) {
+          double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+          if (!(from_zero && s == 0)) {
+            double xun[7], xpn[7];
+            tail_gather(c[k], nbm[k], v, sx, xu, xp, xun, xpn);
+            st_rows(c[k], A.alpha, xun, xpn, au, ap);
+            xur = xu[v];
+            xpr = xp[v];
+          }
+          double ou, op;
+          st_jacobi(c[k], A.alpha, A.omega, au, ap, xur, xpr, TL(l, 4)[v], TL(l, 5)[v], ou, op);
+          yu[v] = ou;
+          yp[v] = op;
+        }
+      }
+      __syncthreads();
+      buf = dst;
+    }
+  };
+  // ---- down leg ----
+  for (int l = 0; l < A.nlev; ++l) {
+    const TailLevel& L = A.L[l];
+    const bool last = (l + 1 == A.nlev);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k)
+      if (tid + k * NT < L.n) tail_load(L, tid + k * NT, c[k], nbm[k]);
+    int buf = 0;
+    sweeps(l, last ? A.coarse_sweeps : A.nu, true, buf);
+    cur[l] = buf;
+    if (!last) {
+      const int sx = L.nx + 1;
+      const double *xu = TL(l, 2 * buf), *xp = TL(l, 2 * buf + 1);
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        const int v = tid + k * NT;
+        if (v < L.n) {
+          double xun[7], xpn[7], au, ap;
+          tail_gather(c[k], nbm[k], v, sx, xu, xp, xun, xpn);
+          st_rows(c[k], A.alpha, xun, xpn, au, ap);
+          if (c[k].rowbc) au = xu[v];
+          TL(l, 6)[v] = TL(l, 4)[v] - au;
+          TL(l, 7)[v] = TL(l, 5)[v] - ap;
+        }
+      }
+      __syncthreads();
+      const TailLevel& C = A.L[l + 1];
+      for (int cv = tid; cv < C.n; cv += NT)
+        restrict_vertex(cv, L.nx, L.ny, TL(l, 6), TL(l, 7), C.nx, C.mask, TL(l + 1, 4), TL(l + 1, 5));
+      __syncthreads();
+    }
+  }
+  // ---- up leg ----
+  for (int l = A.nlev - 2; l >= 0; --l) {
+    const TailLevel& L = A.L[l];
+    const TailLevel& C = A.L[l + 1];
+    int buf = cur[l];
+    for (int v = tid; v < L.n; v += NT)
+      prolong_vertex(v, C.nx, TL(l + 1, 2 * cur[l + 1]), TL(l + 1, 2 * cur[l + 1] + 1), L.nx, TL(l, 2 * buf),
+                     TL(l, 2 * buf + 1));
+#pragma unroll
+    for (int k = 0; k < VPT; ++k)
+      if (tid + k * NT < L.n) tail_load(L, tid + k * NT, c[k], nbm[k]);
+    __syncthreads();
+    sweeps(l, A.nu, false, buf);
+    cur[l] = buf;
+  }
+  for (int v = tid; v < A.L[0].n; v += NT) {
+    A.L[0].xu[v] = TL(0, 2 * cur[0])[v];
+    A.L[0].xp[v] = TL(0, 2 * cur[0] + 1)[v];
+  }
+#undef TL
+}
+
 void pgxk_mg_tail(hipStream_t st, const TailArgs& A) {
-  hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, st, A);
+  size_t total = 0;
+  for (int l = 0; l < A.nlev; ++l) total += (size_t)8 * A.L[l].n * sizeof(double);
+  if (A.L[0].n <= 1536 && total <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)k_mg_tail_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(512), total, st, A);
+  } else {
+    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, st, A);
+  }
 }
