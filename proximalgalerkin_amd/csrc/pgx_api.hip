@@ -44,6 +44,7 @@ struct pgx_handle {
   int tail_start = -1;  // first level handled by the fused k_mg_tail launch (-1: none)
   int xcd_remap = 2;    // bit 1 of the `first` kernel argument; PGX_XCD_REMAP=0 disables (A/B: +1..3 %)
   int tail_verts = 1100;
+  int spmv_stream = 1;  // PGX_SPMV_STREAM=0: 8-lanes-per-row kernel instead of the CSR-stream kernel
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
   int fused_min = 500000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
@@ -350,6 +351,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
   if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
   if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
+  if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
@@ -588,8 +590,12 @@ static void jacobian_dev(pgx_handle* h, const double* x) {
 
 // y = J x on device vectors of length 2n
 static void spmv_dev(pgx_handle* h, const double* x, double* y) {
-  pgxk_bspmv(h->st, 0, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, x, x + h->n, nullptr, nullptr, 0.0,
-             h->xcd_remap, y, y + h->n);
+  if (h->spmv_stream && 2 * h->fill_lds <= 64 * 1024)
+    pgxk_bspmv_stream(h->st, h->n, h->fill_lds, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, h->mask, x,
+                      x + h->n, h->xcd_remap ? 1 : 0, y, y + h->n);
+  else
+    pgxk_bspmv(h->st, 0, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, x, x + h->n, nullptr, nullptr, 0.0,
+               h->xcd_remap, y, y + h->n);
 }
 
 static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const double* xp, const double* bu,

@@ -112,3 +112,7 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp);
+// CSR-stream form of y = Jx (256 rows per block through LDS); mask = Dirichlet flags of the u block
+void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
+                       const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
+                       const double* xu, const double* xp, int remap, double* yu, double* yp);
