@@ -18,8 +18,8 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="Run examples from paper",
                                      formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument("-N", dest="N", type=int, default=64, help="cells per side of the square mesh")
-    parser.add_argument("--polynomial_order", "-p", dest="polynomial_order", type=int, default=1, choices=[1],
-                        help="Polynomial order of primal space (2 is the next scope row)")
+    parser.add_argument("--polynomial_order", "-p", dest="polynomial_order", type=int, default=1, choices=[1, 2],
+                        help="Polynomial order of primal space")
     parser.add_argument("--alpha-scheme", dest="alpha_scheme", type=str, default="constant",
                         choices=["constant", "double_exponential", "geometric"], help="Step size rule")
     parser.add_argument("--max-iter", "-i", dest="maximum_number_of_outer_loop_iterations", type=int, default=100,

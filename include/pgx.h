@@ -7,7 +7,7 @@
  * or C++ types cross this boundary.  All reals are IEEE fp64, all indices int32.
  *
  * DOF layout of every state / residual vector of length 2*n_vertices:
- *      x = [u_0 .. u_{n-1}, psi_0 .. psi_{n-1}]        (n = n_vertices, P1)
+ *      x = [u_0 .. u_{n-1}, psi_0 .. psi_{n-1}]        (n = n_vertices for P1, pgx_mesh.n_dofs for P2)
  *
  * Conventions:
  *   - every function returns 0 on success, a negative PGX_E* code otherwise; pgx_last_error() gives text.
@@ -72,10 +72,15 @@ typedef struct {
    * Enables the geometric multigrid preconditioner; 0 = general mesh (single-level smoother). */
   int32_t structured_nx;
   int32_t structured_ny;
+  /* degree 2 only (NULL / 0 for degree 1): dofs per field are [vertices | one per edge]; row c lists the 3
+   * vertex ids of cell c (== cells[c]) then its 3 edge dofs (>= n_vertices), local edge i OPPOSITE local
+   * vertex i (the Basix reference-triangle convention the reference's dofmap uses). */
+  const int32_t* cell_dofs; /* [n_cells][6] */
+  int32_t n_dofs;           /* n_vertices + n_edges */
 } pgx_mesh;
 
 typedef struct {
-  int32_t degree;          /* Lagrange degree of both fields; 1 supported */
+  int32_t degree;          /* Lagrange degree of both fields: 1 or 2 (obstacle_pg.py -p) */
   int32_t nq;              /* quadrature points per cell (<= 16) */
   const double* qpts;      /* [nq][2] on the reference triangle */
   const double* qwts;      /* [nq], summing to 1/2 */
@@ -94,7 +99,8 @@ typedef struct {
   double snes_divtol; /* 1e4 */
   int32_t snes_max_it;/* 50; ex 01 sets 100 */
   /* Newton linear solve (replaces ksp preonly + pc lu/mumps): FGMRES + multigrid V-cycle */
-  double ksp_rtol;    /* relative TRUE residual target, default 1e-9 (measured effect on u: DESIGN.md section 3) */
+  double ksp_rtol;    /* relative TRUE residual target; 0 (default) = auto: 1e-9 for P1, 1e-10 for P2, chosen from the
+                         measured effect on the final primal field */
   int32_t ksp_max_it; /* default 200 */
   int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */
   int32_t mg_nu;      /* pre/post smoothing sweeps, default 2 */
@@ -108,7 +114,7 @@ int pgx_create(const pgx_mesh* mesh, const pgx_problem* prob, int device, pgx_ha
 void pgx_destroy(pgx_handle* h);
 const char* pgx_last_error(const pgx_handle* h); /* h may be NULL: error of the last failed pgx_create */
 
-int pgx_num_dofs(const pgx_handle* h, int64_t* ndofs);          /* 2*n_vertices */
+int pgx_num_dofs(const pgx_handle* h, int64_t* ndofs);          /* 2 * dofs per field */
 int pgx_set_state(pgx_handle* h, const double* x);               /* host -> device `sol` */
 int pgx_get_state(pgx_handle* h, double* x);
 int pgx_set_prev(pgx_handle* h, const double* xk);               /* host -> device `sol_k` */

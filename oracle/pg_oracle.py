@@ -401,3 +401,163 @@ def solve_problem(prob: ObstacleP1, max_outer: int, alpha_scheme: str, alpha_max
             break
         xk = x.copy()
     return x, hist
+
+
+# ----------------------------------------------------------------------------------------------
+# General Lagrange degree (1 or 2) on affine triangles: obstacle_pg.py:68-70,288 (`-p {1,2}`)
+# ----------------------------------------------------------------------------------------------
+def build_edges(cells, nv):
+    """Unique edges as sorted vertex pairs; returns (edges (ne,2), cell_edges (nc,3)) with local edge i
+    OPPOSITE local vertex i (Basix/DOLFINx reference-triangle convention: SURVEY.md App. A.2)."""
+    c = cells.astype(np.int64)
+    pairs = np.stack([c[:, [1, 2]], c[:, [0, 2]], c[:, [0, 1]]], axis=1)  # (nc,3,2)
+    pairs.sort(axis=2)
+    key = pairs[:, :, 0] * nv + pairs[:, :, 1]
+    uk, inv = np.unique(key.ravel(), return_inverse=True)
+    edges = np.stack([uk // nv, uk % nv], axis=1).astype(np.int32)
+    return edges, inv.reshape(-1, 3).astype(np.int32)
+
+
+def lagrange_tabulate(degree, X, Y):
+    """Basis values (nq,nd) and reference gradients (nq,nd,2) at reference points.
+    P1: vertex functions. P2: 3 vertex functions l(2l-1) then 3 edge functions 4 l_j l_k (edge i opposite vertex i)."""
+    l = np.stack([1.0 - X - Y, X, Y], axis=1)  # barycentric
+    dl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    if degree == 1:
+        return l, np.broadcast_to(dl[None], (len(X), 3, 2)).copy()
+    N = np.empty((len(X), 6))
+    dN = np.empty((len(X), 6, 2))
+    for i in range(3):
+        N[:, i] = l[:, i] * (2 * l[:, i] - 1)
+        dN[:, i, :] = (4 * l[:, i] - 1)[:, None] * dl[i][None]
+    for i, (j, k) in enumerate(((1, 2), (0, 2), (0, 1))):
+        N[:, 3 + i] = 4 * l[:, j] * l[:, k]
+        dN[:, 3 + i, :] = 4 * (l[:, j][:, None] * dl[k][None] + l[:, k][:, None] * dl[j][None])
+    return N, dN
+
+
+class ObstacleLagrange:
+    """Same discrete problem as ObstacleP1 for Lagrange degree 1 or 2 (equal order for u and psi).
+    Dofs per field: vertices [0,nv) then (degree 2) edges [nv, nv+ne). x = [u | psi]."""
+
+    def __init__(self, coords, cells, degree=1, phi=phi_set, f=0.0, quadrature="tri_deg6_12", g_bc=0.0):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.degree = int(degree)
+        self.nv, self.nc = len(self.coords), len(self.cells)
+        self.f, self.g_bc = float(f), float(g_bc)
+        self.Xq, self.wq = load_quadrature(quadrature)
+        self.Nq, self.dNq = lagrange_tabulate(self.degree, self.Xq[:, 0], self.Xq[:, 1])
+        self.edges, self.cell_edges = build_edges(self.cells, self.nv)
+        if self.degree == 1:
+            self.cell_dofs = self.cells.copy()
+            self.n = self.nv
+            self.dof_coords = self.coords
+        else:
+            self.cell_dofs = np.concatenate([self.cells, self.nv + self.cell_edges], axis=1).astype(np.int32)
+            self.n = self.nv + len(self.edges)
+            self.dof_coords = np.concatenate([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+        self.nd = self.cell_dofs.shape[1]
+        # boundary dofs: vertices of exterior edges (+ the exterior edges themselves for P2)
+        cnt = np.bincount(self.cell_edges.ravel(), minlength=len(self.edges))
+        bedge = np.flatnonzero(cnt == 1)
+        bv = np.unique(self.edges[bedge].ravel())
+        self.bc = (bv if self.degree == 1 else np.concatenate([bv, self.nv + bedge])).astype(np.int32)
+        self.isbc = np.zeros(self.n, dtype=bool)
+        self.isbc[self.bc] = True
+        x = self.coords[self.cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+        self.detJ = np.abs(det)
+        invJ = np.empty_like(J)
+        invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
+        invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
+        self.invJ = invJ
+        # physical gradients at quadrature points: (nc,nq,nd,2)
+        self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)
+        wdet = self.detJ[:, None] * self.wq[None]
+        self.wdet = wdet
+        self.Ke = np.einsum("cq,cqad,cqbd->cab", wdet, self.Gq, self.Gq)
+        self.Me = np.einsum("cq,qa,qb->cab", wdet, self.Nq, self.Nq)
+        self.me = wdet @ self.Nq
+        Nlin = np.stack([1.0 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
+        xq = np.einsum("qa,cad->cqd", Nlin, x)
+        self.phi_q = phi(xq.reshape(-1, 2).T.copy()).reshape(self.nc, -1)
+        self.b_phi = np.bincount(self.cell_dofs.ravel(), weights=((wdet * self.phi_q) @ self.Nq).ravel(), minlength=self.n)
+        self._build_pattern()
+        self.K = self._scalar_csr(self.Ke)
+        self.M = self._scalar_csr(self.Me)
+        self.m_l = np.bincount(self.cell_dofs.ravel(), weights=self.me.ravel(), minlength=self.n)
+
+    def _build_pattern(self):
+        n, nd = self.n, self.nd
+        r = np.repeat(self.cell_dofs, nd, axis=1).ravel().astype(np.int64)
+        c = np.tile(self.cell_dofs, (1, nd)).ravel().astype(np.int64)
+        key = r * n + c
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        starts = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1])))
+        ukey = ks[starts]
+        self._order, self._starts = order, starts
+        self.indices_s = (ukey % n).astype(np.int32)
+        rows = (ukey // n).astype(np.int64)
+        self.indptr_s = np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=n)))).astype(np.int64)
+        self.nnz_s = len(ukey)
+        self._rows_s = rows
+        rbc, cbc = self.isbc[rows], self.isbc[self.indices_s]
+        self._keep_uu = ~(rbc | cbc)
+        self._diag_bc = rbc & (rows == self.indices_s)
+        self._keep_up = ~rbc
+        self._keep_pu = ~cbc
+
+    def _scalar_vals(self, Ae):
+        return np.add.reduceat(Ae.reshape(-1)[self._order], self._starts)
+
+    def _scalar_csr(self, Ae):
+        return sp.csr_matrix((self._scalar_vals(Ae), self.indices_s, self.indptr_s), shape=(self.n, self.n))
+
+    def exp_terms(self, psi):
+        psi_q = psi[self.cell_dofs] @ self.Nq.T
+        with np.errstate(under="ignore"):
+            wE = self.wdet * np.exp(psi_q)
+        return wE @ self.Nq, np.einsum("cq,qa,qb->cab", wE, self.Nq, self.Nq)
+
+    def residual(self, x, xk, alpha):
+        n = self.n
+        u, psi, psik = x[:n], x[n:], xk[n:]
+        ut = u.copy()
+        ut[self.bc] = self.g_bc
+        b_exp_e, _ = self.exp_terms(psi)
+        b_exp = np.bincount(self.cell_dofs.ravel(), weights=b_exp_e.ravel(), minlength=n)
+        Fu = alpha * (self.K @ ut) + self.M @ (psi - psik) - alpha * self.f * self.m_l
+        Fp = self.M @ ut - b_exp - self.b_phi
+        Fu[self.bc] = u[self.bc] - self.g_bc
+        return np.concatenate([Fu, Fp])
+
+    def jacobian_blocks(self, x):
+        return self._scalar_vals(self.exp_terms(x[self.n:])[1])
+
+    def jacobian(self, x, alpha):
+        n = self.n
+        Dv = self.jacobian_blocks(x)
+        mk = lambda v: sp.csr_matrix((v, self.indices_s, self.indptr_s), shape=(n, n))  # noqa: E731
+        A = mk(np.where(self._keep_uu, alpha * self.K.data, 0.0) + self._diag_bc)
+        return sp.bmat([[A, mk(np.where(self._keep_up, self.M.data, 0.0))],
+                        [mk(np.where(self._keep_pu, self.M.data, 0.0)), mk(-Dv)]], format="csr")
+
+    def observables(self, x, xk, alpha):
+        n = self.n
+        cd = self.cell_dofs
+        u, psi, uk, psik = x[:n], x[n:], xk[:n], xk[n:]
+        wd = self.wdet
+        uq, pq, ukq, pkq = (v[cd] @ self.Nq.T for v in (u, psi, uk, psik))
+        gu = np.einsum("ca,cqad->cqd", u[cd], self.Gq)
+        gd = np.einsum("ca,cqad->cqd", (u - uk)[cd], self.Gq)
+        energy = 0.5 * np.sum(wd * np.sum(gu * gu, axis=2)) - self.f * np.sum(wd * uq)
+        compl = abs(np.sum(wd * (pkq - pq) / alpha * uq))
+        feas = np.sum(wd * np.where(uq < 0, -uq, 0.0))
+        dual = np.sum(wd * np.where(pkq < pq, (pq - pkq) / alpha, 0.0))
+        h1 = np.sqrt(np.sum(wd * np.sum(gd * gd, axis=2)) + np.sum(wd * (uq - ukq) ** 2))
+        with np.errstate(under="ignore"):
+            l2 = np.sqrt(np.sum(wd * (np.exp(pq) - np.exp(pkq)) ** 2))
+        return np.array([energy, compl, feas, dual, h1, l2])

@@ -29,6 +29,8 @@ class pgx_mesh(C.Structure):
         ("cells", c_int32_p),
         ("structured_nx", C.c_int32),
         ("structured_ny", C.c_int32),
+        ("cell_dofs", c_int32_p),
+        ("n_dofs", C.c_int32),
     ]
 
 

@@ -16,7 +16,9 @@ struct pgx_handle {
   int device = 0;
   hipStream_t st = nullptr;
   std::string err;
-  int n = 0, nc = 0, nx = 0, ny = 0, nnz = 0;
+  int n = 0, nc = 0, nx = 0, ny = 0, nnz = 0;  // n = mesh vertices = dofs per field of the P1 space
+  int degree = 1;
+  int nd = 0;  // dofs per field of the SOLUTION space: n (P1) or n + n_edges (P2)
   bool structured = false;
   QuadTab q{};
   double f = 0.0, alpha = 1.0;
@@ -31,6 +33,18 @@ struct pgx_handle {
   size_t fill_lds = 0;
   double *Kv = nullptr, *Mv = nullptr, *Dv = nullptr;
   bool jac_valid = false;
+  // operator of the solution space (aliases the P1 arrays above for degree 1)
+  int32_t *s_rowptr = nullptr, *s_colm = nullptr;
+  double *s_K = nullptr, *s_M = nullptr, *s_D = nullptr;
+  int s_nnz = 0;
+  size_t s_fill_lds = 0;
+  std::vector<int32_t> s_h_rowptr, s_h_col;
+  // P2 extras: cell dofs, inverted lists of the P2 plan, P1<->P2 transfers, two-level cycle scratch
+  QuadTab2 q2{};
+  int32_t *cdofs = nullptr, *p2_v2c_ptr = nullptr, *p2_v2c_ent = nullptr, *p2_v2c_pos = nullptr;
+  int32_t *v2e_ptr = nullptr, *v2e = nullptr, *edge_ends = nullptr;
+  double *p2_xu = nullptr, *p2_xp = nullptr, *p2_ru = nullptr, *p2_rp = nullptr;
+  double *c1_bu = nullptr, *c1_bp = nullptr, *c1_xu = nullptr, *c1_xp = nullptr;
   // state
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
   // Krylov workspace
@@ -108,7 +122,7 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->snes_stol = 1e-8;
   o->snes_divtol = 1e4;
   o->snes_max_it = 50;
-  o->ksp_rtol = 1e-9;  // final u moves 9e-14 (bar 1e-10) vs a 1e-13 solve at 2048^2: DESIGN.md section 3
+  o->ksp_rtol = 0.0;  // 0 = auto: 1e-9 for P1, 1e-10 for P2 (measured effect on the final u: DESIGN.md section 3)
   o->ksp_max_it = 200;
   o->ksp_restart = 30;
   o->mg_nu = 2;
@@ -214,6 +228,130 @@ static int build_plan(pgx_handle* h, const pgx_mesh* m, const std::vector<uint8_
   HIPCHK(hipMemcpy(h->v2c_ptr, vptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->v2c_ent, vent.data(), sizeof(int32_t) * vent.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->v2c_pos, vpos.data(), sizeof(int32_t) * vpos.size(), hipMemcpyHostToDevice));
+  return PGX_OK;
+}
+
+// P2 plan: scalar CSR pattern over [vertex | edge] dofs, dof -> (cell, local dof) lists with the row positions
+// of the cell's 6 dofs (two int32 per entry), vertex -> edge-dof lists and edge end points for the transfers.
+static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uint8_t>& hmask) {
+  const int n = h->nd, nc = m->n_cells, nv = m->n_vertices;
+  const int32_t* cd = m->cell_dofs;
+  std::vector<int32_t> vptr(n + 1, 0);
+  for (int c = 0; c < nc; ++c)
+    for (int a = 0; a < 6; ++a) {
+      const int v = cd[6 * c + a];
+      if (v < 0 || v >= n || (a < 3 && v != m->cells[3 * c + a]) || (a >= 3 && v < nv)) {
+        h->err = "cell_dofs must be [vertex ids (== cells) | edge dofs >= n_vertices]";
+        return PGX_EINVAL;
+      }
+      vptr[v + 1]++;
+    }
+  for (int i = 0; i < n; ++i) vptr[i + 1] += vptr[i];
+  std::vector<int32_t> vent(vptr[n]), fillp(vptr.begin(), vptr.end() - 1);
+  for (int c = 0; c < nc; ++c)
+    for (int a = 0; a < 6; ++a) vent[fillp[cd[6 * c + a]]++] = c * 8 + a;
+  std::vector<int32_t>& rowptr = h->s_h_rowptr;
+  std::vector<int32_t>& col = h->s_h_col;
+  rowptr.assign(n + 1, 0);
+  col.clear();
+  col.reserve((size_t)n * 12);
+  std::vector<int32_t> tmp;
+  for (int i = 0; i < n; ++i) {
+    tmp.clear();
+    for (int k = vptr[i]; k < vptr[i + 1]; ++k) {
+      const int c = vent[k] >> 3;
+      for (int b = 0; b < 6; ++b) tmp.push_back(cd[6 * c + b]);
+    }
+    if (tmp.empty()) tmp.push_back(i);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    if (tmp.size() > 255) {
+      h->err = "dof degree > 255 unsupported";
+      return PGX_EINVAL;
+    }
+    col.insert(col.end(), tmp.begin(), tmp.end());
+    rowptr[i + 1] = (int32_t)col.size();
+  }
+  if (col.size() > 0x7fffffffu) {
+    h->err = "nnz overflows int32";
+    return PGX_EINVAL;
+  }
+  h->s_nnz = (int)col.size();
+  std::vector<int32_t> vpos(2 * vent.size());
+  for (int i = 0; i < n; ++i) {
+    const int32_t* rb = col.data() + rowptr[i];
+    const int32_t* re = col.data() + rowptr[i + 1];
+    for (int k = vptr[i]; k < vptr[i + 1]; ++k) {
+      const int c = vent[k] >> 3;
+      uint32_t p0 = 0, p1 = 0;
+      for (int b = 0; b < 6; ++b) {
+        const uint32_t pp = (uint32_t)(std::lower_bound(rb, re, cd[6 * c + b]) - rb);
+        if (b < 4) p0 |= pp << (8 * b);
+        else p1 |= pp << (8 * (b - 4));
+      }
+      vpos[2 * k] = (int32_t)p0;
+      vpos[2 * k + 1] = (int32_t)p1;
+    }
+  }
+  size_t maxlen = 0;
+  for (int i0 = 0; i0 < n; i0 += PGX_BLOCK) {
+    const int i1 = std::min(i0 + PGX_BLOCK, n);
+    maxlen = std::max(maxlen, (size_t)(rowptr[i1] - rowptr[i0]));
+  }
+  h->s_fill_lds = maxlen * sizeof(double);
+  if (h->s_fill_lds > 60 * 1024) {
+    h->err = "row block too dense for the LDS-staged fill";
+    return PGX_EINVAL;
+  }
+  // transfers: edge end points (local edge i is opposite local vertex i) and vertex -> edge dofs
+  const int ne = n - nv;
+  std::vector<int32_t> ends(2 * (size_t)ne, -1), eptr(nv + 1, 0);
+  for (int c = 0; c < nc; ++c)
+    for (int i = 0; i < 3; ++i) {
+      const int e = cd[6 * c + 3 + i] - nv;
+      const int a = m->cells[3 * c + (i + 1) % 3], b = m->cells[3 * c + (i + 2) % 3];
+      const int lo = std::min(a, b), hi = std::max(a, b);
+      if (ends[2 * e] >= 0 && (ends[2 * e] != lo || ends[2 * e + 1] != hi)) {
+        h->err = "cell_dofs: an edge dof is attached to two different vertex pairs";
+        return PGX_EINVAL;
+      }
+      ends[2 * e] = lo;
+      ends[2 * e + 1] = hi;
+    }
+  for (int e = 0; e < ne; ++e) {
+    if (ends[2 * e] < 0) {
+      h->err = "cell_dofs: unused edge dof";
+      return PGX_EINVAL;
+    }
+    eptr[ends[2 * e] + 1]++;
+    eptr[ends[2 * e + 1] + 1]++;
+  }
+  for (int i = 0; i < nv; ++i) eptr[i + 1] += eptr[i];
+  std::vector<int32_t> elist(eptr[nv]), ef(eptr.begin(), eptr.end() - 1);
+  for (int e = 0; e < ne; ++e) {
+    elist[ef[ends[2 * e]]++] = nv + e;
+    elist[ef[ends[2 * e + 1]]++] = nv + e;
+  }
+  std::vector<int32_t> colm(col.size());
+  for (size_t k = 0; k < col.size(); ++k) colm[k] = col[k] | (hmask[col[k]] ? (int32_t)0x80000000 : 0);
+  DALLOC(h->s_rowptr, n + 1);
+  DALLOC(h->s_colm, colm.size());
+  DALLOC(h->p2_v2c_ptr, n + 1);
+  DALLOC(h->p2_v2c_ent, vent.size());
+  DALLOC(h->p2_v2c_pos, vpos.size());
+  DALLOC(h->cdofs, (size_t)6 * nc);
+  DALLOC(h->edge_ends, ends.size());
+  DALLOC(h->v2e_ptr, nv + 1);
+  DALLOC(h->v2e, elist.size());
+  HIPCHK(hipMemcpy(h->s_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->s_colm, colm.data(), sizeof(int32_t) * colm.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->p2_v2c_ptr, vptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->p2_v2c_ent, vent.data(), sizeof(int32_t) * vent.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->p2_v2c_pos, vpos.data(), sizeof(int32_t) * vpos.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->cdofs, cd, sizeof(int32_t) * 6 * (size_t)nc, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->edge_ends, ends.data(), sizeof(int32_t) * ends.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->v2e_ptr, eptr.data(), sizeof(int32_t) * (nv + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->v2e, elist.data(), sizeof(int32_t) * elist.size(), hipMemcpyHostToDevice));
   return PGX_OK;
 }
 
@@ -359,8 +497,13 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     return rc;
   };
   h->device = device;
-  if (p->degree != 1) {
-    h->err = "only degree 1 is implemented";
+  if (p->degree != 1 && p->degree != 2) {
+    h->err = "only Lagrange degree 1 and 2 are implemented";
+    return fail(PGX_EINVAL);
+  }
+  h->degree = p->degree;
+  if (p->degree == 2 && (!m->cell_dofs || m->n_dofs <= m->n_vertices)) {
+    h->err = "degree 2 needs pgx_mesh.cell_dofs [n_cells][6] and n_dofs = n_vertices + n_edges";
     return fail(PGX_EINVAL);
   }
   if (p->nq < 1 || p->nq > PGX_MAX_NQ || !p->qpts || !p->qwts || !p->phi_q || m->n_vertices < 3 || m->n_cells < 1 ||
@@ -375,6 +518,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   hipEventCreate(&h->e0);
   hipEventCreate(&h->e1);
   const int n = h->n = m->n_vertices, nc = h->nc = m->n_cells;
+  const int nd = h->nd = (p->degree == 2) ? m->n_dofs : n;
   h->f = p->f;
   if (m->structured_nx > 0 && m->structured_ny > 0) {
     if ((int64_t)(m->structured_nx + 1) * (m->structured_ny + 1) != n ||
@@ -401,12 +545,32 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
       for (int b = 0; b < 3; ++b) h->q.Mref[a][b] += h->q.w[k] * h->q.N[k][a] * h->q.N[k][b];
     }
   }
-  // Dirichlet data
-  std::vector<uint8_t> hmask(n, 0);
-  std::vector<double> hg(n, 0.0);
+  if (p->degree == 2) {  // P2 tables (basis ordering: SURVEY.md App. A.2)
+    QuadTab2& t = h->q2;
+    t.nq = p->nq;
+    const double dl[3][2] = {{-1.0, -1.0}, {1.0, 0.0}, {0.0, 1.0}};
+    const int ej[3] = {1, 0, 0}, ek[3] = {2, 2, 1};
+    for (int k = 0; k < p->nq; ++k) {
+      const double X = p->qpts[2 * k], Y = p->qpts[2 * k + 1];
+      const double l[3] = {1.0 - X - Y, X, Y};
+      t.w[k] = p->qwts[k];
+      for (int i = 0; i < 3; ++i) {
+        t.L[k][i] = l[i];
+        t.N[k][i] = l[i] * (2.0 * l[i] - 1.0);
+        t.N[k][3 + i] = 4.0 * l[ej[i]] * l[ek[i]];
+        for (int d = 0; d < 2; ++d) {
+          t.dN[k][i][d] = (4.0 * l[i] - 1.0) * dl[i][d];
+          t.dN[k][3 + i][d] = 4.0 * (l[ej[i]] * dl[ek[i]][d] + l[ek[i]] * dl[ej[i]][d]);
+        }
+      }
+    }
+  }
+  // Dirichlet data (dofs of the solution space; the P1 coarse space uses the vertex prefix)
+  std::vector<uint8_t> hmask(nd, 0);
+  std::vector<double> hg(nd, 0.0);
   for (int k = 0; k < p->n_bc; ++k) {
     const int d = p->bc_dofs[k];
-    if (d < 0 || d >= n) {
+    if (d < 0 || d >= nd) {
       h->err = "bc dof out of range";
       return fail(PGX_EINVAL);
     }
@@ -417,13 +581,17 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   auto up = [&]() -> int {
     DALLOC(h->coords, (size_t)2 * n);
     DALLOC(h->cells, (size_t)3 * nc);
-    DALLOC(h->mask, n);
-    DALLOC(h->gbc, n);
-    DALLOC(h->bphi, n);
+    DALLOC(h->mask, nd);
+    DALLOC(h->gbc, nd);
+    DALLOC(h->bphi, nd);
     HIPCHK(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->cells, m->cells, sizeof(int32_t) * 3 * (size_t)nc, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->mask, hmask.data(), n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->gbc, hg.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->mask, hmask.data(), nd, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nd, hipMemcpyHostToDevice));
+    if (p->degree == 2) {
+      int r2 = build_plan_p2(h, m, hmask);
+      if (r2) return r2;
+    }
     // b_phi from phi at quadrature points, then phi_q is dropped (it never changes: obstacle_pg.py:107-111)
     double* phi_q = nullptr;
     const size_t nphi = (size_t)nc * p->nq;
@@ -433,7 +601,10 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     }
     hipError_t e = hipMemcpy(phi_q, p->phi_q, nphi * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->bphi);
+      if (p->degree == 2)
+        pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->bphi);
+      else
+        pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->bphi);
       e = hipStreamSynchronize(h->st);
     }
     hipFree(phi_q);
@@ -450,7 +621,32 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
                    nullptr, h->q, h->Kv);
     pgxk_fill_rows(h->st, 1, n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
                    nullptr, h->q, h->Mv);
-    const size_t n2 = 2 * (size_t)n;
+    if (p->degree == 2) {
+      DALLOC(h->s_K, h->s_nnz);
+      DALLOC(h->s_M, h->s_nnz);
+      DALLOC(h->s_D, h->s_nnz);
+      pgxk_fill_rows_p2(h->st, 0, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
+                        h->coords, nullptr, h->q2, h->s_K);
+      pgxk_fill_rows_p2(h->st, 1, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
+                        h->coords, nullptr, h->q2, h->s_M);
+      DALLOC(h->p2_xu, nd);
+      DALLOC(h->p2_xp, nd);
+      DALLOC(h->p2_ru, nd);
+      DALLOC(h->p2_rp, nd);
+      DALLOC(h->c1_bu, n);
+      DALLOC(h->c1_bp, n);
+      DALLOC(h->c1_xu, n);
+      DALLOC(h->c1_xp, n);
+    } else {
+      h->s_rowptr = h->rowptr;
+      h->s_colm = h->colm;
+      h->s_K = h->Kv;
+      h->s_M = h->Mv;
+      h->s_D = h->Dv;
+      h->s_nnz = h->nnz;
+      h->s_fill_lds = h->fill_lds;
+    }
+    const size_t n2 = 2 * (size_t)nd;
     DALLOC(h->x, n2);
     DALLOC(h->xk, n2);
     DALLOC(h->F, n2);
@@ -505,16 +701,16 @@ extern "C" void pgx_destroy(pgx_handle* h) {
 
 extern "C" int pgx_num_dofs(const pgx_handle* h, int64_t* nd) {
   if (!h || !nd) return PGX_EINVAL;
-  *nd = 2 * (int64_t)h->n;
+  *nd = 2 * (int64_t)h->nd;
   return PGX_OK;
 }
 static int copy_in(pgx_handle* h, double* dst, const double* src) {
-  HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * 2 * (size_t)h->n, hipMemcpyHostToDevice, h->st));
+  HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * 2 * (size_t)h->nd, hipMemcpyHostToDevice, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
 static int copy_out(pgx_handle* h, double* dst, const double* src) {
-  HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * 2 * (size_t)h->nd, hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
@@ -540,14 +736,14 @@ extern "C" int pgx_get_prev(pgx_handle* h, double* x) {
 }
 extern "C" int pgx_advance_prev(pgx_handle* h) {
   NEED(h);
-  HIPCHK(hipMemcpyAsync(h->xk, h->x, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->st));
+  HIPCHK(hipMemcpyAsync(h->xk, h->x, sizeof(double) * 2 * (size_t)h->nd, hipMemcpyDeviceToDevice, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
 extern "C" int pgx_zero_state(pgx_handle* h) {
   NEED(h);
-  HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * 2 * (size_t)h->n, h->st));
-  HIPCHK(hipMemsetAsync(h->xk, 0, sizeof(double) * 2 * (size_t)h->n, h->st));
+  HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * 2 * (size_t)h->nd, h->st));
+  HIPCHK(hipMemsetAsync(h->xk, 0, sizeof(double) * 2 * (size_t)h->nd, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
@@ -561,7 +757,7 @@ extern "C" int pgx_set_alpha(pgx_handle* h, double a) {
 // building blocks
 // ------------------------------------------------------------------------------------------------
 static int dev_norm(pgx_handle* h, const double* v, double* out) {
-  pgxk_multidot(h->st, 2 * (size_t)h->n, 1, v, 0, v, h->partials, h->d_small);
+  pgxk_multidot(h->st, 2 * (size_t)h->nd, 1, v, 0, v, h->partials, h->d_small);
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   *out = std::sqrt(h->h_small[0]);
@@ -570,14 +766,28 @@ static int dev_norm(pgx_handle* h, const double* v, double* out) {
 
 static void residual_dev(pgx_handle* h, const double* x, double* F) {
   PhaseTimer t(h, 0);
+  if (h->degree == 2) {
+    hipMemsetAsync(F, 0, sizeof(double) * 2 * (size_t)h->nd, h->st);
+    pgxk_residual_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->mask, h->gbc, x, h->xk, h->alpha, h->f, h->q2, F);
+    pgxk_residual_final(h->st, h->nd, h->mask, h->gbc, h->bphi, x, F);
+    return;
+  }
   pgxk_residual(h->st, h->nc, h->n, h->cells, h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F);
 }
 
 static void jacobian_dev(pgx_handle* h, const double* x) {
   {
     PhaseTimer t(h, 1);
-    pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
-                   x + h->n, h->q, h->Dv);
+    if (h->degree == 2) {
+      pgxk_fill_rows_p2(h->st, 2, h->nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos,
+                        h->cdofs, h->coords, x + h->nd, h->q2, h->s_D);
+      // Galerkin coarse block T^T D_P2 T == D in the P1 basis with the P2 psi (same quadrature), for the P1 hierarchy
+      pgxk_fill_rows_p1_Dp2(h->st, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cdofs, h->coords,
+                            x + h->nd, h->q2, h->Dv);
+    } else {
+      pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
+                     x + h->n, h->q, h->Dv);
+    }
   }
   if (h->structured) {
     PhaseTimer t(h, 2);
@@ -588,14 +798,14 @@ static void jacobian_dev(pgx_handle* h, const double* x) {
   h->jac_valid = true;
 }
 
-// y = J x on device vectors of length 2n
+// y = J x on device vectors of length 2*nd
 static void spmv_dev(pgx_handle* h, const double* x, double* y) {
-  if (h->spmv_stream && 2 * h->fill_lds <= 64 * 1024)
-    pgxk_bspmv_stream(h->st, h->n, h->fill_lds, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, h->mask, x,
-                      x + h->n, h->xcd_remap ? 1 : 0, y, y + h->n);
+  if (h->spmv_stream && 2 * h->s_fill_lds <= 100 * 1024)
+    pgxk_bspmv_stream(h->st, h->nd, h->s_fill_lds, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, x,
+                      x + h->nd, h->xcd_remap ? 1 : 0, y, y + h->nd);
   else
-    pgxk_bspmv(h->st, 0, h->n, h->rowptr, h->colm, h->Kv, h->Mv, h->Dv, h->alpha, x, x + h->n, nullptr, nullptr, 0.0,
-               h->xcd_remap, y, y + h->n);
+    pgxk_bspmv(h->st, 0, h->nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, x, x + h->nd, nullptr,
+               nullptr, 0.0, h->xcd_remap, y, y + h->nd);
 }
 
 static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const double* xp, const double* bu,
@@ -660,12 +870,53 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
   for (int s = 0; s < nu; ++s) sweep(0);
 }
 
+// P2: two-level cycle.  Smoother = collective damped Jacobi on the P2 block CSR (k_bspmv<2>); coarse space =
+// the P1 subspace with its full multigrid hierarchy (one V-cycle); T = P1->P2 interpolation.
+static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double* outu, double* outp, int nu,
+                      double omega) {
+  const int nd = h->nd;
+  const int nu2 = nu + 1;
+  const double om2 = 0.75 * omega;
+  auto app = [&](int mode, const double* xu, const double* xp, int first, double* yu, double* yp) {
+    pgxk_bspmv(h->st, mode, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, om2,
+               first | h->xcd_remap, yu, yp);
+  };
+  double *Au = outu, *Ap = outp, *Bu = h->p2_xu, *Bp = h->p2_xp;
+  bool toA = false;  // 2*nu2 sweeps in total (even): start in B so that the last one lands in A
+  const double *cu = nullptr, *cp = nullptr;
+  auto sweep = [&](int first) {
+    double* tu = toA ? Au : Bu;
+    double* tp = toA ? Ap : Bp;
+    app(2, cu, cp, first, tu, tp);
+    cu = tu;
+    cp = tp;
+    toA = !toA;
+  };
+  for (int s2 = 0; s2 < nu2; ++s2) sweep(s2 == 0);
+  app(1, cu, cp, 0, h->p2_ru, h->p2_rp);
+  pgxk_p2_restrict(h->st, h->n, nd, h->v2e_ptr, h->v2e, h->mask, h->p2_ru, h->p2_rp, h->c1_bu, h->c1_bp);
+  vcycle(h, 0, h->c1_bu, h->c1_bp, h->c1_xu, h->c1_xp, nu, omega);
+  pgxk_p2_prolong_add(h->st, h->n, nd, h->edge_ends, h->c1_xu, h->c1_xp, (double*)cu, (double*)cp);
+  for (int s2 = 0; s2 < nu2; ++s2) sweep(0);
+  if (cu != Au) {  // odd nu: final sweep landed in the scratch pair
+    hipMemcpyAsync(Au, cu, sizeof(double) * nd, hipMemcpyDeviceToDevice, h->st);
+    hipMemcpyAsync(Ap, cp, sizeof(double) * nd, hipMemcpyDeviceToDevice, h->st);
+  }
+}
+
+static void precond(pgx_handle* h, const double* b, double* z, int nu, double omega) {
+  if (h->degree == 2)  // P2 level: one more sweep at 0.75*omega (prototype sweep in DESIGN.md section 3); P1 levels as usual
+    pcycle_p2(h, b, b + h->nd, z, z + h->nd, nu, omega);
+  else
+    vcycle(h, 0, b, b + h->n, z, z + h->n, nu, omega);
+}
+
 // FGMRES(restart) on J dx = b, right-preconditioned by one V-cycle; CGS2 orthogonalisation with
 // batched device dot products; Givens rotations on the host (one small D2H copy + sync per iteration).
 static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts* o, int* its_out, double* relres) {
-  const size_t n2 = 2 * (size_t)h->n;
-  const int m = std::min(std::max(o->ksp_restart, 1), h->restart);
-  const int n = h->n;
+  const size_t n2 = 2 * (size_t)h->nd;
+  // P2: the two-level preconditioner is weaker on the late large-alpha systems (30-60 its): use the full basis
+  const int m = (h->degree == 2) ? h->restart : std::min(std::max(o->ksp_restart, 1), h->restart);
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m);
   double bnorm;
   int rc = dev_norm(h, b, &bnorm);
@@ -715,7 +966,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       double* zj = h->Z + (size_t)j * n2;
       {
         PhaseTimer t(h, 4);
-        vcycle(h, 0, vj, vj + n, zj, zj + n, o->mg_nu, o->mg_omega);
+        precond(h, vj, zj, o->mg_nu, o->mg_omega);
       }
       {
         PhaseTimer t(h, 3);
@@ -828,18 +1079,20 @@ extern "C" int pgx_jacobian_fill(pgx_handle* h, const double* x) {
 extern "C" int pgx_csr_export(pgx_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col, double* K,
                               double* M, double* D) {
   NEED(h);
-  if (nrows) *nrows = h->n;
-  if (nnz) *nnz = h->nnz;
-  if (rowptr) memcpy(rowptr, h->h_rowptr.data(), sizeof(int32_t) * (h->n + 1));
-  if (col) memcpy(col, h->h_col.data(), sizeof(int32_t) * h->nnz);
-  if (K) HIPCHK(hipMemcpy(K, h->Kv, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
-  if (M) HIPCHK(hipMemcpy(M, h->Mv, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
+  const std::vector<int32_t>& hr = (h->degree == 2) ? h->s_h_rowptr : h->h_rowptr;
+  const std::vector<int32_t>& hc = (h->degree == 2) ? h->s_h_col : h->h_col;
+  if (nrows) *nrows = h->nd;
+  if (nnz) *nnz = h->s_nnz;
+  if (rowptr) memcpy(rowptr, hr.data(), sizeof(int32_t) * (h->nd + 1));
+  if (col) memcpy(col, hc.data(), sizeof(int32_t) * h->s_nnz);
+  if (K) HIPCHK(hipMemcpy(K, h->s_K, sizeof(double) * h->s_nnz, hipMemcpyDeviceToHost));
+  if (M) HIPCHK(hipMemcpy(M, h->s_M, sizeof(double) * h->s_nnz, hipMemcpyDeviceToHost));
   if (D) {
     if (!h->jac_valid) {
       h->err = "pgx_csr_export(D) before pgx_jacobian_fill";
       return PGX_ESTATE;
     }
-    HIPCHK(hipMemcpy(D, h->Dv, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(D, h->s_D, sizeof(double) * h->s_nnz, hipMemcpyDeviceToHost));
   }
   return PGX_OK;
 }
@@ -864,7 +1117,7 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
     h->err = "pgx_spmv_bench before pgx_jacobian_fill";
     return PGX_ESTATE;
   }
-  const size_t n2 = 2 * (size_t)h->n;
+  const size_t n2 = 2 * (size_t)h->nd;
   pgxk_set(h->st, n2, 1.0, h->V);
   for (int k = 0; k < 3; ++k) spmv_dev(h, h->V, h->w);
   HIPCHK(hipEventRecord(h->e0, h->st));
@@ -875,7 +1128,7 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
   HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
   *avg_ms = (double)ms / reps;
   if (bytes)  // one pattern (4 B) + three value streams (24 B) per scalar nnz; rowptr; x read once; y written
-    *bytes = 28.0 * h->nnz + 4.0 * (h->n + 1) + 8.0 * n2 + 8.0 * n2;
+    *bytes = 28.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
   return PGX_OK;
 }
 
@@ -884,8 +1137,14 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
   if (!out) return PGX_EINVAL;
   {
     PhaseTimer t(h, 6);
-    pgxk_observables(h->st, h->nc, h->n, h->cells, h->coords, h->x, h->xk, h->alpha, h->f, h->q, h->obs_partials,
-                     h->obs_blocks, h->d_out6);
+    if (h->degree == 2) {
+      pgxk_observables_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->x, h->xk, h->alpha, h->f, h->q2,
+                                h->obs_partials, h->obs_blocks);
+      pgxk_observables_final(h->st, h->obs_blocks, h->obs_partials, h->d_out6);
+    } else {
+      pgxk_observables(h->st, h->nc, h->n, h->cells, h->coords, h->x, h->xk, h->alpha, h->f, h->q, h->obs_partials,
+                       h->obs_blocks, h->d_out6);
+    }
   }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_out6, sizeof(double) * 6, hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
@@ -913,7 +1172,10 @@ extern "C" int pgx_profile_get(pgx_handle* h, double ms[8], int reset) {
 extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   NEED(h);
   if (!opts || !reason) return PGX_EINVAL;
-  const size_t n2 = 2 * (size_t)h->n;
+  pgx_snes_opts optv = *opts;
+  if (!(optv.ksp_rtol > 0.0)) optv.ksp_rtol = (h->degree == 2) ? 1e-10 : 1e-9;
+  opts = &optv;
+  const size_t n2 = 2 * (size_t)h->nd;
   hipEvent_t w0 = nullptr, w1 = nullptr;
   if (h->prof) {
     hipEventCreate(&w0);

@@ -116,3 +116,33 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
                        const double* xu, const double* xp, int remap, double* yu, double* yp);
+
+// ---- P2 (pgx_p2.hip) -------------------------------------------------------------------------------
+struct QuadTab2 {
+  double L[PGX_MAX_NQ][3];      // P1 (barycentric) basis at quadrature points
+  double N[PGX_MAX_NQ][6];      // P2 basis: 3 vertex functions l(2l-1), 3 edge functions 4 l_j l_k (edge i opposite vertex i)
+  double dN[PGX_MAX_NQ][6][2];  // reference gradients
+  double w[PGX_MAX_NQ];
+  int nq;
+};
+void pgxk_bphi_p2(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords, const double* phi_q,
+                  QuadTab2 q, double* bphi);
+void pgxk_residual_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
+                            const uint8_t* mask, const double* gbc, const double* x, const double* xk, double alpha,
+                            double f, QuadTab2 q, double* F);
+void pgxk_residual_final(hipStream_t st, int n, const uint8_t* mask, const double* gbc, const double* bphi,
+                         const double* x, double* F);
+void pgxk_fill_rows_p2(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr,
+                       const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs,
+                       const double* coords, const double* psi, QuadTab2 q, double* out);
+void pgxk_fill_rows_p1_Dp2(hipStream_t st, int nv, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
+                           const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs, const double* coords,
+                           const double* psi, QuadTab2 q, double* out);
+void pgxk_p2_restrict(hipStream_t st, int nv, int n2, const int32_t* v2e_ptr, const int32_t* v2e, const uint8_t* mask1,
+                      const double* ru2, const double* rp2, double* bu1, double* bp1);
+void pgxk_p2_prolong_add(hipStream_t st, int nv, int n2, const int32_t* edge_ends, const double* cu, const double* cp,
+                         double* xu, double* xp);
+void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
+                               const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
+                               int nblocks);
+void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6);

@@ -157,6 +157,12 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_final(int n, const uint8
   if (mask[i]) F[i] = x[i] - gbc[i];
 }
 
+void pgxk_residual_final(hipStream_t st, int n, const uint8_t* mask, const double* gbc, const double* bphi,
+                         const double* x, double* F) {
+  hipLaunchKernelGGL(k_residual_final, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, mask, gbc,
+                     bphi, x, F);
+}
+
 void pgxk_residual(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const uint8_t* mask,
                    const double* gbc, const double* bphi, const double* x, const double* xk, double alpha, double f,
                    QuadTab q, double* F) {
@@ -393,6 +399,11 @@ void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
                        const double* xu, const double* xp, int remap, double* yu, double* yp) {
   const int cap = (int)(fill_lds_bytes / sizeof(double));
+  static bool attr_set = false;
+  if (!attr_set) {  // P2 rows (up to 19 nnz) need more than the default 64 KB of dynamic LDS
+    hipFuncSetAttribute((const void*)k_bspmv_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_bspmv_stream, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK),
                      2 * fill_lds_bytes, st, n, cap, rowptr, colm, K, M, D, alpha, mask, xu, xp, remap, yu, yp);
 }
@@ -480,6 +491,10 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_final(int nblocks, co
       out6[k] = v;
     }
   }
+}
+
+void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6) {
+  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6);
 }
 
 int pgxk_observables_blocks(int nc) {

@@ -57,6 +57,28 @@ class Mesh:
     def cell_name(self):
         return "triangle"
 
+    def edges(self):
+        """(edges (ne,2) sorted vertex pairs, cell_edges (nc,3)); local edge i is OPPOSITE local vertex i (the
+        Basix reference-triangle convention). Edge numbering = lexicographic order of (min,max) vertex pairs."""
+        if getattr(self, "_edges", None) is None:
+            nv = self.num_vertices
+            c = self.cells.astype(np.int64)
+            pairs = np.stack([c[:, [1, 2]], c[:, [0, 2]], c[:, [0, 1]]], axis=1)
+            pairs.sort(axis=2)
+            key = pairs[:, :, 0] * nv + pairs[:, :, 1]
+            uk, inv = np.unique(key.ravel(), return_inverse=True)
+            self._edges = (np.stack([uk // nv, uk % nv], axis=1).astype(np.int32), inv.reshape(-1, 3).astype(np.int32))
+        return self._edges
+
+    def exterior_dofs(self, degree):
+        """Dofs of a degree-k Lagrange space on exterior facets (locate_dofs_topological, obstacle_pg.py:76-79)."""
+        bv = self.exterior_vertices()
+        if degree == 1:
+            return bv
+        edges, cell_edges = self.edges()
+        cnt = np.bincount(cell_edges.ravel(), minlength=len(edges))
+        return np.concatenate([bv, self.num_vertices + np.flatnonzero(cnt == 1)]).astype(np.int32)
+
     def exterior_vertices(self):
         """Vertices on exterior facets (edges that belong to exactly one cell):
         mesh.exterior_facet_indices + locate_dofs_topological of obstacle_pg.py:76-79 for P1."""
@@ -108,9 +130,25 @@ class FunctionSpace:
 
     @property
     def block_size(self):
-        if self.degree != 1:
-            raise NotImplementedError("P1 only in this round (P2 is the next section-8 row)")
-        return self.mesh.num_vertices
+        if self.degree == 1:
+            return self.mesh.num_vertices
+        if self.degree == 2:  # dofs per field: vertices then one per edge
+            return self.mesh.num_vertices + len(self.mesh.edges()[0])
+        raise NotImplementedError("Lagrange degree 1 or 2 (obstacle_pg.py:288)")
+
+    def cell_dofs(self):
+        """[nc][3] (P1) or [nc][6] (P2: 3 vertex dofs then 3 edge dofs, edge i opposite vertex i)."""
+        if self.degree == 1:
+            return self.mesh.cells
+        return np.ascontiguousarray(
+            np.concatenate([self.mesh.cells, self.mesh.num_vertices + self.mesh.edges()[1]], axis=1), dtype=np.int32)
+
+    def dof_coordinates(self):
+        x = self.mesh.geometry
+        if self.degree == 1:
+            return x
+        e = self.mesh.edges()[0]
+        return np.concatenate([x, 0.5 * (x[e[:, 0]] + x[e[:, 1]])])
 
     @property
     def num_dofs(self):

@@ -42,7 +42,7 @@ def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict 
     V = fem.functionspace(msh, ("Lagrange", polynomial_order), ncomp=2)  # :68-70
     alpha = fem.Constant(msh, 1.0)  # :73
     f = fem.Constant(msh, 0.0)  # :74
-    dofs = msh.exterior_vertices()  # :76-79
+    dofs = msh.exterior_dofs(polynomial_order)  # :76-79
     bcs = fem.dirichletbc(0.0, dofs, V.sub(0))  # :81-83
     sol, sol_k = fem.Function(V), fem.Function(V)  # :86-87
     quadrature_degree = 6  # :106

@@ -173,8 +173,10 @@ class NonlinearProblem:
         self._keep = (mesh.geometry, mesh.cells, F.phi.points, F.phi.weights,
                       np.ascontiguousarray(F.phi.values), np.ascontiguousarray(bc_dofs, dtype=np.int32),
                       np.ascontiguousarray(bc_vals, dtype=np.float64))
+        cdofs = V.cell_dofs() if V.degree == 2 else None
+        self._keep_cd = cdofs
         pm = _lib.pgx_mesh(mesh.num_vertices, mesh.num_cells, _lib.dptr(self._keep[0]), _lib.iptr(self._keep[1]),
-                           *(mesh.structured or (0, 0)))
+                           *(mesh.structured or (0, 0)), _lib.iptr(cdofs), V.block_size if V.degree == 2 else 0)
         pp = _lib.pgx_problem(V.degree, len(self._keep[3]), _lib.dptr(self._keep[2]), _lib.dptr(self._keep[3]),
                               _lib.dptr(self._keep[4]), F.f.value, len(self._keep[5]), _lib.iptr(self._keep[5]),
                               _lib.dptr(self._keep[6]))

@@ -1,0 +1,105 @@
+"""P2 (obstacle_pg.py -p 2) HIP path vs the CPU oracle, through the C ABI.
+Tolerances as in test_gpu_parity.py: kernels 1e-12, full run identical counts and u <= 1e-10 relative L2."""
+import numpy as np
+import pytest
+
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DOMAIN = ((-1.0, -1.0), (1.0, 1.0))
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _setup(N, M=None):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import setup_problem
+
+    M = N if M is None else M
+    msh = fem.create_rectangle(DOMAIN, (N, M))
+    problem, sol, sol_k, alpha = setup_problem(msh, 2)
+    coords, cells = O.create_rectangle(N, M)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    assert sol.function_space.block_size == prob.n
+    return problem, sol, sol_k, alpha, prob
+
+
+def _iterates(n2, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n2) * 0.1
+    xk = rng.standard_normal(n2) * 0.1
+    n = n2 // 2
+    x[n:] = -np.abs(rng.standard_normal(n)) * np.where(rng.random(n) < 0.3, 200.0, 2.0)
+    return x, xk
+
+
+@pytest.mark.parametrize("N,M", [(4, 4), (9, 6), (32, 32)])
+def test_p2_kernels_match_oracle(require_gpu, N, M):
+    problem, sol, sol_k, alpha, prob = _setup(N, M)
+    x, xk = _iterates(2 * prob.n, 3)
+    alpha.value = 1.75
+    sol_k.x.array[:] = xk
+    F, fn = problem.residual(x)
+    Fr = prob.residual(x, xk, 1.75)
+    assert _rel(F, Fr) < 1e-12 and abs(fn - np.linalg.norm(Fr)) < 1e-12 * np.linalg.norm(Fr)
+    problem.assemble_jacobian(x)
+    rowptr, col, K, Mv, D = problem.export_blocks()
+    assert np.array_equal(rowptr, prob.indptr_s.astype(np.int32)) and np.array_equal(col, prob.indices_s)
+    assert _rel(K, prob.K.data) < 1e-12 and _rel(Mv, prob.M.data) < 1e-12
+    assert _rel(D, prob.jacobian_blocks(x)) < 1e-12
+    J = prob.jacobian(x, 1.75)
+    v = np.random.default_rng(5).standard_normal(2 * prob.n)
+    assert _rel(problem.spmv(v), J @ v) < 1e-12
+    sol.x.array[:] = np.clip(x, -40, None)
+    assert np.allclose(problem.observables(), prob.observables(np.clip(x, -40, None), xk, 1.75), rtol=1e-12, atol=1e-14)
+    problem.close()
+
+
+@pytest.mark.parametrize("scheme,alpha_max,tol,N", [("double_exponential", 1e2, 1e-4, 32), ("constant", 1e5, 1e-6, 16)])
+def test_p2_full_run_matches_oracle(require_gpu, scheme, alpha_max, tol, N):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import COLUMNS, solve_problem
+
+    msh = fem.create_rectangle(DOMAIN, (N, N))
+    sol, newton, hist = solve_problem(msh, 2, 100, scheme, alpha_max, tol, verbose=False, return_history=True)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    x_ref, h_ref = O.solve_problem(prob, 100, scheme, alpha_max, tol)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    n = prob.n
+    assert _rel(sol.x.array[:n], x_ref[:n]) < 1e-10
+    for c in COLUMNS:
+        assert np.allclose(hist[c], h_ref[c], rtol=1e-7, atol=1e-11), c
+
+
+def test_p2_unstructured_numbering(require_gpu):
+    """permuted vertex ids -> general mesh: P2 assembly/SpMV must not depend on structure; the solve then uses
+    the P2 smoother + single-level P1 smoother as preconditioner"""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import setup_problem
+
+    N = 8
+    coords, cells = O.create_rectangle(N, N)
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(len(coords))
+    inv = np.argsort(perm)
+    msh = fem.Mesh(coords[inv], perm[cells].astype(np.int32)[rng.permutation(len(cells))])
+    problem, sol, sol_k, alpha = setup_problem(msh, 2)
+    prob = O.ObstacleLagrange(msh.geometry, msh.cells, 2)
+    x, xk = _iterates(2 * prob.n, 6)
+    sol_k.x.array[:] = xk
+    F, _ = problem.residual(x)
+    assert _rel(F, prob.residual(x, xk, 1.0)) < 1e-12
+    problem.assemble_jacobian(x)
+    v = rng.standard_normal(2 * prob.n)
+    assert _rel(problem.spmv(v), prob.jacobian(x, 1.0) @ v) < 1e-12
+    sol.x.array[:] = 0.0
+    sol_k.x.array[:] = 0.0
+    problem.solve()
+    z = np.zeros(2 * prob.n)
+    x_ref, r_ref, its_ref = O.newton_solve(prob, z, z, 1.0, O.SnesOptions(rtol=1e-6, max_it=100))
+    assert problem.solver.getIterationNumber() == its_ref
+    assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-9
+    problem.close()

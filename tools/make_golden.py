@@ -41,7 +41,20 @@ def run(N, scheme, alpha_max, tol, tag):
     print(tag, N, hist["Newton steps"])
 
 
+def run_p2(N, scheme, alpha_max, tol, tag):
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    its = []
+    x, hist = O.solve_problem(prob, 100, scheme, alpha_max, tol, iterates=its)
+    np.savez_compressed(OUT / f"obstacle_p2_n{N}_{tag}.npz", N=N, scheme=scheme, alpha_max=alpha_max, tol=tol, x_final=x,
+                        **{("hist_" + k.replace(" ", "_")): np.asarray(v) for k, v in hist.items()},
+                        x_iter=its[2], xk_iter=its[1], F_iter=prob.residual(its[2], its[1], 2.5),
+                        D_iter=prob.jacobian_blocks(its[2]), obs_iter=prob.observables(its[2], its[1], 2.5))
+    print("P2", tag, N, hist["Newton steps"])
+
+
 if __name__ == "__main__":
+    run_p2(16, "double_exponential", 1e2, 1e-4, "settingsB")
     run(16, "double_exponential", 1e2, 1e-4, "settingsB")
     run(16, "constant", 1e5, 1e-6, "settingsA")
     run(32, "double_exponential", 1e2, 1e-4, "settingsB")

@@ -9,7 +9,8 @@ opts = {"snes_linesearch_type": "none", "snes_rtol": 1e-6, "snes_max_it": 100, "
 for kv in sys.argv[3:]:
     k, v = kv.split("="); opts[k] = float(v) if "." in v or "e" in v else int(v)
 msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
-problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options=opts)
+import os
+problem, sol, sol_k, alpha = setup_problem(msh, int(os.environ.get("PG_DEGREE", "1")), petsc_options=opts)
 S = dict(A=("constant", 1e5, 1e-6, 100), B=("double_exponential", 1e2, 1e-4, 500))[scheme]
 h = run_outer_loop(problem, sol, sol_k, alpha, S[3], S[0], S[1], S[2], verbose=True)
 print("newton", h["Newton steps"], "total", sum(h["Newton steps"]))
