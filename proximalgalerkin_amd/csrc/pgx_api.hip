@@ -764,7 +764,7 @@ static int dev_norm(pgx_handle* h, const double* v, double* out) {
   return PGX_OK;
 }
 
-static void residual_dev(pgx_handle* h, const double* x, double* F) {
+static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d = 0) {
   PhaseTimer t(h, 0);
   if (h->degree == 2) {
     hipMemsetAsync(F, 0, sizeof(double) * 2 * (size_t)h->nd, h->st);
@@ -772,11 +772,14 @@ static void residual_dev(pgx_handle* h, const double* x, double* F) {
     pgxk_residual_final(h->st, h->nd, h->mask, h->gbc, h->bphi, x, F);
     return;
   }
-  pgxk_residual(h->st, h->nc, h->n, h->cells, h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F);
+  // row-parallel, atomic-free, bitwise reproducible; with_d: also fills D(psi) at the same x (Newton driver)
+  pgxk_resid_fill_p1(h->st, with_d, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
+                     h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv);
 }
 
-static void jacobian_dev(pgx_handle* h, const double* x) {
-  {
+// have_d: D(psi) at this x was already produced by residual_dev(..., with_d=1)
+static void jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
+  if (!(have_d && h->degree == 1)) {
     PhaseTimer t(h, 1);
     if (h->degree == 2) {
       pgxk_fill_rows_p2(h->st, 2, h->nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos,
@@ -1186,7 +1189,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   double fnorm = 0, fnorm0 = 0, ttol = 0;
   int rc = PGX_OK;
   HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
-  residual_dev(h, h->xw, h->F);
+  residual_dev(h, h->xw, h->F, 1);
   rc = dev_norm(h, h->F, &fnorm);
   if (rc) return rc;
   fnorm0 = fnorm;
@@ -1201,7 +1204,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       rsn = PGX_SNES_DIVERGED_MAX_IT;
       break;
     }
-    jacobian_dev(h, h->xw);
+    jacobian_dev(h, h->xw, true);
     pgxk_scale_copy(h->st, n2, -1.0, h->F, h->rhs);
     int kits = 0;
     double relres = 0;
@@ -1215,7 +1218,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       break;
     }
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
-    residual_dev(h, h->xw, h->F);
+    residual_dev(h, h->xw, h->F, 1);
     rc = dev_norm(h, h->F, &fnorm);
     if (rc) return rc;
     if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);

@@ -146,3 +146,8 @@ void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdo
                                const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
                                int nblocks);
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6);
+// fused, atomic-free residual (+ optional D(psi) fill) for P1: see k_resid_fill_p1
+void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
+                        const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
+                        const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
+                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout);

@@ -239,6 +239,96 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows(int n, const int32_t* _
   for (int k = threadIdx.x; k < len; k += PGX_BLOCK) out[base + k] = acc[k];
 }
 
+// Fused residual + D(psi) fill, row-parallel (the Newton driver's kernel).  k_fill_rows<2> already evaluates
+// exp(psi_h) at every quadrature point of every (vertex, incident cell) pair; the residual entries of that
+// pair come out of the same loop at no extra exp cost (b_exp,a = row sum of the D_e row because the hat
+// functions sum to 1).  One launch replaces memset + k_residual_p1 (6 fp64 atomics per cell, ~1 ms at
+// 2048^2) + k_residual_final + k_fill_rows<2>, and the result is bitwise reproducible (no atomics).
+template <bool WRITE_D>
+__global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1(int n, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ v2c_ptr,
+                                                             const int32_t* __restrict__ v2c_ent,
+                                                             const int32_t* __restrict__ v2c_pos,
+                                                             const int32_t* __restrict__ cells,
+                                                             const double* __restrict__ coords,
+                                                             const uint8_t* __restrict__ mask,
+                                                             const double* __restrict__ gbc,
+                                                             const double* __restrict__ bphi,
+                                                             const double* __restrict__ x,
+                                                             const double* __restrict__ xk, double alpha, double f,
+                                                             QuadTab q, double* __restrict__ F,
+                                                             double* __restrict__ Dout) {
+  extern __shared__ double acc[];
+  const int i0 = blockIdx.x * PGX_BLOCK;
+  const int i = i0 + threadIdx.x;
+  const int iend = min(i0 + PGX_BLOCK, n);
+  const int base = rowptr[i0];
+  const int len = rowptr[iend] - base;
+  if (WRITE_D) {
+    for (int k = threadIdx.x; k < len; k += PGX_BLOCK) acc[k] = 0.0;
+    __syncthreads();
+  }
+  if (i < n) {
+    double* row = acc + (rowptr[i] - base);
+    double Fu = 0.0, Fp = 0.0;
+    const int ke = v2c_ptr[i + 1];
+    for (int k = v2c_ptr[i]; k < ke; ++k) {
+      const int e = v2c_ent[k];
+      const int c = e >> 2, a = e & 3;
+      const int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
+      const P1Geom g = p1_geom(coords[2 * v[0]], coords[2 * v[0] + 1], coords[2 * v[1]], coords[2 * v[1] + 1],
+                               coords[2 * v[2]], coords[2 * v[2] + 1]);
+      double u[3], p[3], dp[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        u[b] = mask[v[b]] ? gbc[v[b]] : x[v[b]];
+        p[b] = x[n + v[b]];
+        dp[b] = p[b] - xk[n + v[b]];
+      }
+      double d[3] = {0.0, 0.0, 0.0};
+      for (int k2 = 0; k2 < q.nq; ++k2) {
+        const double pq = p[0] * q.N[k2][0] + p[1] * q.N[k2][1] + p[2] * q.N[k2][2];
+        const double wa = q.w[k2] * exp(pq) * q.N[k2][a];
+        d[0] += wa * q.N[k2][0];
+        d[1] += wa * q.N[k2][1];
+        d[2] += wa * q.N[k2][2];
+      }
+      const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
+      const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
+      const double Ku = 0.5 * g.adet * (g.G[a][0] * gx + g.G[a][1] * gy);
+      const double Mdp = g.adet * (q.Mref[a][0] * dp[0] + q.Mref[a][1] * dp[1] + q.Mref[a][2] * dp[2]);
+      const double Mu = g.adet * (q.Mref[a][0] * u[0] + q.Mref[a][1] * u[1] + q.Mref[a][2] * u[2]);
+      Fu += alpha * Ku + Mdp - alpha * f * g.adet * q.mref[a];
+      Fp += Mu - g.adet * (d[0] + d[1] + d[2]);
+      if (WRITE_D) {
+        const int pos = v2c_pos[k];
+        row[pos & 0xff] += g.adet * d[0];
+        row[(pos >> 8) & 0xff] += g.adet * d[1];
+        row[(pos >> 16) & 0xff] += g.adet * d[2];
+      }
+    }
+    F[i] = mask[i] ? x[i] - gbc[i] : Fu;
+    F[n + i] = Fp - bphi[i];
+  }
+  if (WRITE_D) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < len; k += PGX_BLOCK) Dout[base + k] = acc[k];
+  }
+}
+
+void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
+                        const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
+                        const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
+                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout) {
+  dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (write_d)
+    hipLaunchKernelGGL(k_resid_fill_p1<true>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, F, Dout);
+  else
+    hipLaunchKernelGGL(k_resid_fill_p1<false>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, F, Dout);
+}
+
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                     const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
                     const double* psi, QuadTab q, double* out) {
