@@ -49,7 +49,7 @@ struct pgx_handle {
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
   // Krylov workspace
   int restart = 0;
-  double *V = nullptr, *Z = nullptr, *w = nullptr, *d_small = nullptr, *partials = nullptr;
+  double *V = nullptr, *Z = nullptr, *w = nullptr, *d_small = nullptr, *partials = nullptr, *partials2 = nullptr;
   double* h_small = nullptr;  // pinned
   // multigrid
   std::vector<GridLevel> lev;
@@ -661,6 +661,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     DALLOC(h->w, n2);
     DALLOC(h->d_small, 4 * (h->restart + 2));
     DALLOC(h->partials, (size_t)PGX_RED_BLOCKS * (h->restart + 2));
+    DALLOC(h->partials2, ((n2 + PGX_BLOCK - 1) / PGX_BLOCK) * (size_t)(h->restart + 2));
     HIPCHK(hipHostMalloc((void**)&h->h_small, sizeof(double) * 4 * (h->restart + 2)));
     DALLOC(h->tmp_u, n);
     DALLOC(h->tmp_p, n);
@@ -986,10 +987,9 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         PhaseTimer t(h, 5);
         double* d_h1 = h->d_small;
         double* d_h2 = h->d_small + (m + 2);
+        // pass 1: h1 = V^T w.  passes 2+3 fused: w' = w - V h1 and [h2; |w'|^2] in one sweep over the basis.
         pgxk_multidot(h->st, n2, j + 1, h->V, n2, wj, h->partials, d_h1);
-        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h1, wj);
-        pgxk_multidot(h->st, n2, j + 2, h->V, n2, wj, h->partials, d_h2);
-        pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h2, wj);
+        pgxk_axpy_dot(h->st, n2, j + 1, h->V, n2, d_h1, wj, h->partials2, d_h2);
         HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
         double hh = 0.0;
@@ -999,6 +999,8 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
           hh += h2 * h2;
         }
         hn = std::sqrt(std::max(h->h_small[(m + 2) + j + 1] - hh, 0.0));
+        // pass 4 fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
+        if (hn > 0.0) pgxk_multiaxpy_scale(h->st, n2, j + 1, h->V, n2, d_h2, 1.0 / hn, wj);
       }
       H[(size_t)(j + 1) * m + j] = hn;
       for (int i = 0; i < j; ++i) {
@@ -1026,7 +1028,6 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         ++j;
         break;
       }
-      pgxk_scale_copy(h->st, n2, 1.0 / hn, wj, wj);
     }
     // y = H^-1 g (upper triangular), x += Z y
     for (int i = j - 1; i >= 0; --i) {

@@ -151,3 +151,8 @@ void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, co
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                         const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
                         const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout);
+// CGS2 with fused passes: (w' = w - V h1; [h2; |w'|^2] = [V,w']^T w') in one pass, then v = (w' - V h2)*scale
+void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h1, double* w,
+                   double* partials, double* out);
+void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h,
+                          double scale, double* w);

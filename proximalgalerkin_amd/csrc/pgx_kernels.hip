@@ -728,6 +728,116 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_multiaxpy(size_t len2, const doub
   }
 }
 
+// CGS2, passes 2+3 fused:  w' = w - V h1  and then  [h2; |w'|^2] = [V, w']^T w'  in ONE pass over the basis.
+// A block owns a 256-element slice of every basis vector: while it forms w' it parks the slices in LDS
+// (nv x 2 KB), then dots them against w' from LDS - the basis is read from HBM once instead of twice.
+// Two-stage fixed-shape reduction (per-block partials, then k_reduce_partials) -> bitwise reproducible.
+__global__ void __launch_bounds__(PGX_BLOCK) k_axpy_dot(size_t len, int nv, const double* __restrict__ V, size_t ldv,
+                                                        const double* __restrict__ h1, double* __restrict__ w,
+                                                        double* __restrict__ partials) {
+  extern __shared__ double sh[];  // [nv+1][256] slices (+ w'), then hs[nv]
+  double* hs = sh + (size_t)(nv + 1) * PGX_BLOCK;
+  const int t = threadIdx.x;
+  if (t < nv) hs[t] = h1[t];
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * PGX_BLOCK + t;
+  const bool live = i < len;
+  double wv = live ? w[i] : 0.0;
+#pragma unroll 8
+  for (int v = 0; v < nv; ++v) {
+    const double a = live ? V[(size_t)v * ldv + i] : 0.0;
+    sh[v * PGX_BLOCK + t] = a;
+    wv -= hs[v] * a;
+  }
+  if (live) w[i] = wv;
+  sh[nv * PGX_BLOCK + t] = wv;
+  __syncthreads();
+  const int lane = t & (WAVE - 1), wid = t / WAVE;
+  const double* wl = sh + (size_t)nv * PGX_BLOCK;
+  double wr[PGX_BLOCK / WAVE];
+#pragma unroll
+  for (int r = 0; r < PGX_BLOCK / WAVE; ++r) wr[r] = wl[lane + WAVE * r];
+  for (int v = wid; v <= nv; v += PGX_BLOCK / WAVE) {
+    const double* sv = sh + (size_t)v * PGX_BLOCK;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < PGX_BLOCK / WAVE; ++r) s += sv[lane + WAVE * r] * wr[r];
+    s = wave_sum(s);
+    if (lane == 0) partials[(size_t)v * gridDim.x + blockIdx.x] = s;  // [v][block]: coalesced second stage
+  }
+}
+
+// out[v] = sum_b p[v][b]  (row-contiguous partials)
+__global__ void __launch_bounds__(PGX_BLOCK) k_reduce_rows(int nb, const double* __restrict__ p,
+                                                           double* __restrict__ out) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  const double* row = p + (size_t)blockIdx.x * nb;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += row[b];
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+// out[0..nv-1] = h2, out[nv] = |w'|^2.  partials must hold ceil(len/256) * (nv+1) doubles.
+void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h1, double* w,
+                   double* partials, double* out) {
+  const unsigned nb = (unsigned)((len + PGX_BLOCK - 1) / PGX_BLOCK);
+  const size_t lds = ((size_t)(nv + 1) * PGX_BLOCK + nv) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_axpy_dot, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_axpy_dot, dim3(nb), dim3(PGX_BLOCK), lds, st, len, nv, V, ldv, h1, w, partials);
+  hipLaunchKernelGGL(k_reduce_rows, dim3(nv + 1), dim3(PGX_BLOCK), 0, st, (int)nb, partials, out);
+}
+
+// CGS2 pass 4 fused with the normalisation:  v_next = (w - V h2) * scale
+template <int NV>
+__global__ void __launch_bounds__(PGX_BLOCK) k_multiaxpy_scale(size_t len2, const double2* __restrict__ V, size_t ldv2,
+                                                               const double* __restrict__ h, double scale, int last,
+                                                               double2* __restrict__ w) {
+  double hv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) hv[v] = h[v];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 wv = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double2 a = V[v * ldv2 + i];
+      wv.x -= hv[v] * a.x;
+      wv.y -= hv[v] * a.y;
+    }
+    if (last) {
+      wv.x *= scale;
+      wv.y *= scale;
+    }
+    w[i] = wv;
+  }
+}
+
+void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h,
+                          double scale, double* w) {
+  const size_t len2 = len / 2, ldv2 = ldv / 2;
+  dim3 grid = stream_grid(len2), block(PGX_BLOCK);
+  int done = 0;
+  while (done < nv) {
+    const int rem = nv - done;
+    const double2* Vp = (const double2*)(V + (size_t)done * ldv);
+    const int step = rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+    const int last = (done + step == nv);
+    if (step == 8)
+      hipLaunchKernelGGL(k_multiaxpy_scale<8>, grid, block, 0, st, len2, Vp, ldv2, h + done, scale, last, (double2*)w);
+    else if (step == 4)
+      hipLaunchKernelGGL(k_multiaxpy_scale<4>, grid, block, 0, st, len2, Vp, ldv2, h + done, scale, last, (double2*)w);
+    else if (step == 2)
+      hipLaunchKernelGGL(k_multiaxpy_scale<2>, grid, block, 0, st, len2, Vp, ldv2, h + done, scale, last, (double2*)w);
+    else
+      hipLaunchKernelGGL(k_multiaxpy_scale<1>, grid, block, 0, st, len2, Vp, ldv2, h + done, scale, last, (double2*)w);
+    done += step;
+  }
+}
+
 void pgxk_multiaxpy(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w) {
   const size_t len2 = len / 2, ldv2 = ldv / 2;
   dim3 grid = stream_grid(len2), block(PGX_BLOCK);
