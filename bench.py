@@ -65,6 +65,17 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
     return steps / dt, steps, dt
 
 
+def reduce_over_ranks(dist, dt, newton_total, outer_total, device):
+    """Launch-contract aggregation: wall time = MAX over ranks, work counts = SUM over ranks (whole-job value)."""
+    import torch
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([newton_total, outer_total], device=device, dtype=torch.float64)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(c[0].item()), int(c[1].item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,12 +147,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([newton_total, outer_total], device="cuda", dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        newton_total, outer_total = int(c[0].item()), int(c[1].item())
+        dt, newton_total, outer_total = reduce_over_ranks(dist, dt, newton_total, outer_total, "cuda")
     lin_its = problem.solver.getLinearSolveIterations()
 
     # ---- roofline of the dominant kernel (k_bspmv): HIP events on the library's own stream ----
@@ -149,7 +155,6 @@ def main():
     spmv_ms, spmv_bytes = problem.spmv_bench(reps=50)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     n = msh.num_vertices
-    rowptr_nnz = None
     prof = problem.profile() if args.profile else None
 
     out = None
@@ -170,24 +175,28 @@ def main():
             "config": {
                 "workload": f"{N}x{N} right-diagonal P1 obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
                             f"settings {args.settings}: alpha {S['alpha_scheme']}, alpha_max {S['alpha_max']:g}, "
-                            f"tol {S['tol_exit']:g}; snes_rtol 1e-6, ksp_rtol 1e-10",
+                            f"tol {S['tol_exit']:g}; snes_rtol 1e-6, Newton linear solves to true relative residual 1e-9",
                 "mixed_unknowns": 2 * n,
                 "step": "one full LVPP solve from the zero state",
                 "newton_iterations_per_step": newton_total / args.steps / world,
                 "proximal_iterations_per_step": outer_total / args.steps / world,
-                "parallelism": "replicas" if world > 1 else "single",
+                "parallelism": ("replicas: N INDEPENDENT solves, one per GPU - the strip domain decomposition of "
+                                "DESIGN.md section 7 is not implemented, so this is NOT a speed-up measurement")
+                if world > 1 else "single",
             },
             "proximal_iterations_per_s": outer_total / dt,
             "last_newton_linear_iterations": lin_its,
             "setup_s": t_setup,
             "roofline": {
-                "kernel": "k_bspmv (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
+                "kernel": "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) for this kernel
+                # at this size: profiles/r01_spmv_pmc_traffic.json.  Only meaningful for the default 2048^2 workload.
+                "traffic": 993765512.8 if N == 2048 else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)
