@@ -433,6 +433,11 @@ static int build_multigrid(pgx_handle* h) {
   }
   // fused tail: every level with at most PGX_TAIL_VERTS vertices (and at most PGX_TAIL_MAX of them)
   const int nl = (int)h->lev.size();
+  {  // a coarsest grid that could not be coarsened to a handful of vertices (odd cell counts) gets a sweep
+     // count that grows with its size: Jacobi is then a poor but non-trivial coarse solver
+    const GridLevel& Lc = h->lev.back();
+    if (nl > 1 && Lc.n > 100 && !getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = std::min(400, 4 * std::max(Lc.nx, Lc.ny));
+  }
   for (int l = 1; l < nl; ++l)
     if (h->lev[l].n <= h->tail_verts && nl - l <= PGX_TAIL_MAX) {
       h->tail_start = l;
@@ -491,6 +496,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
+  if (const char* e = getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
     pgx_destroy(h);
