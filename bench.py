@@ -175,7 +175,7 @@ def main():
             "config": {
                 "workload": f"{N}x{N} right-diagonal P1 obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
                             f"settings {args.settings}: alpha {S['alpha_scheme']}, alpha_max {S['alpha_max']:g}, "
-                            f"tol {S['tol_exit']:g}; snes_rtol 1e-6, Newton linear solves to true relative residual 1e-9",
+                            f"tol {S['tol_exit']:g}; snes_rtol 1e-6, Newton linear solves to true relative residual 1e-10",
                 "mixed_unknowns": 2 * n,
                 "step": "one full LVPP solve from the zero state",
                 "newton_iterations_per_step": newton_total / args.steps / world,

@@ -99,7 +99,7 @@ typedef struct {
   double snes_divtol; /* 1e4 */
   int32_t snes_max_it;/* 50; ex 01 sets 100 */
   /* Newton linear solve (replaces ksp preonly + pc lu/mumps): FGMRES + multigrid V-cycle */
-  double ksp_rtol;    /* relative TRUE residual target; 0 (default) = auto: 1e-9 for P1, 1e-10 for P2, chosen from the
+  double ksp_rtol;    /* relative TRUE residual target; 0 (default) = auto: 1e-10 for P1, 1e-11 for P2, chosen from the
                          measured effect on the final primal field */
   int32_t ksp_max_it; /* default 200 */
   int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */

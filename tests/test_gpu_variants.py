@@ -1,0 +1,121 @@
+"""More parity cases for the HIP path (through the C ABI) against the CPU oracle: data the default example
+does not exercise (f != 0, g != 0), non-square structured meshes through the full multigrid solve, odd cell
+counts (truncated hierarchies), and a genuinely unstructured mesh of the reference's disk domain."""
+import numpy as np
+import pytest
+
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _problem(msh, f=0.0, g=0.0, degree=1):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import phi_set
+    from proximalgalerkin_amd.problem import NonlinearProblem, ObstacleResidual, derivative
+
+    V = fem.functionspace(msh, ("Lagrange", degree))
+    sol, sol_k = fem.Function(V), fem.Function(V)
+    alpha, fc = fem.Constant(msh, 1.0), fem.Constant(msh, f)
+    phi = fem.QuadratureFunction(msh, 6)
+    phi.interpolate(phi_set)
+    bc = fem.dirichletbc(g, msh.exterior_dofs(degree), V.sub(0))
+    F = ObstacleResidual(sol, sol_k, alpha, fc, phi, 6)
+    opts = {"snes_rtol": 1e-6, "snes_max_it": 100, "snes_linesearch_type": "none", "snes_error_if_not_converged": True}
+    return NonlinearProblem(F, sol, bcs=[bc], J=derivative(F, sol), petsc_options=opts), sol, sol_k, alpha
+
+
+def _outer(problem, sol, sol_k, alpha, prob, scheme="double_exponential", alpha_max=1e2, tol=1e-4, g=0.0):
+    """run the proximal loop on both sides from a BC-satisfying start and compare"""
+    from proximalgalerkin_amd.obstacle import run_outer_loop
+
+    hist = run_outer_loop(problem, sol, sol_k, alpha, 100, scheme, alpha_max, tol, device_resident=False)
+    x_ref, h_ref = O.solve_problem(prob, 100, scheme, alpha_max, tol)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-10
+    return hist, h_ref
+
+
+def test_forcing_and_inhomogeneous_dirichlet_data(require_gpu):
+    """f = -2 pushes the membrane down (more contact), g = -0.05 on the boundary: exercises the lifting path
+    of lvpp/problem.py:54-67 (F[bc] = x[bc] - g, columns moved to the right-hand side) and the alpha*f term."""
+    from proximalgalerkin_amd import fem
+
+    N = 32
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+    problem, sol, sol_k, alpha = _problem(msh, f=-2.0, g=-0.05)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N), f=-2.0, g_bc=-0.05)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(2 * prob.n) * 0.1  # violates the BC on purpose: lifting must handle it
+    xk = rng.standard_normal(2 * prob.n) * 0.1
+    alpha.value = 3.0
+    sol_k.x.array[:] = xk
+    F, _ = problem.residual(x)
+    assert _rel(F, prob.residual(x, xk, 3.0)) < 1e-12
+    # one Newton solve from a start that violates the BC: first step must land exactly on g
+    sol.x.array[:] = 0.0
+    sol_k.x.array[:] = 0.0
+    alpha.value = 1.0
+    problem.solve()
+    z = np.zeros(2 * prob.n)
+    x_ref, reason, its = O.newton_solve(prob, z, z, 1.0, O.SnesOptions(rtol=1e-6, max_it=100))
+    assert problem.solver.getIterationNumber() == its and problem.solver.getConvergedReason() == reason
+    assert np.all(sol.x.array[prob.bc] == -0.05)
+    assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-10
+    problem.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 32), (48, 80), (30, 30), (33, 20)])
+def test_rectangular_and_truncated_hierarchies(require_gpu, nx, ny):
+    """nx != ny, and cell counts with few factors of two (30 -> 15 stops after one coarsening, 33 none):
+    the multigrid hierarchy is shorter but the answer must not change."""
+    from proximalgalerkin_amd import fem
+
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (nx, ny))
+    problem, sol, sol_k, alpha = _problem(msh)
+    coords, cells = O.create_rectangle(nx, ny)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(nx, ny))
+    _outer(problem, sol, sol_k, alpha, prob)
+    problem.close()
+
+
+def test_unstructured_disk_mesh(require_gpu):
+    """The reference's own ex-01 domain is a gmsh disk (generate_mesh_gmsh.py:23). A Delaunay disk mesh runs
+    through the mesh-agnostic kernels with the single-level preconditioner; centre value -> phi(0)=0.5 contact."""
+    from scipy.spatial import Delaunay
+
+    from proximalgalerkin_amd import fem
+
+    pts = [(0.0, 0.0)]
+    nr = 12
+    for k in range(1, nr + 1):
+        m = max(6, int(round(2 * np.pi * k)))
+        th = 2 * np.pi * (np.arange(m) + 0.5 * (k % 2)) / m
+        pts += list(zip(k / nr * np.cos(th), k / nr * np.sin(th)))
+    pts = np.array(pts)
+    msh = fem.Mesh(pts, Delaunay(pts).simplices.astype(np.int32))
+    problem, sol, sol_k, alpha = _problem(msh)
+    prob = O.ObstacleP1(msh.geometry, msh.cells, msh.exterior_vertices())
+    hist, _ = _outer(problem, sol, sol_k, alpha, prob)
+    u = sol.x.array[:prob.n]
+    assert abs(u[0] - 0.5) < 5e-3  # contact at the centre: u = phi(0) = r0
+    r = np.linalg.norm(pts, axis=1)
+    assert np.all(u[r > 0.999] == 0.0)
+    problem.close()
+
+
+def test_p2_with_forcing(require_gpu):
+    from proximalgalerkin_amd import fem
+
+    N = 12
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+    problem, sol, sol_k, alpha = _problem(msh, f=-1.0, degree=2)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2, f=-1.0)
+    _outer(problem, sol, sol_k, alpha, prob)
+    problem.close()
