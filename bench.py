@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=2048, help="cells per side (BASELINE config: 2048)")
     ap.add_argument("--settings", choices=["A", "B"], default="B")
+    ap.add_argument("--degree", type=int, choices=[1, 2], default=1, help="Lagrange degree (obstacle_pg.py -p)")
     ap.add_argument("--cpu-n", type=int, default=384, help="mesh size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
@@ -118,7 +119,7 @@ def main():
         for kv in args.opts.split(","):
             k, v = kv.split("=")
             petsc_options[k] = float(v) if any(c in v for c in ".e") else int(v)
-    problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options=petsc_options, device=local_rank)
+    problem, sol, sol_k, alpha = setup_problem(msh, args.degree, petsc_options=petsc_options, device=local_rank)
     t_setup = time.perf_counter() - t_setup
     if args.profile:
         problem.profile(enable=True, reset=True)
@@ -173,10 +174,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{N}x{N} right-diagonal P1 obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
+                "workload": f"{N}x{N} right-diagonal P{args.degree} obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
                             f"settings {args.settings}: alpha {S['alpha_scheme']}, alpha_max {S['alpha_max']:g}, "
                             f"tol {S['tol_exit']:g}; snes_rtol 1e-6, Newton linear solves to true relative residual 1e-10",
-                "mixed_unknowns": 2 * n,
+                "mixed_unknowns": sol.function_space.num_dofs,
                 "step": "one full LVPP solve from the zero state",
                 "newton_iterations_per_step": newton_total / args.steps / world,
                 "proximal_iterations_per_step": outer_total / args.steps / world,

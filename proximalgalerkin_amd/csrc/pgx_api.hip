@@ -661,13 +661,20 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     DALLOC(h->rhs, n2);
     HIPCHK(hipMemsetAsync(h->x, 0, n2 * sizeof(double), h->st));
     HIPCHK(hipMemsetAsync(h->xk, 0, n2 * sizeof(double), h->st));
+    // Krylov basis capacity: 50 vectors cover P1 (restart 30).  The P2 two-level preconditioner leaves outlier
+    // modes on the late large-alpha systems whose number grows with N; restarting then stagnates, so P2 keeps
+    // up to 300 basis vectors within a 96 GB budget (V and Z) - HBM capacity is what MI355X has plenty of.
     h->restart = 50;
+    if (p->degree == 2) {
+      const double per_vec = 2.0 * (double)n2 * sizeof(double);
+      h->restart = (int)std::max(50.0, std::min(300.0, 96e9 / per_vec));
+    }
     DALLOC(h->V, (size_t)(h->restart + 1) * n2);
     DALLOC(h->Z, (size_t)h->restart * n2);
     DALLOC(h->w, n2);
     DALLOC(h->d_small, 4 * (h->restart + 2));
     DALLOC(h->partials, (size_t)PGX_RED_BLOCKS * (h->restart + 2));
-    DALLOC(h->partials2, ((n2 + PGX_BLOCK - 1) / PGX_BLOCK) * (size_t)(h->restart + 2));
+    DALLOC(h->partials2, ((n2 + PGX_BLOCK - 1) / PGX_BLOCK) * (size_t)62);
     HIPCHK(hipHostMalloc((void**)&h->h_small, sizeof(double) * 4 * (h->restart + 2)));
     DALLOC(h->tmp_u, n);
     DALLOC(h->tmp_p, n);
@@ -995,7 +1002,12 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         double* d_h2 = h->d_small + (m + 2);
         // pass 1: h1 = V^T w.  passes 2+3 fused: w' = w - V h1 and [h2; |w'|^2] in one sweep over the basis.
         pgxk_multidot(h->st, n2, j + 1, h->V, n2, wj, h->partials, d_h1);
-        pgxk_axpy_dot(h->st, n2, j + 1, h->V, n2, d_h1, wj, h->partials2, d_h2);
+        if (j + 1 <= 60) {
+          pgxk_axpy_dot(h->st, n2, j + 1, h->V, n2, d_h1, wj, h->partials2, d_h2);
+        } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
+          pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h1, wj);
+          pgxk_multidot(h->st, n2, j + 2, h->V, n2, wj, h->partials, d_h2);
+        }
         HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
         double hh = 0.0;
