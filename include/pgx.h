@@ -103,7 +103,7 @@ typedef struct {
                          measured effect on the final primal field */
   int32_t ksp_max_it; /* default 200 */
   int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */
-  int32_t mg_nu;      /* pre/post smoothing sweeps, default 2 */
+  int32_t mg_nu;      /* pre/post smoothing sweeps, default 6 (even values run as fused double sweeps) */
   double mg_omega;    /* collective-Jacobi damping, default 0.8 */
   int32_t monitor;    /* 1 = print per-Newton-step residuals (snes_monitor/ksp_monitor) */
 } pgx_snes_opts;

@@ -125,7 +125,8 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->ksp_rtol = 0.0;  // 0 = auto: 1e-10 for P1, 1e-11 for P2 (measured effect on the final u: DESIGN.md section 3)
   o->ksp_max_it = 200;
   o->ksp_restart = 30;
-  o->mg_nu = 2;
+  o->mg_nu = 6;  // 2048^2 sweep (profiles/): nu=2 780 ms, 4 707, 6 660, 8 692, 10 763 per solve - more smoothing shrinks the
+                  // Krylov space, whose orthogonalisation cost grows with its square
   o->mg_omega = 0.8;
   o->monitor = 0;
 }
@@ -853,14 +854,32 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
   double* Bp = (l == 0) ? h->tmp_p : L.xp2;
   double* ru = (l == 0) ? h->res_u : L.ru;
   double* rp = (l == 0) ? h->res_p : L.rp;
-  if (h->structured && !last && nu == 2 && h->fused_legs && L.n >= h->fused_min) {
-    // 3 launches per level: S(S(0)) | P^T(b - Jx) | S(S(x + P x_c))   (pgx_kernels.hip, "Fused V-cycle legs")
+  if (h->structured && !last && nu >= 2 && nu % 2 == 0 && h->fused_legs && L.n >= h->fused_min) {
+    // per level: nu/2 double-sweep launches | P^T(b - Jx) | nu/2 double-sweep launches (the first one also adds
+    // the prolongated coarse correction)   (pgx_kernels.hip, "Fused V-cycle legs")
     GridLevel& C = h->lev[l + 1];
     const int remap = h->xcd_remap ? 1 : 0;
-    pgxk_st_smooth2(h->st, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, Bu, Bp);
-    pgxk_st_resid_restrict(h->st, L, h->alpha, Bu, Bp, bu, bp, C, remap, C.bu, C.bp);
+    double *cu = Bu, *cp = Bp, *ou = Au, *op = Ap;  // current / other buffer pair
+    pgxk_st_smooth2(h->st, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
+    for (int s = 1; s < nu / 2; ++s) {
+      pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+      std::swap(cu, ou);
+      std::swap(cp, op);
+    }
+    pgxk_st_resid_restrict(h->st, L, h->alpha, cu, cp, bu, bp, C, remap, C.bu, C.bp);
     vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
-    pgxk_st_smooth2(h->st, 1, L, h->alpha, Bu, Bp, &C, C.xu, C.xp, bu, bp, omega, remap, Au, Ap);
+    pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, &C, C.xu, C.xp, bu, bp, omega, remap, ou, op);
+    std::swap(cu, ou);
+    std::swap(cp, op);
+    for (int s = 1; s < nu / 2; ++s) {
+      pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+      std::swap(cu, ou);
+      std::swap(cp, op);
+    }
+    if (cu != Au) {  // nu/2 odd launches per leg end in the scratch pair only when nu/2 is even
+      hipMemcpyAsync(Au, cu, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
+      hipMemcpyAsync(Ap, cp, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
+    }
     return;
   }
   const int total = last ? (h->lev.size() == 1 ? 2 * nu : h->coarse_sweeps) : 2 * nu;

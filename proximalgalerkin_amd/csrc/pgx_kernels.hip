@@ -1255,8 +1255,12 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
         const int sxc = nxc + 1;
         const int ic = gi >> 1, jc = gj >> 1;
         const int c0 = jc * sxc + ic, c1 = (jc + (gj & 1)) * sxc + (ic + (gi & 1));
-        a = xu[v] + 0.5 * (cu[c0] + cu[c1]);
-        c2 = xp[v] + 0.5 * (cp[c0] + cp[c1]);
+        a = xu[v];
+        c2 = xp[v];
+        if (cu) {  // cu == nullptr: plain double sweep of the current iterate (no coarse correction to add)
+          a += 0.5 * (cu[c0] + cu[c1]);
+          c2 += 0.5 * (cp[c0] + cp[c1]);
+        }
       }
       s0u[p] = a;
       s0p[p] = c2;
@@ -1337,7 +1341,7 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
   const StConst sc = make_stconst(L);
   if (post)
     hipLaunchKernelGGL((k_st_smooth2<TX, TY, true>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
-                       alpha, xu, xp, cu, cp, C->nx, bu, bp, omega, remap, yu, yp);
+                       alpha, xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
   else
     hipLaunchKernelGGL((k_st_smooth2<TX, TY, false>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
                        alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
