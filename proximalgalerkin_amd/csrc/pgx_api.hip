@@ -59,6 +59,7 @@ struct pgx_handle {
   int xcd_remap = 2;    // bit 1 of the `first` kernel argument; PGX_XCD_REMAP=0 disables (A/B: +1..3 %)
   int tail_verts = 1100;
   int spmv_stream = 1;  // PGX_SPMV_STREAM=0: 8-lanes-per-row kernel instead of the CSR-stream kernel
+  int nu_coarse = 0;    // PGX_NU_COARSE: cap on the sweeps of unfused (small) levels; 0 = same as the fine levels
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
   int fused_min = 500000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
@@ -495,6 +496,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
   if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
   if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
+  if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   if (const char* e = getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = atoi(e);
@@ -840,7 +842,7 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
                    double omega) {
   GridLevel& L = h->lev[l];
   if (l > 0 && l == h->tail_start) {  // all remaining levels in ONE launch (k_mg_tail); result in L.xu/L.xp
-    h->tail.nu = nu;
+    h->tail.nu = (h->nu_coarse > 0) ? std::min(nu, h->nu_coarse) : nu;
     h->tail.omega = omega;
     h->tail.alpha = h->alpha;
     h->tail.coarse_sweeps = h->coarse_sweeps;
@@ -882,6 +884,7 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
     }
     return;
   }
+  if (l > 0 && h->nu_coarse > 0) nu = std::min(nu, h->nu_coarse);  // small levels are launch-latency bound: fewer sweeps
   const int total = last ? (h->lev.size() == 1 ? 2 * nu : h->coarse_sweeps) : 2 * nu;
   bool toA = (total % 2) == 1;  // alternate targets so that the final sweep lands in A
   const double *cu = nullptr, *cp = nullptr;

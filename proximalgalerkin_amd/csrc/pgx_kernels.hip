@@ -10,6 +10,7 @@
 //   k_st_apply<MODE>, k_rap7, k_restrict, k_prolong_add, k_csr_to_stencil   7-point stencil multigrid
 //   k_multidot<NV>, k_multiaxpy<NV>, ...                                     Krylov vector kernels
 #include "pgx_internal.h"
+#include <algorithm>
 
 #define WAVE 64
 
@@ -738,32 +739,49 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_axpy_dot(size_t len, int nv, cons
   extern __shared__ double sh[];  // [nv+1][256] slices (+ w'), then hs[nv]
   double* hs = sh + (size_t)(nv + 1) * PGX_BLOCK;
   const int t = threadIdx.x;
-  if (t < nv) hs[t] = h1[t];
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * PGX_BLOCK + t;
-  const bool live = i < len;
-  double wv = live ? w[i] : 0.0;
-#pragma unroll 8
-  for (int v = 0; v < nv; ++v) {
-    const double a = live ? V[(size_t)v * ldv + i] : 0.0;
-    sh[v * PGX_BLOCK + t] = a;
-    wv -= hs[v] * a;
-  }
-  if (live) w[i] = wv;
-  sh[nv * PGX_BLOCK + t] = wv;
-  __syncthreads();
   const int lane = t & (WAVE - 1), wid = t / WAVE;
-  const double* wl = sh + (size_t)nv * PGX_BLOCK;
-  double wr[PGX_BLOCK / WAVE];
+  if (t < nv) hs[t] = h1[t];
+  constexpr int NW = PGX_BLOCK / WAVE;
+  constexpr int MAXA = 16;  // ceil(62 / 4): vectors handled by one wave
+  double acc[MAXA];
 #pragma unroll
-  for (int r = 0; r < PGX_BLOCK / WAVE; ++r) wr[r] = wl[lane + WAVE * r];
-  for (int v = wid; v <= nv; v += PGX_BLOCK / WAVE) {
-    const double* sv = sh + (size_t)v * PGX_BLOCK;
-    double s = 0.0;
+  for (int k = 0; k < MAXA; ++k) acc[k] = 0.0;
+  const size_t nchunks = (len + PGX_BLOCK - 1) / PGX_BLOCK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    __syncthreads();  // previous chunk's LDS image fully consumed (also orders the hs[] fill the first time)
+    const size_t i = chunk * PGX_BLOCK + t;
+    const bool live = i < len;
+    double wv = live ? w[i] : 0.0;
+#pragma unroll 8
+    for (int v = 0; v < nv; ++v) {
+      const double a = live ? V[(size_t)v * ldv + i] : 0.0;
+      sh[v * PGX_BLOCK + t] = a;
+      wv -= hs[v] * a;
+    }
+    if (live) w[i] = wv;
+    sh[nv * PGX_BLOCK + t] = wv;
+    __syncthreads();
+    const double* wl = sh + (size_t)nv * PGX_BLOCK;
+    double wr[NW];
 #pragma unroll
-    for (int r = 0; r < PGX_BLOCK / WAVE; ++r) s += sv[lane + WAVE * r] * wr[r];
-    s = wave_sum(s);
-    if (lane == 0) partials[(size_t)v * gridDim.x + blockIdx.x] = s;  // [v][block]: coalesced second stage
+    for (int r = 0; r < NW; ++r) wr[r] = wl[lane + WAVE * r];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+      const int v = wid + NW * k;
+      if (v <= nv) {
+        const double* sv = sh + (size_t)v * PGX_BLOCK;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) acc[k] += sv[lane + WAVE * r] * wr[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXA; ++k) {
+    const int v = wid + NW * k;
+    if (v <= nv) {
+      const double r = wave_sum(acc[k]);
+      if (lane == 0) partials[(size_t)v * gridDim.x + blockIdx.x] = r;  // [v][block]: coalesced second stage
+    }
   }
 }
 
@@ -781,7 +799,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_reduce_rows(int nb, const double*
 // out[0..nv-1] = h2, out[nv] = |w'|^2.  partials must hold ceil(len/256) * (nv+1) doubles.
 void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h1, double* w,
                    double* partials, double* out) {
-  const unsigned nb = (unsigned)((len + PGX_BLOCK - 1) / PGX_BLOCK);
+  size_t nchunks = (len + PGX_BLOCK - 1) / PGX_BLOCK;
+  const unsigned nb = (unsigned)std::min<size_t>(nchunks, 4096);  // blocks loop over chunks: 8x fewer partials at 2048^2
   const size_t lds = ((size_t)(nv + 1) * PGX_BLOCK + nv) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
