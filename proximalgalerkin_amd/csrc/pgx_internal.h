@@ -5,6 +5,11 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// storage type of the multigrid D(psi) stencils.  They only feed the PRECONDITIONER (the exact operator's CSR D stays
+// fp64), so fp32 would be admissible; measured on MI355X it made the smoother kernels 27 % SLOWER (same Krylov counts),
+// so the stencils stay fp64.
+typedef double dsten_t;
+
 #define PGX_MAX_NQ 16
 #define PGX_BLOCK 256
 
@@ -26,7 +31,7 @@ struct GridLevel {
   double *K, *M;             // [7*n] unmasked symmetric stencils, fixed at create
   // D(psi), refreshed every Newton step, symmetric-half storage [4*n]: slots 0:(0,0) 1:(+1,0) 2:(0,+1) 3:(+1,+1);
   // the three negative-direction links are the neighbours' positive ones (D is symmetric).
-  double* Dh;
+  dsten_t* Dh;
   // On a uniform grid every interior vertex has the same K and M stencil: passed in the kernarg segment
   // instead of streaming 14 coefficient arrays. Verified on the host at create; 0 -> explicit arrays.
   int uniform;
@@ -47,7 +52,8 @@ struct StConst {
 #define PGX_TAIL_VERTS 17000  // 129x129 vertices and below
 struct TailLevel {
   int nx, ny, n;
-  const double *K, *M, *Dh;
+  const double *K, *M;
+  const dsten_t* Dh;
   StConst sc;
   const uint8_t* mask;
   double *xu, *xp, *xu2, *xp2, *bu, *bp, *ru, *rp;
@@ -95,9 +101,9 @@ void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ld
 void pgxk_csr_to_stencil(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm, const double* vals,
                          double* S);
 void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
-                           const double* vals, double* Sh);
+                           const double* vals, dsten_t* Sh);
 void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridLevel& c, double* Sc);
-void pgxk_rap7h(hipStream_t st, const GridLevel& f, const double* Sfh, const GridLevel& c, double* Sch);
+void pgxk_rap7h(hipStream_t st, const GridLevel& f, const dsten_t* Sfh, const GridLevel& c, dsten_t* Sch);
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
                    const double* bu, const double* bp, double omega, int first, double* yu, double* yp);
 void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const double* rp, const GridLevel& c,

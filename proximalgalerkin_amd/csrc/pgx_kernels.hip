@@ -982,7 +982,7 @@ void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridL
 
 // Load the 7 coefficients of a symmetric-half stencil at vertex v=(i,j): the negative-direction links
 // are the neighbours' positive ones.  Sh slots: 0:(0,0) 1:(+1,0) 2:(0,+1) 3:(+1,+1).
-__device__ __forceinline__ void ld7h(const double* __restrict__ Sh, int n, int sx, int v, int i, int j, int nx,
+__device__ __forceinline__ void ld7h(const dsten_t* __restrict__ Sh, int n, int sx, int v, int i, int j, int nx,
                                      int ny, double d[7]) {
   d[0] = Sh[v];
   d[1] = (i < nx) ? Sh[(size_t)n + v] : 0.0;
@@ -996,7 +996,7 @@ __device__ __forceinline__ void ld7h(const double* __restrict__ Sh, int n, int s
 __global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil_h(int n, int sx, const int32_t* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ colm,
                                                                 const double* __restrict__ vals,
-                                                                double* __restrict__ Sh) {
+                                                                dsten_t* __restrict__ Sh) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s[4] = {0, 0, 0, 0};
@@ -1009,17 +1009,17 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil_h(int n, int sx, c
     else if (o == sx + 1) s[3] = v;
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) Sh[(size_t)k * n + i] = s[k];
+  for (int k = 0; k < 4; ++k) Sh[(size_t)k * n + i] = (dsten_t)s[k];
 }
 void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
-                           const double* vals, double* Sh) {
+                           const double* vals, dsten_t* Sh) {
   hipLaunchKernelGGL(k_csr_to_stencil_h, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, sx, rowptr,
                      colm, vals, Sh);
 }
 
 // Galerkin coarsening on symmetric-half storage: only the 4 stored coarse slots are produced.
-__global__ void __launch_bounds__(PGX_BLOCK) k_rap7h(int nxf, int nyf, int nf, const double* __restrict__ Sfh, int nxc,
-                                                     int nyc, int ncv, double* __restrict__ Sch) {
+__global__ void __launch_bounds__(PGX_BLOCK) k_rap7h(int nxf, int nyf, int nf, const dsten_t* __restrict__ Sfh, int nxc,
+                                                     int nyc, int ncv, dsten_t* __restrict__ Sch) {
   const int C = blockIdx.x * blockDim.x + threadIdx.x;
   if (C >= ncv) return;
   constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
@@ -1051,10 +1051,10 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_rap7h(int nxf, int nyf, int nf, c
   for (int q = 0; q < 4; ++q) {
     const int nx_ = I + OX[KEEP[q]], ny_ = Jc + OY[KEEP[q]];
     const bool ok = nx_ >= 0 && nx_ <= nxc && ny_ >= 0 && ny_ <= nyc;
-    Sch[(size_t)q * ncv + C] = ok ? out[q] : 0.0;
+    Sch[(size_t)q * ncv + C] = (dsten_t)(ok ? out[q] : 0.0);
   }
 }
-void pgxk_rap7h(hipStream_t st, const GridLevel& f, const double* Sfh, const GridLevel& c, double* Sch) {
+void pgxk_rap7h(hipStream_t st, const GridLevel& f, const dsten_t* Sfh, const GridLevel& c, dsten_t* Sch) {
   hipLaunchKernelGGL(k_rap7h, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, f.nx, f.ny, f.n, Sfh,
                      c.nx, c.ny, c.n, Sch);
 }
@@ -1077,7 +1077,7 @@ void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const
 // vertices read arrays.
 template <int MODE>
 __device__ __forceinline__ void st_vertex(int v, int nx, int ny, int n, const double* __restrict__ K,
-                                          const double* __restrict__ M, const double* __restrict__ Dh,
+                                          const double* __restrict__ M, const dsten_t* __restrict__ Dh,
                                           const StConst& sc, const uint8_t* __restrict__ mask, double alpha,
                                           const double* xu, const double* xp, const double* bu, const double* bp,
                                           double omega, int first, double* yu, double* yp) {
@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void st_vertex(int v, int nx, int ny, int n, const do
 template <int MODE>
 __global__ void __launch_bounds__(PGX_BLOCK) k_st_apply(int nx, int ny, int n, const double* __restrict__ K,
                                                         const double* __restrict__ M,
-                                                        const double* __restrict__ Dh, StConst sc,
+                                                        const dsten_t* __restrict__ Dh, StConst sc,
                                                         const uint8_t* __restrict__ mask, double alpha,
                                                         const double* __restrict__ xu, const double* __restrict__ xp,
                                                         const double* __restrict__ bu, const double* __restrict__ bp,
@@ -1177,7 +1177,7 @@ struct StCoef {
 };
 
 __device__ __forceinline__ void st_load_coef(int v, int i, int j, int nx, int ny, int n, const double* __restrict__ K,
-                                             const double* __restrict__ M, const double* __restrict__ Dh,
+                                             const double* __restrict__ M, const dsten_t* __restrict__ Dh,
                                              const StConst& sc, const uint8_t* __restrict__ mask, StCoef& c) {
   const int sx = nx + 1;
   c.ok[0] = true;
@@ -1244,7 +1244,7 @@ __device__ __forceinline__ void st_jacobi(const StCoef& c, double alpha, double 
 template <int TX, int TY, bool POST>
 __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n, const double* __restrict__ K,
                                                           const double* __restrict__ M,
-                                                          const double* __restrict__ Dh, StConst sc,
+                                                          const dsten_t* __restrict__ Dh, StConst sc,
                                                           const uint8_t* __restrict__ mask, double alpha,
                                                           const double* __restrict__ xu, const double* __restrict__ xp,
                                                           const double* __restrict__ cu, const double* __restrict__ cp,
@@ -1370,7 +1370,7 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
 // fine residual vector never exists in memory.
 __global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict(int nx, int ny, int n, const double* __restrict__ K,
                                                                  const double* __restrict__ M,
-                                                                 const double* __restrict__ Dh, StConst sc,
+                                                                 const dsten_t* __restrict__ Dh, StConst sc,
                                                                  const uint8_t* __restrict__ mask, double alpha,
                                                                  const double* __restrict__ xu,
                                                                  const double* __restrict__ xp,
@@ -1417,7 +1417,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict(int nx, int ny,
 template <int CX, int CY>
 __global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict_t(int nx, int ny, int n, const double* __restrict__ K,
                                                                    const double* __restrict__ M,
-                                                                   const double* __restrict__ Dh, StConst sc,
+                                                                   const dsten_t* __restrict__ Dh, StConst sc,
                                                                    const uint8_t* __restrict__ mask, double alpha,
                                                                    const double* __restrict__ xu,
                                                                    const double* __restrict__ xp,
