@@ -68,9 +68,6 @@ void pgxk_mg_tail(hipStream_t st, const TailArgs& A);
 // ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
                QuadTab q, double* bphi);
-void pgxk_residual(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const uint8_t* mask,
-                   const double* gbc, const double* bphi, const double* x, const double* xk, double alpha, double f,
-                   QuadTab q, double* F);
 // mode 0: K, 1: M, 2: D(psi)
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                     const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,

@@ -1,14 +1,17 @@
 // HIP kernels for gfx950 (MI355X / CDNA4).  Everything here is fp64, HBM-bandwidth-bound work:
 // no MFMA.  64-wide wavefronts are assumed throughout (shuffle widths, reductions).
 //
-// Kernel inventory (DESIGN.md holds the byte counts and rooflines):
-//   k_bphi, k_residual_p1          cell-parallel element evaluation, fp64 atomics
-//   k_fill_rows<MODE>              row-parallel (owner-computes) fill of the K / M / D(psi) CSR blocks,
-//                                  LDS-staged so the CSR value stream is written fully coalesced
-//   k_bspmv<MODE,LPR>              block-CSR SpMV for J=[[aK,M],[M,-D]] sharing ONE pattern (28 B/nnz
-//                                  instead of 4x12 B/nnz), also the level-0 collective-Jacobi smoother
-//   k_st_apply<MODE>, k_rap7, k_restrict, k_prolong_add, k_csr_to_stencil   7-point stencil multigrid
-//   k_multidot<NV>, k_multiaxpy<NV>, ...                                     Krylov vector kernels
+// Kernel inventory (DESIGN.md section 5 holds the byte counts, timings and rooflines):
+//   k_resid_fill_p1<WRITE_D>       fused, atomic-free residual + D(psi) fill, row-parallel through an LDS row image
+//   k_fill_rows<MODE>              row-parallel fill of the K / M / D(psi) CSR blocks (setup, pgx_jacobian_fill)
+//   k_bspmv_stream                 y = Jx for J=[[aK,M],[M,-D]] with ONE shared pattern (28 B/nnz), CSR-stream via LDS
+//   k_bspmv<MODE,LPR>              lanes-per-row variant: fallback, and the smoother/residual on general meshes
+//   k_st_smooth2<PRE|POST>         two collective-Jacobi sweeps per launch on LDS tiles (+ prolongation)
+//   k_st_resid_restrict_t          b_c = P^T(b - Jx) in one launch;  k_st_apply<MODE> plain sweeps on mid levels
+//   k_mg_tail_lds / k_mg_tail      whole V-cycle of all small levels in one launch
+//   k_rap7 / k_rap7h, k_csr_to_stencil(_h), k_restrict, k_prolong_add   hierarchy set-up and transfers
+//   k_multidot<NV>, k_axpy_dot, k_multiaxpy_scale<NV>, ...                3-pass CGS2 and Krylov vector kernels
+//   k_observables (+ P2 twins in pgx_p2.hip)
 #include "pgx_internal.h"
 #include <algorithm>
 
@@ -102,52 +105,11 @@ void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double
 }
 
 // ------------------------------------------------------------------------------------------------
-// residual F(x) (obstacle_pg.py:116-124) with the BC contract of lvpp/problem.py:54-67
-//   cell pass : F_u += a K_e u~ + M_e (psi-psi_k) - a f m_e ;  F_psi += M_e u~ - b_exp(psi)
-//               with u~ = u on free dofs, g on Dirichlet dofs (== apply_lifting with scale -1)
-//   final pass: F_psi -= b_phi ;  F_u[bc] = u[bc] - g (set_bc(F,bcs,x,-1))
+// residual F(x) (obstacle_pg.py:116-124) with the BC contract of lvpp/problem.py:54-67.  P1 uses the fused
+// row-parallel k_resid_fill_p1 below (the first version, a cell-parallel kernel with 6 fp64 atomics per cell,
+// took 0.98 ms at 2048^2 and was not reproducible run to run).  k_residual_final is the last pass of the P2 path:
+//   F_psi -= b_phi ;  F_u[bc] = u[bc] - g   (set_bc(F,bcs,x,-1))
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PGX_BLOCK) k_residual_p1(int nc, int n, const int32_t* __restrict__ cells,
-                                                           const double* __restrict__ coords,
-                                                           const uint8_t* __restrict__ mask,
-                                                           const double* __restrict__ gbc,
-                                                           const double* __restrict__ x,
-                                                           const double* __restrict__ xk, double alpha, double f,
-                                                           QuadTab q, double* __restrict__ F) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
-  int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
-  double u[3], p[3], dp[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    u[a] = mask[v[a]] ? gbc[v[a]] : x[v[a]];
-    p[a] = x[n + v[a]];
-    dp[a] = p[a] - xk[n + v[a]];
-  }
-  const P1Geom g = p1_geom(coords[2 * v[0]], coords[2 * v[0] + 1], coords[2 * v[1]], coords[2 * v[1] + 1],
-                           coords[2 * v[2]], coords[2 * v[2] + 1]);
-  double be[3] = {0, 0, 0};
-  for (int k = 0; k < q.nq; ++k) {
-    const double pq = p[0] * q.N[k][0] + p[1] * q.N[k][1] + p[2] * q.N[k][2];
-    const double we = q.w[k] * exp(pq);
-    be[0] += we * q.N[k][0];
-    be[1] += we * q.N[k][1];
-    be[2] += we * q.N[k][2];
-  }
-  // grad u~ (constant on the cell)
-  const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
-  const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
-  const double half = 0.5 * g.adet;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const double Ku = half * (g.G[a][0] * gx + g.G[a][1] * gy);
-    const double Mdp = g.adet * (q.Mref[a][0] * dp[0] + q.Mref[a][1] * dp[1] + q.Mref[a][2] * dp[2]);
-    const double Mu = g.adet * (q.Mref[a][0] * u[0] + q.Mref[a][1] * u[1] + q.Mref[a][2] * u[2]);
-    atomicAdd(&F[v[a]], alpha * Ku + Mdp - alpha * f * g.adet * q.mref[a]);
-    atomicAdd(&F[n + v[a]], Mu - g.adet * be[a]);
-  }
-}
-
 __global__ void __launch_bounds__(PGX_BLOCK) k_residual_final(int n, const uint8_t* __restrict__ mask,
                                                               const double* __restrict__ gbc,
                                                               const double* __restrict__ bphi,
@@ -160,16 +122,6 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_final(int n, const uint8
 
 void pgxk_residual_final(hipStream_t st, int n, const uint8_t* mask, const double* gbc, const double* bphi,
                          const double* x, double* F) {
-  hipLaunchKernelGGL(k_residual_final, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, mask, gbc,
-                     bphi, x, F);
-}
-
-void pgxk_residual(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const uint8_t* mask,
-                   const double* gbc, const double* bphi, const double* x, const double* xk, double alpha, double f,
-                   QuadTab q, double* F) {
-  hipMemsetAsync(F, 0, sizeof(double) * 2 * (size_t)n, st);
-  hipLaunchKernelGGL(k_residual_p1, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, n, cells,
-                     coords, mask, gbc, x, xk, alpha, f, q, F);
   hipLaunchKernelGGL(k_residual_final, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, mask, gbc,
                      bphi, x, F);
 }
@@ -1366,54 +1318,12 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
                        alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
 }
 
-// b_c = P^T (b - J x): one thread per COARSE vertex evaluates the (up to) 7 fine residuals it needs; the
-// fine residual vector never exists in memory.
-__global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict(int nx, int ny, int n, const double* __restrict__ K,
-                                                                 const double* __restrict__ M,
-                                                                 const dsten_t* __restrict__ Dh, StConst sc,
-                                                                 const uint8_t* __restrict__ mask, double alpha,
-                                                                 const double* __restrict__ xu,
-                                                                 const double* __restrict__ xp,
-                                                                 const double* __restrict__ bu,
-                                                                 const double* __restrict__ bp, int nxc, int nyc,
-                                                                 int ncv, const uint8_t* __restrict__ mask_c, int remap,
-                                                                 double* __restrict__ cbu, double* __restrict__ cbp) {
-  const int C = xcd_block(blockIdx.x, gridDim.x, remap) * blockDim.x + threadIdx.x;
-  if (C >= ncv) return;
-  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
-  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
-  const int sxc = nxc + 1, sx = nx + 1;
-  const int I = C % sxc, J = C / sxc;
-  const int off[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
-  double su = 0.0, sp = 0.0;
-#pragma unroll
-  for (int o = 0; o < 7; ++o) {
-    const int gi = 2 * I + OX[o], gj = 2 * J + OY[o];
-    if (gi < 0 || gi > nx || gj < 0 || gj > ny) continue;
-    const int v = gj * sx + gi;
-    StCoef c;
-    st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
-    double xun[7], xpn[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int nb = c.ok[s] ? v + off[s] : v;
-      xun[s] = mask[nb] ? 0.0 : xu[nb];
-      xpn[s] = xp[nb];
-    }
-    double au, ap;
-    st_rows(c, alpha, xun, xpn, au, ap);
-    if (c.rowbc) au = xu[v];
-    const double w = pw(OX[o], OY[o]);
-    su += w * (bu[v] - au);
-    sp += w * (bp[v] - ap);
-  }
-  cbu[C] = mask_c[C] ? 0.0 : su;
-  cbp[C] = sp;
-}
-// Tile version (the one used): a block owns a CXxCY tile of COARSE vertices; the fine residual is
+// b_c = P^T (b - J x) without a residual round trip through HBM.  (A first version with one thread per COARSE vertex
+// evaluating its 7 fine residuals itself measured 189 us on level 0 - strided gathers - against 121 us for separate
+// residual + restriction launches; the tile version below takes 65 us.)
+// A block owns a CXxCY tile of COARSE vertices; the fine residual is
 // evaluated ONCE per fine vertex of the (2CX+1)x(2CY+1) footprint with row-contiguous (coalesced) accesses
-// into LDS, then each thread restricts one coarse vertex from LDS.  The strided coarse-thread kernel above
-// measured 189 us on level 0 against 121 us for separate residual + restriction launches.
+// into LDS, then each thread restricts one coarse vertex from LDS.
 template <int CX, int CY>
 __global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict_t(int nx, int ny, int n, const double* __restrict__ K,
                                                                    const double* __restrict__ M,
