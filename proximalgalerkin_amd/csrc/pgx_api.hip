@@ -60,6 +60,7 @@ struct pgx_handle {
   int tail_verts = 1100;
   int spmv_stream = 1;  // PGX_SPMV_STREAM=0: 8-lanes-per-row kernel instead of the CSR-stream kernel
   int nu_coarse = 0;    // PGX_NU_COARSE: cap on the sweeps of unfused (small) levels; 0 = same as the fine levels
+  int fused_k3 = 1;     // PGX_FUSED_K3=0: two sweeps per launch even when nu is a multiple of 3
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
   int fused_min = 500000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
@@ -496,6 +497,7 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
   if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
   if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
+  if (const char* e = getenv("PGX_FUSED_K3")) h->fused_k3 = atoi(e);
   if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
@@ -856,29 +858,31 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
   double* Bp = (l == 0) ? h->tmp_p : L.xp2;
   double* ru = (l == 0) ? h->res_u : L.ru;
   double* rp = (l == 0) ? h->res_p : L.rp;
-  if (h->structured && !last && nu >= 2 && nu % 2 == 0 && h->fused_legs && L.n >= h->fused_min) {
-    // per level: nu/2 double-sweep launches | P^T(b - Jx) | nu/2 double-sweep launches (the first one also adds
-    // the prolongated coarse correction)   (pgx_kernels.hip, "Fused V-cycle legs")
+  const int Kf = (nu % 3 == 0 && h->fused_k3) ? 3 : (nu % 2 == 0 ? 2 : 0);  // sweeps per fused launch
+  if (h->structured && !last && Kf && h->fused_legs && L.n >= h->fused_min) {
+    // per level: nu/K multi-sweep launches | P^T(b - Jx) | nu/K multi-sweep launches (the first one also adds the
+    // prolongated coarse correction)   (pgx_kernels.hip, "Fused V-cycle legs", k_st_smoothK)
     GridLevel& C = h->lev[l + 1];
     const int remap = h->xcd_remap ? 1 : 0;
+    const int nl = nu / Kf;
     double *cu = Bu, *cp = Bp, *ou = Au, *op = Ap;  // current / other buffer pair
-    pgxk_st_smooth2(h->st, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
-    for (int s = 1; s < nu / 2; ++s) {
-      pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+    pgxk_st_smoothK(h->st, Kf, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
+    for (int s = 1; s < nl; ++s) {
+      pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
       std::swap(cu, ou);
       std::swap(cp, op);
     }
     pgxk_st_resid_restrict(h->st, L, h->alpha, cu, cp, bu, bp, C, remap, C.bu, C.bp);
     vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
-    pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, &C, C.xu, C.xp, bu, bp, omega, remap, ou, op);
+    pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, &C, C.xu, C.xp, bu, bp, omega, remap, ou, op);
     std::swap(cu, ou);
     std::swap(cp, op);
-    for (int s = 1; s < nu / 2; ++s) {
-      pgxk_st_smooth2(h->st, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+    for (int s = 1; s < nl; ++s) {
+      pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
       std::swap(cu, ou);
       std::swap(cp, op);
     }
-    if (cu != Au) {  // nu/2 odd launches per leg end in the scratch pair only when nu/2 is even
+    if (cu != Au) {
       hipMemcpyAsync(Au, cu, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
       hipMemcpyAsync(Ap, cp, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
     }

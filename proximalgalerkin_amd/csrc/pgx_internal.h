@@ -159,3 +159,7 @@ void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t l
                    double* partials, double* out);
 void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h,
                           double scale, double* w);
+// K (2 or 3) collective-Jacobi sweeps per launch; see k_st_smoothK
+void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
+                     const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
+                     const double* bp, double omega, int remap, double* yu, double* yp);

@@ -1318,6 +1318,117 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
                        alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
 }
 
+// K sweeps per launch (generalisation of k_st_smooth2; K=3 serves the default nu=6 with ONE pass over the level
+// per leg).  The iterate lives in an LDS ping-pong image of the tile + K-vertex halo; sweep s is evaluated on the
+// tile + (K-s) halo, the last sweep writes the tile to HBM.  Redundant work for 64x16, K=3: 1.33 / 1.16 / 1.0.
+template <int TX, int TY, int K, bool POST>
+__global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n, const double* __restrict__ Kc,
+                                                          const double* __restrict__ M,
+                                                          const dsten_t* __restrict__ Dh, StConst sc,
+                                                          const uint8_t* __restrict__ mask, double alpha,
+                                                          const double* __restrict__ xu, const double* __restrict__ xp,
+                                                          const double* __restrict__ cu, const double* __restrict__ cp,
+                                                          int nxc, const double* __restrict__ bu,
+                                                          const double* __restrict__ bp, double omega, int remap,
+                                                          double* __restrict__ yu, double* __restrict__ yp) {
+  constexpr int W0 = TX + 2 * K, H0 = TY + 2 * K;
+  __shared__ double su_[2][W0 * H0], sp_[2][W0 * H0];
+  __shared__ uint8_t smk[W0 * H0];
+  const int sx = nx + 1;
+  const int ntx = (nx + TX) / TX;
+  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
+  const int i0 = (b % ntx) * TX - K, j0 = (b / ntx) * TY - K;  // origin of the halo image
+  const int tid = threadIdx.x;
+  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+  for (int p = tid; p < W0 * H0; p += PGX_BLOCK) {
+    const int gi = i0 + p % W0, gj = j0 + p / W0;
+    const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+    const int v = gj * sx + gi;
+    smk[p] = in ? mask[v] : 1;
+    if (POST) {
+      double a = 0.0, c2 = 0.0;
+      if (in) {
+        a = xu[v];
+        c2 = xp[v];
+        if (cu) {
+          const int sxc = nxc + 1;
+          const int ic = gi >> 1, jc = gj >> 1;
+          const int c0 = jc * sxc + ic, c1 = (jc + (gj & 1)) * sxc + (ic + (gi & 1));
+          a += 0.5 * (cu[c0] + cu[c1]);
+          c2 += 0.5 * (cp[c0] + cp[c1]);
+        }
+      }
+      su_[0][p] = a;
+      sp_[0][p] = c2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 1; s <= K; ++s) {
+    const int wr = W0 - 2 * s, hr = H0 - 2 * s;  // region of this sweep, offset s inside the image
+    const double* srcu = su_[(s - 1) & 1];
+    const double* srcp = sp_[(s - 1) & 1];
+    double* dstu = su_[s & 1];
+    double* dstp = sp_[s & 1];
+    for (int p = tid; p < wr * hr; p += PGX_BLOCK) {
+      const int li = s + p % wr, lj = s + p / wr;
+      const int gi = i0 + li, gj = j0 + lj;
+      const int q0 = lj * W0 + li;
+      double ou = 0.0, op = 0.0;
+      const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+      if (in) {
+        const int v = gj * sx + gi;
+        StCoef c;
+        st_load_coef(v, gi, gj, nx, ny, n, Kc, M, Dh, sc, mask, c);
+        double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+        if (POST || s > 1) {
+          double xun[7], xpn[7];
+#pragma unroll
+          for (int o = 0; o < 7; ++o) {
+            const int q = (lj + OY[o]) * W0 + (li + OX[o]);
+            xun[o] = smk[q] ? 0.0 : srcu[q];
+            xpn[o] = srcp[q];
+          }
+          st_rows(c, alpha, xun, xpn, au, ap);
+          xur = srcu[q0];
+          xpr = srcp[q0];
+        }
+        st_jacobi(c, alpha, omega, au, ap, xur, xpr, bu[v], bp[v], ou, op);
+        if (s == K) {
+          yu[v] = ou;
+          yp[v] = op;
+        }
+      }
+      if (s < K) {
+        dstu[q0] = ou;
+        dstp[q0] = op;
+      }
+    }
+    if (s < K) __syncthreads();
+  }
+}
+
+// post=0: S^K(0);  post=1: S^K((xu,xp) + P (cu,cp)) (cu may be null)   -- out of place; K in {2,3}
+void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
+                     const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
+                     const double* bp, double omega, int remap, double* yu, double* yp) {
+  if (K == 2) {
+    pgxk_st_smooth2(st, post, L, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    return;
+  }
+  constexpr int TX = 64, TY = 16;
+  const int ntx = (L.nx + TX) / TX, nty = (L.ny + TY) / TY;
+  dim3 grid(ntx * nty), block(PGX_BLOCK);
+  const StConst sc = make_stconst(L);
+  if (post)
+    hipLaunchKernelGGL((k_st_smoothK<TX, TY, 3, true>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
+                       alpha, xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
+  else
+    hipLaunchKernelGGL((k_st_smoothK<TX, TY, 3, false>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc,
+                       L.mask, alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
+}
+
 // b_c = P^T (b - J x) without a residual round trip through HBM.  (A first version with one thread per COARSE vertex
 // evaluating its 7 fine residuals itself measured 189 us on level 0 - strided gathers - against 121 us for separate
 // residual + restriction launches; the tile version below takes 65 us.)
