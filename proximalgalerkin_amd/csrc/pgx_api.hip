@@ -1121,6 +1121,7 @@ extern "C" int pgx_jacobian_fill(pgx_handle* h, const double* x) {
   }
   jacobian_dev(h, xd);
   HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipGetLastError());
   return PGX_OK;
 }
 
@@ -1289,6 +1290,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   }
   if (rsn > 0) HIPCHK(hipMemcpyAsync(h->x, h->xw, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
+  HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the solve must not pass silently
   if (h->prof) {
     hipEventRecord(w1, h->st);
     hipEventSynchronize(w1);

@@ -17,6 +17,16 @@
 
 #define WAVE 64
 
+// hipFuncSetAttribute is per device: remember, per (kernel slot, device), whether the dynamic-LDS limit was raised
+static bool first_use_on_device(int slot) {
+  static bool done[4][64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (done[slot][dev]) return false;
+  done[slot][dev] = true;
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
@@ -442,11 +452,8 @@ void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
                        const double* xu, const double* xp, int remap, double* yu, double* yp) {
   const int cap = (int)(fill_lds_bytes / sizeof(double));
-  static bool attr_set = false;
-  if (!attr_set) {  // P2 rows (up to 19 nnz) need more than the default 64 KB of dynamic LDS
+  if (first_use_on_device(0))  // P2 rows (up to 19 nnz) need more than the default 64 KB of dynamic LDS
     hipFuncSetAttribute((const void*)k_bspmv_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_bspmv_stream, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK),
                      2 * fill_lds_bytes, st, n, cap, rowptr, colm, K, M, D, alpha, mask, xu, xp, remap, yu, yp);
 }
@@ -754,11 +761,8 @@ void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t l
   size_t nchunks = (len + PGX_BLOCK - 1) / PGX_BLOCK;
   const unsigned nb = (unsigned)std::min<size_t>(nchunks, 4096);  // blocks loop over chunks: 8x fewer partials at 2048^2
   const size_t lds = ((size_t)(nv + 1) * PGX_BLOCK + nv) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (first_use_on_device(1))
     hipFuncSetAttribute((const void*)k_axpy_dot, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_axpy_dot, dim3(nb), dim3(PGX_BLOCK), lds, st, len, nv, V, ldv, h1, w, partials);
   hipLaunchKernelGGL(k_reduce_rows, dim3(nv + 1), dim3(PGX_BLOCK), 0, st, (int)nb, partials, out);
 }
@@ -1808,11 +1812,8 @@ void pgxk_mg_tail(hipStream_t st, const TailArgs& A) {
   size_t total = 0;
   for (int l = 0; l < A.nlev; ++l) total += (size_t)8 * A.L[l].n * sizeof(double);
   if (A.L[0].n <= 1536 && total <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_device(2))
       hipFuncSetAttribute((const void*)k_mg_tail_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
     hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(512), total, st, A);
   } else {
     hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, st, A);
