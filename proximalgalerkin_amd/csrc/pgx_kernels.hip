@@ -1173,6 +1173,22 @@ __device__ __forceinline__ void st_rows(const StCoef& c, double alpha, const dou
   }
 }
 
+// LDS-image variants for the fused sweep kernels: no per-link validity tests.  Out-of-grid halo entries of the image
+// are 0 and Dirichlet entries of u are stored as 0 (pre-masked), and every link that leaves the grid has a zero
+// coefficient (interior constants only apply to interior vertices), so the plain 7-term sums are exact.
+__device__ __forceinline__ void st_rows_img(const StCoef& c, double alpha, const double* __restrict__ iu,
+                                            const double* __restrict__ ip, int q0, int W, double& au, double& ap) {
+  const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+  au = 0.0;
+  ap = 0.0;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const double xu = iu[q0 + off[s]], xp = ip[q0 + off[s]];
+    au += alpha * c.kv[s] * xu + c.mv[s] * xp;
+    ap += c.mv[s] * xu - c.dv[s] * xp;
+  }
+}
+
 __device__ __forceinline__ void st_jacobi(const StCoef& c, double alpha, double omega, double au, double ap,
                                           double xur, double xpr, double buv, double bpv, double& yu, double& yp) {
   if (c.rowbc) au = xur;
@@ -1210,20 +1226,16 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
   constexpr int W2 = TX + 4, H2 = TY + 4, W1 = TX + 2, H1 = TY + 2;
   __shared__ double s0u[POST ? W2 * H2 : 1], s0p[POST ? W2 * H2 : 1];
   __shared__ double s1u[W1 * H1], s1p[W1 * H1];
-  __shared__ uint8_t smk[W2 * H2];
   const int sx = nx + 1;
   const int ntx = (nx + TX) / TX;  // ceil((nx+1)/TX)
   const int b = xcd_block(blockIdx.x, gridDim.x, remap);
   const int i0 = (b % ntx) * TX, j0 = (b / ntx) * TY;
   const int tid = threadIdx.x;
-  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
-  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
-  // phase 0: Dirichlet mask (and, POST, the corrected iterate x + P x_c) on the tile + 2-halo
-  for (int p = tid; p < W2 * H2; p += PGX_BLOCK) {
+  // phase 0 (POST): the corrected iterate x + P x_c on the tile + 2-halo
+  for (int p = tid; POST && p < W2 * H2; p += PGX_BLOCK) {
     const int gi = i0 - 2 + p % W2, gj = j0 - 2 + p / W2;
     const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
     const int v = gj * sx + gi;
-    smk[p] = in ? mask[v] : 1;
     if (POST) {
       double a = 0.0, c2 = 0.0;
       if (in) {
@@ -1237,7 +1249,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
           c2 += 0.5 * (cp[c0] + cp[c1]);
         }
       }
-      s0u[p] = a;
+      s0u[p] = (in && mask[v]) ? 0.0 : a;  // pre-masked image: Dirichlet entries of u read as 0 by neighbours
       s0p[p] = c2;
     }
   }
@@ -1253,19 +1265,13 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
       st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
       double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
       if (POST) {
-        double xun[7], xpn[7];
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-          const int q = (lj + 1 + OY[s]) * W2 + (li + 1 + OX[s]);
-          xun[s] = smk[q] ? 0.0 : s0u[q];
-          xpn[s] = s0p[q];
-        }
-        st_rows(c, alpha, xun, xpn, au, ap);
         const int q0 = (lj + 1) * W2 + (li + 1);
+        st_rows_img(c, alpha, s0u, s0p, q0, W2, au, ap);
         xur = s0u[q0];
         xpr = s0p[q0];
       }
       st_jacobi(c, alpha, omega, au, ap, xur, xpr, bu[v], bp[v], r1u, r1p);
+      if (c.rowbc) r1u = 0.0;  // pre-masked image (the bc row's own update never reads it: yu = bu)
     }
     s1u[p] = r1u;
     s1p[p] = r1p;
@@ -1279,17 +1285,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
     const int v = gj * sx + gi;
     StCoef c;
     st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
-    double xun[7], xpn[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int q1 = (lj + 1 + OY[s]) * W1 + (li + 1 + OX[s]);
-      const int q2 = (lj + 2 + OY[s]) * W2 + (li + 2 + OX[s]);
-      xun[s] = smk[q2] ? 0.0 : s1u[q1];
-      xpn[s] = s1p[q1];
-    }
     double au, ap, ou, op;
-    st_rows(c, alpha, xun, xpn, au, ap);
     const int q0 = (lj + 1) * W1 + (li + 1);
+    st_rows_img(c, alpha, s1u, s1p, q0, W1, au, ap);
     st_jacobi(c, alpha, omega, au, ap, s1u[q0], s1p[q0], bu[v], bp[v], ou, op);
     yu[v] = ou;
     yp[v] = op;
@@ -1337,19 +1335,15 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
                                                           double* __restrict__ yu, double* __restrict__ yp) {
   constexpr int W0 = TX + 2 * K, H0 = TY + 2 * K;
   __shared__ double su_[2][W0 * H0], sp_[2][W0 * H0];
-  __shared__ uint8_t smk[W0 * H0];
   const int sx = nx + 1;
   const int ntx = (nx + TX) / TX;
   const int b = xcd_block(blockIdx.x, gridDim.x, remap);
   const int i0 = (b % ntx) * TX - K, j0 = (b / ntx) * TY - K;  // origin of the halo image
   const int tid = threadIdx.x;
-  constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
-  constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
-  for (int p = tid; p < W0 * H0; p += PGX_BLOCK) {
+  for (int p = tid; POST && p < W0 * H0; p += PGX_BLOCK) {
     const int gi = i0 + p % W0, gj = j0 + p / W0;
     const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
     const int v = gj * sx + gi;
-    smk[p] = in ? mask[v] : 1;
     if (POST) {
       double a = 0.0, c2 = 0.0;
       if (in) {
@@ -1363,7 +1357,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
           c2 += 0.5 * (cp[c0] + cp[c1]);
         }
       }
-      su_[0][p] = a;
+      su_[0][p] = (in && mask[v]) ? 0.0 : a;  // pre-masked image
       sp_[0][p] = c2;
     }
   }
@@ -1387,14 +1381,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
         st_load_coef(v, gi, gj, nx, ny, n, Kc, M, Dh, sc, mask, c);
         double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
         if (POST || s > 1) {
-          double xun[7], xpn[7];
-#pragma unroll
-          for (int o = 0; o < 7; ++o) {
-            const int q = (lj + OY[o]) * W0 + (li + OX[o]);
-            xun[o] = smk[q] ? 0.0 : srcu[q];
-            xpn[o] = srcp[q];
-          }
-          st_rows(c, alpha, xun, xpn, au, ap);
+          st_rows_img(c, alpha, srcu, srcp, q0, W0, au, ap);
           xur = srcu[q0];
           xpr = srcp[q0];
         }
@@ -1403,6 +1390,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
           yu[v] = ou;
           yp[v] = op;
         }
+        if (c.rowbc) ou = 0.0;  // pre-masked image
       }
       if (s < K) {
         dstu[q0] = ou;
