@@ -427,9 +427,11 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
   double* sp = sprod + cap;
 #pragma unroll 4
   for (int k = tid; k < len; k += PGX_BLOCK) {
-    const int cm = cb[k];
+    // the CSR streams are read exactly once: non-temporal loads keep them from evicting the gathered x from L2
+    const int cm = __builtin_nontemporal_load(cb + k);
     const int c = cm & 0x7fffffff;
-    const double kv = Kb[k], mv = Mb[k], dv = Db[k];
+    const double kv = __builtin_nontemporal_load(Kb + k), mv = __builtin_nontemporal_load(Mb + k),
+                 dv = __builtin_nontemporal_load(Db + k);
     const double xuv = (cm < 0) ? 0.0 : xu[c];
     const double xpv = xp[c];
     su[k] = alpha * kv * xuv + mv * xpv;
@@ -444,8 +446,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
     ap += sp[k];
   }
   if (mask[row]) au = xu[row];
-  yu[row] = au;
-  yp[row] = ap;
+  __builtin_nontemporal_store(au, yu + row);
+  __builtin_nontemporal_store(ap, yp + row);
 }
 
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
