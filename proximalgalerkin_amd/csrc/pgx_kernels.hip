@@ -47,6 +47,13 @@ __device__ __forceinline__ int xcd_block(int b, int nb, int enable) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// non-temporal 16-B load (streamed-once data: Krylov basis slices)
+__device__ __forceinline__ double2 ldnt2(const double2* p) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d v = __builtin_nontemporal_load((const v2d*)p);
+  return make_double2(v.x, v.y);
+}
+
 // sum over the block; result valid in thread 0. `sm` must hold blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* sm) {
   v = wave_sum(v);
@@ -623,7 +630,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_multidot(size_t len2, const doubl
     const double2 wv = w[i];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const double2 a = V[v * ldv2 + i];
+      const double2 a = ldnt2(V + v * ldv2 + i);
       acc[v] += a.x * wv.x + a.y * wv.y;
     }
   }
@@ -715,7 +722,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_axpy_dot(size_t len, int nv, cons
     double wv = live ? w[i] : 0.0;
 #pragma unroll 8
     for (int v = 0; v < nv; ++v) {
-      const double a = live ? V[(size_t)v * ldv + i] : 0.0;
+      const double a = live ? __builtin_nontemporal_load(V + (size_t)v * ldv + i) : 0.0;
       sh[v * PGX_BLOCK + t] = a;
       wv -= hs[v] * a;
     }
@@ -781,7 +788,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_multiaxpy_scale(size_t len2, cons
     double2 wv = w[i];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const double2 a = V[v * ldv2 + i];
+      const double2 a = ldnt2(V + v * ldv2 + i);
       wv.x -= hv[v] * a.x;
       wv.y -= hv[v] * a.y;
     }
