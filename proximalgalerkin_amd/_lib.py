@@ -11,7 +11,9 @@ import pathlib
 import numpy as np
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libpgx.so"
+import os as _os
+
+LIB_PATH = pathlib.Path(_os.environ.get("PGX_LIB", _HERE / "libpgx.so"))  # PGX_LIB: A/B builds of the same library
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

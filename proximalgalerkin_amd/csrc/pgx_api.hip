@@ -62,7 +62,7 @@ struct pgx_handle {
   int nu_coarse = 0;    // PGX_NU_COARSE: cap on the sweeps of unfused (small) levels; 0 = same as the fine levels
   int fused_k3 = 1;     // PGX_FUSED_K3=0: two sweeps per launch even when nu is a multiple of 3
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
-  int fused_min = 500000;  // fused legs only pay on levels large enough to hide their 3-phase latency
+  int fused_min = 60000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
   // observables
   double *obs_partials = nullptr, *d_out6 = nullptr;

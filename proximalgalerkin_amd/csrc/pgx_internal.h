@@ -12,6 +12,12 @@ typedef double dsten_t;
 
 #define PGX_MAX_NQ 16
 #define PGX_BLOCK 256
+#ifndef PGX_TILE_X
+#define PGX_TILE_X 32  // tile of the fused multi-sweep smoothers (vertices). Measured ms per 2048^2 solve: 64x16 611,
+                       // 32x16 564, 16x32 575, 64x8 582, 32x12 583, 32x24 586, 16x16 595, 32x8 597, 48x16 602, 128x8 693:
+                       // the kernels are latency-bound, so LDS footprint (occupancy) beats halo redundancy
+#define PGX_TILE_Y 16
+#endif
 
 // Quadrature + P1 reference-element tables, passed BY VALUE as a kernel argument: they land in the
 // kernarg segment and are read with scalar loads (wave-uniform), no constant-memory symbol to manage.
