@@ -81,8 +81,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", dest="n", type=int, default=2048, help="cells per side (BASELINE config: 2048); not --n: that
-                    is an ambiguous prefix of torch.distributed.run's own options")
+    # not "--n": that is an ambiguous prefix of torch.distributed.run's own options
+    ap.add_argument("--cells", dest="n", type=int, default=2048, help="cells per side (BASELINE config: 2048)")
     ap.add_argument("--settings", choices=["A", "B"], default="B")
     ap.add_argument("--degree", type=int, choices=[1, 2], default=1, help="Lagrange degree (obstacle_pg.py -p)")
     ap.add_argument("--cpu-n", type=int, default=384, help="mesh size of the bounded CPU-baseline sample")
