@@ -38,3 +38,24 @@ def test_two_rank_gloo_aggregation():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == (1.5, 45, 16)  # max time, summed Newton and proximal iteration counts
+
+
+def test_bench_cli_parses_and_flags_survive_torchrun_abbreviation_rules():
+    """bench.py must import and parse; none of its long options may be an ambiguous PREFIX of a torch.distributed.run
+    option (argparse abbreviation matching made `--n` fail under the launcher)."""
+    import pathlib
+    import re
+    import subprocess
+    import sys
+
+    from torch.distributed.run import get_args_parser
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ours = set(re.findall(r"--[a-z][a-z0-9-]*", out.stdout)) - {"--help"}
+    assert {"--gpus", "--steps", "--warmup"} <= ours
+    theirs = [s for a in get_args_parser()._actions for s in a.option_strings if s.startswith("--")]
+    for o in ours:
+        clashes = [t for t in theirs if t.startswith(o)]
+        assert not clashes, (o, clashes)
