@@ -97,11 +97,18 @@ def main():
     import torch
 
     dist = None
+    # test hooks (a 1-GPU box cannot host two NCCL ranks): BENCH_DIST_BACKEND=gloo, BENCH_FORCE_DEVICE=0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
 
@@ -149,7 +156,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        dt, newton_total, outer_total = reduce_over_ranks(dist, dt, newton_total, outer_total, "cuda")
+        dt, newton_total, outer_total = reduce_over_ranks(dist, dt, newton_total, outer_total,
+                                                          "cuda" if backend == "nccl" else "cpu")
     lin_its = problem.solver.getLinearSolveIterations()
 
     # ---- roofline of the dominant kernel (k_bspmv): HIP events on the library's own stream ----
