@@ -170,7 +170,8 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "proximal-Newton iterations/sec, 2048^2 P1 obstacle (LVPP Newton inner loop)",
+            # BASELINE.json's metric is quoted on 2048^2 P1; other --cells/--degree runs say what they measured
+            "metric": f"proximal-Newton iterations/sec, {N}^2 P{args.degree} obstacle (LVPP Newton inner loop)",
             "value": newton_total / dt,
             "unit": "Newton iterations/s",
             "n_gpus": world,

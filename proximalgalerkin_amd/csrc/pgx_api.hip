@@ -54,6 +54,7 @@ struct pgx_handle {
   // multigrid
   std::vector<GridLevel> lev;
   double *tmp_u = nullptr, *tmp_p = nullptr, *res_u = nullptr, *res_p = nullptr;  // level-0 scratch (each n)
+  double omega_now = 0.0;  // smoother damping in force for the current Newton solve (fgmres lowers it on stagnation)
   int coarse_sweeps = 4;  // prototype (oracle/krylov_proto.py): 2..60 sweeps give identical Krylov counts
   int tail_start = -1;  // first level handled by the fused k_mg_tail launch (-1: none)
   int xcd_remap = 2;    // bit 1 of the `first` kernel argument; PGX_XCD_REMAP=0 disables (A/B: +1..3 %)
@@ -977,6 +978,13 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
   double res = bnorm;
   double prev_cycle_res = bnorm;
   bool first_cycle = true;
+  // Smoother damping.  The default 0.8 is the fast choice while psi is smooth on the mesh scale (lambda_max of the
+  // Jacobi-scaled element matrices is 2); an overshot Newton iterate makes exp(psi) jump by orders of magnitude
+  // inside single elements, lambda_max approaches its bound 3 (dofs per triangle) and only omega < 2/3 is a
+  // convergent smoother.  FGMRES tolerates a changing preconditioner, so on stagnation (30 iterations that gain
+  // < 10x) the rest of this Newton solve runs at the unconditionally stable value.
+  const double omega_safe = 0.6;
+  double omega = (h->omega_now > 0.0) ? std::min(h->omega_now, o->mg_omega) : o->mg_omega;
   while (true) {
     double beta;
     if (first_cycle && its >= o->ksp_max_it) break;
@@ -1009,7 +1017,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       double* zj = h->Z + (size_t)j * n2;
       {
         PhaseTimer t(h, 4);
-        precond(h, vj, zj, o->mg_nu, o->mg_omega);
+        precond(h, vj, zj, o->mg_nu, omega);
       }
       {
         PhaseTimer t(h, 3);
@@ -1069,6 +1077,12 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         return PGX_OK;
       }
       if (res <= target || hn == 0.0) {
+        ++j;
+        break;
+      }
+      if (omega > omega_safe && j + 1 == std::min(m, 30) && res > 0.1 * beta) {
+        h->omega_now = omega = omega_safe;  // sticky until pgx_newton_solve returns: later iterates are rough too
+        if (o->monitor > 1) printf("      ksp stagnates: smoother damping -> %.2f for the rest of this Newton solve\n", omega);
         ++j;
         break;
       }
@@ -1235,6 +1249,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   }
   int its = 0, lin = 0, rsn = 0;
   double fnorm = 0, fnorm0 = 0, ttol = 0;
+  h->omega_now = 0.0;
   int rc = PGX_OK;
   HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   residual_dev(h, h->xw, h->F, 1);
