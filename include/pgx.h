@@ -50,6 +50,7 @@ extern "C" {
 #define PGX_ENODEV (-3)   /* no usable GPU */
 #define PGX_ENOMEM (-4)
 #define PGX_ESTATE (-5)   /* call order violated (e.g. spmv before jacobian_fill) */
+#define PGX_ECOMM (-6)    /* communicator failure / a peer rank did not arrive (text in pgx_last_error) */
 
 /* PETSc SNESConvergedReason values mirrored by pgx_newton_solve */
 #define PGX_SNES_CONVERGED_FNORM_ABS 2
@@ -150,6 +151,53 @@ int pgx_observables(pgx_handle* h, double out[6]);
  * [6] observables [7] total newton_solve wall */
 int pgx_profile_enable(pgx_handle* h, int on);
 int pgx_profile_get(pgx_handle* h, double ms[8], int reset);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sharded path: one handle per GPU, the structured mesh cut into horizontal strips of
+ * vertex rows.  Replaces what the reference inherits from DOLFINx/PETSc over MPI:
+ *   Vec.ghostUpdate(INSERT, FORWARD)   src/lvpp/problem.py:56,58,71,73  -> halo exchange of ghost vertex rows
+ *   F.ghostUpdate(ADD, REVERSE)        src/lvpp/problem.py:66           -> not needed: ghost cells are assembled
+ *                                                                          redundantly (owner computes whole rows)
+ *   comm.allreduce(scalar)             obstacle_pg.py:50 (six calls :196-201), SNES/KSP norms and dots
+ *                                                                       -> ONE packed all-reduce per use
+ * Every rank passes its LOCAL strip (owned rows + ghost rows, see pgx_partition_rows) as an ordinary structured
+ * pgx_mesh / pgx_problem; vectors crossing the ABI are local (owned + ghost entries), like DOLFINx's x.array.
+ * All calls on a sharded handle are COLLECTIVE: every rank of the communicator must make the same calls in the
+ * same order.  Iteration counts and results equal the single-handle solve (same algebra; only the summation
+ * order of dot products differs).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pgx_comm pgx_comm; /* opaque: neighbour halo exchange + all-reduce(sum) on device buffers */
+
+typedef struct pgx_partition {
+  int32_t rank, size;   /* strip index (0 = lowest rows) and number of strips */
+  int32_t global_ny;    /* cell rows of the GLOBAL mesh; must be divisible by size * 2^dist_levels */
+  int32_t dist_levels;  /* multigrid levels kept distributed (ghost depth 2^dist_levels on the fine grid);
+                           coarser levels are replicated on every rank.  0 = choose (at most 3) */
+} pgx_partition;
+
+/* Which global vertex rows the local mesh of `part->rank` must contain: rows [row0, row0+nrows), of which
+ * [own0, own0+nown) are owned (the others are ghosts).  Fills part->dist_levels when it was 0.  No GPU needed. */
+int pgx_partition_rows(pgx_partition* part, int32_t* row0, int32_t* nrows, int32_t* own0, int32_t* nown);
+
+/* RCCL transport, one process per GPU (torch.distributed launch): rank 0 creates the id, the host broadcasts
+ * the 128 bytes by any means, every rank calls init.  ncclSend/ncclRecv to the two strip neighbours over xGMI,
+ * ncclAllReduce for packed scalars - all enqueued on the handle's stream (no host synchronisation). */
+int pgx_comm_rccl_unique_id(char id[128]);
+int pgx_comm_rccl_init(const char id[128], int rank, int size, int device, pgx_comm** out);
+/* In-process transport: `size` communicators for `size` handles driven by `size` host threads of ONE process
+ * (any mix of devices, also all on one GPU).  Same call sequence as RCCL through host-synchronised device
+ * copies; used by the test-suite to run the sharded algorithm on a single-GPU box. */
+int pgx_comm_local_group(int size, pgx_comm** out /* [size] */);
+void pgx_comm_free(pgx_comm* c);
+const char* pgx_comm_last_error(void);
+
+int pgx_create_sharded(const pgx_mesh* local_mesh, const pgx_problem* local_prob, const pgx_partition* part,
+                       pgx_comm* comm, int device, pgx_handle** out);
+/* owned entries of a local vector: fields [0,n) and [n,2n) each hold owned entries at [offset, offset+count) */
+int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count);
+/* refresh the ghost entries of device `sol` and `sol_k` from their owners (after pgx_set_state / pgx_set_prev
+ * with host arrays whose ghost entries are stale) */
+int pgx_sync_ghosts(pgx_handle* h);
 
 #ifdef __cplusplus
 }

@@ -66,8 +66,18 @@ class pgx_snes_opts(C.Structure):
     ]
 
 
+class pgx_partition(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int32),
+        ("size", C.c_int32),
+        ("global_ny", C.c_int32),
+        ("dist_levels", C.c_int32),
+    ]
+
+
 # every symbol include/pgx.h declares: (name, restype, argtypes)
 _H = C.c_void_p
+_COMM = C.c_void_p
 SYMBOLS = [
     ("pgx_default_opts", None, [C.POINTER(pgx_snes_opts)]),
     ("pgx_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.c_int, C.POINTER(_H)]),
@@ -92,6 +102,18 @@ SYMBOLS = [
     ("pgx_observables", C.c_int, [_H, c_double_p]),
     ("pgx_profile_enable", C.c_int, [_H, C.c_int]),
     ("pgx_profile_get", C.c_int, [_H, c_double_p, C.c_int]),
+    # sharded path
+    ("pgx_partition_rows", C.c_int,
+     [C.POINTER(pgx_partition), c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    ("pgx_comm_rccl_unique_id", C.c_int, [C.c_char_p]),
+    ("pgx_comm_rccl_init", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_COMM)]),
+    ("pgx_comm_local_group", C.c_int, [C.c_int, C.POINTER(_COMM)]),
+    ("pgx_comm_free", None, [_COMM]),
+    ("pgx_comm_last_error", C.c_char_p, []),
+    ("pgx_create_sharded", C.c_int,
+     [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.POINTER(pgx_partition), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_owned_range", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("pgx_sync_ghosts", C.c_int, [_H]),
 ]
 
 _lib = None

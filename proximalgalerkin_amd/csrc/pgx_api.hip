@@ -8,12 +8,34 @@
 #include <vector>
 
 #include "../../include/pgx.h"
+#include "pgx_comm.h"
 #include "pgx_internal.h"
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;
+
+// Sharded path (include/pgx.h): geometry of this rank's strip on each distributed multigrid level.  Local vertex rows
+// of level l are [ghost-low: glo | owned: H | ghost-high: ghi]; g = 2^(ldist-l) is the ghost depth: glo = g (0 on rank 0),
+// ghi = g+1 (0 on the last rank, whose H includes the top row of the mesh).  Local row 0 is an even global row on every
+// level, so vertex coarsening of the local grid IS the local part of the global coarsening.
+struct DistLevel {
+  int g, glo, H, ghi;
+};
+struct Dist {
+  bool on = false;
+  pgx_comm* comm = nullptr;
+  int rank = 0, size = 1, ldist = 0, global_ny = 0;
+  std::vector<DistLevel> L;
+  GridLevel view{};  // this rank's rows of the first replicated level (pointers into that level's global arrays)
+  int view_row0 = 0, view_glo = 0, view_H = 0, view_own0 = 0;
+  double* view_S = nullptr;  // [7 * view.n] strip-shaped coarse stencils before they are merged into the global level
+  size_t own_off = 0, own_cnt = 0;  // owned entries per field on level 0: [own_off, own_off + own_cnt)
+  int cell0 = 0, ncell_own = 0;     // owned cells (row-major cell order)
+  double *sb = nullptr, *wc = nullptr;  // local scatter buffer (2n), owned-compact scratch (2*own_cnt)
+};
 
 struct pgx_handle {
   int device = 0;
+  Dist dist;
   hipStream_t st = nullptr;
   std::string err;
   int n = 0, nc = 0, nx = 0, ny = 0, nnz = 0;  // n = mesh vertices = dofs per field of the P1 space
@@ -392,6 +414,111 @@ static int detect_uniform(pgx_handle* h, GridLevel& L) {
   return PGX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// sharded path: strip partition arithmetic (no GPU needed) and the ghost-row exchange
+// ------------------------------------------------------------------------------------------------
+static int partition_resolve(pgx_partition* pt, std::string& err) {
+  if (!pt || pt->size < 1 || pt->rank < 0 || pt->rank >= pt->size || pt->global_ny < 1 || pt->dist_levels < 0) {
+    err = "pgx_partition: need 0 <= rank < size, global_ny >= 1, dist_levels >= 0";
+    return PGX_EINVAL;
+  }
+  if (pt->global_ny % pt->size) {
+    err = "pgx_partition: global_ny must be divisible by the number of strips";
+    return PGX_EINVAL;
+  }
+  const int Hh = pt->global_ny / pt->size;
+  // level l keeps Hh/2^l owned rows and 2^(ld-l) ghost rows: strips must coarsen ld times and still own g+1 = 3 rows
+  auto ok = [&](int l) { return l >= 1 && l <= 8 && Hh % (1 << l) == 0 && (Hh >> (l - 1)) >= 4; };
+  int ld = pt->dist_levels;
+  if (ld == 0) {
+    for (ld = 3; ld >= 1 && !ok(ld); --ld) {}
+    if (ld < 1) {
+      err = "pgx_partition: strips too thin to shard (need global_ny / size divisible by 2 and >= 4)";
+      return PGX_EINVAL;
+    }
+    pt->dist_levels = ld;
+  } else if (!ok(ld)) {
+    err = "pgx_partition: global_ny / size must be divisible by 2^dist_levels and leave >= 4 rows on the last distributed level";
+    return PGX_EINVAL;
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_partition_rows(pgx_partition* pt, int32_t* row0, int32_t* nrows, int32_t* own0, int32_t* nown) {
+  std::string err;
+  const int rc = partition_resolve(pt, err);
+  if (rc) {
+    g_create_error = err;
+    return rc;
+  }
+  const int Hh = pt->global_ny / pt->size, g0 = 1 << pt->dist_levels;
+  const int r0 = pt->rank * Hh - (pt->rank > 0 ? g0 : 0);
+  const int r1 = (pt->rank + 1 < pt->size) ? (pt->rank + 1) * Hh + g0 : pt->global_ny;  // last local vertex row
+  if (row0) *row0 = r0;
+  if (nrows) *nrows = r1 - r0 + 1;
+  if (own0) *own0 = pt->rank * Hh;
+  if (nown) *nown = Hh + (pt->rank + 1 == pt->size ? 1 : 0);
+  return PGX_OK;
+}
+
+// refresh every ghost row of a (u, psi) pair on distributed level l from the owning neighbours
+static int halo_level(pgx_handle* h, int l, double* fu, double* fp) {
+  const DistLevel& d = h->dist.L[l];
+  const size_t sx = (size_t)h->lev[l].nx + 1;
+  double* f[2] = {fu, fp};
+  const int rc = h->dist.comm->halo(h->st, f, 2, d.glo * sx, (d.g + 1) * sx, 0, d.g * sx, (d.glo + d.H - d.g) * sx,
+                                    d.g * sx, (d.glo + d.H) * sx, (d.g + 1) * sx);
+  if (rc) h->err = h->dist.comm->err;
+  return rc;
+}
+static int allreduce_dev(pgx_handle* h, double* dev, size_t n) {
+  const int rc = h->dist.comm->allreduce(h->st, dev, n);
+  if (rc) h->err = h->dist.comm->err;
+  return rc;
+}
+
+// fused tail: every level from `first` on with at most PGX_TAIL_VERTS vertices (and at most PGX_TAIL_MAX of them)
+static void setup_tail(pgx_handle* h, int first) {
+  const int nl = (int)h->lev.size();
+  {  // a coarsest grid that could not be coarsened to a handful of vertices (odd cell counts) gets a sweep
+     // count that grows with its size: Jacobi is then a poor but non-trivial coarse solver
+    const GridLevel& Lc = h->lev.back();
+    if (nl > 1 && Lc.n > 100 && !getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = std::min(400, 4 * std::max(Lc.nx, Lc.ny));
+  }
+  for (int l = std::max(first, 1); l < nl; ++l)
+    if (h->lev[l].n <= h->tail_verts && nl - l <= PGX_TAIL_MAX) {
+      h->tail_start = l;
+      break;
+    }
+  if (h->tail_start > 0) {
+    h->tail.nlev = nl - h->tail_start;
+    for (int l = h->tail_start; l < nl; ++l) {
+      const GridLevel& L = h->lev[l];
+      TailLevel& T = h->tail.L[l - h->tail_start];
+      T.nx = L.nx;
+      T.ny = L.ny;
+      T.n = L.n;
+      T.K = L.K;
+      T.M = L.M;
+      T.Dh = L.Dh;
+      for (int s = 0; s < 7; ++s) {
+        T.sc.K[s] = L.Kc[s];
+        T.sc.M[s] = L.Mc[s];
+      }
+      T.sc.uniform = L.uniform;
+      T.mask = L.mask;
+      T.xu = L.xu;
+      T.xp = L.xp;
+      T.xu2 = L.xu2;
+      T.xp2 = L.xp2;
+      T.bu = L.bu;
+      T.bp = L.bp;
+      T.ru = L.ru;
+      T.rp = L.rp;
+    }
+  }
+}
+
 static int build_multigrid(pgx_handle* h) {
   GridLevel L0{};
   L0.nx = h->nx;
@@ -435,51 +562,155 @@ static int build_multigrid(pgx_handle* h) {
     if (rc) return rc;
     h->lev.push_back(L);
   }
-  // fused tail: every level with at most PGX_TAIL_VERTS vertices (and at most PGX_TAIL_MAX of them)
-  const int nl = (int)h->lev.size();
-  {  // a coarsest grid that could not be coarsened to a handful of vertices (odd cell counts) gets a sweep
-     // count that grows with its size: Jacobi is then a poor but non-trivial coarse solver
-    const GridLevel& Lc = h->lev.back();
-    if (nl > 1 && Lc.n > 100 && !getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = std::min(400, 4 * std::max(Lc.nx, Lc.ny));
+  setup_tail(h, 1);
+  HIPCHK(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+
+// all solver-side arrays of one stencil level (K, M are filled by the caller)
+static int alloc_level(pgx_handle* h, GridLevel& L, bool contiguous_rhs) {
+  DALLOC(L.K, (size_t)7 * L.n);
+  DALLOC(L.M, (size_t)7 * L.n);
+  DALLOC(L.Dh, (size_t)4 * L.n);
+  DALLOC(L.mask, L.n);
+  DALLOC(L.xu, L.n);
+  DALLOC(L.xp, L.n);
+  DALLOC(L.xu2, L.n);
+  DALLOC(L.xp2, L.n);
+  if (contiguous_rhs) {  // (bu | bp) in one block: one memset + one all-reduce for the pair
+    DALLOC(L.bu, (size_t)2 * L.n);
+    L.bp = L.bu + L.n;
+  } else {
+    DALLOC(L.bu, L.n);
+    DALLOC(L.bp, L.n);
   }
-  for (int l = 1; l < nl; ++l)
-    if (h->lev[l].n <= h->tail_verts && nl - l <= PGX_TAIL_MAX) {
-      h->tail_start = l;
-      break;
-    }
-  if (h->tail_start > 0) {
-    h->tail.nlev = nl - h->tail_start;
-    for (int l = h->tail_start; l < nl; ++l) {
-      const GridLevel& L = h->lev[l];
-      TailLevel& T = h->tail.L[l - h->tail_start];
-      T.nx = L.nx;
-      T.ny = L.ny;
-      T.n = L.n;
-      T.K = L.K;
-      T.M = L.M;
-      T.Dh = L.Dh;
-      for (int s = 0; s < 7; ++s) {
-        T.sc.K[s] = L.Kc[s];
-        T.sc.M[s] = L.Mc[s];
-      }
-      T.sc.uniform = L.uniform;
-      T.mask = L.mask;
-      T.xu = L.xu;
-      T.xp = L.xp;
-      T.xu2 = L.xu2;
-      T.xp2 = L.xp2;
-      T.bu = L.bu;
-      T.bp = L.bp;
-      T.ru = L.ru;
-      T.rp = L.rp;
-    }
+  DALLOC(L.ru, L.n);
+  DALLOC(L.rp, L.n);
+  return PGX_OK;
+}
+
+// Sharded hierarchy: levels [0, ldist) are this rank's strips (ghost depth 2^(ldist-l)); level ldist and below are the
+// GLOBAL grids, replicated on every rank.  Galerkin coarsening of a strip needs no communication: a coarse stencil at
+// ghost depth d uses fine stencils up to depth 2d+1, so "valid up to depth g-1" is inherited from level to level.  Only
+// the step onto the first replicated level merges the ranks' rows (owned rows, zeros elsewhere, one all-reduce).
+static int build_multigrid_dist(pgx_handle* h) {
+  Dist& D = h->dist;
+  const int ld = D.ldist;
+  GridLevel L0{};
+  L0.nx = h->nx;
+  L0.ny = h->ny;
+  L0.n = h->n;
+  L0.mask = h->mask;
+  h->lev.push_back(L0);
+  DALLOC(h->lev[0].K, (size_t)7 * h->n);
+  DALLOC(h->lev[0].M, (size_t)7 * h->n);
+  DALLOC(h->lev[0].Dh, (size_t)4 * h->n);
+  pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Kv, h->lev[0].K);
+  pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Mv, h->lev[0].M);
+  int rc = detect_uniform(h, h->lev[0]);
+  if (rc) return rc;
+  for (int l = 1; l < ld; ++l) {
+    const GridLevel Fl = h->lev.back();
+    GridLevel L{};
+    L.nx = Fl.nx / 2;
+    L.ny = Fl.ny / 2;
+    L.n = (L.nx + 1) * (L.ny + 1);
+    rc = alloc_level(h, L, false);
+    if (rc) return rc;
+    pgxk_coarse_mask(h->st, L, L.mask, Fl);
+    pgxk_rap7(h->st, Fl, Fl.K, L, L.K);
+    pgxk_rap7(h->st, Fl, Fl.M, L, L.M);
+    rc = detect_uniform(h, L);
+    if (rc) return rc;
+    h->lev.push_back(L);
   }
+  // first replicated level: the global grid, and this rank's view of it
+  const GridLevel Fl = h->lev.back();
+  GridLevel G{};
+  G.nx = h->nx >> ld;
+  G.ny = D.global_ny >> ld;
+  G.n = (G.nx + 1) * (G.ny + 1);
+  rc = alloc_level(h, G, true);
+  if (rc) return rc;
+  const int sxc = G.nx + 1;
+  const int Hh = D.global_ny / D.size;
+  D.view_own0 = (D.rank * Hh) >> ld;
+  D.view_glo = D.rank > 0 ? 1 : 0;
+  D.view_H = (Hh >> ld) + (D.rank + 1 == D.size ? 1 : 0);
+  D.view_row0 = D.view_own0 - D.view_glo;
+  GridLevel& V = D.view;
+  V = G;
+  V.ny = Fl.ny / 2;
+  V.n = sxc * (V.ny + 1);
+  if (V.nx * 2 != Fl.nx || D.view_row0 + V.ny > G.ny || V.ny + 1 != D.view_glo + D.view_H + (D.rank + 1 < D.size ? 2 : 0)) {
+    h->err = "sharded hierarchy: strip view of the first replicated level is inconsistent";
+    return PGX_EINVAL;
+  }
+  const size_t voff = (size_t)D.view_row0 * sxc;
+  V.mask = G.mask + voff;
+  V.xu = G.xu + voff;
+  V.xp = G.xp + voff;
+  V.bu = G.bu + voff;
+  V.bp = G.bp + voff;
+  V.K = V.M = nullptr;  // a view carries vectors and the mask only
+  V.Dh = nullptr;
+  DALLOC(D.view_S, (size_t)7 * V.n);
+  for (int which = 0; which < 2; ++which) {
+    pgxk_rap7(h->st, Fl, which ? Fl.M : Fl.K, V, D.view_S);
+    double* dst = which ? G.M : G.K;
+    pgxk_view_to_global(h->st, 7, V.n, G.n, sxc, D.view_row0, D.view_own0, D.view_H, D.view_S, dst);
+    rc = allreduce_dev(h, dst, (size_t)7 * G.n);
+    if (rc) return rc;
+  }
+  {  // Dirichlet mask of the replicated level: injection on the strip, merged like the stencils (setup only)
+    uint8_t* vm = nullptr;
+    DALLOC(vm, V.n);
+    GridLevel Vm = V;
+    pgxk_coarse_mask(h->st, Vm, vm, Fl);
+    std::vector<uint8_t> hv(V.n);
+    HIPCHK(hipMemcpyAsync(hv.data(), vm, V.n, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    std::vector<double> hg(G.n, 0.0);
+    for (int J = D.view_own0; J < D.view_own0 + D.view_H; ++J)
+      for (int I = 0; I < sxc; ++I) hg[(size_t)J * sxc + I] = hv[(size_t)(J - D.view_row0) * sxc + I];
+    HIPCHK(hipMemcpyAsync(G.ru, hg.data(), sizeof(double) * G.n, hipMemcpyHostToDevice, h->st));
+    rc = allreduce_dev(h, G.ru, G.n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(hg.data(), G.ru, sizeof(double) * G.n, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    std::vector<uint8_t> gm(G.n);
+    for (int v = 0; v < G.n; ++v) gm[v] = hg[v] != 0.0;
+    HIPCHK(hipMemcpy(G.mask, gm.data(), G.n, hipMemcpyHostToDevice));
+  }
+  rc = detect_uniform(h, G);
+  if (rc) return rc;
+  h->lev.push_back(G);
+  int nx = G.nx, ny = G.ny;
+  while (nx % 2 == 0 && ny % 2 == 0 && nx > 2 && ny > 2) {
+    nx /= 2;
+    ny /= 2;
+    GridLevel L{};
+    L.nx = nx;
+    L.ny = ny;
+    L.n = (nx + 1) * (ny + 1);
+    rc = alloc_level(h, L, false);
+    if (rc) return rc;
+    const GridLevel& Ff = h->lev.back();
+    pgxk_coarse_mask(h->st, L, L.mask, Ff);
+    pgxk_rap7(h->st, Ff, Ff.K, L, L.K);
+    pgxk_rap7(h->st, Ff, Ff.M, L, L.M);
+    rc = detect_uniform(h, L);
+    if (rc) return rc;
+    h->lev.push_back(L);
+  }
+  setup_tail(h, ld);
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, pgx_handle** out) {
+static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, const pgx_partition* part, pgx_comm* comm,
+                       pgx_handle** out) {
   if (!m || !p || !out) {
     g_create_error = "null argument";
     return PGX_EINVAL;
@@ -541,6 +772,56 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     h->structured = true;
     h->nx = m->structured_nx;
     h->ny = m->structured_ny;
+  }
+  if (part) {  // sharded: this mesh is one strip of a global structured mesh (include/pgx.h, "Sharded path")
+    pgx_partition pt = *part;
+    int32_t row0 = 0, nrows = 0, own0 = 0, nown = 0;
+    if (pgx_partition_rows(&pt, &row0, &nrows, &own0, &nown)) {
+      h->err = g_create_error;
+      return fail(PGX_EINVAL);
+    }
+    if (!comm || comm->rank != pt.rank || comm->size != pt.size) {
+      h->err = "pgx_create_sharded: communicator rank/size differ from the partition's";
+      return fail(PGX_EINVAL);
+    }
+    if (!h->structured || p->degree != 1) {
+      h->err = "pgx_create_sharded: only structured P1 meshes are sharded (strip decomposition)";
+      return fail(PGX_EINVAL);
+    }
+    if (h->ny + 1 != nrows || h->nx % (1 << pt.dist_levels)) {
+      h->err = "pgx_create_sharded: local mesh must hold exactly the vertex rows of pgx_partition_rows, and nx must be "
+               "divisible by 2^dist_levels";
+      return fail(PGX_EINVAL);
+    }
+    for (int c = 0; c < nc; ++c) {  // owned cells are addressed as a contiguous range: cells must be ordered by rows
+      const int v0 = std::min(m->cells[3 * c], std::min(m->cells[3 * c + 1], m->cells[3 * c + 2]));
+      if (v0 / (h->nx + 1) != c / (2 * h->nx)) {
+        h->err = "pgx_create_sharded: cells must be ordered row by row (cell 2*(j*nx+i)+t)";
+        return fail(PGX_EINVAL);
+      }
+    }
+    Dist& D = h->dist;
+    D.on = true;
+    D.comm = comm;
+    D.rank = pt.rank;
+    D.size = pt.size;
+    D.ldist = pt.dist_levels;
+    D.global_ny = pt.global_ny;
+    const int Hh = pt.global_ny / pt.size;
+    for (int l = 0; l < D.ldist; ++l) {
+      DistLevel d;
+      d.g = 1 << (D.ldist - l);
+      d.glo = pt.rank > 0 ? d.g : 0;
+      d.H = (Hh >> l) + (pt.rank + 1 == pt.size ? 1 : 0);
+      d.ghi = pt.rank + 1 < pt.size ? d.g + 1 : 0;
+      D.L.push_back(d);
+    }
+    const size_t sx = (size_t)h->nx + 1;
+    D.own_off = D.L[0].glo * sx;
+    D.own_cnt = D.L[0].H * sx;
+    const int cell_rows = (pt.rank + 1 == pt.size) ? D.L[0].H - 1 : D.L[0].H;
+    D.cell0 = 2 * h->nx * D.L[0].glo;
+    D.ncell_own = 2 * h->nx * cell_rows;
   }
   // quadrature tables
   h->q.nq = p->nq;
@@ -689,7 +970,11 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
     h->obs_blocks = pgxk_observables_blocks(nc);
     DALLOC(h->obs_partials, (size_t)h->obs_blocks * 6);
     DALLOC(h->d_out6, 6);
-    r = build_multigrid(h);
+    if (h->dist.on) {
+      DALLOC(h->dist.sb, n2);
+      DALLOC(h->dist.wc, 2 * h->dist.own_cnt + 2);
+    }
+    r = h->dist.on ? build_multigrid_dist(h) : build_multigrid(h);
     if (r) return r;
     HIPCHK(hipStreamSynchronize(h->st));
     return PGX_OK;
@@ -698,6 +983,18 @@ extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, p
   if (rc) return fail(rc);
   *out = h;
   return PGX_OK;
+}
+
+extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, pgx_handle** out) {
+  return create_impl(m, p, device, nullptr, nullptr, out);
+}
+extern "C" int pgx_create_sharded(const pgx_mesh* m, const pgx_problem* p, const pgx_partition* part, pgx_comm* comm,
+                                  int device, pgx_handle** out) {
+  if (!part || !comm) {
+    g_create_error = "pgx_create_sharded: null partition / communicator";
+    return PGX_EINVAL;
+  }
+  return create_impl(m, p, device, part, comm, out);
 }
 
 extern "C" void pgx_destroy(pgx_handle* h) {
@@ -767,6 +1064,21 @@ extern "C" int pgx_zero_state(pgx_handle* h) {
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
+extern "C" int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count) {
+  if (!h) return PGX_EINVAL;
+  if (offset) *offset = h->dist.on ? (int64_t)h->dist.own_off : 0;
+  if (count) *count = h->dist.on ? (int64_t)h->dist.own_cnt : (int64_t)h->nd;
+  return PGX_OK;
+}
+extern "C" int pgx_sync_ghosts(pgx_handle* h) {
+  NEED(h);
+  if (!h->dist.on) return PGX_OK;
+  int rc = halo_level(h, 0, h->x, h->x + h->n);
+  if (!rc) rc = halo_level(h, 0, h->xk, h->xk + h->n);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
 extern "C" int pgx_set_alpha(pgx_handle* h, double a) {
   if (!h || !(a > 0.0)) return PGX_EINVAL;
   h->alpha = a;
@@ -776,8 +1088,14 @@ extern "C" int pgx_set_alpha(pgx_handle* h, double a) {
 // ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
-static int dev_norm(pgx_handle* h, const double* v, double* out) {
-  pgxk_multidot(h->st, 2 * (size_t)h->nd, 1, v, 0, v, h->partials, h->d_small);
+// 2-norm of a device vector.  Sharded handles pass OWNED-COMPACT vectors (len = 2 * own_cnt): the squared norms of
+// the ranks are summed by one all-reduce before the square root.
+static int dev_norm(pgx_handle* h, const double* v, double* out, size_t len = 0) {
+  pgxk_multidot(h->st, len ? len : 2 * (size_t)h->nd, 1, v, 0, v, h->partials, h->d_small);
+  if (h->dist.on) {
+    const int rc = allreduce_dev(h, h->d_small, 1);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   *out = std::sqrt(h->h_small[0]);
@@ -798,7 +1116,7 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
 }
 
 // have_d: D(psi) at this x was already produced by residual_dev(..., with_d=1)
-static void jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
+static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
   if (!(have_d && h->degree == 1)) {
     PhaseTimer t(h, 1);
     if (h->degree == 2) {
@@ -815,10 +1133,22 @@ static void jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
   if (h->structured) {
     PhaseTimer t(h, 2);
     pgxk_csr_to_stencil_h(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].Dh);
-    for (size_t l = 1; l < h->lev.size(); ++l)
-      pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, h->lev[l], h->lev[l].Dh);
+    const int ld = h->dist.on ? h->dist.ldist : 0;
+    for (size_t l = 1; l < h->lev.size(); ++l) {
+      if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks
+        const Dist& D = h->dist;
+        const GridLevel& G = h->lev[l];
+        pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, D.view, D.view_S);
+        pgxk_view_to_global(h->st, 4, D.view.n, G.n, G.nx + 1, D.view_row0, D.view_own0, D.view_H, D.view_S, G.Dh);
+        const int rc = allreduce_dev(h, G.Dh, (size_t)4 * G.n);
+        if (rc) return rc;
+      } else {
+        pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, h->lev[l], h->lev[l].Dh);
+      }
+    }
   }
   h->jac_valid = true;
+  return PGX_OK;
 }
 
 // y = J x on device vectors of length 2*nd
@@ -914,6 +1244,103 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
   for (int s = 0; s < nu; ++s) sweep(0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sharded V-cycle (include/pgx.h "Sharded path").  Same sweeps, residuals and transfers as vcycle()
+// - the algebra is identical to the single-handle cycle - on strips with ghost rows.  "Validity depth" d of a vector
+// means: correct on global rows [a-d, a+H+d] of the strip [a, a+H).  A halo exchange sets d = g (all local rows);
+// K Jacobi sweeps in one launch cost K rows (each sweep reads the neighbours' previous values), the fused
+// residual+restriction needs d >= 2, x + P x_c needs d >= K for the sweeps that follow.  Exchanges are issued only
+// when the depth runs out: with ghost depth 8/4/2 on the three distributed levels and nu = 6 that is 2 + 5 + 7
+// exchanges and one all-reduce (coarse right-hand side) per cycle.
+// ------------------------------------------------------------------------------------------------
+static int vcycle_dist(pgx_handle* h, int l, double* bu, double* bp, double* outu, double* outp, int need_out, int nu,
+                       double omega) {
+  Dist& D = h->dist;
+  GridLevel& L = h->lev[l];
+  const int g = D.L[l].g;
+  const int K = (nu % 3 == 0 && g >= 3 && h->fused_k3) ? 3 : 2;
+  if (nu % K) {
+    h->err = "sharded V-cycle: mg_nu must be even (or a multiple of 3 with deep enough ghost rows)";
+    return PGX_EINVAL;
+  }
+  const int remap = h->xcd_remap ? 1 : 0;
+  const int nl = nu / K;
+  int rc = halo_level(h, l, bu, bp);  // restriction / the Krylov vector are correct on owned rows only
+  if (rc) return rc;
+  double *cu = (l == 0) ? h->tmp_u : L.xu2, *cp = (l == 0) ? h->tmp_p : L.xp2, *ou = outu, *op = outp;
+  int xv;  // validity depth of (cu, cp)
+  pgxk_st_smoothK(h->st, K, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
+  xv = g - K;  // first sweep from zero is pointwise: valid where b and the operator are (depth g-1)
+  auto more = [&](const GridLevel* C, const double* ccu, const double* ccp) -> int {
+    if (xv < K) {
+      const int r = halo_level(h, l, cu, cp);
+      if (r) return r;
+      xv = g;
+    }
+    pgxk_st_smoothK(h->st, K, 1, L, h->alpha, cu, cp, C, ccu, ccp, bu, bp, omega, remap, ou, op);
+    std::swap(cu, ou);
+    std::swap(cp, op);
+    xv -= K;
+    return PGX_OK;
+  };
+  for (int s = 1; s < nl; ++s)
+    if ((rc = more(nullptr, nullptr, nullptr))) return rc;
+  if (xv < 2) {  // P^T (b - J x) on the owned coarse rows reads the residual one row out, i.e. x two rows out
+    if ((rc = halo_level(h, l, cu, cp))) return rc;
+    xv = g;
+  }
+  const GridLevel* C;
+  if (l + 1 < D.ldist) {
+    GridLevel& Cl = h->lev[l + 1];
+    pgxk_st_resid_restrict(h->st, L, h->alpha, cu, cp, bu, bp, Cl, remap, Cl.bu, Cl.bp);
+    if ((rc = vcycle_dist(h, l + 1, Cl.bu, Cl.bp, Cl.xu, Cl.xp, D.L[l + 1].g, nu, omega))) return rc;
+    C = &Cl;
+  } else {
+    // onto the replicated level: every rank restricts into its view, clears the view's ghost rows, and the all-reduce
+    // assembles the global right-hand side (exactly one non-zero contribution per entry)
+    GridLevel& G = h->lev[l + 1];
+    const GridLevel& V = D.view;
+    const size_t sxc = (size_t)G.nx + 1;
+    if (hipMemsetAsync(G.bu, 0, sizeof(double) * 2 * (size_t)G.n, h->st) != hipSuccess) return PGX_EHIP;
+    pgxk_st_resid_restrict(h->st, L, h->alpha, cu, cp, bu, bp, V, remap, V.bu, V.bp);
+    const size_t lo = (size_t)D.view_glo * sxc, hi0 = (size_t)(D.view_glo + D.view_H) * sxc,
+                 hi = (size_t)V.n - hi0;
+    double* const halves[2] = {V.bu, V.bp};
+    for (double* b : halves) {
+      if (lo) hipMemsetAsync(b, 0, sizeof(double) * lo, h->st);
+      if (hi) hipMemsetAsync(b + hi0, 0, sizeof(double) * hi, h->st);
+    }
+    if ((rc = allreduce_dev(h, G.bu, 2 * (size_t)G.n))) return rc;
+    vcycle(h, l + 1, G.bu, G.bp, G.xu, G.xp, nu, omega);  // identical work on every rank
+    C = &V;
+  }
+  // x + P x_c is correct to depth min(xv, g): the coarse correction covers every local row
+  if ((rc = more(C, C->xu, C->xp))) return rc;
+  for (int s = 1; s < nl; ++s)
+    if ((rc = more(nullptr, nullptr, nullptr))) return rc;
+  if (xv < need_out) {
+    if ((rc = halo_level(h, l, cu, cp))) return rc;
+    xv = g;
+  }
+  if (cu != outu) {
+    hipMemcpyAsync(outu, cu, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
+    hipMemcpyAsync(outp, cp, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
+  }
+  return PGX_OK;
+}
+
+// owned entries of a local (u | psi) vector <-> owned-compact vector [u_owned | psi_owned]
+static void gather_owned(pgx_handle* h, const double* loc, double* cmp) {
+  const Dist& D = h->dist;
+  hipMemcpyAsync(cmp, loc + D.own_off, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+  hipMemcpyAsync(cmp + D.own_cnt, loc + h->n + D.own_off, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+}
+static void scatter_owned(pgx_handle* h, const double* cmp, double* loc) {
+  const Dist& D = h->dist;
+  hipMemcpyAsync(loc + D.own_off, cmp, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+  hipMemcpyAsync(loc + h->n + D.own_off, cmp + D.own_cnt, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+}
+
 // P2: two-level cycle.  Smoother = collective damped Jacobi on the P2 block CSR (k_bspmv<2>); coarse space =
 // the P1 subspace with its full multigrid hierarchy (one V-cycle); T = P1->P2 interpolation.
 static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double* outu, double* outp, int nu,
@@ -948,22 +1375,33 @@ static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double*
   }
 }
 
-static void precond(pgx_handle* h, const double* b, double* z, int nu, double omega) {
+static int precond(pgx_handle* h, const double* b, double* z, int nu, double omega) {
+  if (h->dist.on) {  // b is owned-compact, z local (owned + ghost rows, correct at least one row beyond the strip)
+    scatter_owned(h, b, h->dist.sb);
+    return vcycle_dist(h, 0, h->dist.sb, h->dist.sb + h->n, z, z + h->n, 1, nu, omega);
+  }
   if (h->degree == 2)  // P2 level: one more sweep at 0.75*omega (prototype sweep in DESIGN.md section 3); P1 levels as usual
     pcycle_p2(h, b, b + h->nd, z, z + h->nd, nu, omega);
   else
     vcycle(h, 0, b, b + h->n, z, z + h->n, nu, omega);
+  return PGX_OK;
 }
 
 // FGMRES(restart) on J dx = b, right-preconditioned by one V-cycle; CGS2 orthogonalisation with
 // batched device dot products; Givens rotations on the host (one small D2H copy + sync per iteration).
 static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts* o, int* its_out, double* relres) {
   const size_t n2 = 2 * (size_t)h->nd;
+  // Sharded: the Krylov space lives on OWNED dofs (basis vectors V_j, b, residuals are owned-compact, length nk, so the
+  // tuned vector kernels run unchanged and every dot product is "local partial + one all-reduce"); the operators work
+  // on local vectors with ghost rows (Z_j, x), with a gather after every SpMV.
+  const bool dist = h->dist.on;
+  const size_t nk = dist ? 2 * h->dist.own_cnt : n2;
+  double* const wk = dist ? h->dist.wc : h->w;
   // P2: the two-level preconditioner is weaker on the late large-alpha systems (30-60 its): use the full basis
   const int m = (h->degree == 2) ? h->restart : std::min(std::max(o->ksp_restart, 1), h->restart);
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m);
   double bnorm;
-  int rc = dev_norm(h, b, &bnorm);
+  int rc = dev_norm(h, b, &bnorm, nk);
   if (rc) return rc;
   pgxk_set(h->st, n2, 0.0, x);
   *its_out = 0;
@@ -990,14 +1428,15 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     if (first_cycle && its >= o->ksp_max_it) break;
     if (first_cycle) {
       beta = bnorm;
-      pgxk_scale_copy(h->st, n2, 1.0 / beta, b, h->V);
+      pgxk_scale_copy(h->st, nk, 1.0 / beta, b, h->V);
     } else {
       // r = b - J x
       PhaseTimer t(h, 3);
       spmv_dev(h, x, h->w);
-      pgxk_scale_copy(h->st, n2, -1.0, h->w, h->w);
-      pgxk_axpy(h->st, n2, 1.0, b, h->w);
-      rc = dev_norm(h, h->w, &beta);
+      if (dist) gather_owned(h, h->w, wk);
+      pgxk_scale_copy(h->st, nk, -1.0, wk, wk);
+      pgxk_axpy(h->st, nk, 1.0, b, wk);
+      rc = dev_norm(h, wk, &beta, nk);
       if (rc) return rc;
       res = beta;
       if (o->monitor > 1) printf("      ksp true residual after cycle: %.6e (rel %.3e)\n", beta, beta / bnorm);
@@ -1006,42 +1445,51 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       if (beta > 0.1 * prev_cycle_res && beta <= 1e-7 * bnorm) break;
       if (its >= o->ksp_max_it) break;
       prev_cycle_res = beta;
-      pgxk_scale_copy(h->st, n2, 1.0 / beta, h->w, h->V);
+      pgxk_scale_copy(h->st, nk, 1.0 / beta, wk, h->V);
     }
     first_cycle = false;
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;
     for (; j < m && its < o->ksp_max_it; ++j) {
-      double* vj = h->V + (size_t)j * n2;
+      double* vj = h->V + (size_t)j * nk;
       double* zj = h->Z + (size_t)j * n2;
       {
         PhaseTimer t(h, 4);
-        precond(h, vj, zj, o->mg_nu, omega);
+        rc = precond(h, vj, zj, o->mg_nu, omega);
+        if (rc) return rc;
       }
       {
         PhaseTimer t(h, 3);
-        spmv_dev(h, zj, h->V + (size_t)(j + 1) * n2);
+        if (dist) {
+          spmv_dev(h, zj, h->w);
+          gather_owned(h, h->w, h->V + (size_t)(j + 1) * nk);
+        } else {
+          spmv_dev(h, zj, h->V + (size_t)(j + 1) * n2);
+        }
       }
       // w = J z_j was written straight into the V_{j+1} slot.  CGS2 (classical Gram-Schmidt, always two
       // passes: one pass loses orthogonality on these ill-conditioned systems and the true residual stalls).
       // Each pass is ONE batched dot kernel [h; ww] = [V_0..V_j, w]^T w plus one batched axpy; the norm of the
       // result comes from Pythagoras on the second pass (|w''|^2 = ww' - |h2|^2, cancellation-free because
       // the second pass removes almost nothing), so no separate norm kernel.
-      double* wj = h->V + (size_t)(j + 1) * n2;
+      double* wj = h->V + (size_t)(j + 1) * nk;
       double hn = 0.0;
       {
         PhaseTimer t(h, 5);
         double* d_h1 = h->d_small;
         double* d_h2 = h->d_small + (m + 2);
         // pass 1: h1 = V^T w.  passes 2+3 fused: w' = w - V h1 and [h2; |w'|^2] in one sweep over the basis.
-        pgxk_multidot(h->st, n2, j + 1, h->V, n2, wj, h->partials, d_h1);
+        // Sharded: each batch of partial dot products is completed by ONE packed all-reduce, enqueued on the stream.
+        pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h1);
+        if (dist && (rc = allreduce_dev(h, d_h1, j + 1))) return rc;
         if (j + 1 <= 60) {
-          pgxk_axpy_dot(h->st, n2, j + 1, h->V, n2, d_h1, wj, h->partials2, d_h2);
+          pgxk_axpy_dot(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials2, d_h2);
         } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
-          pgxk_multiaxpy(h->st, n2, j + 1, h->V, n2, d_h1, wj);
-          pgxk_multidot(h->st, n2, j + 2, h->V, n2, wj, h->partials, d_h2);
+          pgxk_multiaxpy(h->st, nk, j + 1, h->V, nk, d_h1, wj);
+          pgxk_multidot(h->st, nk, j + 2, h->V, nk, wj, h->partials, d_h2);
         }
+        if (dist && (rc = allreduce_dev(h, d_h2, j + 2))) return rc;
         HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
         double hh = 0.0;
@@ -1052,7 +1500,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         }
         hn = std::sqrt(std::max(h->h_small[(m + 2) + j + 1] - hh, 0.0));
         // pass 4 fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
-        if (hn > 0.0) pgxk_multiaxpy_scale(h->st, n2, j + 1, h->V, n2, d_h2, 1.0 / hn, wj);
+        if (hn > 0.0) pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
       }
       H[(size_t)(j + 1) * m + j] = hn;
       for (int i = 0; i < j; ++i) {
@@ -1117,7 +1565,13 @@ extern "C" int pgx_residual(pgx_handle* h, const double* x, double* F, double* f
   }
   residual_dev(h, xd, h->F);
   if (fnorm) {
-    int rc = dev_norm(h, h->F, fnorm);
+    int rc;
+    if (h->dist.on) {  // collective: 2-norm over the owned entries of all ranks
+      gather_owned(h, h->F, h->dist.wc);
+      rc = dev_norm(h, h->dist.wc, fnorm, 2 * h->dist.own_cnt);
+    } else {
+      rc = dev_norm(h, h->F, fnorm);
+    }
     if (rc) return rc;
   }
   if (F) return copy_out(h, F, h->F);
@@ -1133,7 +1587,10 @@ extern "C" int pgx_jacobian_fill(pgx_handle* h, const double* x) {
     if (rc) return rc;
     xd = h->xw;
   }
-  jacobian_dev(h, xd);
+  {
+    const int rc = jacobian_dev(h, xd);
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());
   return PGX_OK;
@@ -1169,8 +1626,9 @@ extern "C" int pgx_spmv(pgx_handle* h, const double* x, double* y) {
   }
   int rc = copy_in(h, h->V, x);
   if (rc) return rc;
+  if (h->dist.on && (rc = halo_level(h, 0, h->V, h->V + h->n))) return rc;  // ghost entries from their owners
   spmv_dev(h, h->V, h->w);
-  return copy_out(h, y, h->w);
+  return copy_out(h, y, h->w);  // owned rows are J x of the GLOBAL operator; ghost rows are not meaningful
 }
 
 extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
@@ -1204,6 +1662,14 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
       pgxk_observables_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->x, h->xk, h->alpha, h->f, h->q2,
                                 h->obs_partials, h->obs_blocks);
       pgxk_observables_final(h->st, h->obs_blocks, h->obs_partials, h->d_out6);
+    } else if (h->dist.on) {
+      // owned cells only (a contiguous range in row-major cell order), raw sums, ONE packed all-reduce for the six
+      // scalars (the reference all-reduces each one separately, obstacle_pg.py:196-201), then abs / sqrt
+      const Dist& D = h->dist;
+      pgxk_observables(h->st, D.ncell_own, h->n, h->cells + 3 * (size_t)D.cell0, h->coords, h->x, h->xk, h->alpha, h->f,
+                       h->q, h->obs_partials, pgxk_observables_blocks(D.ncell_own), h->d_out6, 1);
+      const int rc = allreduce_dev(h, h->d_out6, 6);
+      if (rc) return rc;
     } else {
       pgxk_observables(h->st, h->nc, h->n, h->cells, h->coords, h->x, h->xk, h->alpha, h->f, h->q, h->obs_partials,
                        h->obs_blocks, h->d_out6);
@@ -1212,6 +1678,11 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_out6, sizeof(double) * 6, hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   for (int k = 0; k < 6; ++k) out[k] = h->h_small[k];
+  if (h->dist.on) {
+    out[1] = std::fabs(out[1]);
+    out[4] = std::sqrt(out[4]);
+    out[5] = std::sqrt(out[5]);
+  }
   return PGX_OK;
 }
 
@@ -1251,9 +1722,23 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   double fnorm = 0, fnorm0 = 0, ttol = 0;
   h->omega_now = 0.0;
   int rc = PGX_OK;
+  // Sharded: x, xw, dx, F are local vectors (owned + ghost rows); norms run on owned-compact copies (rhs doubles as the
+  // compact copy of F), and the ghost rows of the iterate are refreshed after every update, before the next assembly.
+  const bool dist = h->dist.on;
+  const size_t nk = dist ? 2 * h->dist.own_cnt : n2;
+  auto owned_norm = [&](const double* v, double* out) -> int {
+    if (!dist) return dev_norm(h, v, out);
+    gather_owned(h, v, h->dist.wc);
+    return dev_norm(h, h->dist.wc, out, nk);
+  };
   HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   residual_dev(h, h->xw, h->F, 1);
-  rc = dev_norm(h, h->F, &fnorm);
+  if (dist) {
+    gather_owned(h, h->F, h->rhs);
+    rc = dev_norm(h, h->rhs, &fnorm, nk);
+  } else {
+    rc = dev_norm(h, h->F, &fnorm);
+  }
   if (rc) return rc;
   fnorm0 = fnorm;
   if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
@@ -1267,8 +1752,9 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       rsn = PGX_SNES_DIVERGED_MAX_IT;
       break;
     }
-    jacobian_dev(h, h->xw, true);
-    pgxk_scale_copy(h->st, n2, -1.0, h->F, h->rhs);
+    rc = jacobian_dev(h, h->xw, true);
+    if (rc) return rc;
+    pgxk_scale_copy(h->st, nk, -1.0, dist ? h->rhs : h->F, h->rhs);
     int kits = 0;
     double relres = 0;
     rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
@@ -1281,8 +1767,14 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       break;
     }
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
+    if (dist && (rc = halo_level(h, 0, h->xw, h->xw + h->n))) return rc;
     residual_dev(h, h->xw, h->F, 1);
-    rc = dev_norm(h, h->F, &fnorm);
+    if (dist) {
+      gather_owned(h, h->F, h->rhs);
+      rc = dev_norm(h, h->rhs, &fnorm, nk);
+    } else {
+      rc = dev_norm(h, h->F, &fnorm);
+    }
     if (rc) return rc;
     if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
     if (!std::isfinite(fnorm)) {
@@ -1293,9 +1785,9 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
     } else {
       double snorm, xnorm;
-      rc = dev_norm(h, h->dx, &snorm);
+      rc = owned_norm(h->dx, &snorm);
       if (rc) return rc;
-      rc = dev_norm(h, h->xw, &xnorm);
+      rc = owned_norm(h->xw, &xnorm);
       if (rc) return rc;
       if (snorm < opts->snes_stol * xnorm)
         rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;

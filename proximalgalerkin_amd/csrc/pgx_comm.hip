@@ -1,0 +1,301 @@
+// Transports of the sharded path.  See pgx_comm.h and include/pgx.h ("Sharded path").
+//
+//  * RCCL: what a torch.distributed launch uses (one process per GPU).  The halo exchange is one grouped
+//    ncclSend/ncclRecv batch to the two strip neighbours (point-to-point over the direct xGMI link; messages are
+//    16 KB .. 300 KB, i.e. latency-bound), the reductions are ncclAllReduce on a few doubles.  Everything is enqueued
+//    on the handle's stream: no host synchronisation is added to the solver.  librccl is opened with dlopen so that
+//    libpgx.so itself has no link-time dependency on it (single-GPU users never touch it).
+//  * local group: N communicators for N host threads of one process; same call sequence through host-synchronised
+//    device copies.  Lets the complete sharded algorithm run on a one-GPU box (tests/test_gpu_sharded.py).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/pgx.h"
+#include "pgx_comm.h"
+
+static thread_local std::string g_comm_error;
+extern "C" const char* pgx_comm_last_error(void) { return g_comm_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// RCCL
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // prefer a copy that is already in the process (torch ships its own librccl.so)
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* nm : names)
+      if (!api.lib) api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* nm : names)
+      if (!api.lib) api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) {
+      api.err = std::string("cannot open librccl: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char* s) {
+      void* p = dlsym(api.lib, s);
+      if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + s;
+      return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  });
+  return &api;
+}
+
+struct RcclComm : pgx_comm {
+  RcclApi* a = nullptr;
+  ncclComm_t c = nullptr;
+  int device = 0;
+  ~RcclComm() override {
+    if (c) a->CommDestroy(c);
+  }
+  int fail(const char* what, ncclResult_t r) {
+    err = std::string(what) + ": " + a->GetErrorString(r);
+    return PGX_ECOMM;
+  }
+  int halo(hipStream_t st, double* const* f, int nf, size_t send_lo, size_t n_send_lo, size_t recv_lo, size_t n_recv_lo,
+           size_t send_hi, size_t n_send_hi, size_t recv_hi, size_t n_recv_hi) override {
+    const bool lo = rank > 0, hi = rank + 1 < size;
+    if (!lo && !hi) return PGX_OK;
+    ncclResult_t r = a->GroupStart();
+    if (r != ncclSuccess) return fail("ncclGroupStart", r);
+    for (int k = 0; k < nf && r == ncclSuccess; ++k) {
+      if (lo) {
+        r = a->Send(f[k] + send_lo, n_send_lo, ncclDouble, rank - 1, c, st);
+        if (r == ncclSuccess) r = a->Recv(f[k] + recv_lo, n_recv_lo, ncclDouble, rank - 1, c, st);
+      }
+      if (hi && r == ncclSuccess) {
+        r = a->Send(f[k] + send_hi, n_send_hi, ncclDouble, rank + 1, c, st);
+        if (r == ncclSuccess) r = a->Recv(f[k] + recv_hi, n_recv_hi, ncclDouble, rank + 1, c, st);
+      }
+    }
+    const ncclResult_t r2 = a->GroupEnd();
+    if (r != ncclSuccess) return fail("ncclSend/ncclRecv", r);
+    if (r2 != ncclSuccess) return fail("ncclGroupEnd", r2);
+    return PGX_OK;
+  }
+  int allreduce(hipStream_t st, double* dev, size_t n) override {
+    if (size == 1) return PGX_OK;
+    const ncclResult_t r = a->AllReduce(dev, dev, n, ncclDouble, ncclSum, c, st);
+    if (r != ncclSuccess) return fail("ncclAllReduce", r);
+    return PGX_OK;
+  }
+};
+}  // namespace
+
+extern "C" int pgx_comm_rccl_unique_id(char id[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  RcclApi* a = rccl_api();
+  if (!a->err.empty() || !id) {
+    g_comm_error = id ? a->err : "null argument";
+    return PGX_ECOMM;
+  }
+  ncclUniqueId u;
+  const ncclResult_t r = a->GetUniqueId(&u);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclGetUniqueId: ") + a->GetErrorString(r);
+    return PGX_ECOMM;
+  }
+  memcpy(id, u.internal, 128);
+  return PGX_OK;
+}
+
+extern "C" int pgx_comm_rccl_init(const char id[128], int rank, int size, int device, pgx_comm** out) {
+  if (!id || !out || size < 1 || rank < 0 || rank >= size) {
+    g_comm_error = "pgx_comm_rccl_init: bad argument";
+    return PGX_EINVAL;
+  }
+  *out = nullptr;
+  RcclApi* a = rccl_api();
+  if (!a->err.empty()) {
+    g_comm_error = a->err;
+    return PGX_ECOMM;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_comm_error = "hipSetDevice failed";
+    return PGX_ENODEV;
+  }
+  std::unique_ptr<RcclComm> c(new RcclComm());
+  c->a = a;
+  c->rank = rank;
+  c->size = size;
+  c->device = device;
+  ncclUniqueId u;
+  memcpy(u.internal, id, 128);
+  const ncclResult_t r = a->CommInitRank(&c->c, size, u, rank);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclCommInitRank: ") + a->GetErrorString(r);
+    c->c = nullptr;
+    return PGX_ECOMM;
+  }
+  *out = c.release();
+  return PGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-process thread group
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct LocalShared {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  unsigned long gen = 0;
+  bool broken = false;
+  struct Pub {
+    double* f[8];
+    int nf = 0;
+    size_t send_lo = 0, n_send_lo = 0, send_hi = 0, n_send_hi = 0;
+    std::vector<double> red;
+  };
+  std::vector<Pub> pub;
+  // all ranks arrive or the group is declared broken (a peer returned early with an error): no silent hang
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const unsigned long my = gen;
+    if (++waiting == n) {
+      waiting = 0;
+      ++gen;
+      cv.notify_all();
+      return true;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != my || broken; })) broken = true;
+    if (broken) cv.notify_all();
+    return !broken;
+  }
+};
+
+struct LocalComm : pgx_comm {
+  std::shared_ptr<LocalShared> s;
+  int dead() {
+    err = "local group: a peer rank did not arrive within 120 s (it failed, or the ranks made different calls)";
+    return PGX_ECOMM;
+  }
+  int hipfail(hipError_t e) {
+    err = std::string("local group: ") + hipGetErrorString(e);
+    {
+      std::lock_guard<std::mutex> lk(s->m);
+      s->broken = true;
+    }
+    s->cv.notify_all();
+    return PGX_EHIP;
+  }
+  int halo(hipStream_t st, double* const* f, int nf, size_t send_lo, size_t n_send_lo, size_t recv_lo, size_t n_recv_lo,
+           size_t send_hi, size_t n_send_hi, size_t recv_hi, size_t n_recv_hi) override {
+    if (size == 1) return PGX_OK;
+    if (nf > 8) {
+      err = "local group: more than 8 arrays per exchange";
+      return PGX_EINVAL;
+    }
+    hipError_t e = hipStreamSynchronize(st);  // my rows are final before the neighbours read them
+    if (e != hipSuccess) return hipfail(e);
+    LocalShared::Pub& p = s->pub[rank];
+    p.nf = nf;
+    for (int k = 0; k < nf; ++k) p.f[k] = f[k];
+    p.send_lo = send_lo;
+    p.n_send_lo = n_send_lo;
+    p.send_hi = send_hi;
+    p.n_send_hi = n_send_hi;
+    if (!s->barrier()) return dead();
+    if (rank > 0) {
+      const LocalShared::Pub& q = s->pub[rank - 1];
+      if (q.nf != nf || q.n_send_hi != n_recv_lo) {
+        err = "local group: halo layouts of neighbouring ranks disagree";
+        return PGX_ECOMM;
+      }
+      for (int k = 0; k < nf && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(f[k] + recv_lo, q.f[k] + q.send_hi, n_recv_lo * sizeof(double), hipMemcpyDefault, st);
+    }
+    if (rank + 1 < size && e == hipSuccess) {
+      const LocalShared::Pub& q = s->pub[rank + 1];
+      if (q.nf != nf || q.n_send_lo != n_recv_hi) {
+        err = "local group: halo layouts of neighbouring ranks disagree";
+        return PGX_ECOMM;
+      }
+      for (int k = 0; k < nf && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(f[k] + recv_hi, q.f[k] + q.send_lo, n_recv_hi * sizeof(double), hipMemcpyDefault, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(e);
+    if (!s->barrier()) return dead();  // the neighbours have read my rows: they may change again
+    return PGX_OK;
+  }
+  int allreduce(hipStream_t st, double* dev, size_t n) override {
+    if (size == 1) return PGX_OK;
+    std::vector<double>& mine = s->pub[rank].red;
+    mine.resize(n);
+    hipError_t e = hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(e);
+    if (!s->barrier()) return dead();
+    std::vector<double> sum(n, 0.0);
+    for (int r = 0; r < size; ++r) {  // fixed rank order: bitwise identical on every rank
+      const std::vector<double>& o = s->pub[r].red;
+      if (o.size() != n) {
+        err = "local group: all-reduce lengths of the ranks disagree";
+        return PGX_ECOMM;
+      }
+      for (size_t i = 0; i < n; ++i) sum[i] += o[i];
+    }
+    e = hipMemcpyAsync(dev, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(e);
+    if (!s->barrier()) return dead();
+    return PGX_OK;
+  }
+};
+}  // namespace
+
+extern "C" int pgx_comm_local_group(int size, pgx_comm** out) {
+  if (size < 1 || !out) {
+    g_comm_error = "pgx_comm_local_group: bad argument";
+    return PGX_EINVAL;
+  }
+  auto s = std::make_shared<LocalShared>();
+  s->n = size;
+  s->pub.resize(size);
+  for (int r = 0; r < size; ++r) {
+    LocalComm* c = new LocalComm();
+    c->rank = r;
+    c->size = size;
+    c->s = s;
+    out[r] = c;
+  }
+  return PGX_OK;
+}
+
+extern "C" void pgx_comm_free(pgx_comm* c) { delete c; }

@@ -83,7 +83,8 @@ void pgxk_bspmv(hipStream_t st, int mode, int n, const int32_t* rowptr, const in
                 const double* M, const double* D, double alpha, const double* xu, const double* xp, const double* bu,
                 const double* bp, double omega, int first, double* yu, double* yp);
 void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
-                      const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks, double* out6);
+                      const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks, double* out6,
+                      int raw = 0);
 int pgxk_observables_blocks(int nc);
 
 // vectors (length len)
@@ -114,6 +115,8 @@ void pgxk_restrict(hipStream_t st, const GridLevel& f, const double* ru, const d
 void pgxk_prolong_add(hipStream_t st, const GridLevel& c, const double* cu, const double* cp, const GridLevel& f,
                       double* xu, double* xp);
 void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const GridLevel& f);
+void pgxk_view_to_global(hipStream_t st, int ns, int n_view, int n_glob, int sx, int row0, int own0, int nown,
+                         const double* in, double* out);
 // fused V-cycle legs (nu = 2): two Jacobi sweeps per launch on LDS tiles, residual+restriction in one launch
 void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha, const double* xu, const double* xp,
                      const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,

@@ -536,8 +536,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables(int nc, int n, const 
   }
 }
 
+// raw != 0: plain sums (sharded path: the all-reduce comes before abs / sqrt)
 __global__ void __launch_bounds__(PGX_BLOCK) k_observables_final(int nblocks, const double* __restrict__ partials,
-                                                                 double* __restrict__ out6) {
+                                                                 double* __restrict__ out6, int raw) {
   __shared__ double sm[PGX_BLOCK / WAVE];
   for (int k = 0; k < 6; ++k) {
     double s = 0.0;
@@ -545,15 +546,15 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_final(int nblocks, co
     const double r = block_sum(s, sm);
     if (threadIdx.x == 0) {
       double v = r;
-      if (k == 1) v = fabs(v);
-      if (k >= 4) v = sqrt(v);
+      if (k == 1 && !raw) v = fabs(v);
+      if (k >= 4 && !raw) v = sqrt(v);
       out6[k] = v;
     }
   }
 }
 
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6) {
-  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6);
+  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6, 0);
 }
 
 int pgxk_observables_blocks(int nc) {
@@ -563,10 +564,10 @@ int pgxk_observables_blocks(int nc) {
 
 void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
                       const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks,
-                      double* out6) {
+                      double* out6, int raw) {
   hipLaunchKernelGGL(k_observables, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cells, coords, x, xk, alpha, f, q,
                      partials);
-  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6);
+  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6, raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1034,6 +1035,25 @@ __global__ void k_coarse_mask(int nxc, int nyc, int ncv, int nxf, const uint8_t*
 void pgxk_coarse_mask(hipStream_t st, const GridLevel& c, uint8_t* mask_c, const GridLevel& f) {
   hipLaunchKernelGGL(k_coarse_mask, dim3((c.n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, c.nx, c.ny, c.n,
                      f.nx, f.mask, mask_c);
+}
+
+// Sharded path: ns SoA arrays computed on this rank's strip view of a replicated level -> the level's global arrays,
+// owned rows copied, every other row 0 (the all-reduce that follows then assembles the level exactly: one non-zero
+// contribution per entry).
+__global__ void __launch_bounds__(PGX_BLOCK) k_view_to_global(int ns, int n_view, int n_glob, int sx, int row0,
+                                                              int own0, int nown, const double* __restrict__ in,
+                                                              double* __restrict__ out) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)ns * n_glob) return;
+  const int s = (int)(t / n_glob), v = (int)(t % n_glob);
+  const int J = v / sx;
+  out[t] = (J >= own0 && J < own0 + nown) ? in[(size_t)s * n_view + (v - row0 * sx)] : 0.0;
+}
+void pgxk_view_to_global(hipStream_t st, int ns, int n_view, int n_glob, int sx, int row0, int own0, int nown,
+                         const double* in, double* out) {
+  const size_t tot = (size_t)ns * n_glob;
+  hipLaunchKernelGGL(k_view_to_global, dim3((unsigned)((tot + PGX_BLOCK - 1) / PGX_BLOCK)), dim3(PGX_BLOCK), 0, st, ns,
+                     n_view, n_glob, sx, row0, own0, nown, in, out);
 }
 
 // One vertex of the collective operator / smoother on stencil storage (same three modes as k_bspmv).

@@ -39,12 +39,13 @@ class Mesh:
     """Simplicial mesh. `structured=(nx, ny)` marks the right-diagonal triangulation with vertex
     v=j*(nx+1)+i (enables the geometric-multigrid preconditioner)."""
 
-    def __init__(self, coords, cells, structured=None):
+    def __init__(self, coords, cells, structured=None, partition=None):
         self.geometry = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         if self.geometry.ndim != 2 or self.geometry.shape[1] != 2 or self.cells.ndim != 2 or self.cells.shape[1] != 3:
             raise ValueError("expected coords (nv,2) and triangle cells (nc,3)")
         self.structured = tuple(int(s) for s in structured) if structured else None
+        self.partition = partition  # StripPartition: this Mesh is one rank's strip (owned + ghost vertex rows)
 
     @property
     def num_vertices(self):
@@ -85,6 +86,9 @@ class Mesh:
         if self.structured:
             nx, ny = self.structured
             i, j = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+            if self.partition is not None:  # a strip: only the GLOBAL boundary is exterior, not the cut lines
+                j = j + self.partition.row0
+                ny = self.partition.global_ny
             return np.flatnonzero(((i == 0) | (i == nx) | (j == 0) | (j == ny)).ravel()).astype(np.int32)
         c = self.cells.astype(np.int64)
         e = np.concatenate([c[:, [0, 1]], c[:, [1, 2]], c[:, [2, 0]]])
@@ -95,14 +99,55 @@ class Mesh:
         return np.unique(np.concatenate([b // self.num_vertices, b % self.num_vertices])).astype(np.int32)
 
 
-def create_rectangle(points, n, diagonal="right"):
-    """dolfinx.mesh.create_rectangle(comm, points, n) for triangles, default (right) diagonal."""
+@dataclass(frozen=True)
+class StripPartition:
+    """Which vertex rows of the global nx x global_ny mesh this rank holds: rows [row0, row0+nrows), of which
+    [own0, own0+nown) are owned and the rest are ghosts (pgx_partition_rows, include/pgx.h)."""
+    comm: object
+    global_ny: int
+    dist_levels: int
+    row0: int
+    nrows: int
+    own0: int
+    nown: int
+
+    @property
+    def rank(self):
+        return self.comm.rank
+
+    @property
+    def size(self):
+        return self.comm.size
+
+
+def strip_partition(comm, global_ny, dist_levels=0):
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    pt = _lib.pgx_partition(comm.rank, comm.size, int(global_ny), int(dist_levels))
+    out = [C.c_int32(0) for _ in range(4)]
+    rc = lib.pgx_partition_rows(C.byref(pt), *[C.byref(o) for o in out])
+    _lib.check(lib, None, rc, "pgx_partition_rows")
+    return StripPartition(comm, int(global_ny), int(pt.dist_levels), *[o.value for o in out])
+
+
+def create_rectangle(points, n, diagonal="right", comm=None, dist_levels=0):
+    """dolfinx.mesh.create_rectangle(comm, points, n) for triangles, default (right) diagonal.  With a
+    `comm` (proximalgalerkin_amd.comm.Communicator) only this rank's strip of vertex rows is built - the analogue of
+    DOLFINx distributing the mesh over MPI.COMM_WORLD (obstacle_pg.py:64)."""
     if diagonal != "right":
         raise NotImplementedError("only the default 'right' diagonal is implemented")
     (x0, y0), (x1, y1) = points
     nx, ny = int(n[0]), int(n[1])
     xs = np.linspace(x0, x1, nx + 1)
     ys = np.linspace(y0, y1, ny + 1)
+    part = None
+    if comm is not None:
+        part = strip_partition(comm, ny, dist_levels)
+        ys = ys[part.row0:part.row0 + part.nrows]  # bitwise the coordinates of the global mesh
+        ny = part.nrows - 1
     X, Y = np.meshgrid(xs, ys, indexing="xy")
     coords = np.stack([X.ravel(), Y.ravel()], axis=1)
     i, j = np.meshgrid(np.arange(nx, dtype=np.int64), np.arange(ny, dtype=np.int64), indexing="xy")
@@ -112,7 +157,7 @@ def create_rectangle(points, n, diagonal="right"):
     cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
     cells[0::2] = np.stack([v0, v1, v3], axis=1)
     cells[1::2] = np.stack([v0, v2, v3], axis=1)
-    return Mesh(coords, cells, structured=(nx, ny))
+    return Mesh(coords, cells, structured=(nx, ny), partition=part)
 
 
 def create_unit_square(nx, ny):

@@ -181,8 +181,14 @@ class NonlinearProblem:
                               _lib.dptr(self._keep[4]), F.f.value, len(self._keep[5]), _lib.iptr(self._keep[5]),
                               _lib.dptr(self._keep[6]))
         h = C.c_void_p()
-        rc = lib.pgx_create(C.byref(pm), C.byref(pp), int(device), C.byref(h))
-        _lib.check(lib, None, rc, "pgx_create")
+        self.partition = part = getattr(mesh, "partition", None)
+        if part is None:
+            rc = lib.pgx_create(C.byref(pm), C.byref(pp), int(device), C.byref(h))
+            _lib.check(lib, None, rc, "pgx_create")
+        else:  # this mesh is one rank's strip: every call below is collective over part.comm (include/pgx.h)
+            pt = _lib.pgx_partition(part.rank, part.size, part.global_ny, part.dist_levels)
+            rc = lib.pgx_create_sharded(C.byref(pm), C.byref(pp), C.byref(pt), part.comm._c, int(device), C.byref(h))
+            _lib.check(lib, None, rc, "pgx_create_sharded")
         self._h = h
         self.ndofs = V.num_dofs
         F.sol.x._binding = (self, "state")
@@ -210,8 +216,13 @@ class NonlinearProblem:
             v._dev_valid, v._host_valid = True, False
 
     def _sync_inputs(self):
+        stale = not (self.F_form.sol.x._dev_valid and self.F_form.sol_k.x._dev_valid)
         self._push("state", self.F_form.sol.x)
         self._push("prev", self.F_form.sol_k.x)
+        if stale and self.partition is not None:
+            # host arrays were written: their ghost entries are whatever the caller left there, the owners' values
+            # win (Vec.ghostUpdate(INSERT, FORWARD), lvpp/problem.py:56)
+            _lib.check(self._lib, self._h, self._lib.pgx_sync_ghosts(self._h), "pgx_sync_ghosts")
         _lib.check(self._lib, self._h, self._lib.pgx_set_alpha(self._h, float(self.F_form.alpha.value)),
                    "pgx_set_alpha")
 
@@ -283,6 +294,13 @@ class NonlinearProblem:
         out = np.empty(6)
         _lib.check(self._lib, self._h, self._lib.pgx_observables(self._h, _lib.dptr(out)), "pgx_observables")
         return out
+
+    def owned_range(self):
+        """(offset, count): owned entries of each field block of a local vector (everything for an unsharded mesh)."""
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_owned_range(self._h, C.byref(off), C.byref(cnt)),
+                   "pgx_owned_range")
+        return off.value, cnt.value
 
     def profile(self, enable=None, reset=False):
         if enable is not None:
