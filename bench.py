@@ -9,7 +9,10 @@ with its Newton iterations, observables and stopping test) from the zero state, 
 already resident in HBM.  `value` = Newton iterations per second over the timed K steps
 (BASELINE.json metric "proximal-Newton iterations/sec"); proximal iterations/s is reported beside it.
 
-N>1: one process per GPU under torch.distributed.run; see DESIGN.md section "multi-GPU".
+N>1: one process per GPU under torch.distributed.run.  The SAME problem is cut into N horizontal strips (sharded
+path of include/pgx.h: RCCL halo exchange of ghost vertex rows + packed all-reduces), so the numbers at N = 1, 2, 4, 8
+are a strong-scaling series of one fixed workload; `--replicas` runs N independent solves instead (and says so).
+DESIGN.md section 7.
 """
 import argparse
 import json
@@ -89,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
     ap.add_argument("--opts", default="", help="extra solver options key=val,key=val (e.g. ksp_gmres_restart=20)")
+    ap.add_argument("--replicas", action="store_true", help="N>1: N independent solves instead of one sharded solve")
+    ap.add_argument("--dist-levels", type=int, default=0, help="sharded: multigrid levels kept distributed (0 = auto)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +124,15 @@ def main():
     N = args.n
     # ---- setup (untimed): mesh, obstacle at quadrature points, plan, constant blocks, MG hierarchy ----
     t_setup = time.perf_counter()
-    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+    sharded = world > 1 and not args.replicas
+    comm = None
+    if sharded:
+        if args.degree != 1:
+            raise SystemExit("bench.py: the sharded path covers P1; use --replicas for --degree 2")
+        from proximalgalerkin_amd.comm import rccl_from_torch_distributed
+
+        comm = rccl_from_torch_distributed(local_rank)  # id broadcast through the torch.distributed group
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N), comm=comm, dist_levels=args.dist_levels)
     petsc_options = None
     if args.opts:
         petsc_options = {"snes_error_if_not_converged": True, "snes_linesearch_type": "none", "snes_rtol": 1e-6,
@@ -156,8 +169,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        dt, newton_total, outer_total = reduce_over_ranks(dist, dt, newton_total, outer_total,
-                                                          "cuda" if backend == "nccl" else "cpu")
+        dt, nsum, osum = reduce_over_ranks(dist, dt, newton_total, outer_total, "cuda" if backend == "nccl" else "cpu")
+        if sharded:  # ONE solve: every rank counted the same iterations; the job's work is that solve, once
+            assert nsum == newton_total * world and osum == outer_total * world, "ranks disagree on iteration counts"
+        else:
+            newton_total, outer_total = nsum, osum
+    units = 1 if sharded else world  # solves per step over the whole job
     lin_its = problem.solver.getLinearSolveIterations()
 
     # ---- roofline of the dominant kernel (k_bspmv): HIP events on the library's own stream ----
@@ -166,6 +183,14 @@ def main():
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     n = msh.num_vertices
     prof = problem.profile() if args.profile else None
+    if sharded:
+        parallelism = (f"sharded: ONE {N}x{N} solve on {world} strips of {N // world} vertex rows (+ ghost rows, "
+                       f"{msh.partition.dist_levels} distributed multigrid levels, coarser levels replicated), RCCL halo "
+                       f"exchange + packed all-reduces over xGMI")
+    elif world > 1:
+        parallelism = "replicas: N INDEPENDENT solves, one per GPU (--replicas) - NOT a speed-up measurement"
+    else:
+        parallelism = "single"
 
     out = None
     if rank == 0:
@@ -179,7 +204,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -187,19 +212,18 @@ def main():
                 "workload": f"{N}x{N} right-diagonal P{args.degree} obstacle problem on [-1,1]^2, phi_set obstacle, f=0, "
                             f"settings {args.settings}: alpha {S['alpha_scheme']}, alpha_max {S['alpha_max']:g}, "
                             f"tol {S['tol_exit']:g}; snes_rtol 1e-6, Newton linear solves to true relative residual 1e-10",
-                "mixed_unknowns": sol.function_space.num_dofs,
+                "mixed_unknowns": 2 * (N + 1) ** 2 if args.degree == 1 else sol.function_space.num_dofs,
                 "step": "one full LVPP solve from the zero state",
-                "newton_iterations_per_step": newton_total / args.steps / world,
-                "proximal_iterations_per_step": outer_total / args.steps / world,
-                "parallelism": ("replicas: N INDEPENDENT solves, one per GPU - the strip domain decomposition of "
-                                "DESIGN.md section 7 is not implemented, so this is NOT a speed-up measurement")
-                if world > 1 else "single",
+                "newton_iterations_per_step": newton_total / args.steps / units,
+                "proximal_iterations_per_step": outer_total / args.steps / units,
+                "parallelism": parallelism,
             },
             "proximal_iterations_per_s": outer_total / dt,
             "last_newton_linear_iterations": lin_its,
             "setup_s": t_setup,
             "roofline": {
-                "kernel": "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
+                "kernel": "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)"
+                          + (", rank 0's strip" if sharded else ""),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -207,7 +231,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) for this kernel
                 # at this size: profiles/r01_spmv_pmc_traffic.json.  Only meaningful for the default 2048^2 workload.
-                "traffic": 993765512.8 if N == 2048 else None,
+                "traffic": 993765512.8 if (N == 2048 and not sharded) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)
@@ -228,6 +252,8 @@ def main():
                           f"does not fit a bounded sample - see DESIGN.md for the measured scaling",
             }
     problem.close()
+    if comm is not None:
+        comm.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -174,3 +174,31 @@ def test_partition_errors_are_reported(require_gpu):
         fem.create_rectangle(DOMAIN, (32, 33), comm=cs[0])
     with pytest.raises(_lib.PgxError, match="too thin|divisible"):
         fem.create_rectangle(DOMAIN, (32, 4), comm=cs[0])
+
+
+def test_sharded_full_size_2048_on_8_strips(require_gpu):
+    """BASELINE.json config 2 cut the way the 8-GPU launch cuts it (8 strips of 256 vertex rows, 3 distributed
+    levels): same Newton counts as the single-handle solve, primal field within 1e-10."""
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    N, R = 2048, 8
+    sx, ng = N + 1, (N + 1) ** 2
+
+    def solve(c):
+        msh = fem.create_rectangle(DOMAIN, (N, N), comm=c)
+        problem, sol, sol_k, alpha = setup_problem(msh, 1)
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 500, "double_exponential", 1e2, 1e-4)
+        x = sol.x.array.copy()
+        rng = problem.owned_range()
+        problem.close()
+        return x, hist, msh.partition, rng
+
+    xg, hg, _, _ = solve(None)
+    u = np.full(ng, np.nan)
+    for x, hist, part, (off, cnt) in _run_ranks(pcomm.local_group(R), solve):
+        assert part.dist_levels == 3 and part.nown in (256, 257)
+        assert hist["Newton steps"] == hg["Newton steps"]
+        u[part.own0 * sx:part.own0 * sx + cnt] = x[off:off + cnt]
+    assert np.linalg.norm(u - xg[:ng]) <= 1e-10 * np.linalg.norm(xg[:ng])
