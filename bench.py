@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--opts", default="", help="extra solver options key=val,key=val (e.g. ksp_gmres_restart=20)")
     ap.add_argument("--replicas", action="store_true", help="N>1: N independent solves instead of one sharded solve")
     ap.add_argument("--dist-levels", type=int, default=0, help="sharded: multigrid levels kept distributed (0 = auto)")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="N>1: abort the process after this many seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +107,10 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
-    if world > 1:
+    # BENCH_FORCE_SHARDED=1: take the sharded (RCCL) branch even with ONE rank - everything the N>1 launch executes except
+    # traffic between ranks; this is how a one-GPU box exercises it (tests/test_gpu_sharded.py)
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -124,7 +128,20 @@ def main():
     N = args.n
     # ---- setup (untimed): mesh, obstacle at quadrature points, plan, constant blocks, MG hierarchy ----
     t_setup = time.perf_counter()
-    sharded = world > 1 and not args.replicas
+    sharded = (world > 1 and not args.replicas) or force_sharded
+    if dist is not None:
+        # every call on a sharded handle is collective: if one rank dies the others would wait in RCCL for ever.
+        # Bound the damage: the whole run has args.watchdog seconds.
+        import threading
+
+        def _abort():
+            sys.stderr.write(f"bench.py rank {rank}: no result after {args.watchdog} s - aborting (stuck collective?)\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd = threading.Timer(args.watchdog, _abort)
+        wd.daemon = True
+        wd.start()
     comm = None
     if sharded:
         if args.degree != 1:
@@ -231,7 +248,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) for this kernel
                 # at this size: profiles/r01_spmv_pmc_traffic.json.  Only meaningful for the default 2048^2 workload.
-                "traffic": 993765512.8 if (N == 2048 and not sharded) else None,
+                "traffic": 993765512.8 if (N == 2048 and args.degree == 1 and not sharded) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)

@@ -202,3 +202,32 @@ def test_sharded_full_size_2048_on_8_strips(require_gpu):
         assert hist["Newton steps"] == hg["Newton steps"]
         u[part.own0 * sx:part.own0 * sx + cnt] = x[off:off + cnt]
     assert np.linalg.norm(u - xg[:ng]) <= 1e-10 * np.linalg.norm(xg[:ng])
+
+
+def test_bench_sharded_branch_runs_over_rccl_with_one_rank(require_gpu):
+    """bench.py's N>1 branch (torch.distributed init, ncclUniqueId broadcast, RCCL communicator, strip mesh, collective
+    solve, strong-scaling JSON) executed end to end with ONE rank - all a one-GPU box can host (RCCL refuses two ranks on
+    one device)."""
+    import json
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_SHARDED="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--cells", "256", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--watchdog", "300"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("sharded: ONE 256x256 solve on 1 strips")
+    assert d["config"]["mixed_unknowns"] == 2 * 257 * 257
+    assert d["config"]["newton_iterations_per_step"] == 19 and d["value"] > 0  # 256^2 settings B: 19 Newton steps
+    assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d
