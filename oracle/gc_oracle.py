@@ -1,0 +1,169 @@
+"""CPU oracle for the LVPP Newton loop of example 06 (gradient constraint |grad u| <= phi, vector latent variable).
+
+TEST INFRASTRUCTURE ONLY (same rules as oracle/pg_oracle.py): nothing under ``proximalgalerkin_amd/`` imports this.
+
+PARITY UNPINNED: the reference's arithmetic lives in DOLFINx/Basix/FFCx/PETSc+MUMPS (absent here) and the reference
+holds no tests or golden data for this path; this file restates the algorithm from the reference's call sites.
+
+Restated from /root/reference/examples/06_gradient_constraints/gradient_constraint_dolfinx.py:
+* mesh     : create_unit_square(N, M) (:36) == right-diagonal triangulation of [0,1]^2 (pg_oracle.create_rectangle).
+* spaces   : mixed [P_k, (P_{k-1})^2] with k = primal_degree = 2 (:38-46, choices :246-250): u in P2, psi in vector P1.
+* data     : phi, f interpolated into the PRIMAL space U (:55-61), i.e. P2 nodal interpolants; defaults
+             phi = 0.1 + 0.2 x + 0.4 y, f = 15 sin^2(pi x) (:289-297).
+* residual : :100-107 with the degree-10 measure of :53
+               R_u   = alpha (grad u, grad v) + (psi, grad v) - alpha (f, v) - (psi0, grad v)
+               R_psi = (grad u, w) - (phi psi / sqrt(1+|psi|^2), w)
+* Jacobian : derivative of the above (NonlinearProblem default J, :111); block form [[alpha K, G^T],[G, -N(psi)]],
+               N = (phi [I/s - psi psi^T/s^3] dpsi, w), s = sqrt(1+|psi|^2)  (native statement: examples/09_eikonal/
+               ex40.cpp:350-369).
+* BCs      : u = 0 on all exterior facets (:63-69,109-111), none on psi; DOLFINx lifting/set_bc contract as in ex 01.
+* Newton   : SNES newtonls, linesearch none, atol = rtol = stol = 1e-9, max_it 20, LU (:116-131).
+* outer    : alpha = alpha_0 (constant) | alpha_0 + alpha_c i (linear) | alpha_0 2^i (doubling) (:171-177);
+             stop when ||u - u_prev||_L2 < stopping_tol (:184-186,199-200); w0 <- sol (:205).
+
+DOF layout: x = [u_0..u_{n2-1} | psi_x(0..nv-1) | psi_y(0..nv-1)], u dofs = [vertices | edges] as in pg_oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import pg_oracle as O
+
+
+def phi_default(x):
+    return 0.1 + 0.2 * x[0] + 0.4 * x[1]  # gradient_constraint_dolfinx.py:291-292
+
+
+def f_default(x):
+    return 15.0 * np.sin(np.pi * x[0]) * np.sin(np.pi * x[0])  # :296-297 (both factors use x[0])
+
+
+class GradientConstraintP2:
+    def __init__(self, coords, cells, phi=phi_default, f=f_default, quadrature="tri_deg10_gj36"):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.nv, self.nc = len(self.coords), len(self.cells)
+        self.Xq, self.wq = O.load_quadrature(quadrature)
+        X, Y = self.Xq[:, 0], self.Xq[:, 1]
+        self.Lq, _ = O.lagrange_tabulate(1, X, Y)          # (nq,3)
+        self.Nq, self.dNq = O.lagrange_tabulate(2, X, Y)   # (nq,6), (nq,6,2)
+        self.edges, self.cell_edges = O.build_edges(self.cells, self.nv)
+        self.cell_dofs = np.concatenate([self.cells, self.nv + self.cell_edges], axis=1).astype(np.int32)
+        self.n2 = self.nv + len(self.edges)
+        self.ntot = self.n2 + 2 * self.nv
+        self.dof_coords = np.concatenate([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+        cnt = np.bincount(self.cell_edges.ravel(), minlength=len(self.edges))
+        bedge = np.flatnonzero(cnt == 1)
+        bv = np.unique(self.edges[bedge].ravel())
+        self.bc = np.concatenate([bv, self.nv + bedge]).astype(np.int32)
+        self.isbc = np.zeros(self.n2, dtype=bool)
+        self.isbc[self.bc] = True
+
+        x = self.coords[self.cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+        invJ = np.empty_like(J)
+        invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
+        invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
+        self.wdet = np.abs(det)[:, None] * self.wq[None]                 # (nc,nq)
+        self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)             # physical P2 gradients (nc,nq,6,2)
+        self.phi_dofs = phi(self.dof_coords.T.copy())
+        self.f_dofs = f(self.dof_coords.T.copy())
+        self.phi_q = self.phi_dofs[self.cell_dofs] @ self.Nq.T           # (nc,nq)
+        f_q = self.f_dofs[self.cell_dofs] @ self.Nq.T
+        self.Ke = np.einsum("cq,cqad,cqbd->cab", self.wdet, self.Gq, self.Gq)
+        # Ge[c, b, d, a] = int L_b d_d N_a   (rows: psi dof (b,d); cols: u dof a)
+        self.Ge = np.einsum("cq,qb,cqad->cbda", self.wdet, self.Lq, self.Gq)
+        self.b_f = np.bincount(self.cell_dofs.ravel(), weights=((self.wdet * f_q) @ self.Nq).ravel(), minlength=self.n2)
+        self.Me = np.einsum("cq,qa,qb->cab", self.wdet, self.Nq, self.Nq)  # P2 mass (for the L2 increment)
+
+        cd, cv = self.cell_dofs, self.cells
+        self.K = sp.coo_matrix((self.Ke.ravel(), (np.repeat(cd, 6, axis=1).ravel(), np.tile(cd, (1, 6)).ravel())),
+                               shape=(self.n2, self.n2)).tocsr()
+        self.M2 = sp.coo_matrix((self.Me.ravel(), (np.repeat(cd, 6, axis=1).ravel(), np.tile(cd, (1, 6)).ravel())),
+                                shape=(self.n2, self.n2)).tocsr()
+        rows_v = np.repeat(cv, 6, axis=1).ravel()
+        cols_u = np.tile(cd, (1, 3)).ravel()
+        self.Gx = sp.coo_matrix((self.Ge[:, :, 0, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self.Gy = sp.coo_matrix((self.Ge[:, :, 1, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self._rv = np.repeat(cv, 3, axis=1).ravel()
+        self._cv = np.tile(cv, (1, 3)).ravel()
+
+    def split(self, x):
+        return x[: self.n2], x[self.n2: self.n2 + self.nv], x[self.n2 + self.nv:]
+
+    def latent_terms(self, px, py, with_matrix=True):
+        """(b_x, b_y) = int phi psi_c/s L_b ; N blocks (xx, xy, yy) as nv x nv CSR."""
+        cv = self.cells
+        pxq, pyq = px[cv] @ self.Lq.T, py[cv] @ self.Lq.T
+        s = np.sqrt(1.0 + pxq * pxq + pyq * pyq)
+        wp = self.wdet * self.phi_q
+        bx = np.bincount(cv.ravel(), weights=((wp * pxq / s) @ self.Lq).ravel(), minlength=self.nv)
+        by = np.bincount(cv.ravel(), weights=((wp * pyq / s) @ self.Lq).ravel(), minlength=self.nv)
+        if not with_matrix:
+            return bx, by, None
+        s3 = s ** 3
+        mk = lambda c: sp.coo_matrix((np.einsum("cq,qa,qb->cab", c, self.Lq, self.Lq).ravel(), (self._rv, self._cv)),  # noqa: E731
+                                     shape=(self.nv, self.nv)).tocsr()
+        Nxx = mk(wp * (1.0 / s - pxq * pxq / s3))
+        Nxy = mk(wp * (-pxq * pyq / s3))
+        Nyy = mk(wp * (1.0 / s - pyq * pyq / s3))
+        return bx, by, (Nxx, Nxy, Nyy)
+
+    def residual(self, x, xk, alpha):
+        u, px, py = self.split(x)
+        _, pkx, pky = self.split(xk)
+        ut = u.copy()
+        ut[self.bc] = 0.0
+        bx, by, _ = self.latent_terms(px, py, with_matrix=False)
+        Fu = alpha * (self.K @ ut) + self.Gx.T @ (px - pkx) + self.Gy.T @ (py - pky) - alpha * self.b_f
+        Fu[self.bc] = u[self.bc]
+        return np.concatenate([Fu, self.Gx @ ut - bx, self.Gy @ ut - by])
+
+    def jacobian(self, x, alpha):
+        _, px, py = self.split(x)
+        _, _, (Nxx, Nxy, Nyy) = self.latent_terms(px, py)
+        free = sp.diags((~self.isbc).astype(float))
+        A = free @ (alpha * self.K) @ free + sp.diags(self.isbc.astype(float))
+        Gx, Gy = self.Gx @ free, self.Gy @ free
+        return sp.bmat([[A, Gx.T, Gy.T], [Gx, -Nxx, -Nxy], [Gy, -Nxy.T, -Nyy]], format="csr")
+
+    def l2_increment(self, x, xk):
+        d = x[: self.n2] - xk[: self.n2]
+        return float(np.sqrt(max(d @ (self.M2 @ d), 0.0)))
+
+
+def alpha_value(scheme, alpha_0, alpha_c, i):
+    if scheme == "constant":
+        return alpha_0
+    if scheme == "linear":
+        return alpha_0 + alpha_c * i
+    return alpha_0 * 2 ** i  # doubling
+
+
+def solve_problem(prob: GradientConstraintP2, alpha_scheme="doubling", alpha_0=1.0, alpha_c=1.0, max_iterations=25,
+                  stopping_tol=1e-8, snes: O.SnesOptions | None = None, linear_solve=None, verbose=False, iterates=None):
+    """Mirror of gradient_constraint_dolfinx.solve_problem's loop (:168-205). Returns (x, newton_iterations, L2_diffs)."""
+    snes = snes or O.SnesOptions(rtol=1e-9, atol=1e-9, stol=1e-9, max_it=20)
+    x = np.zeros(prob.ntot)
+    xk = x.copy()
+    its_all, diffs = [], []
+    for i in range(max_iterations):
+        alpha = alpha_value(alpha_scheme, alpha_0, alpha_c, i)
+        xn, reason, its = O.newton_solve(prob, x, xk, alpha, snes, linear_solve)
+        if reason <= 0:
+            raise RuntimeError(f"SNES diverged at LVPP step {i}: reason {reason} after {its} its")
+        x = xn
+        d = prob.l2_increment(x, xk)
+        its_all.append(its)
+        diffs.append(d)
+        if iterates is not None:
+            iterates.append(x.copy())
+        if verbose:
+            print(f"Iteration {i + 1}: alpha={alpha:g} converged={reason} newton={its} |delta u|={d:.6e} max|psi|={np.abs(x[prob.n2:]).max():.3e}")
+        if d < stopping_tol:
+            break
+        xk = x.copy()
+    return x, np.array(its_all), np.array(diffs)

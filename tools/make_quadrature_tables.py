@@ -15,6 +15,14 @@ tri_deg6_12 : fully symmetric 12-point, degree-6 rule on the reference triangle
               Weights sum to 1/2 (reference-triangle area), matching the convention of
               SURVEY.md App. A.2.
 
+tri_deg10_gj36 : collapsed (Duffy) Gauss-Jacobi rule, 6 x 6 = 36 points, exact to degree 11 >= 10: Gauss-Jacobi(1,0) in
+              the collapsing direction times Gauss-Legendre across - Basix's "gauss_jacobi" scheme with
+              m = (degree+2)//2 points per direction.  Example 06 fixes quadrature_degree=10
+              (/root/reference/examples/06_gradient_constraints/gradient_constraint_dolfinx.py:53); Basix's DEFAULT for
+              that degree is a 25-point Xiao-Gimbutas table that cannot be derived offline, hence this derivable rule
+              (parity with FEniCSx unpinned, oracle <-> HIP exact by construction).  Nodes are roots of the Jacobi /
+              Legendre polynomials refined with mpmath, weights from the moment equations, 50 digits.
+
 The reference fixes quadrature_degree=6 for every integral of example 01
 (/root/reference/examples/01_obstacle_problem/obstacle_pg.py:106,115).  Basix's default table for
 that degree is not available offline => parity with a real FEniCSx run is
@@ -75,6 +83,36 @@ def residual(*params):
     return out
 
 
+def gauss_jacobi_01(m, a):
+    """m-point Gauss rule on [0,1] for the weight (1-t)^a, a in {0,1}: (nodes, weights) as mpf lists."""
+    import numpy as np
+    from scipy.special import roots_jacobi
+
+    guess, _ = roots_jacobi(m, a, 0)
+    nodes = [mp.findroot(lambda t: mp.jacobi(m, a, 0, t), mp.mpf(float(g)), tol=1e-45) for g in guess]
+    nodes = [(1 + t) / 2 for t in nodes]  # [-1,1] -> [0,1]; weight (1-t)^a keeps its form up to a constant
+    A = mp.matrix(m, m)
+    b = mp.matrix(m, 1)
+    for k in range(m):
+        for i, t in enumerate(nodes):
+            A[k, i] = t**k
+        b[k] = mp.quad(lambda t: (1 - t) ** a * t**k, [0, 1])
+    w = mp.lu_solve(A, b)
+    return nodes, [w[i] for i in range(m)]
+
+
+def collapsed_rule(m):
+    """x = xi, y = eta (1 - xi): int_T f = int_0^1 int_0^1 f (1-xi) d eta d xi."""
+    xi, wxi = gauss_jacobi_01(m, 1)
+    eta, weta = gauss_jacobi_01(m, 0)
+    pts, wts = [], []
+    for a, wa in zip(xi, wxi):
+        for b, wb in zip(eta, weta):
+            pts.append((a, b * (1 - a)))
+            wts.append(wa * wb)
+    return pts, wts
+
+
 def main():
     # Dunavant p=6 published values (weights there sum to 1; halve for area 1/2)
     guess = [
@@ -107,6 +145,20 @@ def main():
             "points": [[float(x), float(y)] for (x, y) in pts],
             "weights": [float(w) for w in wts],
         }
+    }
+    pts10, wts10 = collapsed_rule(6)
+    worst10 = mp.mpf(0)
+    for p in range(12):
+        for q in range(12 - p):
+            s = sum(w * x**p * y**q for (x, y), w in zip(pts10, wts10))
+            worst10 = max(worst10, abs(s - moments_exact(p, q)))
+    assert worst10 < mp.mpf(10) ** (-35), worst10
+    table["tri_deg10_gj36"] = {
+        "cell": "triangle",
+        "degree": 10,
+        "source": "collapsed Gauss-Jacobi(1,0) x Gauss-Legendre, 6 x 6 points (exact to degree 11); tools/make_quadrature_tables.py",
+        "points": [[float(x), float(y)] for (x, y) in pts10],
+        "weights": [float(w) for w in wts10],
     }
     out = pathlib.Path(__file__).resolve().parents[1] / "proximalgalerkin_amd" / "tables" / "quadrature.json"
     out.write_text(json.dumps(table, indent=1) + "\n")
