@@ -1,0 +1,76 @@
+/*
+ * pgx_nd.h - C ABI of the sparse direct solver inside libpgx.so: geometric nested-dissection multifrontal LU on the GPU.
+ *
+ * Replaces, for the Newton linear systems of this repository's hot path, what the reference requests from PETSc with
+ *     "ksp_type": "preonly", "pc_type": "lu", "pc_factor_mat_solver_type": "mumps"
+ * (examples/01_obstacle_problem/obstacle_pg.py:129-131; examples/06_gradient_constraints/
+ *  gradient_constraint_dolfinx.py:118-121 incl. "mat_mumps_icntl_14"; examples/02_signorini/signorini_dolfinx.py
+ *  petsc_options), i.e. MatLUFactorSymbolic / MatLUFactorNumeric / MatSolve of a MUMPS-backed PC:
+ *
+ *   pgx_nd_create   PCSetUp symbolic phase (ordering + symbolic factorisation), once per sparsity pattern
+ *   pgx_nd_factor   MatLUFactorNumeric, once per Newton step
+ *   pgx_nd_solve    MatSolve / KSPSolve(preonly)
+ *
+ * The matrix is a general CSR matrix with structurally symmetric pattern; dofs are grouped into NODES (all dofs living
+ * on one mesh entity: u, psi, ... of a vertex or edge midpoint).  Nodes are eliminated as blocks in a nested-dissection
+ * order obtained by recursive coordinate bisection; no pivoting across nodes (the saddle-point Newton matrices of the
+ * LVPP examples are strongly factorisable in any node order, see oracle/nd_proto.py and DESIGN.md).
+ * Plain pointers and sizes only.  Returns 0 or a negative PGX_E* code (include/pgx.h); text via pgx_nd_last_error.
+ */
+#ifndef PGX_ND_H
+#define PGX_ND_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgx_nd pgx_nd;
+
+typedef struct {
+  int64_t n;                 /* matrix order */
+  const int32_t* rowptr;     /* [n+1] host; column indices sorted within each row */
+  const int32_t* col;        /* [nnz] host */
+  int32_t n_nodes;
+  const int32_t* node_of_dof;/* [n] host: node owning each dof */
+  int32_t dim;               /* 2 or 3 */
+  const double* node_coords; /* [n_nodes][dim] host */
+  int32_t leaf_nodes;        /* stop bisecting below this many nodes; 0 = default (64) */
+} pgx_nd_matrix;
+
+/* Host-only symbolic statistics (no GPU needed). */
+typedef struct {
+  int64_t n_fronts, n_levels, max_front;   /* max padded front order */
+  int64_t arena_doubles;                   /* padded storage of all frontal matrices */
+  int64_t factor_nnz;                      /* unpadded entries kept (L and U) */
+  double flops;                            /* unpadded factorisation flops */
+  double flops_padded;                     /* flops the level-batched kernels execute */
+} pgx_nd_stats;
+
+/* device < 0: symbolic phase only (no GPU touched) - for pgx_nd_get_stats / pgx_nd_export_* on CPU-only machines. */
+int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream /* may be NULL: own stream */, pgx_nd** out);
+void pgx_nd_destroy(pgx_nd* s);
+const char* pgx_nd_last_error(const pgx_nd* s);
+int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st);
+
+/* Numeric factorisation of the matrix whose CSR values (same pattern as at create) are DEVICE-resident (on_device != 0)
+ * or on the host.  Asynchronous on the solver's stream when on_device; pgx_nd_solve orders after it. */
+int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device);
+/* x = A^{-1} b; b, x device pointers (on_device != 0) or host; b == x allowed. */
+int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
+/* accumulated device time of the last factor / solve calls in ms (HIP events; 0 until pgx_nd_timing(s,1)) */
+int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
+
+/* Symbolic structure, for tests (the numpy emulation in tests/test_nd_symbolic.py factorises with exactly these maps).
+ * Call with NULL arrays to get sizes.  Layout: fronts are numbered level by level, root level first ("slots");
+ * level l holds slots [lev_start[l], lev_start[l+1]) and pads every front to pivot order P[l], border B[l], M = P+B,
+ * stored column-major at arena offset lev_off[l] + (slot - lev_start[l]) * M*M.  Local index of an own dof k: k; of the
+ * s-th border dof: P + s.  rel[rel_ptr[f] + s] = local index in the PARENT's front of border dof s of front f. */
+int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B, int64_t* lev_off);
+int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t* fp, int32_t* fb, int32_t* parent, int32_t* slot01,
+                         int64_t* dof_ptr, int32_t* own_dofs, int64_t* rel_ptr, int32_t* rel);
+int pgx_nd_export_dest(const pgx_nd* s, int64_t* nnz, int64_t* dest);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -17,6 +17,7 @@ LIB_PATH = pathlib.Path(_os.environ.get("PGX_LIB", _HERE / "libpgx.so"))  # PGX_
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
 
 
 class PgxError(RuntimeError):
@@ -63,6 +64,31 @@ class pgx_snes_opts(C.Structure):
         ("mg_nu", C.c_int32),
         ("mg_omega", C.c_double),
         ("monitor", C.c_int32),
+    ]
+
+
+class pgx_nd_matrix(C.Structure):  # include/pgx_nd.h
+    _fields_ = [
+        ("n", C.c_int64),
+        ("rowptr", C.POINTER(C.c_int32)),
+        ("col", C.POINTER(C.c_int32)),
+        ("n_nodes", C.c_int32),
+        ("node_of_dof", C.POINTER(C.c_int32)),
+        ("dim", C.c_int32),
+        ("node_coords", C.POINTER(C.c_double)),
+        ("leaf_nodes", C.c_int32),
+    ]
+
+
+class pgx_nd_stats(C.Structure):
+    _fields_ = [
+        ("n_fronts", C.c_int64),
+        ("n_levels", C.c_int64),
+        ("max_front", C.c_int64),
+        ("arena_doubles", C.c_int64),
+        ("factor_nnz", C.c_int64),
+        ("flops", C.c_double),
+        ("flops_padded", C.c_double),
     ]
 
 
@@ -114,6 +140,18 @@ SYMBOLS = [
      [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.POINTER(pgx_partition), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_owned_range", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("pgx_sync_ghosts", C.c_int, [_H]),
+    # sparse direct solver (include/pgx_nd.h)
+    ("pgx_nd_create", C.c_int, [C.POINTER(pgx_nd_matrix), C.c_int, C.c_void_p, C.POINTER(_H)]),
+    ("pgx_nd_destroy", None, [_H]),
+    ("pgx_nd_last_error", C.c_char_p, [_H]),
+    ("pgx_nd_get_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
+    ("pgx_nd_factor", C.c_int, [_H, c_double_p, C.c_int]),
+    ("pgx_nd_solve", C.c_int, [_H, c_double_p, c_double_p, C.c_int]),
+    ("pgx_nd_timing", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_nd_export_levels", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_int64_p]),
+    ("pgx_nd_export_fronts", C.c_int,
+     [_H, c_int64_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int64_p, c_int32_p, c_int64_p, c_int32_p]),
+    ("pgx_nd_export_dest", C.c_int, [_H, c_int64_p, c_int64_p]),
 ]
 
 _lib = None

@@ -1,0 +1,828 @@
+// pgx_nd.hip - geometric nested-dissection multifrontal LU on the GPU (C ABI: include/pgx_nd.h).
+//
+// Replaces PETSc "pc_type lu / pc_factor_mat_solver_type mumps" of the reference (obstacle_pg.py:129-131,
+// gradient_constraint_dolfinx.py:118-121) for the Newton systems of the LVPP examples.
+//
+// Host (symbolic, once per pattern): node graph -> recursive coordinate bisection (separator = nodes of the lower half
+// adjacent to the upper half) -> postorder, border ("struct") sets, fronts grouped by tree DEPTH into levels; all fronts
+// of a level are padded to a common pivot order P and border B so that a level is ONE strided batch.
+// Device (numeric, every Newton step): zero the arena, scatter the CSR values to their frontal positions (precomputed,
+// conflict-free), then per level, deepest first: extend-add the children's Schur complements (two conflict-free passes,
+// no atomics -> bitwise reproducible), LU of the pivot blocks without pivoting, two triangular solves, one GEMM update.
+// Solve: the same tree walk on per-front vectors (forward bottom-up, backward top-down).
+//
+// MI355X notes: the arena is sized for 288 GB HBM3E (tens of GB of fronts are kept resident so that the solve phase and
+// the next factorisation re-use the allocation); the GEMM-shaped work (Schur updates) runs on the fp64 matrix cores through
+// rocBLAS/rocSOLVER strided-batched calls; assembly, extend-add and the vector tree walks are hand-written kernels.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/pgx.h"
+#include "../../include/pgx_nd.h"
+
+static thread_local std::string g_nd_error;
+
+struct NdLevel {
+  int64_t start = 0, count = 0;
+  int P = 0, B = 0;
+  int64_t off = 0;   // arena offset (doubles)
+  int64_t voff = 0;  // vector arena offset
+};
+
+struct pgx_nd {
+  int device = -1;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int64_t n = 0, nnz = 0, nfronts = 0;
+  std::vector<NdLevel> lev;
+  std::vector<int32_t> fp, fb, parent, slot01, child0, child1, flevel;
+  std::vector<int64_t> dof_ptr, rel_ptr, dest, fbase;
+  std::vector<int32_t> own_dofs, rel;
+  pgx_nd_stats stats{};
+  int64_t arena_len = 0, vec_len = 0;
+  // device
+  double *arena = nullptr, *vec = nullptr, *d_vals = nullptr, *d_b = nullptr;
+  int64_t *d_dest = nullptr, *d_dof_ptr = nullptr, *d_rel_ptr = nullptr, *d_fbase = nullptr, *d_vbase = nullptr;
+  int32_t *d_fp = nullptr, *d_fb = nullptr, *d_parent = nullptr, *d_slot01 = nullptr, *d_child0 = nullptr,
+          *d_child1 = nullptr, *d_own_dofs = nullptr, *d_rel = nullptr, *d_fM = nullptr, *d_fP = nullptr;
+  rocblas_handle blas = nullptr;
+  int* d_info = nullptr;
+  bool factored = false;
+  bool timing = false;
+  double factor_ms = 0, solve_ms = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<void*> allocs;
+};
+
+extern "C" const char* pgx_nd_last_error(const pgx_nd* s) { return s ? s->err.c_str() : g_nd_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// symbolic phase (host)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct TNode {
+  int parent = -1, child[2] = {-1, -1}, depth = 0;
+  std::vector<int32_t> own;     // graph nodes eliminated at this tree node
+  std::vector<int32_t> border;  // graph nodes of ancestors coupled to the subtree, sorted by elimination position
+};
+
+struct Symbolic {
+  const pgx_nd_matrix* A;
+  int64_t n;
+  int32_t nn, dim, leaf;
+  std::vector<int64_t> nd_ptr;
+  std::vector<int32_t> nd_dofs;
+  std::vector<int64_t> gptr;
+  std::vector<int32_t> gadj;
+  std::vector<TNode> T;
+  std::vector<int32_t> mark;
+  int32_t stamp = 0;
+  std::vector<double> keys;
+
+  void build_graph() {
+    const int32_t* nod = A->node_of_dof;
+    nd_ptr.assign(nn + 1, 0);
+    for (int64_t i = 0; i < n; ++i) nd_ptr[nod[i] + 1]++;
+    for (int32_t g = 0; g < nn; ++g) nd_ptr[g + 1] += nd_ptr[g];
+    nd_dofs.resize(n);
+    std::vector<int64_t> fill(nd_ptr.begin(), nd_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) nd_dofs[fill[nod[i]]++] = (int32_t)i;
+    gptr.assign(nn + 1, 0);
+    std::vector<int32_t> seen(nn, -1);
+    for (int pass = 0; pass < 2; ++pass) {
+      std::fill(seen.begin(), seen.end(), -1);
+      for (int32_t g = 0; g < nn; ++g) {
+        int64_t cnt = 0;
+        for (int64_t q = nd_ptr[g]; q < nd_ptr[g + 1]; ++q) {
+          int32_t i = nd_dofs[q];
+          for (int32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
+            int32_t h = nod[A->col[k]];
+            if (h != g && seen[h] != g) {
+              seen[h] = g;
+              if (pass) gadj[gptr[g] + cnt] = h;
+              ++cnt;
+            }
+          }
+        }
+        if (!pass) gptr[g + 1] = cnt;
+      }
+      if (!pass) {
+        for (int32_t g = 0; g < nn; ++g) gptr[g + 1] += gptr[g];
+        gadj.resize(gptr[nn]);
+      }
+    }
+  }
+
+  int bisect(int32_t* V, int64_t cnt, int parent, int depth) {
+    int tid = (int)T.size();
+    T.emplace_back();
+    T[tid].parent = parent;
+    T[tid].depth = depth;
+    if (cnt <= leaf) {
+      T[tid].own.assign(V, V + cnt);
+      return tid;
+    }
+    const double* X = A->node_coords;
+    int ax = 0;
+    double best = -1;
+    for (int d = 0; d < dim; ++d) {
+      double lo = 1e300, hi = -1e300;
+      for (int64_t k = 0; k < cnt; ++k) {
+        double c = X[(int64_t)V[k] * dim + d];
+        lo = std::min(lo, c);
+        hi = std::max(hi, c);
+      }
+      if (hi - lo > best) best = hi - lo, ax = d;
+    }
+    keys.resize(cnt);
+    for (int64_t k = 0; k < cnt; ++k) keys[k] = X[(int64_t)V[k] * dim + ax];
+    std::nth_element(keys.begin(), keys.begin() + cnt / 2, keys.begin() + cnt);
+    const double med = keys[cnt / 2];
+    auto key_of = [&](int32_t g) { return X[(int64_t)g * dim + ax]; };
+    int32_t* mid = std::stable_partition(V, V + cnt, [&](int32_t g) { return key_of(g) < med; });
+    int64_t na = mid - V;
+    if (na == 0 || na == cnt) {  // more than half of the nodes share the extreme coordinate: split by count
+      std::stable_sort(V, V + cnt, [&](int32_t a, int32_t b) {
+        for (int d = 0; d < dim; ++d) {
+          int dd = (ax + d) % dim;
+          double ca = X[(int64_t)a * dim + dd], cb = X[(int64_t)b * dim + dd];
+          if (ca != cb) return ca < cb;
+        }
+        return a < b;
+      });
+      na = cnt / 2;
+    }
+    // separator: nodes of the lower half adjacent to the upper half
+    ++stamp;
+    for (int64_t k = na; k < cnt; ++k) mark[V[k]] = stamp;
+    int32_t* sep_begin = std::stable_partition(V, V + na, [&](int32_t g) {
+      for (int64_t q = gptr[g]; q < gptr[g + 1]; ++q)
+        if (mark[gadj[q]] == stamp) return false;
+      return true;
+    });
+    int64_t nin = sep_begin - V;  // interior of the lower half: V[0,nin); separator V[nin,na); upper half V[na,cnt)
+    T[tid].own.assign(V + nin, V + na);
+    // move the upper half next to the interior so both children own contiguous ranges
+    std::vector<int32_t> upper(V + na, V + cnt);
+    std::copy(upper.begin(), upper.end(), V + nin);
+    int nc = 0;
+    if (nin > 0) {
+      int c = bisect(V, nin, tid, depth + 1);
+      T[tid].child[nc++] = c;
+    }
+    if (cnt - na > 0) {
+      int c = bisect(V + nin, cnt - na, tid, depth + 1);
+      T[tid].child[nc++] = c;
+    }
+    return tid;
+  }
+};
+}  // namespace
+
+static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
+  Symbolic S;
+  S.A = A;
+  S.n = A->n;
+  S.nn = A->n_nodes;
+  S.dim = A->dim;
+  S.leaf = A->leaf_nodes > 0 ? A->leaf_nodes : 64;
+  const int64_t n = S.n;
+  const int32_t nn = S.nn;
+  for (int64_t i = 0; i < n; ++i)
+    if (A->node_of_dof[i] < 0 || A->node_of_dof[i] >= nn) {
+      s->err = "node_of_dof out of range";
+      return PGX_EINVAL;
+    }
+  S.build_graph();
+  S.mark.assign(nn, 0);
+  std::vector<int32_t> ids(nn);
+  std::iota(ids.begin(), ids.end(), 0);
+  S.T.reserve(4 * (size_t)(nn / S.leaf + 2));
+  S.bisect(ids.data(), nn, -1, 0);
+  std::vector<TNode>& T = S.T;
+  const int nt = (int)T.size();
+  // postorder
+  std::vector<int> post;
+  post.reserve(nt);
+  {
+    std::vector<std::pair<int, int>> stack;
+    stack.push_back({0, 0});
+    while (!stack.empty()) {
+      auto [t, k] = stack.back();
+      stack.pop_back();
+      if (k < 2 && T[t].child[k] >= 0) {
+        stack.push_back({t, k + 1});
+        stack.push_back({T[t].child[k], 0});
+      } else if (k < 2) {
+        stack.push_back({t, 2});
+      } else {
+        post.push_back(t);
+      }
+    }
+  }
+  std::vector<int> order_of(nt);
+  for (int k = 0; k < nt; ++k) order_of[post[k]] = k;
+  std::vector<int32_t> tnode(nn);
+  std::vector<int64_t> node_pos(nn);
+  {
+    int64_t k = 0;
+    for (int t : post)
+      for (int32_t g : T[t].own) tnode[g] = t, node_pos[g] = k++;
+    if (k != nn) {
+      s->err = "nested dissection lost nodes";
+      return PGX_EINVAL;
+    }
+  }
+  // border sets, bottom-up
+  {
+    std::vector<int32_t> seen(nn, -1);
+    for (int t : post) {
+      std::vector<int32_t>& b = T[t].border;
+      auto consider = [&](int32_t h) {
+        if (order_of[tnode[h]] > order_of[t] && seen[h] != t) seen[h] = t, b.push_back(h);
+      };
+      for (int32_t g : T[t].own)
+        for (int64_t q = S.gptr[g]; q < S.gptr[g + 1]; ++q) consider(S.gadj[q]);
+      for (int c = 0; c < 2; ++c)
+        if (T[t].child[c] >= 0)
+          for (int32_t h : T[T[t].child[c]].border) consider(h);
+      std::sort(b.begin(), b.end(), [&](int32_t a, int32_t c) { return node_pos[a] < node_pos[c]; });
+    }
+  }
+  // levels by depth; slots ordered by postorder inside a level
+  int maxd = 0;
+  for (auto& t : T) maxd = std::max(maxd, t.depth);
+  const int L = maxd + 1;
+  s->lev.assign(L, NdLevel());
+  std::vector<int> slot_of(nt);
+  auto ndofs = [&](int32_t g) { return (int)(S.nd_ptr[g + 1] - S.nd_ptr[g]); };
+  std::vector<int> tp(nt), tb(nt);
+  for (int t = 0; t < nt; ++t) {
+    int p = 0, b = 0;
+    for (int32_t g : T[t].own) p += ndofs(g);
+    for (int32_t g : T[t].border) b += ndofs(g);
+    tp[t] = p, tb[t] = b;
+    s->lev[T[t].depth].count++;
+    s->lev[T[t].depth].P = std::max(s->lev[T[t].depth].P, p);
+    s->lev[T[t].depth].B = std::max(s->lev[T[t].depth].B, b);
+  }
+  int64_t off = 0, voff = 0, start = 0;
+  s->stats = pgx_nd_stats();
+  for (int l = 0; l < L; ++l) {
+    NdLevel& Lv = s->lev[l];
+    if (Lv.P == 0) Lv.P = 1;  // degenerate (only empty separators): keep a 1x1 identity pivot
+    Lv.start = start;
+    Lv.off = off;
+    Lv.voff = voff;
+    int64_t M = Lv.P + Lv.B;
+    off += Lv.count * M * M;
+    voff += Lv.count * M;
+    start += Lv.count;
+    double P = Lv.P, B = Lv.B;
+    s->stats.flops_padded += Lv.count * (2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B);
+    s->stats.max_front = std::max<int64_t>(s->stats.max_front, M);
+  }
+  s->arena_len = off;
+  s->vec_len = voff;
+  s->nfronts = nt;
+  s->stats.n_fronts = nt;
+  s->stats.n_levels = L;
+  s->stats.arena_doubles = off;
+  {
+    std::vector<int64_t> next(L);
+    for (int l = 0; l < L; ++l) next[l] = s->lev[l].start;
+    for (int t : post) slot_of[t] = (int)next[T[t].depth]++;
+  }
+  s->fp.assign(nt, 0);
+  s->fb.assign(nt, 0);
+  s->parent.assign(nt, -1);
+  s->slot01.assign(nt, 0);
+  s->child0.assign(nt, -1);
+  s->child1.assign(nt, -1);
+  s->flevel.assign(nt, 0);
+  s->fbase.assign(nt, 0);
+  s->dof_ptr.assign(nt + 1, 0);
+  s->rel_ptr.assign(nt + 1, 0);
+  for (int t = 0; t < nt; ++t) {
+    int f = slot_of[t];
+    s->fp[f] = tp[t];
+    s->fb[f] = tb[t];
+    s->flevel[f] = T[t].depth;
+    const NdLevel& Lv = s->lev[T[t].depth];
+    int64_t M = Lv.P + Lv.B;
+    s->fbase[f] = Lv.off + (f - Lv.start) * M * M;
+    if (T[t].parent >= 0) s->parent[f] = slot_of[T[t].parent];
+    for (int c = 0; c < 2; ++c)
+      if (T[t].child[c] >= 0) {
+        (c == 0 ? s->child0 : s->child1)[f] = slot_of[T[t].child[c]];
+        s->slot01[slot_of[T[t].child[c]]] = c;
+      }
+    s->dof_ptr[f + 1] = tp[t];
+    s->rel_ptr[f + 1] = tb[t];
+    double p = tp[t], b = tb[t];
+    s->stats.flops += 2.0 / 3 * p * p * p + 2 * p * p * b + 2 * p * b * b;
+    s->stats.factor_nnz += (int64_t)(p * p + 2 * p * b);
+  }
+  for (int f = 0; f < nt; ++f) s->dof_ptr[f + 1] += s->dof_ptr[f], s->rel_ptr[f + 1] += s->rel_ptr[f];
+  s->own_dofs.resize(s->dof_ptr[nt]);
+  s->rel.resize(s->rel_ptr[nt]);
+  s->nnz = A->rowptr[n];
+  s->dest.assign(s->nnz, -1);
+  // local indices, child -> parent maps, assembly destinations
+  std::vector<int32_t> loc(n, -1), loc_owner(n, -1);
+  auto find_entry = [&](int32_t row, int32_t colv) -> int64_t {
+    const int32_t* b = A->col + A->rowptr[row];
+    const int32_t* e = A->col + A->rowptr[row + 1];
+    const int32_t* it = std::lower_bound(b, e, colv);
+    return (it != e && *it == colv) ? (int64_t)(it - A->col) : -1;
+  };
+  for (int t : post) {
+    const int f = slot_of[t];
+    const NdLevel& Lv = s->lev[T[t].depth];
+    const int64_t M = Lv.P + Lv.B;
+    int k = 0;
+    int64_t w = s->dof_ptr[f];
+    for (int32_t g : T[t].own)
+      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+        int32_t i = S.nd_dofs[q];
+        loc[i] = k++;
+        loc_owner[i] = t;
+        s->own_dofs[w++] = i;
+      }
+    k = Lv.P;
+    for (int32_t g : T[t].border)
+      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+        int32_t i = S.nd_dofs[q];
+        loc[i] = k++;
+        loc_owner[i] = t;
+      }
+    for (int c = 0; c < 2; ++c) {
+      int ct = T[t].child[c];
+      if (ct < 0) continue;
+      int64_t r = s->rel_ptr[slot_of[ct]];
+      for (int32_t g : T[ct].border)
+        for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+          int32_t i = S.nd_dofs[q];
+          if (loc_owner[i] != t) {
+            s->err = "symbolic inconsistency: child border not contained in the parent front";
+            return PGX_EINVAL;
+          }
+          s->rel[r++] = loc[i];
+        }
+    }
+    for (int32_t g : T[t].own)
+      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+        const int32_t i = S.nd_dofs[q];
+        const int64_t r = loc[i];
+        for (int32_t e = A->rowptr[i]; e < A->rowptr[i + 1]; ++e) {
+          const int32_t j = A->col[e];
+          const int tj = tnode[A->node_of_dof[j]];
+          if (order_of[tj] < order_of[t]) continue;  // assembled from the other side (earlier front)
+          if (loc_owner[j] != t) {
+            s->err = "symbolic inconsistency: coupled dof missing from the front";
+            return PGX_EINVAL;
+          }
+          const int64_t c = loc[j];
+          s->dest[e] = s->fbase[f] + c * M + r;
+          if (tj != t) {
+            int64_t et = find_entry(j, i);
+            if (et >= 0) s->dest[et] = s->fbase[f] + r * M + c;
+          }
+        }
+      }
+  }
+  for (int64_t e = 0; e < s->nnz; ++e)
+    if (s->dest[e] < 0) {
+      s->err = "matrix pattern is not structurally symmetric (or columns are not sorted)";
+      return PGX_EINVAL;
+    }
+  return PGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_nd_scatter(int64_t nnz, const int64_t* __restrict__ dest, const double* __restrict__ vals,
+                             double* __restrict__ arena) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; k < nnz; k += stride) arena[dest[k]] = __builtin_nontemporal_load(vals + k);
+}
+
+// identity on the padded part of every pivot block
+__global__ void k_nd_pad(int64_t nfronts, const int32_t* __restrict__ fp, const int32_t* __restrict__ fP,
+                         const int32_t* __restrict__ fM, const int64_t* __restrict__ fbase, double* __restrict__ arena) {
+  const int64_t f = blockIdx.x;
+  if (f >= nfronts) return;
+  const int64_t M = fM[f];
+  double* F = arena + fbase[f];
+  for (int k = fp[f] + threadIdx.x; k < fP[f]; k += blockDim.x) F[k * M + k] = 1.0;
+}
+
+// extend-add of the Schur complements of the fronts [c0, c0+nc) (one level) whose child slot equals `pass`
+__global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int32_t* __restrict__ fb,
+                                const int32_t* __restrict__ slot01, const int32_t* __restrict__ parent,
+                                const int32_t* __restrict__ fM, const int64_t* __restrict__ fbase,
+                                const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel,
+                                double* __restrict__ arena) {
+  const int64_t f = c0 + blockIdx.x;
+  if (slot01[f] != pass) return;
+  const int b = fb[f];
+  const int32_t* R = rel + rel_ptr[f];
+  const double* src = arena + fbase[f] + (int64_t)Pc * Mc + Pc;
+  const int pf = parent[f];
+  const int64_t Mp = fM[pf];
+  double* dst = arena + fbase[pf];
+  const int64_t total = (int64_t)b * b;
+  for (int64_t idx = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.y * blockDim.x) {
+    const int c = (int)(idx / b), r = (int)(idx - (int64_t)c * b);
+    dst[(int64_t)R[c] * Mp + R[r]] += src[(int64_t)c * Mc + r];
+  }
+}
+
+// forward assembly of the per-front vectors of one level: own part from the right-hand side, border part from the children
+__global__ void k_nd_fwd_assemble(int64_t f0, int P, int M, const int32_t* __restrict__ fp, const int32_t* __restrict__ fb,
+                                  const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
+                                  const int32_t* __restrict__ fP, const int64_t* __restrict__ vbase,
+                                  const int64_t* __restrict__ dof_ptr, const int32_t* __restrict__ own_dofs,
+                                  const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel,
+                                  const double* __restrict__ b, double* __restrict__ vec) {
+  const int64_t f = f0 + blockIdx.x;
+  double* w = vec + vbase[f];
+  const int p = fp[f];
+  const int32_t* od = own_dofs + dof_ptr[f];
+  for (int k = threadIdx.x; k < M; k += blockDim.x) w[k] = k < p ? b[od[k]] : 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = pass == 0 ? child0[f] : child1[f];
+    __syncthreads();
+    if (c < 0) continue;
+    const double* wc = vec + vbase[c] + fP[c];
+    const int32_t* R = rel + rel_ptr[c];
+    const int bc = fb[c];
+    for (int k = threadIdx.x; k < bc; k += blockDim.x) w[R[k]] += wc[k];
+  }
+}
+
+// backward: border values from the parent's vector
+__global__ void k_nd_bwd_gather(int64_t f0, int P, const int32_t* __restrict__ fb, const int32_t* __restrict__ parent,
+                                const int64_t* __restrict__ vbase, const int64_t* __restrict__ rel_ptr,
+                                const int32_t* __restrict__ rel, double* __restrict__ vec) {
+  const int64_t f = f0 + blockIdx.x;
+  double* w = vec + vbase[f] + P;
+  const double* wp = vec + vbase[parent[f]];
+  const int32_t* R = rel + rel_ptr[f];
+  const int b = fb[f];
+  for (int k = threadIdx.x; k < b; k += blockDim.x) w[k] = wp[R[k]];
+}
+
+__global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, const int64_t* __restrict__ vbase,
+                             const int64_t* __restrict__ dof_ptr, const int32_t* __restrict__ own_dofs,
+                             const double* __restrict__ vec, double* __restrict__ x) {
+  const int64_t f = blockIdx.x;
+  if (f >= nfronts) return;
+  const double* w = vec + vbase[f];
+  const int32_t* od = own_dofs + dof_ptr[f];
+  const int p = fp[f];
+  for (int k = threadIdx.x; k < p; k += blockDim.x) x[od[k]] = w[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+#define NDHIP(call)                                                   \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      s->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      return PGX_EHIP;                                                \
+    }                                                                 \
+  } while (0)
+#define NDBLAS(call)                                                            \
+  do {                                                                          \
+    rocblas_status e_ = (call);                                                 \
+    if (e_ != rocblas_status_success) {                                         \
+      s->err = std::string(#call) + ": " + rocblas_status_to_string(e_);        \
+      return PGX_EHIP;                                                          \
+    }                                                                           \
+  } while (0)
+
+template <typename T>
+static int nd_upload(pgx_nd* s, T** d, const std::vector<T>& h) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(h.size(), 1) * sizeof(T));
+  if (e != hipSuccess) {
+    s->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return PGX_ENOMEM;
+  }
+  s->allocs.push_back(q);
+  *d = (T*)q;
+  if (!h.empty()) NDHIP(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PGX_OK;
+}
+template <typename T>
+static int nd_alloc(pgx_nd* s, T** d, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) {
+    s->err = std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e);
+    return PGX_ENOMEM;
+  }
+  s->allocs.push_back(q);
+  *d = (T*)q;
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream, pgx_nd** out) {
+  if (!A || !out || A->n <= 0 || !A->rowptr || !A->col || !A->node_of_dof || !A->node_coords || A->n_nodes <= 0 ||
+      (A->dim != 2 && A->dim != 3)) {
+    g_nd_error = "pgx_nd_create: bad arguments";
+    return PGX_EINVAL;
+  }
+  pgx_nd* s = new pgx_nd();
+  s->n = A->n;
+  int rc = nd_symbolic(s, A);
+  if (rc) {
+    g_nd_error = s->err;
+    delete s;
+    return rc;
+  }
+  if (device < 0) {
+    *out = s;
+    return PGX_OK;
+  }
+  auto fail = [&](int code) {
+    g_nd_error = s->err;
+    pgx_nd_destroy(s);
+    return code;
+  };
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) {
+    s->err = "pgx_nd_create: no usable GPU (the direct solver has no CPU fallback)";
+    return fail(PGX_ENODEV);
+  }
+  s->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    s->err = "hipSetDevice failed";
+    return fail(PGX_EHIP);
+  }
+  if (hip_stream) {
+    s->st = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreate(&s->st) != hipSuccess) {
+      s->err = "hipStreamCreate failed";
+      return fail(PGX_EHIP);
+    }
+    s->own_stream = true;
+  }
+  std::vector<int32_t> fM(s->nfronts), fP(s->nfronts);
+  std::vector<int64_t> vbase(s->nfronts);
+  for (int64_t f = 0; f < s->nfronts; ++f) {
+    const NdLevel& Lv = s->lev[s->flevel[f]];
+    fM[f] = Lv.P + Lv.B;
+    fP[f] = Lv.P;
+    vbase[f] = Lv.voff + (f - Lv.start) * (int64_t)(Lv.P + Lv.B);
+  }
+#define UP(d, h)                        \
+  if ((rc = nd_upload(s, &s->d, h))) return fail(rc);
+  UP(d_dest, s->dest) UP(d_dof_ptr, s->dof_ptr) UP(d_rel_ptr, s->rel_ptr) UP(d_fbase, s->fbase) UP(d_fp, s->fp) UP(d_fb, s->fb)
+  UP(d_parent, s->parent) UP(d_slot01, s->slot01) UP(d_child0, s->child0) UP(d_child1, s->child1) UP(d_own_dofs, s->own_dofs)
+  UP(d_rel, s->rel)
+#undef UP
+  if ((rc = nd_upload(s, &s->d_fM, fM)) || (rc = nd_upload(s, &s->d_fP, fP)) || (rc = nd_upload(s, &s->d_vbase, vbase)))
+    return fail(rc);
+  if ((rc = nd_alloc(s, &s->arena, (size_t)s->arena_len)) || (rc = nd_alloc(s, &s->vec, (size_t)s->vec_len)) ||
+      (rc = nd_alloc(s, &s->d_vals, (size_t)s->nnz)) || (rc = nd_alloc(s, &s->d_b, (size_t)s->n)))
+    return fail(rc);
+  int64_t maxbatch = 1;
+  for (auto& L : s->lev) maxbatch = std::max(maxbatch, L.count);
+  if ((rc = nd_alloc(s, &s->d_info, (size_t)maxbatch))) return fail(rc);
+  if (rocblas_create_handle(&s->blas) != rocblas_status_success) {
+    s->err = "rocblas_create_handle failed";
+    return fail(PGX_EHIP);
+  }
+  rocblas_set_stream(s->blas, s->st);
+  rocblas_set_pointer_mode(s->blas, rocblas_pointer_mode_host);
+  hipEventCreate(&s->e0);
+  hipEventCreate(&s->e1);
+  // the dest map is only needed on the device from here on
+  *out = s;
+  return PGX_OK;
+}
+
+extern "C" void pgx_nd_destroy(pgx_nd* s) {
+  if (!s) return;
+  if (s->device >= 0) {
+    hipSetDevice(s->device);
+    if (s->st) hipStreamSynchronize(s->st);
+    if (s->blas) rocblas_destroy_handle(s->blas);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->e0) hipEventDestroy(s->e0);
+    if (s->e1) hipEventDestroy(s->e1);
+    if (s->own_stream && s->st) hipStreamDestroy(s->st);
+  }
+  delete s;
+}
+
+extern "C" int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st) {
+  if (!s || !st) return PGX_EINVAL;
+  *st = s->stats;
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms) {
+  if (!s) return PGX_EINVAL;
+  if (factor_ms) *factor_ms = s->factor_ms;
+  if (solve_ms) *solve_ms = s->solve_ms;
+  s->timing = enable != 0;
+  s->factor_ms = s->solve_ms = 0;
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
+  if (!s || !vals) return PGX_EINVAL;
+  if (s->device < 0) {
+    s->err = "pgx_nd_factor: symbolic-only handle (created with device < 0); there is no CPU numeric phase";
+    return PGX_ENODEV;
+  }
+  NDHIP(hipSetDevice(s->device));
+  const double* dv = vals;
+  if (!on_device) {
+    NDHIP(hipMemcpyAsync(s->d_vals, vals, (size_t)s->nnz * sizeof(double), hipMemcpyHostToDevice, s->st));
+    dv = s->d_vals;
+  }
+  if (s->timing) hipEventRecord(s->e0, s->st);
+  NDHIP(hipMemsetAsync(s->arena, 0, (size_t)s->arena_len * sizeof(double), s->st));
+  {
+    int blocks = (int)std::min<int64_t>((s->nnz + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, s->nnz, s->d_dest, dv, s->arena);
+    hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)s->nfronts), dim3(64), 0, s->st, s->nfronts, s->d_fp, s->d_fP, s->d_fM,
+                       s->d_fbase, s->arena);
+  }
+  const double one = 1.0, minus1 = -1.0;
+  const int L = (int)s->lev.size();
+  for (int l = L - 1; l >= 0; --l) {
+    const NdLevel& Lv = s->lev[l];
+    const int P = Lv.P, B = Lv.B, M = P + B;
+    const int64_t stride = (int64_t)M * M;
+    double* F = s->arena + Lv.off;
+    if (l + 1 < L) {
+      const NdLevel& C = s->lev[l + 1];
+      if (C.B > 0) {
+        int64_t per = (int64_t)C.B * C.B;
+        unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 1024));
+        // keep the grid bounded for very wide levels
+        while ((int64_t)gy * C.count > (int64_t)1 << 22 && gy > 1) gy /= 2;
+        for (int pass = 0; pass < 2; ++pass)
+          hipLaunchKernelGGL(k_nd_extend_add, dim3((unsigned)C.count, gy), dim3(256), 0, s->st, C.start, pass, C.P,
+                             C.P + C.B, s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel,
+                             s->arena);
+      }
+    }
+    NDBLAS(rocsolver_dgetrf_npvt_strided_batched(s->blas, P, P, F, M, stride, s->d_info, (int)Lv.count));
+    if (B > 0) {
+      // U12 = L11^{-1} F12 ; L21 = F21 U11^{-1} ; F22 -= L21 U12
+      NDBLAS(rocblas_dtrsm_strided_batched(s->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                           rocblas_diagonal_unit, P, B, &one, F, M, stride, F + (int64_t)P * M, M, stride,
+                                           (int)Lv.count));
+      NDBLAS(rocblas_dtrsm_strided_batched(s->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                                           rocblas_diagonal_non_unit, B, P, &one, F, M, stride, F + P, M, stride,
+                                           (int)Lv.count));
+      NDBLAS(rocblas_dgemm_strided_batched(s->blas, rocblas_operation_none, rocblas_operation_none, B, B, P, &minus1,
+                                           F + P, M, stride, F + (int64_t)P * M, M, stride, &one,
+                                           F + (int64_t)P * M + P, M, stride, (int)Lv.count));
+    }
+  }
+  if (s->timing) {
+    hipEventRecord(s->e1, s->st);
+    hipEventSynchronize(s->e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, s->e0, s->e1);
+    s->factor_ms += ms;
+  }
+  NDHIP(hipGetLastError());
+  if (!on_device) NDHIP(hipStreamSynchronize(s->st));
+  s->factored = true;
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device) {
+  if (!s || !b || !x) return PGX_EINVAL;
+  if (s->device < 0) {
+    s->err = "pgx_nd_solve: symbolic-only handle";
+    return PGX_ENODEV;
+  }
+  if (!s->factored) {
+    s->err = "pgx_nd_solve before pgx_nd_factor";
+    return PGX_ESTATE;
+  }
+  NDHIP(hipSetDevice(s->device));
+  const double* db = b;
+  double* dx = x;
+  if (!on_device) {
+    NDHIP(hipMemcpyAsync(s->d_b, b, (size_t)s->n * sizeof(double), hipMemcpyHostToDevice, s->st));
+    db = s->d_b;
+    dx = s->d_b;
+  }
+  if (s->timing) hipEventRecord(s->e0, s->st);
+  const double one = 1.0, minus1 = -1.0;
+  const int L = (int)s->lev.size();
+  for (int l = L - 1; l >= 0; --l) {
+    const NdLevel& Lv = s->lev[l];
+    const int P = Lv.P, B = Lv.B, M = P + B;
+    const int64_t stride = (int64_t)M * M;
+    const double* F = s->arena + Lv.off;
+    double* w = s->vec + Lv.voff;
+    hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, M, s->d_fp, s->d_fb,
+                       s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
+                       db, s->vec);
+    NDBLAS(rocblas_dtrsv_strided_batched(s->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, P, F,
+                                         M, stride, w, 1, M, (int)Lv.count));
+    if (B > 0)
+      NDBLAS(rocblas_dgemv_strided_batched(s->blas, rocblas_operation_none, B, P, &minus1, F + P, M, stride, w, 1, M, &one,
+                                           w + P, 1, M, (int)Lv.count));
+  }
+  for (int l = 0; l < L; ++l) {
+    const NdLevel& Lv = s->lev[l];
+    const int P = Lv.P, B = Lv.B, M = P + B;
+    const int64_t stride = (int64_t)M * M;
+    const double* F = s->arena + Lv.off;
+    double* w = s->vec + Lv.voff;
+    if (B > 0) {
+      hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
+                         s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
+      NDBLAS(rocblas_dgemv_strided_batched(s->blas, rocblas_operation_none, P, B, &minus1, F + (int64_t)P * M, M, stride,
+                                           w + P, 1, M, &one, w, 1, M, (int)Lv.count));
+    }
+    NDBLAS(rocblas_dtrsv_strided_batched(s->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, P,
+                                         F, M, stride, w, 1, M, (int)Lv.count));
+  }
+  hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
+                     s->d_dof_ptr, s->d_own_dofs, s->vec, dx);
+  if (s->timing) {
+    hipEventRecord(s->e1, s->st);
+    hipEventSynchronize(s->e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, s->e0, s->e1);
+    s->solve_ms += ms;
+  }
+  NDHIP(hipGetLastError());
+  if (!on_device) {
+    NDHIP(hipMemcpyAsync(x, s->d_b, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    NDHIP(hipStreamSynchronize(s->st));
+  }
+  return PGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// symbolic export (tests)
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B,
+                                    int64_t* lev_off) {
+  if (!s || !n_levels) return PGX_EINVAL;
+  const int64_t L = (int64_t)s->lev.size();
+  *n_levels = L;
+  for (int64_t l = 0; l < L; ++l) {
+    if (lev_start) lev_start[l] = s->lev[l].start;
+    if (P) P[l] = s->lev[l].P;
+    if (B) B[l] = s->lev[l].B;
+    if (lev_off) lev_off[l] = s->lev[l].off;
+  }
+  if (lev_start) lev_start[L] = s->nfronts;
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t* fp, int32_t* fb, int32_t* parent,
+                                    int32_t* slot01, int64_t* dof_ptr, int32_t* own_dofs, int64_t* rel_ptr, int32_t* rel) {
+  if (!s || !n_fronts) return PGX_EINVAL;
+  *n_fronts = s->nfronts;
+  auto cp = [](auto* dst, const auto& v) {
+    if (dst) std::copy(v.begin(), v.end(), dst);
+  };
+  cp(fp, s->fp);
+  cp(fb, s->fb);
+  cp(parent, s->parent);
+  cp(slot01, s->slot01);
+  cp(dof_ptr, s->dof_ptr);
+  cp(own_dofs, s->own_dofs);
+  cp(rel_ptr, s->rel_ptr);
+  cp(rel, s->rel);
+  return PGX_OK;
+}
+
+extern "C" int pgx_nd_export_dest(const pgx_nd* s, int64_t* nnz, int64_t* dest) {
+  if (!s || !nnz) return PGX_EINVAL;
+  *nnz = s->nnz;
+  if (dest) std::copy(s->dest.begin(), s->dest.end(), dest);
+  return PGX_OK;
+}

@@ -1,0 +1,97 @@
+"""Sparse direct solver (geometric nested-dissection multifrontal LU on the GPU) - host mirror of include/pgx_nd.h.
+
+Stands where the reference configures PETSc with ``"ksp_type": "preonly", "pc_type": "lu",
+"pc_factor_mat_solver_type": "mumps"`` (examples/01_obstacle_problem/obstacle_pg.py:129-131,
+examples/06_gradient_constraints/gradient_constraint_dolfinx.py:118-121).  No CPU numeric phase exists: `factor` and
+`solve` raise without a GPU; `device=-1` builds the symbolic structure only (statistics, tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DirectSolver:
+    def __init__(self, indptr, indices, node_of_dof, node_coords, leaf_nodes: int = 0, device: int = 0):
+        self._lib = L.load()
+        self._h = L._H()
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.node_of_dof = np.ascontiguousarray(node_of_dof, dtype=np.int32)
+        self.node_coords = np.ascontiguousarray(node_coords, dtype=np.float64)
+        self.n = len(self.indptr) - 1
+        m = L.pgx_nd_matrix(self.n, L.iptr(self.indptr), L.iptr(self.indices), int(self.node_coords.shape[0]),
+                            L.iptr(self.node_of_dof), int(self.node_coords.shape[1]), L.dptr(self.node_coords),
+                            int(leaf_nodes))
+        rc = self._lib.pgx_nd_create(C.byref(m), int(device), None, C.byref(self._h))
+        if rc:
+            msg = self._lib.pgx_nd_last_error(None)
+            raise L.PgxError(f"pgx_nd_create failed (code {rc}): {msg.decode() if msg else ''}")
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self._lib.pgx_nd_last_error(self._h)
+            raise L.PgxError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+    def stats(self) -> dict:
+        st = L.pgx_nd_stats()
+        self._check(self._lib.pgx_nd_get_stats(self._h, C.byref(st)), "pgx_nd_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def factor(self, data):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        assert data.shape == (int(self.indptr[-1]),)
+        self._check(self._lib.pgx_nd_factor(self._h, L.dptr(data), 0), "pgx_nd_factor")
+
+    def solve(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty_like(b)
+        self._check(self._lib.pgx_nd_solve(self._h, L.dptr(b), L.dptr(x), 0), "pgx_nd_solve")
+        return x
+
+    def timing(self, enable=True):
+        f, s = C.c_double(), C.c_double()
+        self._check(self._lib.pgx_nd_timing(self._h, int(enable), C.byref(f), C.byref(s)), "pgx_nd_timing")
+        return f.value, s.value
+
+    def export_symbolic(self) -> dict:
+        """The level/front/destination maps the device numeric phase uses (tests emulate it with numpy)."""
+        lib, h = self._lib, self._h
+        i64, i32 = np.int64, np.int32
+        p64 = lambda a: a.ctypes.data_as(L.c_int64_p)  # noqa: E731
+        nl = C.c_int64()
+        self._check(lib.pgx_nd_export_levels(h, C.byref(nl), None, None, None, None), "export_levels")
+        nl = nl.value
+        lev_start, P, B, lev_off = np.zeros(nl + 1, i64), np.zeros(nl, i32), np.zeros(nl, i32), np.zeros(nl, i64)
+        n1 = C.c_int64()
+        lib.pgx_nd_export_levels(h, C.byref(n1), p64(lev_start), L.iptr(P), L.iptr(B), p64(lev_off))
+        nf = C.c_int64()
+        lib.pgx_nd_export_fronts(h, C.byref(nf), None, None, None, None, None, None, None, None)
+        nf = nf.value
+        fp, fb, par, s01 = (np.zeros(nf, i32) for _ in range(4))
+        dof_ptr, rel_ptr = np.zeros(nf + 1, i64), np.zeros(nf + 1, i64)
+        lib.pgx_nd_export_fronts(h, C.byref(n1), L.iptr(fp), L.iptr(fb), L.iptr(par), L.iptr(s01), p64(dof_ptr), None,
+                                 p64(rel_ptr), None)
+        own, rel = np.zeros(max(int(dof_ptr[-1]), 1), i32), np.zeros(max(int(rel_ptr[-1]), 1), i32)
+        lib.pgx_nd_export_fronts(h, C.byref(n1), None, None, None, None, None, L.iptr(own), None, L.iptr(rel))
+        nnz = C.c_int64()
+        lib.pgx_nd_export_dest(h, C.byref(nnz), None)
+        dest = np.zeros(nnz.value, i64)
+        lib.pgx_nd_export_dest(h, C.byref(nnz), p64(dest))
+        return dict(lev_start=lev_start, P=P, B=B, lev_off=lev_off, fp=fp, fb=fb, parent=par, slot01=s01,
+                    dof_ptr=dof_ptr, own_dofs=own[: int(dof_ptr[-1])], rel_ptr=rel_ptr, rel=rel[: int(rel_ptr[-1])],
+                    dest=dest)
+
+    def close(self):
+        if self._h:
+            self._lib.pgx_nd_destroy(self._h)
+            self._h = L._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,98 @@
+"""numpy emulation of the DEVICE numeric phase of pgx_nd (proximalgalerkin_amd/csrc/pgx_nd.hip) driven by the maps the
+C++ symbolic phase exports.  Test infrastructure: validates ordering, level padding, assembly destinations and the
+child->parent maps on machines without a GPU.  Mirrors pgx_nd_factor / pgx_nd_solve statement by statement."""
+import numpy as np
+
+
+def _lu_nopivot(A):
+    p = A.shape[0]
+    for k in range(p):
+        A[k + 1:, k] /= A[k, k]
+        A[k + 1:, k + 1:] -= np.outer(A[k + 1:, k], A[k, k + 1:])
+
+
+def factor(sym, vals):
+    P, B, off, start = sym["P"], sym["B"], sym["lev_off"], sym["lev_start"]
+    L = len(P)
+    M = P.astype(np.int64) + B
+    total = int(off[-1] + (start[-1] - start[-2]) * M[-1] * M[-1])
+    arena = np.zeros(total)
+    assert len(np.unique(sym["dest"])) == len(sym["dest"]), "assembly destinations collide"
+    arena[sym["dest"]] = vals
+    level_of = np.zeros(int(start[-1]), dtype=np.int64)
+    for l in range(L):
+        level_of[start[l]: start[l + 1]] = l
+
+    def front(f):
+        l = level_of[f]
+        base = off[l] + (f - start[l]) * M[l] * M[l]
+        return arena[base: base + M[l] * M[l]].reshape(M[l], M[l]).T  # column-major view: F[r, c]
+
+    for f in range(int(start[-1])):
+        l = level_of[f]
+        F = front(f)
+        for k in range(sym["fp"][f], P[l]):
+            F[k, k] = 1.0
+    for l in range(L - 1, -1, -1):
+        if l + 1 < L:
+            for ps in (0, 1):
+                for c in range(int(start[l + 1]), int(start[l + 2])):
+                    if sym["slot01"][c] != ps:
+                        continue
+                    b = sym["fb"][c]
+                    R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + b]
+                    Fc = front(c)
+                    Fp = front(sym["parent"][c])
+                    Fp[np.ix_(R, R)] += Fc[P[l + 1]: P[l + 1] + b, P[l + 1]: P[l + 1] + b]
+        for f in range(int(start[l]), int(start[l + 1])):
+            F = front(f)
+            p = P[l]
+            F11 = F[:p, :p]
+            _lu_nopivot(F11)
+            if B[l]:
+                Lm = np.tril(F11, -1) + np.eye(p)
+                U = np.triu(F11)
+                F[:p, p:] = np.linalg.solve(Lm, F[:p, p:])
+                F[p:, :p] = np.linalg.solve(U.T, F[p:, :p].T).T
+                F[p:, p:] -= F[p:, :p] @ F[:p, p:]
+    return dict(arena=arena, front=front, level_of=level_of, M=M)
+
+
+def solve(sym, fac, b):
+    P, B, start = sym["P"], sym["B"], sym["lev_start"]
+    L = len(P)
+    nf = int(start[-1])
+    front, level_of, M = fac["front"], fac["level_of"], fac["M"]
+    w = [None] * nf
+    children = [[] for _ in range(nf)]
+    for f in range(nf):
+        if sym["parent"][f] >= 0:
+            children[sym["parent"][f]].append(f)
+    for l in range(L - 1, -1, -1):
+        for f in range(int(start[l]), int(start[l + 1])):
+            v = np.zeros(M[l])
+            p = sym["fp"][f]
+            v[:p] = b[sym["own_dofs"][sym["dof_ptr"][f]: sym["dof_ptr"][f] + p]]
+            for c in sorted(children[f], key=lambda c: sym["slot01"][c]):
+                bc = sym["fb"][c]
+                R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + bc]
+                v[R] += w[c][P[l + 1]: P[l + 1] + bc]
+            F = front(f)
+            pp = P[l]
+            v[:pp] = np.linalg.solve(np.tril(F[:pp, :pp], -1) + np.eye(pp), v[:pp])
+            v[pp:] -= F[pp:, :pp] @ v[:pp]
+            w[f] = v
+    x = np.zeros_like(b, dtype=float)
+    for l in range(L):
+        for f in range(int(start[l]), int(start[l + 1])):
+            v, F, pp = w[f], front(f), P[l]
+            if B[l]:
+                bf = sym["fb"][f]
+                R = sym["rel"][sym["rel_ptr"][f]: sym["rel_ptr"][f] + bf]
+                if sym["parent"][f] >= 0:
+                    v[pp: pp + bf] = w[sym["parent"][f]][R]
+                v[:pp] -= F[:pp, pp:] @ v[pp:]
+            v[:pp] = np.linalg.solve(np.triu(F[:pp, :pp]), v[:pp])
+            p = sym["fp"][f]
+            x[sym["own_dofs"][sym["dof_ptr"][f]: sym["dof_ptr"][f] + p]] = v[:p]
+    return x

@@ -1,0 +1,69 @@
+"""GPU numeric phase of the sparse direct solver (pgx_nd) against SuperLU, through the C ABI, on Newton matrices of
+examples 01 (P1, P2) and 06 built by the CPU oracle.  Tolerances: residual 1e-10 relative (fp64 LU without pivoting
+across nodes), solution 1e-7 relative to SuperLU (the late ex 06 matrices have condition numbers ~1e10)."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import gc_oracle as G
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(J, node_of_dof, node_coords, leaf, rtol_res=1e-10, rtol_x=1e-7):
+    from proximalgalerkin_amd.direct import DirectSolver
+    J = J.tocsr()
+    J.sort_indices()
+    ds = DirectSolver(J.indptr, J.indices, node_of_dof, node_coords, leaf_nodes=leaf, device=0)
+    ds.factor(J.data)
+    rng = np.random.default_rng(3)
+    lu = spla.splu(J.tocsc())
+    for _ in range(2):
+        b = rng.standard_normal(J.shape[0])
+        x = ds.solve(b)
+        assert np.all(np.isfinite(x))
+        assert np.linalg.norm(J @ x - b) <= rtol_res * np.linalg.norm(b)
+        xr = lu.solve(b)
+        assert np.linalg.norm(x - xr) <= rtol_x * np.linalg.norm(xr)
+    # refactor with other values on the same pattern (what every Newton step does)
+    J2 = J.copy()
+    J2.data = J.data * (1.0 + 0.1 * np.sin(np.arange(J.nnz)))
+    J2 = (J2 + J2.T) * 0.5
+    J2.sort_indices()
+    assert np.array_equal(J2.indices, J.indices)
+    ds.factor(J2.data)
+    b = rng.standard_normal(J.shape[0])
+    x = ds.solve(b)
+    assert np.linalg.norm(J2 @ x - b) <= 1e-9 * np.linalg.norm(b)
+    ds.close()
+
+
+@pytest.mark.parametrize("N,leaf", [(12, 8), (40, 32), (64, 0)])
+def test_ex01_p1_newton_matrix(require_gpu, N, leaf):
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    its = []
+    O.solve_problem(p1, 500, "double_exponential", 1e2, 1e-4, iterates=its)
+    J = p1.jacobian(its[-2], 100.0)  # late step: exp(psi) underflows in the contact zone
+    _check(J, np.concatenate([np.arange(p1.n)] * 2), p1.coords, leaf)
+
+
+def test_ex01_p2_newton_matrix(require_gpu):
+    N = 24
+    coords, cells = O.create_rectangle(N, N)
+    p2 = O.ObstacleLagrange(coords, cells, degree=2)
+    its = []
+    O.solve_problem(p2, 500, "double_exponential", 1e2, 1e-4, iterates=its)
+    _check(p2.jacobian(its[-2], 100.0), np.concatenate([np.arange(p2.n)] * 2), p2.dof_coords, 24)
+
+
+def test_ex06_newton_matrix(require_gpu):
+    N = 20
+    c6, e6 = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    g = G.GradientConstraintP2(c6, e6)
+    its = []
+    G.solve_problem(g, max_iterations=8, iterates=its)
+    nod = np.concatenate([np.arange(g.n2), np.arange(g.nv), np.arange(g.nv)])
+    _check(g.jacobian(its[1], 4.0), nod, g.dof_coords, 16)
+    _check(g.jacobian(its[-1], 256.0), nod, g.dof_coords, 16, rtol_res=1e-9, rtol_x=1e-5)

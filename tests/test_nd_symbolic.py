@@ -1,0 +1,67 @@
+"""CPU tests of the sparse direct solver's symbolic phase (C++ in libpgx.so, no GPU touched): the exported level /
+front / destination maps are fed to a numpy emulation of the device numeric phase (tests/nd_emulate.py) and the result
+is compared with SuperLU on Newton matrices of examples 01 (P1, P2) and 06."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import gc_oracle as G
+from oracle import pg_oracle as O
+from proximalgalerkin_amd.direct import DirectSolver
+from tests import nd_emulate as E
+
+
+def _cases():
+    N = 12
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    rng = np.random.default_rng(1)
+    x = 0.3 * rng.standard_normal(2 * p1.n)
+    x[p1.n:] -= 40.0 * (np.hypot(*p1.coords.T) < 0.4)  # exp(psi) underflows towards 0 in a "contact zone"
+    yield "ex01-P1", p1.jacobian(x, 7.0), np.concatenate([np.arange(p1.n)] * 2), p1.coords, 8
+    p2 = O.ObstacleLagrange(coords, cells, degree=2)
+    x = 0.3 * rng.standard_normal(2 * p2.n)
+    yield "ex01-P2", p2.jacobian(x, 3.0), np.concatenate([np.arange(p2.n)] * 2), p2.dof_coords, 12
+    c6, e6 = O.create_rectangle(10, 10, (0.0, 0.0), (1.0, 1.0))
+    g = G.GradientConstraintP2(c6, e6)
+    x = rng.standard_normal(g.ntot) * 3.0
+    yield "ex06", g.jacobian(x, 16.0), np.concatenate([np.arange(g.n2), np.arange(g.nv), np.arange(g.nv)]), g.dof_coords, 10
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_symbolic_maps_reproduce_lu(case):
+    name, J, node_of_dof, node_coords, leaf = case
+    J = J.tocsr()
+    J.sort_indices()
+    ds = DirectSolver(J.indptr, J.indices, node_of_dof, node_coords, leaf_nodes=leaf, device=-1)
+    st = ds.stats()
+    assert st["n_levels"] >= 3 and st["flops_padded"] >= st["flops"] > 0
+    sym = ds.export_symbolic()
+    # every dof is owned by exactly one front
+    assert np.array_equal(np.sort(sym["own_dofs"]), np.arange(J.shape[0]))
+    fac = E.factor(sym, J.data)
+    b = np.random.default_rng(0).standard_normal(J.shape[0])
+    x = E.solve(sym, fac, b)
+    xr = spla.splu(J.tocsc()).solve(b)
+    assert np.linalg.norm(J @ x - b) <= 1e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
+
+
+def test_symbolic_handle_refuses_numeric_phase_without_gpu():
+    coords, cells = O.create_rectangle(4, 4)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(4, 4))
+    J = p1.jacobian(np.zeros(2 * p1.n), 1.0).tocsr()
+    J.sort_indices()
+    ds = DirectSolver(J.indptr, J.indices, np.concatenate([np.arange(p1.n)] * 2), p1.coords, device=-1)
+    from proximalgalerkin_amd._lib import PgxError
+    with pytest.raises(PgxError):
+        ds.factor(J.data)
+
+
+def test_unsymmetric_pattern_is_rejected():
+    import scipy.sparse as sp
+    A = sp.csr_matrix(np.array([[1.0, 2.0, 0.0], [0.0, 1.0, 0.0], [0.0, 3.0, 1.0]]))
+    from proximalgalerkin_amd._lib import PgxError
+    with pytest.raises(PgxError):
+        DirectSolver(A.indptr, A.indices, np.arange(3), np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]]), leaf_nodes=1,
+                     device=-1)
