@@ -12,11 +12,16 @@
 // Solve: the same tree walk on per-front vectors (forward bottom-up, backward top-down).
 //
 // MI355X notes: the arena is sized for 288 GB HBM3E (tens of GB of fronts are kept resident so that the solve phase and
-// the next factorisation re-use the allocation); the GEMM-shaped work (Schur updates) runs on the fp64 matrix cores through
-// rocBLAS/rocSOLVER strided-batched calls; assembly, extend-add and the vector tree walks are hand-written kernels.
+// the next factorisation re-use the allocation).  All dense work is hand-written and batched over the fronts of a level:
+//   k_nd_diag   LU of one nb x nb diagonal block (nb <= 72) in LDS, no pivoting
+//   k_nd_panel  the two triangular panel solves against that block, 64-wide chunks, right-looking in LDS
+//   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 64x64 tiles, 4 waves x (2x2) MFMA tiles;
+//               operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes
+// organised as a partial left-looking factorisation: the pivot block and both panels are updated step by step, the
+// Schur complement F22 -= L21 U12 is applied ONCE with K = P (its bytes move once; arithmetic intensity P/8 flop/byte).
+// (A first version used rocSOLVER getrf_npvt / rocBLAS trsm+gemm strided-batched: 859 ms at 1024^2, dominated by
+// 4e5 tiny Tensile launches; profiles/r01_nd_rocblas_baseline_kernel_stats.csv.)
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <cmath>
@@ -56,8 +61,7 @@ struct pgx_nd {
   int64_t *d_dest = nullptr, *d_dof_ptr = nullptr, *d_rel_ptr = nullptr, *d_fbase = nullptr, *d_vbase = nullptr;
   int32_t *d_fp = nullptr, *d_fb = nullptr, *d_parent = nullptr, *d_slot01 = nullptr, *d_child0 = nullptr,
           *d_child1 = nullptr, *d_own_dofs = nullptr, *d_rel = nullptr, *d_fM = nullptr, *d_fP = nullptr;
-  rocblas_handle blas = nullptr;
-  int* d_info = nullptr;
+  int* d_info = nullptr;  // [0] = number of (near-)zero pivots met by the last factorisation
   bool factored = false;
   bool timing = false;
   double factor_ms = 0, solve_ms = 0;
@@ -497,6 +501,240 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
   for (int k = threadIdx.x; k < p; k += blockDim.x) x[od[k]] = w[k];
 }
 
+
+// ---- dense kernels, batched over the fronts of one level (blockIdx.x = front within the level) ---------------------
+#define ND_NB 72   // widest pivot panel (diagonal block kept in LDS)
+#define ND_TS 64   // GEMM tile / panel chunk
+#define ND_KC 24   // GEMM k-chunk staged in LDS
+typedef double nd_v4d __attribute__((ext_vector_type(4)));
+
+// LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level
+__global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
+                                                 int* __restrict__ info) {
+  __shared__ double D[ND_NB][ND_NB + 1];
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M + (int64_t)kb * M + kb;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int r = idx % nb, c = idx / nb;
+    D[r][c] = F[(int64_t)c * M + r];
+  }
+  for (int k = 0; k < nb - 1; ++k) {
+    __syncthreads();
+    double piv = D[k][k];
+    if (fabs(piv) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported through info
+      piv = piv < 0 ? -1e-300 : 1e-300;
+      if (tid == 0) {
+        D[k][k] = piv;
+        atomicAdd(info, 1);
+      }
+    }
+    const int m = nb - k - 1;
+    if (tid < m) D[k + 1 + tid][k] /= piv;
+    __syncthreads();
+    for (int idx = tid; idx < m * m; idx += 256) {
+      const int r = k + 1 + idx % m, c = k + 1 + idx / m;
+      D[r][c] -= D[r][k] * D[k][c];
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && fabs(D[nb - 1][nb - 1]) < 1e-300) {
+    D[nb - 1][nb - 1] = 1e-300;
+    atomicAdd(info, 1);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int r = idx % nb, c = idx / nb;
+    F[(int64_t)c * M + r] = D[r][c];
+  }
+}
+
+// panel solves against the factored diagonal block: chunk c < nch : columns [o0, o0+64) of the row panel, X <- L^{-1} X;
+// chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  Right-looking in LDS, one barrier per step.
+__global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb) {
+  __shared__ double T[ND_NB * (ND_NB + 1) / 2];
+  __shared__ double X[ND_NB][ND_TS + 1];
+  __shared__ double invd[ND_NB];
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const int tid = threadIdx.x;
+  const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
+  const bool isL = (int)blockIdx.y >= nch;
+  const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
+  const int w = min(ND_TS, M - o0);
+  const double* Dg = F + (int64_t)kb * M + kb;
+  if (!isL) {
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int r = idx % nb, c = idx / nb;
+      if (r > c) T[r * (r - 1) / 2 + c] = Dg[(int64_t)c * M + r];
+    }
+    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
+      const int k = idx % nb, j = idx / nb;
+      X[k][j] = j < w ? F[(int64_t)(o0 + j) * M + kb + k] : 0.0;
+    }
+    __syncthreads();
+    const int j = tid & 63, g = tid >> 6;
+    for (int k = 0; k < nb - 1; ++k) {
+      const double xk = X[k][j];
+      for (int r = k + 1 + g; r < nb; r += 4) X[r][j] -= T[r * (r - 1) / 2 + k] * xk;
+      __syncthreads();
+    }
+    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
+      const int k = idx % nb, jj = idx / nb;
+      if (jj < w) F[(int64_t)(o0 + jj) * M + kb + k] = X[k][jj];
+    }
+  } else {
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int k = idx % nb, c = idx / nb;
+      if (k <= c) T[c * (c + 1) / 2 + k] = Dg[(int64_t)c * M + k];
+    }
+    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
+      const int i = idx % ND_TS, k = idx / ND_TS;
+      X[k][i] = i < w ? F[(int64_t)(kb + k) * M + o0 + i] : 0.0;
+    }
+    __syncthreads();
+    if (tid < nb) invd[tid] = 1.0 / T[tid * (tid + 1) / 2 + tid];
+    __syncthreads();
+    const int i = tid & 63, g = tid >> 6;
+    for (int k = 0; k < nb - 1; ++k) {
+      const double xk = X[k][i] * invd[k];
+      for (int c = k + 1 + g; c < nb; c += 4) X[c][i] -= xk * T[c * (c + 1) / 2 + k];
+      __syncthreads();
+    }
+    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
+      const int ii = idx % ND_TS, k = idx / ND_TS;
+      if (ii < w) F[(int64_t)(kb + k) * M + o0 + ii] = X[k][ii] * invd[k];
+    }
+  }
+}
+
+// C -= A B with A = F[rows, k0:k1), B = F[k0:k1, cols) on 64x64 tiles.  Tiles never straddle P: row/col blocks are laid
+// out as [s, P) then [P, M).  mode 0: all tiles of the trailing matrix EXCEPT the Schur block (rows >= P and cols >= P);
+// mode 1 (s == P): the Schur block only.
+__global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int P, int s, int k0,
+                                                 int k1, int mode) {
+  __shared__ double As[ND_KC][ND_TS + 8];
+  __shared__ double Bs[ND_TS][ND_KC + 1];
+  const int nb1 = s < P ? (P - s + ND_TS - 1) / ND_TS : 0;
+  const int bi = blockIdx.y, bj = blockIdx.z;
+  if (mode == 0 && bi >= nb1 && bj >= nb1) return;
+  int r0, rmax, c0, cmax;
+  if (bi < nb1) r0 = s + ND_TS * bi, rmax = P; else r0 = P + ND_TS * (bi - nb1), rmax = M;
+  if (bj < nb1) c0 = s + ND_TS * bj, cmax = P; else c0 = P + ND_TS * (bj - nb1), cmax = M;
+  if (r0 >= rmax || c0 >= cmax) return;
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
+  nd_v4d acc[2][2];  // [tj][ti]
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
+  for (int kc = k0; kc < k1; kc += ND_KC) {
+    const int kn = min(ND_KC, k1 - kc);
+    for (int idx = tid; idx < ND_KC * ND_TS; idx += 256) {
+      const int i = idx % ND_TS, k = idx / ND_TS;
+      As[k][i] = (k < kn && r0 + i < rmax) ? F[(int64_t)(kc + k) * M + r0 + i] : 0.0;
+    }
+    for (int idx = tid; idx < ND_KC * ND_TS; idx += 256) {
+      const int k = idx % ND_KC, j = idx / ND_KC;
+      Bs[j][k] = (k < kn && c0 + j < cmax) ? F[(int64_t)(c0 + j) * M + kc + k] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < ND_KC; kk += 4) {
+      const int kq = kk + (l >> 4);
+      const double u0 = Bs[wj + (l & 15)][kq], u1 = Bs[wj + 16 + (l & 15)][kq];
+      const double l0 = As[kq][wi + (l & 15)], l1 = As[kq][wi + 16 + (l & 15)];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const int i = r0 + wi + 16 * ti + (l & 15);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
+        if (i < rmax && j < cmax) F[(int64_t)j * M + i] -= acc[tj][ti][reg];
+      }
+    }
+}
+
+// in-place triangular solve on w[0:P) of every front: upper == 0: unit lower L11; upper != 0: U11.  One workgroup per
+// front, 64-wide blocks: the triangle is solved by wave 0 with lane shuffles, the remaining rows are updated by all.
+__global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
+                                                 int64_t voff, int M, int P, int upper) {
+  __shared__ double Ds[64][65];
+  __shared__ double ys[64];
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  double* w = vec + voff + (int64_t)blockIdx.x * M;
+  const int tid = threadIdx.x;
+  const int nblk = (P + 63) / 64;
+  for (int bb = 0; bb < nblk; ++bb) {
+    const int kb = upper ? (nblk - 1 - bb) * 64 : bb * 64;
+    const int nb = min(64, P - kb);
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int r = idx % nb, c = idx / nb;
+      Ds[r][c] = F[(int64_t)(kb + c) * M + kb + r];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int r = tid;
+      double y = r < nb ? w[kb + r] : 0.0;
+      if (!upper) {
+        for (int k = 0; k < nb; ++k) {
+          const double yk = __shfl(y, k);
+          if (r > k && r < nb) y -= Ds[r][k] * yk;
+        }
+      } else {
+        const double dinv = r < nb ? 1.0 / Ds[r][r] : 0.0;
+        for (int k = nb - 1; k >= 0; --k) {
+          const double xk = __shfl(y * dinv, k);
+          if (r < k) y -= Ds[r][k] * xk;
+          if (r == k) y = xk;
+        }
+      }
+      ys[r] = y;
+      if (r < nb) w[kb + r] = y;
+    }
+    __syncthreads();
+    const int lo = upper ? 0 : kb + nb, hi = upper ? kb : P;
+    for (int r = lo + tid; r < hi; r += 256) {
+      double a = 0.0;
+      for (int k = 0; k < nb; ++k) a += F[(int64_t)(kb + k) * M + r] * ys[k];
+      w[r] -= a;
+    }
+    __syncthreads();
+  }
+}
+
+// border products of the tree walk: mode 0 (forward) w[P+i] -= sum_{k<P} F[P+i, k] w[k]; mode 1 (backward)
+// w[i] -= sum_{j<B} F[i, P+j] w[P+j].  One thread per row, 256 rows per block (blockIdx.y).
+__global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
+                                                 int64_t voff, int M, int P, int B, int mode) {
+  __shared__ double xs[256];
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  double* w = vec + voff + (int64_t)blockIdx.x * M;
+  const int rows = mode == 0 ? B : P, K = mode == 0 ? P : B;
+  const int roff = mode == 0 ? P : 0, coff = mode == 0 ? 0 : P;
+  const int r = blockIdx.y * 256 + threadIdx.x;
+  double a = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int kn = min(256, K - k0);
+    __syncthreads();
+    if ((int)threadIdx.x < kn) xs[threadIdx.x] = w[coff + k0 + threadIdx.x];
+    __syncthreads();
+    if (r < rows) {
+      const double* col = F + (int64_t)(coff + k0) * M + roff + r;
+      for (int k = 0; k < kn; ++k) a += col[(int64_t)k * M] * xs[k];
+    }
+  }
+  if (r < rows) w[roff + r] -= a;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
@@ -507,14 +745,6 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
       s->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
       return PGX_EHIP;                                                \
     }                                                                 \
-  } while (0)
-#define NDBLAS(call)                                                            \
-  do {                                                                          \
-    rocblas_status e_ = (call);                                                 \
-    if (e_ != rocblas_status_success) {                                         \
-      s->err = std::string(#call) + ": " + rocblas_status_to_string(e_);        \
-      return PGX_EHIP;                                                          \
-    }                                                                           \
   } while (0)
 
 template <typename T>
@@ -607,12 +837,6 @@ extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_strea
   int64_t maxbatch = 1;
   for (auto& L : s->lev) maxbatch = std::max(maxbatch, L.count);
   if ((rc = nd_alloc(s, &s->d_info, (size_t)maxbatch))) return fail(rc);
-  if (rocblas_create_handle(&s->blas) != rocblas_status_success) {
-    s->err = "rocblas_create_handle failed";
-    return fail(PGX_EHIP);
-  }
-  rocblas_set_stream(s->blas, s->st);
-  rocblas_set_pointer_mode(s->blas, rocblas_pointer_mode_host);
   hipEventCreate(&s->e0);
   hipEventCreate(&s->e1);
   // the dest map is only needed on the device from here on
@@ -625,7 +849,6 @@ extern "C" void pgx_nd_destroy(pgx_nd* s) {
   if (s->device >= 0) {
     hipSetDevice(s->device);
     if (s->st) hipStreamSynchronize(s->st);
-    if (s->blas) rocblas_destroy_handle(s->blas);
     for (void* p : s->allocs) hipFree(p);
     if (s->e0) hipEventDestroy(s->e0);
     if (s->e1) hipEventDestroy(s->e1);
@@ -669,13 +892,11 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)s->nfronts), dim3(64), 0, s->st, s->nfronts, s->d_fp, s->d_fP, s->d_fM,
                        s->d_fbase, s->arena);
   }
-  const double one = 1.0, minus1 = -1.0;
+  NDHIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
   const int L = (int)s->lev.size();
   for (int l = L - 1; l >= 0; --l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
-    const int64_t stride = (int64_t)M * M;
-    double* F = s->arena + Lv.off;
     if (l + 1 < L) {
       const NdLevel& C = s->lev[l + 1];
       if (C.B > 0) {
@@ -689,18 +910,29 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
                              s->arena);
       }
     }
-    NDBLAS(rocsolver_dgetrf_npvt_strided_batched(s->blas, P, P, F, M, stride, s->d_info, (int)Lv.count));
+    // partial left-looking LU of the level: pivot block + both panels step by step, Schur block once at the end
+    const int nsteps = (P + ND_NB - 1) / ND_NB;
+    int kb = 0;
+    for (int st = 0; st < nsteps; ++st) {
+      const int nb = P / nsteps + (st < P % nsteps ? 1 : 0);
+      hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb, s->d_info);
+      const int R = M - kb - nb;
+      if (R > 0) {
+        const unsigned nch = (unsigned)((R + ND_TS - 1) / ND_TS);
+        hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
+        const int sfirst = kb + nb;
+        if (sfirst < P) {
+          const unsigned nb1 = (unsigned)((P - sfirst + ND_TS - 1) / ND_TS), nb2 = (unsigned)((B + ND_TS - 1) / ND_TS);
+          hipLaunchKernelGGL(k_nd_gemm, dim3((unsigned)Lv.count, nb1 + nb2, nb1 + nb2), dim3(256), 0, s->st, s->arena,
+                             Lv.off, M, P, sfirst, kb, kb + nb, 0);
+        }
+      }
+      kb += nb;
+    }
     if (B > 0) {
-      // U12 = L11^{-1} F12 ; L21 = F21 U11^{-1} ; F22 -= L21 U12
-      NDBLAS(rocblas_dtrsm_strided_batched(s->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                           rocblas_diagonal_unit, P, B, &one, F, M, stride, F + (int64_t)P * M, M, stride,
-                                           (int)Lv.count));
-      NDBLAS(rocblas_dtrsm_strided_batched(s->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                                           rocblas_diagonal_non_unit, B, P, &one, F, M, stride, F + P, M, stride,
-                                           (int)Lv.count));
-      NDBLAS(rocblas_dgemm_strided_batched(s->blas, rocblas_operation_none, rocblas_operation_none, B, B, P, &minus1,
-                                           F + P, M, stride, F + (int64_t)P * M, M, stride, &one,
-                                           F + (int64_t)P * M + P, M, stride, (int)Lv.count));
+      const unsigned nb2 = (unsigned)((B + ND_TS - 1) / ND_TS);
+      hipLaunchKernelGGL(k_nd_gemm, dim3((unsigned)Lv.count, nb2, nb2), dim3(256), 0, s->st, s->arena, Lv.off, M, P, P, 0,
+                         P, 1);
     }
   }
   if (s->timing) {
@@ -735,37 +967,28 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     dx = s->d_b;
   }
   if (s->timing) hipEventRecord(s->e0, s->st);
-  const double one = 1.0, minus1 = -1.0;
   const int L = (int)s->lev.size();
   for (int l = L - 1; l >= 0; --l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
-    const int64_t stride = (int64_t)M * M;
-    const double* F = s->arena + Lv.off;
-    double* w = s->vec + Lv.voff;
     hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, M, s->d_fp, s->d_fb,
                        s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
                        db, s->vec);
-    NDBLAS(rocblas_dtrsv_strided_batched(s->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, P, F,
-                                         M, stride, w, 1, M, (int)Lv.count));
+    hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, P, 0);
     if (B > 0)
-      NDBLAS(rocblas_dgemv_strided_batched(s->blas, rocblas_operation_none, B, P, &minus1, F + P, M, stride, w, 1, M, &one,
-                                           w + P, 1, M, (int)Lv.count));
+      hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((B + 255) / 256)), dim3(256), 0, s->st, s->arena,
+                         Lv.off, s->vec, Lv.voff, M, P, B, 0);
   }
   for (int l = 0; l < L; ++l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
-    const int64_t stride = (int64_t)M * M;
-    const double* F = s->arena + Lv.off;
-    double* w = s->vec + Lv.voff;
     if (B > 0) {
       hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
                          s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
-      NDBLAS(rocblas_dgemv_strided_batched(s->blas, rocblas_operation_none, P, B, &minus1, F + (int64_t)P * M, M, stride,
-                                           w + P, 1, M, &one, w, 1, M, (int)Lv.count));
+      hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, s->st, s->arena,
+                         Lv.off, s->vec, Lv.voff, M, P, B, 1);
     }
-    NDBLAS(rocblas_dtrsv_strided_batched(s->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, P,
-                                         F, M, stride, w, 1, M, (int)Lv.count));
+    hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, P, 1);
   }
   hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
                      s->d_dof_ptr, s->d_own_dofs, s->vec, dx);
