@@ -64,6 +64,7 @@ class pgx_snes_opts(C.Structure):
         ("mg_nu", C.c_int32),
         ("mg_omega", C.c_double),
         ("monitor", C.c_int32),
+        ("pc_type", C.c_int32),
     ]
 
 

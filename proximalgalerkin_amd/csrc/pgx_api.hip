@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/pgx.h"
+#include "../../include/pgx_nd.h"
 #include "pgx_comm.h"
 #include "pgx_internal.h"
 
@@ -87,6 +88,10 @@ struct pgx_handle {
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
   int fused_min = 60000;  // fused legs only pay on levels large enough to hide their 3-phase latency
   TailArgs tail{};
+  // sparse direct preconditioner (pc_type lu): nested-dissection multifrontal LU of the mixed Newton matrix (pgx_nd.hip)
+  pgx_nd* lu = nullptr;
+  double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
+  bool lu_active = false;  // the current Newton solve preconditions with the factorisation
   // observables
   double *obs_partials = nullptr, *d_out6 = nullptr;
   int obs_blocks = 0;
@@ -154,6 +159,7 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
                   // Krylov space, whose orthogonalisation cost grows with its square
   o->mg_omega = 0.8;
   o->monitor = 0;
+  o->pc_type = 0;  // auto: multigrid for P1, sparse LU for P2
 }
 
 extern "C" const char* pgx_last_error(const pgx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -1001,6 +1007,7 @@ extern "C" void pgx_destroy(pgx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
+  if (h->lu) pgx_nd_destroy(h->lu);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_small) hipHostFree(h->h_small);
   if (h->e0) hipEventDestroy(h->e0);
@@ -1375,7 +1382,108 @@ static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double*
   }
 }
 
+// Values of the mixed Newton matrix [[alpha K, M],[M, -D]] with the Dirichlet rows/columns of the u block replaced by
+// identity (the contract of problem.py:69-77), in the CSR layout: row i -> [cols_s(i) | nd + cols_s(i)], row nd+i likewise.
+__global__ void k_mixed_vals(int nd, int nnz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colm,
+                             const double* __restrict__ K, const double* __restrict__ M, const double* __restrict__ D,
+                             double alpha, const uint8_t* __restrict__ mask, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nd) return;
+  const int b = rowptr[i], e = rowptr[i + 1], len = e - b;
+  const bool rowbc = mask[i] != 0;
+  double* uu = out + 2 * (size_t)b;
+  double* up = uu + len;
+  double* pu = out + 2 * (size_t)nnz + 2 * (size_t)b;
+  double* pp = pu + len;
+  for (int k = b; k < e; ++k) {
+    const int32_t cm = colm[k];
+    const bool colbc = cm < 0;
+    const int c = cm & 0x7fffffff;
+    const double m = M[k];
+    uu[k - b] = (rowbc || colbc) ? ((rowbc && c == i) ? 1.0 : 0.0) : alpha * K[k];
+    up[k - b] = rowbc ? 0.0 : m;
+    pu[k - b] = colbc ? 0.0 : m;
+    pp[k - b] = -D[k];
+  }
+}
+
+// symbolic phase of the direct solver, once per handle (first Newton solve that asks for pc_type lu)
+static int ensure_lu(pgx_handle* h) {
+  if (h->lu) return PGX_OK;
+  if (h->dist.on) {
+    h->err = "pc_type lu is not available on a sharded handle";
+    return PGX_EINVAL;
+  }
+  const int nd = h->nd, n = h->n;
+  const std::vector<int32_t>& hr = (h->degree == 2) ? h->s_h_rowptr : h->h_rowptr;
+  const std::vector<int32_t>& hc = (h->degree == 2) ? h->s_h_col : h->h_col;
+  const int64_t nnz = hr[nd];
+  if ((int64_t)4 * nnz > 0x7fffffff) {
+    h->err = "pc_type lu: mixed matrix exceeds int32 nnz";
+    return PGX_EINVAL;
+  }
+  std::vector<int32_t> rp(2 * (size_t)nd + 1), cl(4 * (size_t)nnz), nod(2 * (size_t)nd);
+  for (int i = 0; i < nd; ++i) {
+    const int b = hr[i], len = hr[i + 1] - b;
+    rp[i] = 2 * b;
+    rp[nd + i] = (int32_t)(2 * nnz + 2 * b);
+    for (int k = 0; k < len; ++k) {
+      const int32_t c = hc[b + k] & 0x7fffffff;
+      if (k > 0 && (hc[b + k - 1] & 0x7fffffff) >= c) {
+        h->err = "pc_type lu: scalar pattern is not sorted";
+        return PGX_EINVAL;
+      }
+      cl[2 * (size_t)b + k] = c;
+      cl[2 * (size_t)b + len + k] = nd + c;
+      cl[2 * (size_t)nnz + 2 * (size_t)b + k] = c;
+      cl[2 * (size_t)nnz + 2 * (size_t)b + len + k] = nd + c;
+    }
+    nod[i] = nod[nd + i] = i;
+  }
+  rp[2 * (size_t)nd] = (int32_t)(4 * nnz);
+  std::vector<double> xy(2 * (size_t)nd);
+  HIPCHK(hipMemcpy(xy.data(), h->coords, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+  if (h->degree == 2) {
+    std::vector<int32_t> ends(2 * (size_t)(nd - n));
+    HIPCHK(hipMemcpy(ends.data(), h->edge_ends, sizeof(int32_t) * ends.size(), hipMemcpyDeviceToHost));
+    for (int e = 0; e < nd - n; ++e)
+      for (int d = 0; d < 2; ++d) xy[2 * (size_t)(n + e) + d] = 0.5 * (xy[2 * (size_t)ends[2 * e] + d] + xy[2 * (size_t)ends[2 * e + 1] + d]);
+  }
+  pgx_nd_matrix A{};
+  A.n = 2 * (int64_t)nd;
+  A.rowptr = rp.data();
+  A.col = cl.data();
+  A.n_nodes = nd;
+  A.node_of_dof = nod.data();
+  A.dim = 2;
+  A.node_coords = xy.data();
+  A.leaf_nodes = 0;
+  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  if (rc) {
+    h->err = std::string("pc_type lu: ") + pgx_nd_last_error(nullptr);
+    h->lu = nullptr;
+    return rc;
+  }
+  DALLOC(h->Jmix, 4 * (size_t)nnz);
+  return PGX_OK;
+}
+
+static int lu_factor(pgx_handle* h) {
+  PhaseTimer t(h, 2);
+  hipLaunchKernelGGL(k_mixed_vals, dim3((h->nd + 127) / 128), dim3(128), 0, h->st, h->nd, h->s_nnz, h->s_rowptr, h->s_colm,
+                     h->s_K, h->s_M, h->s_D, h->alpha, h->mask, h->Jmix);
+  int rc = pgx_nd_factor(h->lu, h->Jmix, 1);
+  if (rc) h->err = std::string("pc_type lu: ") + pgx_nd_last_error(h->lu);
+  return rc;
+}
+
 static int precond(pgx_handle* h, const double* b, double* z, int nu, double omega) {
+  if (h->lu_active) {
+    int rc = pgx_nd_solve(h->lu, b, z, 1);
+    if (rc) h->err = std::string("pc_type lu: ") + pgx_nd_last_error(h->lu);
+    return rc;
+  }
   if (h->dist.on) {  // b is owned-compact, z local (owned + ghost rows, correct at least one row beyond the strip)
     scatter_owned(h, b, h->dist.sb);
     return vcycle_dist(h, 0, h->dist.sb, h->dist.sb + h->n, z, z + h->n, 1, nu, omega);
@@ -1711,6 +1819,14 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // (tools/lu_accuracy_check.py, tools/tolerance_sweep.py): small / unstructured meshes are the sensitive ones
   if (!(optv.ksp_rtol > 0.0)) optv.ksp_rtol = (h->degree == 2) ? 1e-11 : 1e-10;
   opts = &optv;
+  // pc_type: 0 auto (multigrid for P1; sparse LU for P2, whose two-level cycle is not robust on the late large-alpha
+  // systems), 1 multigrid V-cycle, 2 sparse LU (what the reference asks PETSc/MUMPS for)
+  const bool use_lu = optv.pc_type == 2 || (optv.pc_type == 0 && h->degree == 2 && !h->dist.on);
+  h->lu_active = false;
+  if (use_lu) {
+    int rcl = ensure_lu(h);
+    if (rcl) return rcl;
+  }
   const size_t n2 = 2 * (size_t)h->nd;
   hipEvent_t w0 = nullptr, w1 = nullptr;
   if (h->prof) {
@@ -1754,6 +1870,10 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     }
     rc = jacobian_dev(h, h->xw, true);
     if (rc) return rc;
+    if (use_lu) {
+      if ((rc = lu_factor(h))) return rc;
+      h->lu_active = true;
+    }
     pgxk_scale_copy(h->st, nk, -1.0, dist ? h->rhs : h->F, h->rhs);
     int kits = 0;
     double relres = 0;
@@ -1795,6 +1915,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
         rsn = PGX_SNES_DIVERGED_DTOL;
     }
   }
+  h->lu_active = false;
   if (rsn > 0) HIPCHK(hipMemcpyAsync(h->x, h->xw, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the solve must not pass silently

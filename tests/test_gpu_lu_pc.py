@@ -1,0 +1,59 @@
+"""Newton solves preconditioned by the sparse direct solver (pc_type pgx_lu; automatic for P2) against the CPU oracle:
+identical Newton / proximal counts, final primal field <= 1e-10 relative L2 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DOMAIN = ((-1.0, -1.0), (1.0, 1.0))
+OPTS = {"ksp_type": "preonly", "pc_type": "pgx_lu", "ksp_error_if_not_converged": True,
+        "snes_error_if_not_converged": True, "snes_linesearch_type": "none", "snes_rtol": 1e-6, "snes_max_it": 100}
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _run(N, degree, opts, scheme="double_exponential", alpha_max=1e2, tol=1e-4):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    msh = fem.create_rectangle(DOMAIN, (N, N))
+    problem, sol, sol_k, alpha = setup_problem(msh, degree, petsc_options=opts)
+    hist = run_outer_loop(problem, sol, sol_k, alpha, 100, scheme, alpha_max, tol)
+    x = sol.x.array.copy()
+    lin = problem.solver.ksp.getIterationNumber() if hasattr(problem.solver.ksp, "getIterationNumber") else None
+    problem.close()
+    return x, hist, lin
+
+
+@pytest.mark.parametrize("N", [24, 64])
+def test_p1_lu_preconditioner_matches_oracle(require_gpu, N):
+    x, hist, _ = _run(N, 1, OPTS)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
+
+
+def test_p1_lu_and_multigrid_agree(require_gpu):
+    N = 128
+    xl, hl, _ = _run(N, 1, OPTS)
+    xm, hm, _ = _run(N, 1, dict(OPTS, pc_type="pgx_mg"))
+    assert hl["Newton steps"] == hm["Newton steps"]
+    n = len(xl) // 2
+    assert _rel(xl[:n], xm[:n]) < 1e-10
+
+
+def test_p2_auto_lu_matches_oracle_where_multigrid_failed(require_gpu):
+    """P2, N = 48: the automatic choice for degree 2 is the sparse LU (the two-level P2 cycle is not robust on the late
+    large-alpha systems: DESIGN.md section 3)."""
+    N = 48
+    x, hist, _ = _run(N, 2, None)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
