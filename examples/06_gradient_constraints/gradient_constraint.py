@@ -1,0 +1,36 @@
+"""Gradient-constraint problem |grad u| <= phi with the proximal Galerkin method on the HIP backend.
+
+Counterpart of /root/reference/examples/06_gradient_constraints/gradient_constraint_dolfinx.py with the same CLI flags
+(:208-320) where they apply: -N -M --alpha_scheme --alpha_0 --alpha_c --max_iterations -s --result_dir;
+--primal_degree is fixed at 2 and --cell_type at triangle (the reference's defaults), --warm_start is not implemented.
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from proximalgalerkin_amd.gradient_constraint import solve_problem  # noqa: E402
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("-N", type=int, default=200, help="Number of elements in x-direction")
+    parser.add_argument("-M", type=int, default=200, help="Number of elements in y-direction")
+    parser.add_argument("--alpha_scheme", type=str, default="doubling", choices=["constant", "linear", "doubling"])
+    parser.add_argument("--alpha_0", type=float, default=1.0, help="Initial value of alpha")
+    parser.add_argument("--alpha_c", type=float, default=1.0, help="Increment of alpha in linear scheme")
+    parser.add_argument("--max_iterations", type=int, default=25, help="Maximum number of iterations")
+    parser.add_argument("-s", "--stopping_tol", type=float, default=1e-8,
+                        help="Stopping tolerance between two successive PG iterations (L2-difference)")
+    parser.add_argument("--result_dir", type=Path, default=Path("results"), help="Directory to store results")
+    a = parser.parse_args()
+    iteration_counts, L2_diffs = solve_problem(N=a.N, M=a.M, alpha_scheme=a.alpha_scheme, alpha_0=a.alpha_0,
+                                               alpha_c=a.alpha_c, max_iterations=a.max_iterations,
+                                               stopping_tol=a.stopping_tol, result_dir=a.result_dir)
+    print(f"Number of LVPP iterations {len(iteration_counts)}")
+    print(f"Minimum number of solves {np.min(iteration_counts)}")
+    print(f"Maximum number of solves {np.max(iteration_counts)}")
+    print(f"Total number of Newton iterations: {np.sum(iteration_counts)}")
+    print(iteration_counts)
+    print(L2_diffs)

@@ -93,6 +93,19 @@ class pgx_nd_stats(C.Structure):
     ]
 
 
+class pgx_gc_problem(C.Structure):  # include/pgx_gc.h
+    _fields_ = [
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("phi_dofs", c_double_p),
+        ("f_dofs", c_double_p),
+        ("n_bc", C.c_int32),
+        ("bc_dofs", c_int32_p),
+        ("bc_vals", c_double_p),
+    ]
+
+
 class pgx_partition(C.Structure):
     _fields_ = [
         ("rank", C.c_int32),
@@ -153,6 +166,25 @@ SYMBOLS = [
     ("pgx_nd_export_fronts", C.c_int,
      [_H, c_int64_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int64_p, c_int32_p, c_int64_p, c_int32_p]),
     ("pgx_nd_export_dest", C.c_int, [_H, c_int64_p, c_int64_p]),
+    # example 06: gradient constraint, vector latent variable (include/pgx_gc.h)
+    ("pgx_gc_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_gc_destroy", None, [_H]),
+    ("pgx_gc_last_error", C.c_char_p, [_H]),
+    ("pgx_gc_num_dofs", C.c_int, [_H, c_int64_p]),
+    ("pgx_gc_set_state", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_get_state", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_set_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_get_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_advance_prev", C.c_int, [_H]),
+    ("pgx_gc_set_alpha", C.c_int, [_H, C.c_double]),
+    ("pgx_gc_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("pgx_gc_jacobian_fill", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_csr_export", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_double_p]),
+    ("pgx_gc_spmv", C.c_int, [_H, c_double_p, c_double_p]),
+    ("pgx_gc_newton_solve", C.c_int,
+     [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pgx_gc_l2_increment", C.c_int, [_H, c_double_p]),
+    ("pgx_gc_profile", C.c_int, [_H, C.c_int, c_double_p]),
 ]
 
 _lib = None

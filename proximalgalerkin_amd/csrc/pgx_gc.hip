@@ -1,0 +1,967 @@
+// pgx_gc.hip - example 06 (gradient constraint, vector latent variable) behind the C ABI of include/pgx_gc.h.
+//
+// Reference: examples/06_gradient_constraints/gradient_constraint_dolfinx.py (:38-46 spaces, :53 degree-10 measure,
+// :100-107 residual, :108-131 NonlinearProblem + SNES options, :171-205 outer loop).  u in P2, psi in (P1)^2,
+// x = [u | psi_x | psi_y].  Newton matrix [[alpha K, G^T],[G, -N(psi)]] lives in ONE mixed CSR array whose pattern and
+// per-cell destination tables are built once on the host; K and G are assembled once on the device, every Newton step
+// only rescales the K slots and re-assembles the 36 N entries per cell.  Linear solves: pgx_nd (sparse LU) + iterative
+// refinement on the exact operator.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pgx_gc.h"
+#include "../../include/pgx_nd.h"
+
+#define GC_MAXQ 40
+struct GcQuad {
+  double X[GC_MAXQ], Y[GC_MAXQ], w[GC_MAXQ];
+  int nq;
+};
+
+static thread_local std::string g_gc_error;
+
+struct pgx_gc_handle {
+  int device = 0;
+  hipStream_t st = nullptr;
+  std::string err;
+  int nv = 0, nc = 0, n2 = 0;
+  int64_t ntot = 0, nnz = 0;
+  GcQuad Q{};
+  double alpha = 1.0;
+  // device data
+  double *coords = nullptr, *phi = nullptr, *f = nullptr, *gbc = nullptr;
+  int32_t* cdofs = nullptr;
+  uint8_t* mask = nullptr;
+  int32_t *rowptr = nullptr, *col = nullptr, *dest36 = nullptr;
+  uint8_t* kind = nullptr;
+  double *Jc = nullptr, *Jv = nullptr;
+  double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr, *r = nullptr, *z = nullptr;
+  double *partials = nullptr, *d_out = nullptr;
+  double* h_out = nullptr;  // pinned
+  std::vector<int32_t> h_rowptr, h_col;
+  pgx_nd* lu = nullptr;
+  bool jac_valid = false;
+  bool prof = false;
+  double ms[6] = {0, 0, 0, 0, 0, 0};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<void*> allocs;
+};
+
+extern "C" const char* pgx_gc_last_error(const pgx_gc_handle* h) { return h ? h->err.c_str() : g_gc_error.c_str(); }
+
+#define GCHIP(call)                                               \
+  do {                                                            \
+    hipError_t e_ = (call);                                       \
+    if (e_ != hipSuccess) {                                       \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      return PGX_EHIP;                                            \
+    }                                                             \
+  } while (0)
+
+template <typename T>
+static int gc_alloc(pgx_gc_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
+    h->err = "hipMalloc failed";
+    return PGX_ENOMEM;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return PGX_OK;
+}
+#define GCALLOC(p, count)                        \
+  do {                                           \
+    int rc_ = gc_alloc(h, &(p), (size_t)(count)); \
+    if (rc_) return rc_;                         \
+  } while (0)
+
+struct GcTimer {
+  pgx_gc_handle* h;
+  int slot;
+  GcTimer(pgx_gc_handle* h_, int s) : h(h_), slot(s) {
+    if (h->prof) hipEventRecord(h->e0, h->st);
+  }
+  ~GcTimer() {
+    if (h->prof) {
+      hipEventRecord(h->e1, h->st);
+      hipEventSynchronize(h->e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, h->e0, h->e1);
+      h->ms[slot] += ms;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// element kernels (one thread per cell)
+// ------------------------------------------------------------------------------------------------------------------
+struct GcGeom {
+  double inv[2][2];  // J^{-1}
+  double adet;
+};
+
+__device__ inline GcGeom gc_geom(const double* __restrict__ coords, const int32_t* __restrict__ cd) {
+  const double x0 = coords[2 * cd[0]], y0 = coords[2 * cd[0] + 1];
+  const double j00 = coords[2 * cd[1]] - x0, j10 = coords[2 * cd[1] + 1] - y0;
+  const double j01 = coords[2 * cd[2]] - x0, j11 = coords[2 * cd[2] + 1] - y0;
+  const double det = j00 * j11 - j01 * j10;
+  GcGeom g;
+  g.inv[0][0] = j11 / det;
+  g.inv[0][1] = -j01 / det;
+  g.inv[1][0] = -j10 / det;
+  g.inv[1][1] = j00 / det;
+  g.adet = fabs(det);
+  return g;
+}
+
+// P1 values l[3], P2 values N[6] and PHYSICAL P2 gradients G[6][2] at reference point (X,Y); edge i opposite vertex i
+__device__ inline void gc_tab(double X, double Y, const GcGeom& g, double l[3], double N[6], double G[6][2]) {
+  l[0] = 1.0 - X - Y;
+  l[1] = X;
+  l[2] = Y;
+  const double dl[3][2] = {{-1.0, -1.0}, {1.0, 0.0}, {0.0, 1.0}};
+  double dN[6][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    N[i] = l[i] * (2.0 * l[i] - 1.0);
+    dN[i][0] = (4.0 * l[i] - 1.0) * dl[i][0];
+    dN[i][1] = (4.0 * l[i] - 1.0) * dl[i][1];
+  }
+  const int ej[3] = {1, 0, 0}, ek[3] = {2, 2, 1};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    N[3 + i] = 4.0 * l[ej[i]] * l[ek[i]];
+    dN[3 + i][0] = 4.0 * (l[ej[i]] * dl[ek[i]][0] + l[ek[i]] * dl[ej[i]][0]);
+    dN[3 + i][1] = 4.0 * (l[ej[i]] * dl[ek[i]][1] + l[ek[i]] * dl[ej[i]][1]);
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    G[a][0] = dN[a][0] * g.inv[0][0] + dN[a][1] * g.inv[1][0];
+    G[a][1] = dN[a][0] * g.inv[0][1] + dN[a][1] * g.inv[1][1];
+  }
+}
+
+__global__ __launch_bounds__(128) void k_gc_residual(int nc, int n2, int nv, const int32_t* __restrict__ cdofs,
+                                                     const double* __restrict__ coords, const uint8_t* __restrict__ mask,
+                                                     const double* __restrict__ gbc, const double* __restrict__ phi,
+                                                     const double* __restrict__ f, const double* __restrict__ x,
+                                                     const double* __restrict__ xk, double alpha, GcQuad Q,
+                                                     double* __restrict__ F) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cd = cdofs + 6 * (size_t)c;
+  const GcGeom g = gc_geom(coords, cd);
+  double u[6], ph[6], ff[6], px[3], py[3], dx0[3], dy0[3];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int d = cd[a];
+    u[a] = mask[d] ? gbc[d] : x[d];
+    ph[a] = phi[d];
+    ff[a] = f[d];
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int v = cd[b];
+    px[b] = x[n2 + v];
+    py[b] = x[n2 + nv + v];
+    dx0[b] = px[b] - xk[n2 + v];
+    dy0[b] = py[b] - xk[n2 + nv + v];
+  }
+  double Ru[6] = {0, 0, 0, 0, 0, 0}, Rx[3] = {0, 0, 0}, Ry[3] = {0, 0, 0};
+  for (int q = 0; q < Q.nq; ++q) {
+    double l[3], N[6], G[6][2];
+    gc_tab(Q.X[q], Q.Y[q], g, l, N, G);
+    const double wd = Q.w[q] * g.adet;
+    double gux = 0, guy = 0, phq = 0, fq = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      gux += u[a] * G[a][0];
+      guy += u[a] * G[a][1];
+      phq += ph[a] * N[a];
+      fq += ff[a] * N[a];
+    }
+    const double pxq = px[0] * l[0] + px[1] * l[1] + px[2] * l[2];
+    const double pyq = py[0] * l[0] + py[1] * l[1] + py[2] * l[2];
+    const double dxq = dx0[0] * l[0] + dx0[1] * l[1] + dx0[2] * l[2];
+    const double dyq = dy0[0] * l[0] + dy0[1] * l[1] + dy0[2] * l[2];
+    const double s = sqrt(1.0 + pxq * pxq + pyq * pyq);
+    const double vx = alpha * gux + dxq, vy = alpha * guy + dyq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) Ru[a] += wd * (vx * G[a][0] + vy * G[a][1] - alpha * fq * N[a]);
+    const double rx = gux - phq * pxq / s, ry = guy - phq * pyq / s;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      Rx[b] += wd * l[b] * rx;
+      Ry[b] += wd * l[b] * ry;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) atomicAdd(&F[cd[a]], Ru[a]);
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    atomicAdd(&F[n2 + cd[b]], Rx[b]);
+    atomicAdd(&F[n2 + nv + cd[b]], Ry[b]);
+  }
+}
+
+__global__ void k_gc_resid_bc(int n2, const uint8_t* __restrict__ mask, const double* __restrict__ gbc,
+                              const double* __restrict__ x, double* __restrict__ F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2 && mask[i]) F[i] = x[i] - gbc[i];
+}
+
+// constant part, once: K (36 entries) and G, G^T (36 + 36) per cell through dest108
+__global__ __launch_bounds__(128) void k_gc_const(int nc, const int32_t* __restrict__ cdofs, const double* __restrict__ coords,
+                                                  const int32_t* __restrict__ dest108, GcQuad Q, double* __restrict__ Jc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cd = cdofs + 6 * (size_t)c;
+  const GcGeom g = gc_geom(coords, cd);
+  double Ke[6][6], Ge[3][2][6];
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) Ke[a][b] = 0.0;
+  for (int b = 0; b < 3; ++b)
+    for (int d = 0; d < 2; ++d)
+      for (int a = 0; a < 6; ++a) Ge[b][d][a] = 0.0;
+  for (int q = 0; q < Q.nq; ++q) {
+    double l[3], N[6], G[6][2];
+    gc_tab(Q.X[q], Q.Y[q], g, l, N, G);
+    const double wd = Q.w[q] * g.adet;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) Ke[a][b] += wd * (G[a][0] * G[b][0] + G[a][1] * G[b][1]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        Ge[b][0][a] += wd * l[b] * G[a][0];
+        Ge[b][1][a] += wd * l[b] * G[a][1];
+      }
+    }
+  }
+  const int32_t* D = dest108 + 108 * (size_t)c;
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) atomicAdd(&Jc[D[a * 6 + b]], Ke[a][b]);
+  for (int b = 0; b < 3; ++b)
+    for (int d = 0; d < 2; ++d)
+      for (int a = 0; a < 6; ++a) {
+        const int e = 36 + ((b * 2 + d) * 6 + a) * 2;
+        atomicAdd(&Jc[D[e]], Ge[b][d][a]);
+        atomicAdd(&Jc[D[e + 1]], Ge[b][d][a]);
+      }
+}
+
+// kind: 0 = K slot (scaled by alpha), 1 = G / G^T slot, 2 = N slot (accumulated by k_gc_jac_N), 3 = BC diagonal, 4 = zeroed by BCs
+__global__ void k_gc_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, const double* __restrict__ Jc, double alpha,
+                              double* __restrict__ Jv) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const int t = kind[k];
+  Jv[k] = t == 0 ? alpha * Jc[k] : t == 1 ? Jc[k] : t == 3 ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(128) void k_gc_jac_N(int nc, int n2, int nv, const int32_t* __restrict__ cdofs,
+                                                  const double* __restrict__ coords, const double* __restrict__ phi,
+                                                  const double* __restrict__ x, const int32_t* __restrict__ dest36, GcQuad Q,
+                                                  double* __restrict__ Jv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cd = cdofs + 6 * (size_t)c;
+  const GcGeom g = gc_geom(coords, cd);
+  double ph[6], px[3], py[3];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) ph[a] = phi[cd[a]];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    px[b] = x[n2 + cd[b]];
+    py[b] = x[n2 + nv + cd[b]];
+  }
+  double Nxx[3][3], Nxy[3][3], Nyy[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) Nxx[a][b] = Nxy[a][b] = Nyy[a][b] = 0.0;
+  for (int q = 0; q < Q.nq; ++q) {
+    double l[3], N[6], G[6][2];
+    gc_tab(Q.X[q], Q.Y[q], g, l, N, G);
+    double phq = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) phq += ph[a] * N[a];
+    const double pxq = px[0] * l[0] + px[1] * l[1] + px[2] * l[2];
+    const double pyq = py[0] * l[0] + py[1] * l[1] + py[2] * l[2];
+    const double s = sqrt(1.0 + pxq * pxq + pyq * pyq);
+    const double s3 = s * s * s;
+    const double wp = Q.w[q] * g.adet * phq;
+    const double cxx = wp * (1.0 / s - pxq * pxq / s3), cxy = wp * (-pxq * pyq / s3), cyy = wp * (1.0 / s - pyq * pyq / s3);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const double ll = l[a] * l[b];
+        Nxx[a][b] += cxx * ll;
+        Nxy[a][b] += cxy * ll;
+        Nyy[a][b] += cyy * ll;
+      }
+  }
+  const int32_t* D = dest36 + 36 * (size_t)c;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const int e = (a * 3 + b) * 4;  // (c,d) = xx, xy, yx, yy
+      atomicAdd(&Jv[D[e]], -Nxx[a][b]);
+      atomicAdd(&Jv[D[e + 1]], -Nxy[a][b]);
+      atomicAdd(&Jv[D[e + 2]], -Nxy[a][b]);
+      atomicAdd(&Jv[D[e + 3]], -Nyy[a][b]);
+    }
+}
+
+// y = A x, 16 lanes per row
+__global__ __launch_bounds__(256) void k_gc_spmv(int64_t nrows, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ col, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
+  double a = 0.0;
+  if (row < nrows)
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 16) a += vals[k] * x[col[k]];
+  a += __shfl_xor(a, 8);
+  a += __shfl_xor(a, 4);
+  a += __shfl_xor(a, 2);
+  a += __shfl_xor(a, 1);
+  if (row < nrows && lane == 0) y[row] = a;
+}
+
+#define GC_RED 512
+// fixed-shape two-stage reductions (bitwise reproducible): partials[b] = sum over the block's slice
+__global__ __launch_bounds__(256) void k_gc_dot(int64_t len, const double* __restrict__ a, const double* __restrict__ b,
+                                                double* __restrict__ partials) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)GC_RED * 256) s += a[i] * b[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_gc_final(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// y = a*x + b*y
+__global__ void k_gc_axpby(int64_t len, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+
+// int (u - uk)^2 with the problem's quadrature: per-block partial sums over cells
+__global__ __launch_bounds__(256) void k_gc_l2(int nc, const int32_t* __restrict__ cdofs, const double* __restrict__ coords,
+                                               const double* __restrict__ x, const double* __restrict__ xk, GcQuad Q,
+                                               double* __restrict__ partials) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < nc; c += GC_RED * 256) {
+    const int32_t* cd = cdofs + 6 * (size_t)c;
+    const GcGeom g = gc_geom(coords, cd);
+    double d[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a] = x[cd[a]] - xk[cd[a]];
+    for (int q = 0; q < Q.nq; ++q) {
+      double l[3], N[6], G[6][2];
+      gc_tab(Q.X[q], Q.Y[q], g, l, N, G);
+      double v = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v += d[a] * N[a];
+      s += Q.w[q] * g.adet * v * v;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host: pattern, destination tables, create
+// ------------------------------------------------------------------------------------------------------------------
+static void par_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+  unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 20000) T = 1;
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + T - 1) / T;
+  for (unsigned t = 0; t < T; ++t) {
+    const int64_t a = t * chunk, b = std::min<int64_t>(n, a + chunk);
+    if (a >= b) break;
+    th.emplace_back([=, &fn] { fn(a, b); });
+  }
+  for (auto& t : th) t.join();
+}
+
+static int gc_norm(pgx_gc_handle* h, const double* v, double* out) {
+  hipLaunchKernelGGL(k_gc_dot, dim3(GC_RED), dim3(256), 0, h->st, h->ntot, v, v, h->partials);
+  hipLaunchKernelGGL(k_gc_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
+  GCHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  *out = std::sqrt(h->h_out[0]);
+  return PGX_OK;
+}
+
+extern "C" void pgx_gc_destroy(pgx_gc_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->st) hipStreamSynchronize(h->st);
+  if (h->lu) pgx_nd_destroy(h->lu);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_out) hipHostFree(h->h_out);
+  if (h->e0) hipEventDestroy(h->e0);
+  if (h->e1) hipEventDestroy(h->e1);
+  if (h->st) hipStreamDestroy(h->st);
+  delete h;
+}
+
+static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_problem* p) {
+  const int nv = m->n_vertices, nc = m->n_cells, n2 = m->n_dofs;
+  const int64_t ntot = (int64_t)n2 + 2 * (int64_t)nv;
+  h->nv = nv, h->nc = nc, h->n2 = n2, h->ntot = ntot;
+  h->Q.nq = p->nq;
+  for (int q = 0; q < p->nq; ++q) h->Q.X[q] = p->qpts[2 * q], h->Q.Y[q] = p->qpts[2 * q + 1], h->Q.w[q] = p->qwts[q];
+  const int32_t* cd = m->cell_dofs;
+  for (int c = 0; c < nc; ++c)
+    for (int a = 0; a < 6; ++a) {
+      const int v = cd[6 * (size_t)c + a];
+      if (v < 0 || v >= n2 || (a < 3 && (v >= nv || v != m->cells[3 * (size_t)c + a])) || (a >= 3 && v < nv)) {
+        h->err = "cell_dofs must be [vertex ids (== cells) | edge dofs >= n_vertices]";
+        return PGX_EINVAL;
+      }
+    }
+  std::vector<uint8_t> hmask(n2, 0);
+  std::vector<double> hg(n2, 0.0);
+  for (int k = 0; k < p->n_bc; ++k) {
+    const int d = p->bc_dofs[k];
+    if (d < 0 || d >= n2) {
+      h->err = "bc dof out of range";
+      return PGX_EINVAL;
+    }
+    hmask[d] = 1;
+    hg[d] = p->bc_vals ? p->bc_vals[k] : 0.0;
+  }
+  // mixed dofs of a cell: 6 u, 3 psi_x, 3 psi_y
+  auto mixed = [&](int c, int32_t md[12]) {
+    for (int a = 0; a < 6; ++a) md[a] = cd[6 * (size_t)c + a];
+    for (int b = 0; b < 3; ++b) md[6 + b] = n2 + cd[6 * (size_t)c + b], md[9 + b] = n2 + nv + cd[6 * (size_t)c + b];
+  };
+  // dof -> cells
+  std::vector<int64_t> dptr(ntot + 1, 0);
+  for (int c = 0; c < nc; ++c) {
+    int32_t md[12];
+    mixed(c, md);
+    for (int a = 0; a < 12; ++a) dptr[md[a] + 1]++;
+  }
+  for (int64_t i = 0; i < ntot; ++i) dptr[i + 1] += dptr[i];
+  std::vector<int32_t> dcell(dptr[ntot]);
+  {
+    std::vector<int64_t> fill(dptr.begin(), dptr.end() - 1);
+    for (int c = 0; c < nc; ++c) {
+      int32_t md[12];
+      mixed(c, md);
+      for (int a = 0; a < 12; ++a) dcell[fill[md[a]]++] = c;
+    }
+  }
+  // pattern: row r couples to every mixed dof of its cells
+  std::vector<int32_t>& rowptr = h->h_rowptr;
+  std::vector<int32_t>& col = h->h_col;
+  rowptr.assign(ntot + 1, 0);
+  par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp;
+    for (int64_t r = a; r < b; ++r) {
+      tmp.clear();
+      for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
+        int32_t md[12];
+        mixed(dcell[q], md);
+        tmp.insert(tmp.end(), md, md + 12);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      rowptr[r + 1] = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+    }
+  });
+  int64_t tot = 0;
+  for (int64_t r = 0; r < ntot; ++r) {
+    tot += rowptr[r + 1];
+    if (tot > 0x7fffffff) {
+      h->err = "mixed matrix exceeds int32 nnz";
+      return PGX_EINVAL;
+    }
+    rowptr[r + 1] = (int32_t)tot;
+  }
+  h->nnz = tot;
+  col.resize(tot);
+  par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp;
+    for (int64_t r = a; r < b; ++r) {
+      tmp.clear();
+      for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
+        int32_t md[12];
+        mixed(dcell[q], md);
+        tmp.insert(tmp.end(), md, md + 12);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      std::copy(tmp.begin(), tmp.end(), col.begin() + rowptr[r]);
+    }
+  });
+  auto find = [&](int32_t r, int32_t c) -> int32_t {
+    const int32_t* b = col.data() + rowptr[r];
+    const int32_t* e = col.data() + rowptr[r + 1];
+    return (int32_t)(std::lower_bound(b, e, c) - col.data());
+  };
+  // slot kinds
+  std::vector<uint8_t> kind(tot);
+  par_for(ntot, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r)
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = col[k];
+        uint8_t t;
+        if (r < n2 && c < n2)
+          t = (hmask[r] || hmask[c]) ? ((r == c && hmask[r]) ? 3 : 4) : 0;
+        else if (r < n2)
+          t = hmask[r] ? 4 : 1;
+        else if (c < n2)
+          t = hmask[c] ? 4 : 1;
+        else
+          t = 2;
+        kind[k] = t;
+      }
+  });
+  // destination tables
+  std::vector<int32_t> d108((size_t)nc * 108), d36((size_t)nc * 36);
+  par_for(nc, [&](int64_t a0, int64_t b0) {
+    for (int64_t c = a0; c < b0; ++c) {
+      int32_t md[12];
+      mixed((int)c, md);
+      int32_t* D = d108.data() + 108 * (size_t)c;
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) D[a * 6 + b] = find(md[a], md[b]);
+      for (int b = 0; b < 3; ++b)
+        for (int d = 0; d < 2; ++d)
+          for (int a = 0; a < 6; ++a) {
+            const int e = 36 + ((b * 2 + d) * 6 + a) * 2;
+            const int32_t pr = md[6 + 3 * d + b];
+            D[e] = find(pr, md[a]);
+            D[e + 1] = find(md[a], pr);
+          }
+      int32_t* E = d36.data() + 36 * (size_t)c;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          for (int cc = 0; cc < 2; ++cc)
+            for (int d = 0; d < 2; ++d) E[(a * 3 + b) * 4 + cc * 2 + d] = find(md[6 + 3 * cc + a], md[6 + 3 * d + b]);
+    }
+  });
+  // node coordinates for the nested-dissection ordering: vertices, then edge midpoints
+  std::vector<double> xy(2 * (size_t)n2, 0.0);
+  std::copy(m->coords, m->coords + 2 * (size_t)nv, xy.begin());
+  for (int c = 0; c < nc; ++c) {
+    const int ej[3] = {1, 0, 0}, ek[3] = {2, 2, 1};
+    for (int i = 0; i < 3; ++i) {
+      const int e = cd[6 * (size_t)c + 3 + i], vj = cd[6 * (size_t)c + ej[i]], vk = cd[6 * (size_t)c + ek[i]];
+      xy[2 * (size_t)e] = 0.5 * (m->coords[2 * (size_t)vj] + m->coords[2 * (size_t)vk]);
+      xy[2 * (size_t)e + 1] = 0.5 * (m->coords[2 * (size_t)vj + 1] + m->coords[2 * (size_t)vk + 1]);
+    }
+  }
+  std::vector<int32_t> nod(ntot);
+  for (int i = 0; i < n2; ++i) nod[i] = i;
+  for (int v = 0; v < nv; ++v) nod[n2 + v] = nod[(size_t)n2 + nv + v] = v;
+  // device
+  GCHIP(hipStreamCreate(&h->st));
+  hipEventCreate(&h->e0);
+  hipEventCreate(&h->e1);
+  pgx_nd_matrix A{};
+  A.n = ntot;
+  A.rowptr = rowptr.data();
+  A.col = col.data();
+  A.n_nodes = n2;
+  A.node_of_dof = nod.data();
+  A.dim = 2;
+  A.node_coords = xy.data();
+  A.leaf_nodes = 0;
+  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  if (rc) {
+    h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
+    h->lu = nullptr;
+    return rc;
+  }
+  GCALLOC(h->coords, 2 * (size_t)nv);
+  GCALLOC(h->cdofs, 6 * (size_t)nc);
+  GCALLOC(h->mask, n2);
+  GCALLOC(h->gbc, n2);
+  GCALLOC(h->phi, n2);
+  GCALLOC(h->f, n2);
+  GCALLOC(h->rowptr, ntot + 1);
+  GCALLOC(h->col, tot);
+  GCALLOC(h->kind, tot);
+  GCALLOC(h->dest36, d36.size());
+  GCALLOC(h->Jc, tot);
+  GCALLOC(h->Jv, tot);
+  for (double** v : {&h->x, &h->xk, &h->F, &h->dx, &h->xw, &h->rhs, &h->r, &h->z}) GCALLOC(*v, ntot);
+  GCALLOC(h->partials, GC_RED);
+  GCALLOC(h->d_out, 2);
+  GCHIP(hipHostMalloc((void**)&h->h_out, 2 * sizeof(double)));
+  GCHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * nv, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->cdofs, cd, sizeof(int32_t) * 6 * (size_t)nc, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->mask, hmask.data(), n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->phi, p->phi_dofs, sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->f, p->f_dofs, sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->dest36, d36.data(), sizeof(int32_t) * d36.size(), hipMemcpyHostToDevice));
+  GCHIP(hipMemsetAsync(h->x, 0, sizeof(double) * ntot, h->st));
+  GCHIP(hipMemsetAsync(h->xk, 0, sizeof(double) * ntot, h->st));
+  GCHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
+  int32_t* d_d108 = nullptr;
+  if (hipMalloc((void**)&d_d108, sizeof(int32_t) * d108.size()) != hipSuccess) {
+    h->err = "hipMalloc(dest108)";
+    return PGX_ENOMEM;
+  }
+  hipError_t e = hipMemcpy(d_d108, d108.data(), sizeof(int32_t) * d108.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_gc_const, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, h->cdofs, h->coords, d_d108, h->Q, h->Jc);
+    e = hipStreamSynchronize(h->st);
+  }
+  hipFree(d_d108);
+  if (e != hipSuccess) {
+    h->err = std::string("constant Jacobian blocks: ") + hipGetErrorString(e);
+    return PGX_EHIP;
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_create(const pgx_mesh* m, const pgx_gc_problem* p, int device, pgx_gc_handle** out) {
+  if (!m || !p || !out || !m->coords || !m->cells || !m->cell_dofs || m->n_dofs <= m->n_vertices || !p->qpts || !p->qwts ||
+      !p->phi_dofs || !p->f_dofs || p->nq <= 0 || p->nq > GC_MAXQ || (p->n_bc > 0 && !p->bc_dofs)) {
+    g_gc_error = "pgx_gc_create: bad arguments";
+    return PGX_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    g_gc_error = "pgx_gc_create: no usable GPU (there is no CPU fallback)";
+    return PGX_ENODEV;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_gc_error = "hipSetDevice failed";
+    return PGX_EHIP;
+  }
+  pgx_gc_handle* h = new pgx_gc_handle();
+  h->device = device;
+  int rc = gc_create_impl(h, m, p);
+  if (rc) {
+    g_gc_error = h->err;
+    pgx_gc_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return PGX_OK;
+}
+
+#define GCNEED(h)                  \
+  if (!(h)) return PGX_EINVAL;     \
+  if (hipSetDevice((h)->device) != hipSuccess) return PGX_EHIP
+
+extern "C" int pgx_gc_num_dofs(const pgx_gc_handle* h, int64_t* ntot) {
+  if (!h || !ntot) return PGX_EINVAL;
+  *ntot = h->ntot;
+  return PGX_OK;
+}
+static int gc_in(pgx_gc_handle* h, double* dst, const double* src) {
+  if (!src) return PGX_EINVAL;
+  GCHIP(hipMemcpyAsync(dst, src, sizeof(double) * h->ntot, hipMemcpyHostToDevice, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+static int gc_out(pgx_gc_handle* h, double* dst, const double* src) {
+  if (!dst) return PGX_EINVAL;
+  GCHIP(hipMemcpyAsync(dst, src, sizeof(double) * h->ntot, hipMemcpyDeviceToHost, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+extern "C" int pgx_gc_set_state(pgx_gc_handle* h, const double* x) {
+  GCNEED(h);
+  return gc_in(h, h->x, x);
+}
+extern "C" int pgx_gc_get_state(pgx_gc_handle* h, double* x) {
+  GCNEED(h);
+  return gc_out(h, x, h->x);
+}
+extern "C" int pgx_gc_set_prev(pgx_gc_handle* h, const double* x) {
+  GCNEED(h);
+  return gc_in(h, h->xk, x);
+}
+extern "C" int pgx_gc_get_prev(pgx_gc_handle* h, double* x) {
+  GCNEED(h);
+  return gc_out(h, x, h->xk);
+}
+extern "C" int pgx_gc_advance_prev(pgx_gc_handle* h) {
+  GCNEED(h);
+  GCHIP(hipMemcpyAsync(h->xk, h->x, sizeof(double) * h->ntot, hipMemcpyDeviceToDevice, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+extern "C" int pgx_gc_set_alpha(pgx_gc_handle* h, double a) {
+  GCNEED(h);
+  if (!(a > 0.0) || !std::isfinite(a)) {
+    h->err = "alpha must be positive and finite";
+    return PGX_EINVAL;
+  }
+  h->alpha = a;
+  h->jac_valid = false;
+  return PGX_OK;
+}
+
+static void gc_residual_dev(pgx_gc_handle* h, const double* x, double* F) {
+  GcTimer t(h, 0);
+  hipMemsetAsync(F, 0, sizeof(double) * h->ntot, h->st);
+  hipLaunchKernelGGL(k_gc_residual, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
+                     h->mask, h->gbc, h->phi, h->f, x, h->xk, h->alpha, h->Q, F);
+  hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, x, F);
+}
+static void gc_jacobian_dev(pgx_gc_handle* h, const double* x) {
+  GcTimer t(h, 1);
+  hipLaunchKernelGGL(k_gc_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
+                     h->alpha, h->Jv);
+  hipLaunchKernelGGL(k_gc_jac_N, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
+                     h->phi, x, h->dest36, h->Q, h->Jv);
+  h->jac_valid = true;
+}
+static void gc_spmv_dev(pgx_gc_handle* h, const double* x, double* y) {
+  GcTimer t(h, 4);
+  hipLaunchKernelGGL(k_gc_spmv, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, h->rowptr, h->col,
+                     h->Jv, x, y);
+}
+
+extern "C" int pgx_gc_residual(pgx_gc_handle* h, const double* x, double* F, double* fnorm) {
+  GCNEED(h);
+  const double* xd = h->x;
+  if (x) {
+    int rc = gc_in(h, h->xw, x);
+    if (rc) return rc;
+    xd = h->xw;
+  }
+  gc_residual_dev(h, xd, h->F);
+  if (fnorm) {
+    int rc = gc_norm(h, h->F, fnorm);
+    if (rc) return rc;
+  }
+  if (F) return gc_out(h, F, h->F);
+  GCHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_jacobian_fill(pgx_gc_handle* h, const double* x) {
+  GCNEED(h);
+  const double* xd = h->x;
+  if (x) {
+    int rc = gc_in(h, h->xw, x);
+    if (rc) return rc;
+    xd = h->xw;
+  }
+  gc_jacobian_dev(h, xd);
+  GCHIP(hipStreamSynchronize(h->st));
+  GCHIP(hipGetLastError());
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_csr_export(pgx_gc_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col,
+                                 double* vals) {
+  GCNEED(h);
+  if (nrows) *nrows = h->ntot;
+  if (nnz) *nnz = h->nnz;
+  if (rowptr) std::copy(h->h_rowptr.begin(), h->h_rowptr.end(), rowptr);
+  if (col) std::copy(h->h_col.begin(), h->h_col.end(), col);
+  if (vals) {
+    if (!h->jac_valid) {
+      h->err = "pgx_gc_csr_export: no Jacobian has been filled";
+      return PGX_ESTATE;
+    }
+    GCHIP(hipMemcpy(vals, h->Jv, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_spmv(pgx_gc_handle* h, const double* x, double* y) {
+  GCNEED(h);
+  if (!x || !y) return PGX_EINVAL;
+  if (!h->jac_valid) {
+    h->err = "pgx_gc_spmv: no Jacobian has been filled";
+    return PGX_ESTATE;
+  }
+  int rc = gc_in(h, h->r, x);
+  if (rc) return rc;
+  gc_spmv_dev(h, h->r, h->z);
+  return gc_out(h, y, h->z);
+}
+
+extern "C" int pgx_gc_l2_increment(pgx_gc_handle* h, double* out) {
+  GCNEED(h);
+  if (!out) return PGX_EINVAL;
+  hipLaunchKernelGGL(k_gc_l2, dim3(GC_RED), dim3(256), 0, h->st, h->nc, h->cdofs, h->coords, h->x, h->xk, h->Q, h->partials);
+  hipLaunchKernelGGL(k_gc_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
+  GCHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  *out = std::sqrt(std::max(h->h_out[0], 0.0));
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_profile(pgx_gc_handle* h, int enable, double ms[6]) {
+  GCNEED(h);
+  if (ms)
+    for (int i = 0; i < 6; ++i) ms[i] = h->ms[i];
+  for (int i = 0; i < 6; ++i) h->ms[i] = 0;
+  h->prof = enable != 0;
+  pgx_nd_timing(h->lu, enable, nullptr, nullptr);
+  return PGX_OK;
+}
+
+// dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
+static int gc_linear_solve(pgx_gc_handle* h, const double* b, double* dx, const pgx_snes_opts* o, int* nsolves, double* relres) {
+  const auto axpby = [&](double a, const double* x, double bb, double* y) {
+    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, a, x, bb, y);
+  };
+  double bnorm = 0, rnorm = 0, prev = 1e300;
+  int rc = gc_norm(h, b, &bnorm);
+  if (rc) return rc;
+  *nsolves = 0;
+  if (bnorm == 0.0) {
+    GCHIP(hipMemsetAsync(dx, 0, sizeof(double) * h->ntot, h->st));
+    *relres = 0.0;
+    return PGX_OK;
+  }
+  const double tol = o->ksp_rtol > 0.0 ? o->ksp_rtol : 1e-12;
+  const int maxit = std::max(1, std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 6, 20));
+  auto lusolve = [&](const double* rhs, double* out) -> int {
+    GcTimer t(h, 3);
+    int r2 = pgx_nd_solve(h->lu, rhs, out, 1);
+    if (r2) h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+    return r2;
+  };
+  if ((rc = lusolve(b, dx))) return rc;
+  ++*nsolves;
+  for (int it = 0;; ++it) {
+    gc_spmv_dev(h, dx, h->r);
+    axpby(1.0, b, -1.0, h->r);  // r = b - J dx
+    if ((rc = gc_norm(h, h->r, &rnorm))) return rc;
+    *relres = rnorm / bnorm;
+    if (o->monitor > 1) printf("      refinement %d  true rel residual %.3e\n", it, *relres);
+    if (!std::isfinite(*relres) || *relres <= tol || it + 1 >= maxit || *relres > 0.5 * prev) break;
+    prev = *relres;
+    if ((rc = lusolve(h->r, h->z))) return rc;
+    ++*nsolves;
+    axpby(1.0, h->z, 1.0, dx);
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_newton_solve(pgx_gc_handle* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
+  GCNEED(h);
+  if (!opts || !reason) return PGX_EINVAL;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  if (h->prof) {
+    hipEventCreate(&w0);
+    hipEventCreate(&w1);
+    hipEventRecord(w0, h->st);
+  }
+  const size_t bytes = sizeof(double) * h->ntot;
+  int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
+  double fnorm = 0, fnorm0 = 0;
+  GCHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
+  gc_residual_dev(h, h->xw, h->F);
+  if ((rc = gc_norm(h, h->F, &fnorm))) return rc;
+  fnorm0 = fnorm;
+  if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
+  if (!std::isfinite(fnorm))
+    rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+  else if (fnorm < opts->snes_atol)
+    rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+  const double ttol = fnorm * opts->snes_rtol;
+  while (rsn == 0) {
+    if (its >= opts->snes_max_it) {
+      rsn = PGX_SNES_DIVERGED_MAX_IT;
+      break;
+    }
+    gc_jacobian_dev(h, h->xw);
+    {
+      GcTimer t(h, 2);
+      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+    }
+    if (rc) {
+      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, -1.0, h->F, 0.0,
+                       h->rhs);
+    int ns = 0;
+    double relres = 0;
+    if ((rc = gc_linear_solve(h, h->rhs, h->dx, opts, &ns, &relres))) return rc;
+    lin += ns;
+    ++its;
+    if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
+    if (!(relres <= 1e-7) || !std::isfinite(relres)) {
+      rsn = PGX_SNES_DIVERGED_LINEAR_SOLVE;
+      break;
+    }
+    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, 1.0, h->dx, 1.0,
+                       h->xw);
+    gc_residual_dev(h, h->xw, h->F);
+    if ((rc = gc_norm(h, h->F, &fnorm))) return rc;
+    if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
+    if (!std::isfinite(fnorm)) {
+      rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+    } else if (fnorm < opts->snes_atol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+    } else if (fnorm <= ttol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
+    } else {
+      double snorm, xnorm;
+      if ((rc = gc_norm(h, h->dx, &snorm))) return rc;
+      if ((rc = gc_norm(h, h->xw, &xnorm))) return rc;
+      if (snorm < opts->snes_stol * xnorm)
+        rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
+      else if (fnorm > opts->snes_divtol * fnorm0)
+        rsn = PGX_SNES_DIVERGED_DTOL;
+    }
+  }
+  if (rsn > 0) GCHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
+  GCHIP(hipStreamSynchronize(h->st));
+  GCHIP(hipGetLastError());
+  if (h->prof) {
+    hipEventRecord(w1, h->st);
+    hipEventSynchronize(w1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, w0, w1);
+    h->ms[5] += ms;
+    hipEventDestroy(w0);
+    hipEventDestroy(w1);
+  }
+  *reason = rsn;
+  if (its_out) *its_out = its;
+  if (lin_out) *lin_out = lin;
+  return PGX_OK;
+}

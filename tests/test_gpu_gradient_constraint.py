@@ -1,0 +1,83 @@
+"""Example 06 (gradient constraint, vector latent variable) HIP path vs the CPU oracle (oracle/gc_oracle.py), through
+the C ABI of include/pgx_gc.h.  Tolerances: element kernels 1e-12 relative (fp64 atomics reorder sums); full LVPP run:
+identical Newton counts per proximal step, final primal field <= 1e-10 relative L2."""
+import numpy as np
+import pytest
+
+from oracle import gc_oracle as G
+from oracle import pg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _setup(N, M=None):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default
+
+    M = N if M is None else M
+    problem = GradientConstraintProblem(fem.create_unit_square(N, M), phi_default, f_default)
+    coords, cells = O.create_rectangle(N, M, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(coords, cells)
+    assert problem.ndofs == prob.ntot
+    return problem, prob
+
+
+@pytest.mark.parametrize("N,M", [(3, 3), (9, 6), (24, 24)])
+def test_kernels_match_oracle(require_gpu, N, M):
+    problem, prob = _setup(N, M)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(prob.ntot)
+    x[prob.n2:] *= np.where(rng.random(2 * prob.nv) < 0.3, 500.0, 2.0)  # |psi| spans what real runs meet
+    xk = rng.standard_normal(prob.ntot) * 0.1
+    for alpha in (1.0, 64.0):
+        problem.set_alpha(alpha)
+        problem.set_prev(xk)
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, alpha)
+        assert _rel(F, Fr) < 1e-12
+        assert abs(fn - np.linalg.norm(Fr)) <= 1e-12 * np.linalg.norm(Fr)
+        J = problem.jacobian(x)
+        Jr = prob.jacobian(x, alpha).tocsr()
+        d = (J - Jr)
+        assert abs(d).max() <= 1e-12 * abs(Jr).max()
+        # entry-wise check of the tiny N block (values down to phi/s^3 ~ 1e-9 relative to the K block)
+        n2 = prob.n2
+        assert abs(d[n2:, n2:]).max() <= 1e-12 * abs(Jr[n2:, n2:]).max()
+        v = rng.standard_normal(prob.ntot)
+        assert _rel(problem.spmv(v), Jr @ v) < 1e-12
+    problem.set_state(x)
+    problem.set_prev(xk)
+    assert abs(problem.l2_increment() - prob.l2_increment(x, xk)) <= 1e-12 * prob.l2_increment(x, xk)
+    problem.close()
+
+
+@pytest.mark.parametrize("N", [8, 20])
+def test_full_lvpp_run_matches_oracle(require_gpu, N):
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    its, diffs, x = solve_problem(N, N, verbose=False, return_solution=True)
+    coords, cells = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(coords, cells)
+    x_ref, its_ref, diffs_ref = G.solve_problem(prob)
+    assert list(its) == list(its_ref)
+    assert _rel(x[: prob.n2], x_ref[: prob.n2]) < 1e-10
+    assert np.allclose(diffs, diffs_ref, rtol=1e-6, atol=1e-13)
+
+
+def test_other_alpha_schemes(require_gpu):
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    N = 10
+    coords, cells = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(coords, cells)
+    for scheme, kw in (("linear", dict(alpha_c=3.0, max_iterations=12)), ("constant", dict(alpha_0=4.0, max_iterations=6))):
+        its, diffs, x = solve_problem(N, N, alpha_scheme=scheme, verbose=False, return_solution=True, stopping_tol=1e-7, **kw)
+        x_ref, its_ref, _ = G.solve_problem(prob, alpha_scheme=scheme, alpha_0=kw.get("alpha_0", 1.0),
+                                            alpha_c=kw.get("alpha_c", 1.0), max_iterations=kw["max_iterations"],
+                                            stopping_tol=1e-7)
+        assert list(its) == list(its_ref)
+        assert _rel(x[: prob.n2], x_ref[: prob.n2]) < 1e-10

@@ -23,4 +23,4 @@ for rep in range(2):
     dt = time.perf_counter() - t
     print(f"  run {rep}: {dt * 1e3:.0f} ms  Newton {hist['Newton steps']} (sum {sum(hist['Newton steps'])}) "
           f"reason {problem.solver.getConvergedReason()}  lin its last {problem.solver.ksp._its}", flush=True)
-print("  phases ms [resid, jac, setup/factor, spmv, pc, orth, obs, total]:", [round(v, 1) for v in problem.profile(reset=True)], flush=True)
+print("  phases ms [resid, jac, setup/factor, spmv, pc, orth, obs, total]:", problem.profile(reset=True), flush=True)
