@@ -34,7 +34,7 @@ typedef struct {
   const int32_t* node_of_dof;/* [n] host: node owning each dof */
   int32_t dim;               /* 2 or 3 */
   const double* node_coords; /* [n_nodes][dim] host */
-  int32_t leaf_nodes;        /* stop bisecting below this many nodes; 0 = default (64) */
+  int32_t leaf_nodes;        /* stop bisecting below this many nodes; 0 = default (16) */
 } pgx_nd_matrix;
 
 /* Host-only symbolic statistics (no GPU needed). */

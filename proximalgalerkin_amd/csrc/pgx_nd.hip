@@ -200,7 +200,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   S.n = A->n;
   S.nn = A->n_nodes;
   S.dim = A->dim;
-  S.leaf = A->leaf_nodes > 0 ? A->leaf_nodes : 64;
+  S.leaf = A->leaf_nodes > 0 ? A->leaf_nodes : 16;  // 1024^2 P1 sweep: 8: 57 ms, 16: 60, 32: 62, 64: 75, 128: 89 per factorisation
   const int64_t n = S.n;
   const int32_t nn = S.nn;
   for (int64_t i = 0; i < n; ++i)
@@ -506,6 +506,7 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 #define ND_NB 72   // widest pivot panel (diagonal block kept in LDS)
 #define ND_TS 64   // GEMM tile / panel chunk
 #define ND_KC 24   // GEMM k-chunk staged in LDS
+#define ND_SLAB 256 // pivots per triangular-solve launch in the solve phase
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 // LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level
@@ -606,6 +607,58 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
   }
 }
 
+// register-resident variant of the panel solves (used for nb <= 24 only: measured SLOWER than the LDS kernel at nb = 72,
+// 50 vs 31 ms per 1024^2 factorisation - uncoalesced column loads, 162 VGPRs): chunk c < nch : columns [o0, o0+64) of the row panel, X <- L^{-1} X;
+// chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  One wave per chunk, one thread per column / row
+// with its nb entries in registers (fully unrolled, NBT = compile-time bound >= nb); the entries of the diagonal block
+// are wave-uniform loads (scalar cache); no LDS, no barriers.
+template <int NBT>
+__global__ __launch_bounds__(64) void k_nd_panel_reg(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb) {
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
+  const bool isL = (int)blockIdx.y >= nch;
+  const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
+  const int t = o0 + threadIdx.x;
+  if (t >= M) return;
+  const double* Dg = F + (int64_t)kb * M + kb;
+  double x[NBT];
+  if (!isL) {
+    double* colp = F + (int64_t)t * M + kb;
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) x[k] = k < nb ? colp[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NBT - 1; ++k) {
+      if (k < nb - 1) {  // wave-uniform
+        const double xk = x[k];
+        const double* Lk = Dg + (int64_t)k * M;
+#pragma unroll
+        for (int r = 0; r < NBT; ++r)
+          if (r > k && r < nb) x[r] -= Lk[r] * xk;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBT; ++k)
+      if (k < nb) colp[k] = x[k];
+  } else {
+    double* rowp = F + (int64_t)kb * M + t;
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) x[k] = k < nb ? rowp[(int64_t)k * M] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      if (k < nb) {  // wave-uniform
+        const double xk = x[k] / Dg[(int64_t)k * M + k];
+        x[k] = xk;
+#pragma unroll
+        for (int c = 0; c < NBT; ++c)
+          if (c > k && c < nb) x[c] -= xk * Dg[(int64_t)c * M + k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBT; ++k)
+      if (k < nb) rowp[(int64_t)k * M] = x[k];
+  }
+}
+
 // C -= A B with A = F[rows, k0:k1), B = F[k0:k1, cols) on 64x64 tiles.  Tiles never straddle P: row/col blocks are laid
 // out as [s, P) then [P, M).  mode 0: all tiles of the trailing matrix EXCEPT the Schur block (rows >= P and cols >= P);
 // mode 1 (s == P): the Schur block only.
@@ -663,19 +716,21 @@ __global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int
     }
 }
 
-// in-place triangular solve on w[0:P) of every front: upper == 0: unit lower L11; upper != 0: U11.  One workgroup per
-// front, 64-wide blocks: the triangle is solved by wave 0 with lane shuffles, the remaining rows are updated by all.
+// in-place triangular solve of the diagonal range [k0,k1) of every front's pivot block on w: upper == 0: unit lower L11;
+// upper != 0: U11.  One workgroup per front, 64-wide blocks: the 64x64 triangle is solved by wave 0 with lane shuffles,
+// the remaining rows OF THE RANGE are updated by all threads; rows outside the range are left to k_nd_gemv (many
+// workgroups), so that the big fronts near the root do not stream their factors through a single CU.
 __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
-                                                 int64_t voff, int M, int P, int upper) {
+                                                 int64_t voff, int M, int k0, int k1, int upper) {
   __shared__ double Ds[64][65];
   __shared__ double ys[64];
   const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   double* w = vec + voff + (int64_t)blockIdx.x * M;
   const int tid = threadIdx.x;
-  const int nblk = (P + 63) / 64;
+  const int nblk = (k1 - k0 + 63) / 64;
   for (int bb = 0; bb < nblk; ++bb) {
-    const int kb = upper ? (nblk - 1 - bb) * 64 : bb * 64;
-    const int nb = min(64, P - kb);
+    const int kb = k0 + (upper ? (nblk - 1 - bb) * 64 : bb * 64);
+    const int nb = min(64, k1 - kb);
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int r = idx % nb, c = idx / nb;
       Ds[r][c] = F[(int64_t)(kb + c) * M + kb + r];
@@ -701,7 +756,7 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
       if (r < nb) w[kb + r] = y;
     }
     __syncthreads();
-    const int lo = upper ? 0 : kb + nb, hi = upper ? kb : P;
+    const int lo = upper ? k0 : kb + nb, hi = upper ? kb : k1;
     for (int r = lo + tid; r < hi; r += 256) {
       double a = 0.0;
       for (int k = 0; k < nb; ++k) a += F[(int64_t)(kb + k) * M + r] * ys[k];
@@ -711,28 +766,26 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
   }
 }
 
-// border products of the tree walk: mode 0 (forward) w[P+i] -= sum_{k<P} F[P+i, k] w[k]; mode 1 (backward)
-// w[i] -= sum_{j<B} F[i, P+j] w[P+j].  One thread per row, 256 rows per block (blockIdx.y).
+// w[r0:r1) -= F[r0:r1, c0:c1) w[c0:c1): one thread per row, 256 rows per block (blockIdx.y), columns staged through LDS
 __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
-                                                 int64_t voff, int M, int P, int B, int mode) {
+                                                 int64_t voff, int M, int r0, int r1, int c0, int c1) {
   __shared__ double xs[256];
   const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   double* w = vec + voff + (int64_t)blockIdx.x * M;
-  const int rows = mode == 0 ? B : P, K = mode == 0 ? P : B;
-  const int roff = mode == 0 ? P : 0, coff = mode == 0 ? 0 : P;
-  const int r = blockIdx.y * 256 + threadIdx.x;
+  const int r = r0 + blockIdx.y * 256 + threadIdx.x;
   double a = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 256) {
-    const int kn = min(256, K - k0);
+  for (int k0 = c0; k0 < c1; k0 += 256) {
+    const int kn = min(256, c1 - k0);
     __syncthreads();
-    if ((int)threadIdx.x < kn) xs[threadIdx.x] = w[coff + k0 + threadIdx.x];
+    if ((int)threadIdx.x < kn) xs[threadIdx.x] = w[k0 + threadIdx.x];
     __syncthreads();
-    if (r < rows) {
-      const double* col = F + (int64_t)(coff + k0) * M + roff + r;
+    if (r < r1) {
+      const double* col = F + (int64_t)k0 * M + r;
+#pragma unroll 4
       for (int k = 0; k < kn; ++k) a += col[(int64_t)k * M] * xs[k];
     }
   }
-  if (r < rows) w[roff + r] -= a;
+  if (r < r1) w[r] -= a;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -919,7 +972,11 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       const int R = M - kb - nb;
       if (R > 0) {
         const unsigned nch = (unsigned)((R + ND_TS - 1) / ND_TS);
-        hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
+        if (nb <= 24)
+          hipLaunchKernelGGL(k_nd_panel_reg<24>, dim3((unsigned)Lv.count, 2 * nch), dim3(64), 0, s->st, s->arena, Lv.off, M, kb,
+                             nb);
+        else
+          hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
         const int sfirst = kb + nb;
         if (sfirst < P) {
           const unsigned nb1 = (unsigned)((P - sfirst + ND_TS - 1) / ND_TS), nb2 = (unsigned)((B + ND_TS - 1) / ND_TS);
@@ -974,10 +1031,15 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, M, s->d_fp, s->d_fb,
                        s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
                        db, s->vec);
-    hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, P, 0);
-    if (B > 0)
-      hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((B + 255) / 256)), dim3(256), 0, s->st, s->arena,
-                         Lv.off, s->vec, Lv.voff, M, P, B, 0);
+    // forward substitution in slabs of ND_SLAB pivots: triangle by one workgroup per front, everything below the slab
+    // (rest of the pivot block AND the border rows) by a gemv over many workgroups
+    for (int k0 = 0; k0 < P; k0 += ND_SLAB) {
+      const int k1 = std::min(P, k0 + ND_SLAB);
+      hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 0);
+      if (k1 < M)
+        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + 255) / 256)), dim3(256), 0, s->st, s->arena,
+                           Lv.off, s->vec, Lv.voff, M, k1, M, k0, k1);
+    }
   }
   for (int l = 0; l < L; ++l) {
     const NdLevel& Lv = s->lev[l];
@@ -986,9 +1048,16 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
                          s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
       hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, s->st, s->arena,
-                         Lv.off, s->vec, Lv.voff, M, P, B, 1);
+                         Lv.off, s->vec, Lv.voff, M, 0, P, P, M);
     }
-    hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, P, 1);
+    const int nsl = (P + ND_SLAB - 1) / ND_SLAB;
+    for (int sl = nsl - 1; sl >= 0; --sl) {
+      const int k0 = sl * ND_SLAB, k1 = std::min(P, k0 + ND_SLAB);
+      hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 1);
+      if (k0 > 0)
+        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + 255) / 256)), dim3(256), 0, s->st, s->arena,
+                           Lv.off, s->vec, Lv.voff, M, 0, k0, k0, k1);
+    }
   }
   hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
                      s->d_dof_ptr, s->d_own_dofs, s->vec, dx);

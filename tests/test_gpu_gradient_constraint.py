@@ -81,3 +81,27 @@ def test_other_alpha_schemes(require_gpu):
                                             stopping_tol=1e-7)
         assert list(its) == list(its_ref)
         assert _rel(x[: prob.n2], x_ref[: prob.n2]) < 1e-10
+
+
+def test_hip_reproduces_golden_fixture(require_gpu):
+    """tests/golden/gradient_constraint_p2_n12_defaults.npz (tools/make_golden.py): kernels at a fixed iterate, then the
+    complete LVPP run."""
+    import pathlib
+
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    z = np.load(pathlib.Path(__file__).resolve().parent / "golden" / "gradient_constraint_p2_n12_defaults.npz")
+    N = int(z["N"])
+    problem, prob = _setup(N)
+    problem.set_alpha(8.0)
+    problem.set_prev(z["xk_iter"])
+    F, _ = problem.residual(z["x_iter"])
+    assert _rel(F, z["F_iter"]) < 1e-12
+    problem.jacobian(z["x_iter"])
+    assert _rel(problem.spmv(z["v"]), z["Jv_iter"]) < 1e-12
+    problem.set_state(z["x_iter"])
+    assert abs(problem.l2_increment() - float(z["l2_iter"])) <= 1e-12 * float(z["l2_iter"])
+    problem.close()
+    its, diffs, x = solve_problem(N, N, verbose=False, return_solution=True)
+    assert list(its) == list(z["newton"])
+    assert _rel(x[: prob.n2], z["x_final"][: prob.n2]) < 1e-10

@@ -53,7 +53,25 @@ def run_p2(N, scheme, alpha_max, tol, tag):
     print("P2", tag, N, hist["Newton steps"])
 
 
+def run_gc(N, tag):
+    """example 06 (oracle/gc_oracle.py), reference defaults: doubling alpha, stopping_tol 1e-8, max 25"""
+    from oracle import gc_oracle as G
+
+    coords, cells = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(coords, cells)
+    its = []
+    x, newton, diffs = G.solve_problem(prob, iterates=its)
+    x3, xk3 = its[3], its[2]
+    J = prob.jacobian(x3, 8.0).tocsr()
+    v = np.sin(np.arange(prob.ntot) * 0.37)
+    np.savez_compressed(OUT / f"gradient_constraint_p2_n{N}_{tag}.npz", N=N, x_final=x, newton=newton, L2_diff=diffs,
+                        x_iter=x3, xk_iter=xk3, F_iter=prob.residual(x3, xk3, 8.0), Jv_iter=J @ v, v=v,
+                        l2_iter=prob.l2_increment(x3, xk3))
+    print("ex06", N, newton)
+
+
 if __name__ == "__main__":
+    run_gc(12, "defaults")
     run_p2(16, "double_exponential", 1e2, 1e-4, "settingsB")
     run(16, "double_exponential", 1e2, 1e-4, "settingsB")
     run(16, "constant", 1e5, 1e-6, "settingsA")
