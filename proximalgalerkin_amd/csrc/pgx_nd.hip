@@ -503,13 +503,17 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 
 
 // ---- dense kernels, batched over the fronts of one level (blockIdx.x = front within the level) ---------------------
-#define ND_NB 72   // widest pivot panel (diagonal block kept in LDS)
-#define ND_TS 64   // GEMM tile / panel chunk
-#define ND_KC 24   // GEMM k-chunk staged in LDS
+#define ND_NB 64   // widest pivot panel (diagonal block kept in LDS; one wavefront lane per row)
+#define ND_TS 64   // panel chunk
+#define ND_KC 16   // GEMM k-chunk staged in LDS
 #define ND_SLAB 256 // pivots per triangular-solve launch in the solve phase
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
-// LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level
+// LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level.  Blocked by 8 columns:
+// (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
+// (b) the 8 x rest block row of U by forward substitution, one thread per column, (c) rank-8 update of the trailing block
+// by all 256 threads: 3 barriers per 8 columns instead of 2 per column (84 -> ~20 us per launch near the root, where the
+// launches of a level form one dependent chain).
 __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
                                                  int* __restrict__ info) {
   __shared__ double D[ND_NB][ND_NB + 1];
@@ -519,30 +523,73 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
     const int r = idx % nb, c = idx / nb;
     D[r][c] = F[(int64_t)c * M + r];
   }
-  for (int k = 0; k < nb - 1; ++k) {
-    __syncthreads();
-    double piv = D[k][k];
-    if (fabs(piv) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported through info
-      piv = piv < 0 ? -1e-300 : 1e-300;
-      if (tid == 0) {
-        D[k][k] = piv;
-        atomicAdd(info, 1);
+  __syncthreads();
+  for (int jb = 0; jb < nb; jb += 8) {
+    const int w = min(8, nb - jb);
+    if (tid < 64) {
+      const int r = tid;
+      const bool act = r >= jb && r < nb;
+      double a[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a[c] = (act && c < w) ? D[r][jb + c] : 0.0;
+      int bad = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < w) {
+          const int pr = jb + c;
+          if (r == pr && fabs(a[c]) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported via info
+            a[c] = a[c] < 0 ? -1e-300 : 1e-300;
+            bad = 1;
+          }
+          double pv[8];
+#pragma unroll
+          for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? __shfl(a[c2], pr) : 0.0;
+          if (act && r > pr) {
+            const double l = a[c] / pv[c];
+            a[c] = l;
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2)
+              if (c2 > c) a[c2] -= l * pv[c2];
+          }
+        }
       }
+      if (bad) atomicAdd(info, 1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (act && c < w) D[r][jb + c] = a[c];
     }
-    const int m = nb - k - 1;
-    if (tid < m) D[k + 1 + tid][k] /= piv;
     __syncthreads();
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int r = k + 1 + idx % m, c = k + 1 + idx / m;
-      D[r][c] -= D[r][k] * D[k][c];
+    const int rest = nb - jb - w;
+    if (rest > 0) {
+      if (tid < rest) {  // U12 = L11^{-1} A12, one column per thread
+        const int c = jb + w + tid;
+        double u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < w) {
+            double v = D[jb + i][c];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < i) v -= D[jb + i][jb + m] * u[m];
+            u[i] = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < w) D[jb + i][c] = u[i];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < rest * rest; idx += 256) {
+        const int r = jb + w + idx % rest, c = jb + w + idx / rest;
+        double v = D[r][c];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          if (m < w) v -= D[r][jb + m] * D[jb + m][c];
+        D[r][c] = v;
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
-  if (tid == 0 && fabs(D[nb - 1][nb - 1]) < 1e-300) {
-    D[nb - 1][nb - 1] = 1e-300;
-    atomicAdd(info, 1);
-  }
-  __syncthreads();
   for (int idx = tid; idx < nb * nb; idx += 256) {
     const int r = idx % nb, c = idx / nb;
     F[(int64_t)c * M + r] = D[r][c];
@@ -550,163 +597,189 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
 }
 
 // panel solves against the factored diagonal block: chunk c < nch : columns [o0, o0+64) of the row panel, X <- L^{-1} X;
-// chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  Right-looking in LDS, one barrier per step.
+// chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  Blocked by 8 pivots in LDS: the 8x8 triangle by
+// one thread per column/row (registers), the rank-8 update of the rest by all 256 threads; the entries of the diagonal
+// block are packed so that the 8 coefficients a thread needs are contiguous.  2 barriers per 8 pivots.
 __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb) {
   __shared__ double T[ND_NB * (ND_NB + 1) / 2];
   __shared__ double X[ND_NB][ND_TS + 1];
-  __shared__ double invd[ND_NB];
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   const int tid = threadIdx.x;
   const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
   const bool isL = (int)blockIdx.y >= nch;
   const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
-  const int w = min(ND_TS, M - o0);
+  const int wd = min(ND_TS, M - o0);
   const double* Dg = F + (int64_t)kb * M + kb;
+  const int j = tid & 63, g = tid >> 6;
   if (!isL) {
+    // T: strict lower triangle, row-major packed: L[r][c] at r(r-1)/2 + c
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int r = idx % nb, c = idx / nb;
       if (r > c) T[r * (r - 1) / 2 + c] = Dg[(int64_t)c * M + r];
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
-      const int k = idx % nb, j = idx / nb;
-      X[k][j] = j < w ? F[(int64_t)(o0 + j) * M + kb + k] : 0.0;
+      const int k = idx % nb, jj = idx / nb;
+      X[k][jj] = jj < wd ? F[(int64_t)(o0 + jj) * M + kb + k] : 0.0;
     }
     __syncthreads();
-    const int j = tid & 63, g = tid >> 6;
-    for (int k = 0; k < nb - 1; ++k) {
-      const double xk = X[k][j];
-      for (int r = k + 1 + g; r < nb; r += 4) X[r][j] -= T[r * (r - 1) / 2 + k] * xk;
+    for (int jb = 0; jb < nb; jb += 8) {
+      const int w = min(8, nb - jb);
+      double xs[8];
+      if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < w) {
+            double v = X[jb + i][j];
+            const double* Lr = T + (jb + i) * (jb + i - 1) / 2 + jb;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < i) v -= Lr[m] * xs[m];
+            xs[i] = v;
+            X[jb + i][j] = v;
+          }
+        }
+      }
       __syncthreads();
+      if (jb + w < nb) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xs[m] = m < w ? X[jb + m][j] : 0.0;
+        for (int r = jb + w + g; r < nb; r += 4) {
+          const double* Lr = T + r * (r - 1) / 2 + jb;
+          double v = X[r][j];
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+            if (m < w) v -= Lr[m] * xs[m];
+          X[r][j] = v;
+        }
+        __syncthreads();
+      }
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
       const int k = idx % nb, jj = idx / nb;
-      if (jj < w) F[(int64_t)(o0 + jj) * M + kb + k] = X[k][jj];
+      if (jj < wd) F[(int64_t)(o0 + jj) * M + kb + k] = X[k][jj];
     }
   } else {
+    // T: upper triangle incl. diagonal, column-major packed: U[k][c] at c(c+1)/2 + k
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int k = idx % nb, c = idx / nb;
       if (k <= c) T[c * (c + 1) / 2 + k] = Dg[(int64_t)c * M + k];
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
       const int i = idx % ND_TS, k = idx / ND_TS;
-      X[k][i] = i < w ? F[(int64_t)(kb + k) * M + o0 + i] : 0.0;
+      X[k][i] = i < wd ? F[(int64_t)(kb + k) * M + o0 + i] : 0.0;
     }
     __syncthreads();
-    if (tid < nb) invd[tid] = 1.0 / T[tid * (tid + 1) / 2 + tid];
-    __syncthreads();
-    const int i = tid & 63, g = tid >> 6;
-    for (int k = 0; k < nb - 1; ++k) {
-      const double xk = X[k][i] * invd[k];
-      for (int c = k + 1 + g; c < nb; c += 4) X[c][i] -= xk * T[c * (c + 1) / 2 + k];
+    for (int jb = 0; jb < nb; jb += 8) {
+      const int w = min(8, nb - jb);
+      double xs[8];
+      if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < w) {
+            const int c = jb + i;
+            const double* Uc = T + c * (c + 1) / 2 + jb;
+            double v = X[c][j];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < i) v -= xs[m] * Uc[m];
+            v /= Uc[i];
+            xs[i] = v;
+            X[c][j] = v;
+          }
+        }
+      }
       __syncthreads();
+      if (jb + w < nb) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xs[m] = m < w ? X[jb + m][j] : 0.0;
+        for (int c = jb + w + g; c < nb; c += 4) {
+          const double* Uc = T + c * (c + 1) / 2 + jb;
+          double v = X[c][j];
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+            if (m < w) v -= xs[m] * Uc[m];
+          X[c][j] = v;
+        }
+        __syncthreads();
+      }
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
       const int ii = idx % ND_TS, k = idx / ND_TS;
-      if (ii < w) F[(int64_t)(kb + k) * M + o0 + ii] = X[k][ii] * invd[k];
+      if (ii < wd) F[(int64_t)(kb + k) * M + o0 + ii] = X[k][ii];
     }
   }
 }
 
-// register-resident variant of the panel solves (used for nb <= 24 only: measured SLOWER than the LDS kernel at nb = 72,
-// 50 vs 31 ms per 1024^2 factorisation - uncoalesced column loads, 162 VGPRs): chunk c < nch : columns [o0, o0+64) of the row panel, X <- L^{-1} X;
-// chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  One wave per chunk, one thread per column / row
-// with its nb entries in registers (fully unrolled, NBT = compile-time bound >= nb); the entries of the diagonal block
-// are wave-uniform loads (scalar cache); no LDS, no barriers.
-template <int NBT>
-__global__ __launch_bounds__(64) void k_nd_panel_reg(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb) {
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
-  const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
-  const bool isL = (int)blockIdx.y >= nch;
-  const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
-  const int t = o0 + threadIdx.x;
-  if (t >= M) return;
-  const double* Dg = F + (int64_t)kb * M + kb;
-  double x[NBT];
-  if (!isL) {
-    double* colp = F + (int64_t)t * M + kb;
-#pragma unroll
-    for (int k = 0; k < NBT; ++k) x[k] = k < nb ? colp[k] : 0.0;
-#pragma unroll
-    for (int k = 0; k < NBT - 1; ++k) {
-      if (k < nb - 1) {  // wave-uniform
-        const double xk = x[k];
-        const double* Lk = Dg + (int64_t)k * M;
-#pragma unroll
-        for (int r = 0; r < NBT; ++r)
-          if (r > k && r < nb) x[r] -= Lk[r] * xk;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NBT; ++k)
-      if (k < nb) colp[k] = x[k];
-  } else {
-    double* rowp = F + (int64_t)kb * M + t;
-#pragma unroll
-    for (int k = 0; k < NBT; ++k) x[k] = k < nb ? rowp[(int64_t)k * M] : 0.0;
-#pragma unroll
-    for (int k = 0; k < NBT; ++k) {
-      if (k < nb) {  // wave-uniform
-        const double xk = x[k] / Dg[(int64_t)k * M + k];
-        x[k] = xk;
-#pragma unroll
-        for (int c = 0; c < NBT; ++c)
-          if (c > k && c < nb) x[c] -= xk * Dg[(int64_t)c * M + k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NBT; ++k)
-      if (k < nb) rowp[(int64_t)k * M] = x[k];
-  }
-}
-
-// C -= A B with A = F[rows, k0:k1), B = F[k0:k1, cols) on 64x64 tiles.  Tiles never straddle P: row/col blocks are laid
-// out as [s, P) then [P, M).  mode 0: all tiles of the trailing matrix EXCEPT the Schur block (rows >= P and cols >= P);
-// mode 1 (s == P): the Schur block only.
+// C -= A B with A = F[rows, k0:k1), B = F[k0:k1, cols) on (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of
+// v_mfma_f64_16x16x4_f64, operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous
+// bytes of C.  The next k-chunk is prefetched into registers while the current one feeds the matrix cores.
+// Tiles never straddle P: row/col blocks are laid out as [s, P) then [P, M).  mode 0: all tiles of the trailing matrix
+// EXCEPT the Schur block (rows >= P and cols >= P); mode 1 (s == P): the Schur block only.
+template <int WT>
 __global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int P, int s, int k0,
                                                  int k1, int mode) {
-  __shared__ double As[ND_KC][ND_TS + 8];
-  __shared__ double Bs[ND_TS][ND_KC + 1];
-  const int nb1 = s < P ? (P - s + ND_TS - 1) / ND_TS : 0;
+  constexpr int TS = 32 * WT;
+  constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
+  __shared__ double As[ND_KC][TS + 8];
+  __shared__ double Bs[TS][ND_KC + 1];
+  const int nb1 = s < P ? (P - s + TS - 1) / TS : 0;
   const int bi = blockIdx.y, bj = blockIdx.z;
   if (mode == 0 && bi >= nb1 && bj >= nb1) return;
   int r0, rmax, c0, cmax;
-  if (bi < nb1) r0 = s + ND_TS * bi, rmax = P; else r0 = P + ND_TS * (bi - nb1), rmax = M;
-  if (bj < nb1) c0 = s + ND_TS * bj, cmax = P; else c0 = P + ND_TS * (bj - nb1), cmax = M;
+  if (bi < nb1) r0 = s + TS * bi, rmax = P; else r0 = P + TS * (bi - nb1), rmax = M;
+  if (bj < nb1) c0 = s + TS * bj, cmax = P; else c0 = P + TS * (bj - nb1), cmax = M;
   if (r0 >= rmax || c0 >= cmax) return;
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
-  const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
-  nd_v4d acc[2][2];  // [tj][ti]
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
-  for (int kc = k0; kc < k1; kc += ND_KC) {
+  const int wi = (wv >> 1) * 16 * WT, wj = (wv & 1) * 16 * WT;
+  nd_v4d acc[WT][WT];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
+  double ra[NLD], rb[NLD];
+  auto fetch = [&](int kc) {
     const int kn = min(ND_KC, k1 - kc);
-    for (int idx = tid; idx < ND_KC * ND_TS; idx += 256) {
-      const int i = idx % ND_TS, k = idx / ND_TS;
-      As[k][i] = (k < kn && r0 + i < rmax) ? F[(int64_t)(kc + k) * M + r0 + i] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + 256 * q;
+      const int i = idx % TS, k = idx / TS;
+      ra[q] = (k < kn && r0 + i < rmax) ? F[(int64_t)(kc + k) * M + r0 + i] : 0.0;
+      const int k2 = idx % ND_KC, j2 = idx / ND_KC;
+      rb[q] = (k2 < kn && c0 + j2 < cmax) ? F[(int64_t)(c0 + j2) * M + kc + k2] : 0.0;
     }
-    for (int idx = tid; idx < ND_KC * ND_TS; idx += 256) {
-      const int k = idx % ND_KC, j = idx / ND_KC;
-      Bs[j][k] = (k < kn && c0 + j < cmax) ? F[(int64_t)(c0 + j) * M + kc + k] : 0.0;
+  };
+  fetch(k0);
+  for (int kc = k0; kc < k1; kc += ND_KC) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + 256 * q;
+      As[idx / TS][idx % TS] = ra[q];
+      Bs[idx / ND_KC][idx % ND_KC] = rb[q];
     }
     __syncthreads();
+    if (kc + ND_KC < k1) fetch(kc + ND_KC);
 #pragma unroll
     for (int kk = 0; kk < ND_KC; kk += 4) {
       const int kq = kk + (l >> 4);
-      const double u0 = Bs[wj + (l & 15)][kq], u1 = Bs[wj + 16 + (l & 15)][kq];
-      const double l0 = As[kq][wi + (l & 15)], l1 = As[kq][wi + 16 + (l & 15)];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l1, acc[1][1], 0, 0, 0);
+      double uf[WT], lf[WT];
+#pragma unroll
+      for (int t = 0; t < WT; ++t) {
+        uf[t] = Bs[wj + 16 * t + (l & 15)][kq];
+        lf[t] = As[kq][wi + 16 * t + (l & 15)];
+      }
+#pragma unroll
+      for (int tj = 0; tj < WT; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < WT; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[tj], lf[ti], acc[tj][ti], 0, 0, 0);
     }
-    __syncthreads();
   }
   // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj)
+  for (int tj = 0; tj < WT; ++tj)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < WT; ++ti) {
       const int i = r0 + wi + 16 * ti + (l & 15);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -724,6 +797,7 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
                                                  int64_t voff, int M, int k0, int k1, int upper) {
   __shared__ double Ds[64][65];
   __shared__ double ys[64];
+  __shared__ double red[4][64];
   const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   double* w = vec + voff + (int64_t)blockIdx.x * M;
   const int tid = threadIdx.x;
@@ -756,13 +830,22 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
       if (r < nb) w[kb + r] = y;
     }
     __syncthreads();
+    // rows of the slab outside the block: 64 rows x 4 column groups per pass (16 independent loads per thread instead of
+    // a 64-long chain), partial sums combined through LDS
     const int lo = upper ? k0 : kb + nb, hi = upper ? kb : k1;
-    for (int r = lo + tid; r < hi; r += 256) {
+    for (int rbase = lo; rbase < hi; rbase += 64) {
+      const int r = rbase + (tid & 63), cg = tid >> 6;
       double a = 0.0;
-      for (int k = 0; k < nb; ++k) a += F[(int64_t)(kb + k) * M + r] * ys[k];
-      w[r] -= a;
+      if (r < hi) {
+        const int kend = min(cg * 16 + 16, nb);
+#pragma unroll 8
+        for (int k = cg * 16; k < kend; ++k) a += F[(int64_t)(kb + k) * M + r] * ys[k];
+      }
+      red[cg][tid & 63] = a;
+      __syncthreads();
+      if (tid < 64 && r < hi) w[r] -= (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -925,6 +1008,19 @@ extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* s
   return PGX_OK;
 }
 
+// trailing / Schur update of one level: 128 x 128 tiles where the fronts are large, 64 x 64 otherwise
+static void nd_launch_gemm(pgx_nd* s, const NdLevel& Lv, int sfirst, int k0, int k1, int mode) {
+  const int P = Lv.P, B = Lv.B, M = P + B;
+  const bool big = (M - sfirst) >= 512;
+  const int TS = big ? 128 : 64;
+  const unsigned nb1 = sfirst < P ? (unsigned)((P - sfirst + TS - 1) / TS) : 0u, nb2 = (unsigned)((B + TS - 1) / TS);
+  const dim3 grid((unsigned)Lv.count, nb1 + nb2, nb1 + nb2);
+  if (big)
+    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, P, sfirst, k0, k1, mode);
+  else
+    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, P, sfirst, k0, k1, mode);
+}
+
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   if (!s || !vals) return PGX_EINVAL;
   if (s->device < 0) {
@@ -972,25 +1068,13 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       const int R = M - kb - nb;
       if (R > 0) {
         const unsigned nch = (unsigned)((R + ND_TS - 1) / ND_TS);
-        if (nb <= 24)
-          hipLaunchKernelGGL(k_nd_panel_reg<24>, dim3((unsigned)Lv.count, 2 * nch), dim3(64), 0, s->st, s->arena, Lv.off, M, kb,
-                             nb);
-        else
-          hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
+        hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
         const int sfirst = kb + nb;
-        if (sfirst < P) {
-          const unsigned nb1 = (unsigned)((P - sfirst + ND_TS - 1) / ND_TS), nb2 = (unsigned)((B + ND_TS - 1) / ND_TS);
-          hipLaunchKernelGGL(k_nd_gemm, dim3((unsigned)Lv.count, nb1 + nb2, nb1 + nb2), dim3(256), 0, s->st, s->arena,
-                             Lv.off, M, P, sfirst, kb, kb + nb, 0);
-        }
+        if (sfirst < P) nd_launch_gemm(s, Lv, sfirst, kb, kb + nb, 0);
       }
       kb += nb;
     }
-    if (B > 0) {
-      const unsigned nb2 = (unsigned)((B + ND_TS - 1) / ND_TS);
-      hipLaunchKernelGGL(k_nd_gemm, dim3((unsigned)Lv.count, nb2, nb2), dim3(256), 0, s->st, s->arena, Lv.off, M, P, P, 0,
-                         P, 1);
-    }
+    if (B > 0) nd_launch_gemm(s, Lv, P, 0, P, 1);
   }
   if (s->timing) {
     hipEventRecord(s->e1, s->st);

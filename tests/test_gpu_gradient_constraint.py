@@ -93,7 +93,7 @@ def test_hip_reproduces_golden_fixture(require_gpu):
     z = np.load(pathlib.Path(__file__).resolve().parent / "golden" / "gradient_constraint_p2_n12_defaults.npz")
     N = int(z["N"])
     problem, prob = _setup(N)
-    problem.set_alpha(8.0)
+    problem.set_alpha(5.0)
     problem.set_prev(z["xk_iter"])
     F, _ = problem.residual(z["x_iter"])
     assert _rel(F, z["F_iter"]) < 1e-12

@@ -62,10 +62,10 @@ def run_gc(N, tag):
     its = []
     x, newton, diffs = G.solve_problem(prob, iterates=its)
     x3, xk3 = its[3], its[2]
-    J = prob.jacobian(x3, 8.0).tocsr()
+    J = prob.jacobian(x3, 5.0).tocsr()
     v = np.sin(np.arange(prob.ntot) * 0.37)
     np.savez_compressed(OUT / f"gradient_constraint_p2_n{N}_{tag}.npz", N=N, x_final=x, newton=newton, L2_diff=diffs,
-                        x_iter=x3, xk_iter=xk3, F_iter=prob.residual(x3, xk3, 8.0), Jv_iter=J @ v, v=v,
+                        x_iter=x3, xk_iter=xk3, F_iter=prob.residual(x3, xk3, 5.0), Jv_iter=J @ v, v=v,  # alpha != the step's own (residual would be ~0)
                         l2_iter=prob.l2_increment(x3, xk3))
     print("ex06", N, newton)
 
