@@ -1,0 +1,74 @@
+/*
+ * pgx_sg.h - C ABI of libpgx.so for the LVPP Newton inner loop of example 02 (Signorini contact of a 3-D linear-elastic
+ * body with a rigid plane; latent variable on the contact surface): everything below `solver.solve()` in
+ * examples/02_signorini/signorini_dolfinx.py:333, i.e. what the reference delegates to DOLFINx assembly (cell + exterior
+ * facet integrals on a submesh, :199-249) + PETSc SNES (newtonls, linesearch none) + MUMPS LU (:271-291).
+ *
+ * Spaces at degree 1 (BASELINE.json config 5): u in (P1)^3 on a tetrahedral mesh, psi in P1 on the contact facets.
+ *        x = [u_x (nv) | u_y (nv) | u_z (nv) | psi (one per contact vertex, ordered by vertex id)]
+ * Residual (:236-249), n_g = -e_z, g = x_z - gap, f = 0:
+ *        R_u   = alpha (sigma(u), eps(v)) - <psi - psi_k, v.n_g>_Gamma
+ *        R_psi = <u.n_g, w>_Gamma + <exp(psi), w>_Gamma - <g, w>_Gamma
+ * Jacobian [[alpha A, +M_G],[-M_G, D(psi)]] (nonsymmetric sign pattern, as UFL's derivative gives it).
+ *
+ *   pgx_sg_create         NonlinearProblem(F, [u, psi], bcs, entity_maps, petsc_options) construction (:281-291)
+ *   pgx_sg_set/get_state, pgx_sg_set/get_prev, pgx_sg_advance_prev   u.x.array / psi.x.array / psi_k, u_prev (:336-343)
+ *   pgx_sg_set_alpha      alpha.value = ... (:323-328)
+ *   pgx_sg_residual / pgx_sg_jacobian_fill / pgx_sg_csr_export / pgx_sg_spmv   SNES callbacks and the PETSc Mat
+ *   pgx_sg_newton_solve   solver.solve() (:333) with reason / iteration count (:334-335); tolerances as set by
+ *                         solver.solver.setTolerances(atol=, rtol=) (:331-332)
+ *   pgx_sg_u_increment    ||u - u_prev||_2 (vector 2-norm, :337-339)
+ * Conventions as in pgx.h.  Linear solves: sparse LU of pgx_nd.h + iterative refinement.  No CPU fallback.
+ */
+#ifndef PGX_SG_H
+#define PGX_SG_H
+#include <stdint.h>
+
+#include "pgx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgx_sg_handle pgx_sg_handle;
+
+typedef struct {
+  int32_t n_vertices, n_cells;
+  const double* coords;    /* [n_vertices][3] */
+  const int32_t* cells;    /* [n_cells][4] */
+  int32_t n_facets;        /* potential-contact facets (facet_tag.find(contact), :186-189) */
+  const int32_t* facets;   /* [n_facets][3] vertex ids */
+} pgx_sg_mesh;
+
+typedef struct {
+  double E, nu, gap;       /* :58-66 */
+  int32_t nq;              /* facet quadrature (degree 4 in the reference, :67-69), <= 16 points */
+  const double* qpts;      /* [nq][2] reference triangle */
+  const double* qwts;      /* [nq], sum 1/2 */
+  int32_t n_bc;            /* Dirichlet dofs of u: component * n_vertices + vertex (:255-268) */
+  const int32_t* bc_dofs;
+  const double* bc_vals;   /* NULL = homogeneous */
+} pgx_sg_problem;
+
+int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int device, pgx_sg_handle** out);
+void pgx_sg_destroy(pgx_sg_handle* h);
+const char* pgx_sg_last_error(const pgx_sg_handle* h);
+int pgx_sg_num_dofs(const pgx_sg_handle* h, int64_t* ntot, int64_t* npsi);
+int pgx_sg_contact_vertices(const pgx_sg_handle* h, int32_t* verts /* [npsi]: vertex of each psi dof */);
+int pgx_sg_set_state(pgx_sg_handle* h, const double* x);
+int pgx_sg_get_state(pgx_sg_handle* h, double* x);
+int pgx_sg_set_prev(pgx_sg_handle* h, const double* x);
+int pgx_sg_get_prev(pgx_sg_handle* h, double* x);
+int pgx_sg_advance_prev(pgx_sg_handle* h);
+int pgx_sg_set_alpha(pgx_sg_handle* h, double alpha);
+int pgx_sg_residual(pgx_sg_handle* h, const double* x, double* F, double* fnorm);
+int pgx_sg_jacobian_fill(pgx_sg_handle* h, const double* x);
+int pgx_sg_csr_export(pgx_sg_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col, double* vals);
+int pgx_sg_spmv(pgx_sg_handle* h, const double* x, double* y);
+int pgx_sg_newton_solve(pgx_sg_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its);
+int pgx_sg_u_increment(pgx_sg_handle* h, double* out);
+int pgx_sg_profile(pgx_sg_handle* h, int enable, double ms[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""CPU oracle for the LVPP Newton loop of example 02 (Signorini contact, 3-D linear elasticity, latent variable on the
+contact surface).  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (DOLFINx/PETSc/MUMPS absent, no reference tests or golden
+data for this path) - restated from /root/reference/examples/02_signorini/signorini_dolfinx.py:
+
+* mesh      : unit cube, nx x ny x nz cubes, 6 tetrahedra per cube around the diagonal v0-v7 (BASELINE.json config 5 asks
+              for a tetrahedral P1 mesh; the script's native mesh is hexahedral, :376-383) [split pattern recalled from
+              dolfinx create_box, not verifiable offline].  Contact surface z = 0, displacement surface z = 1 (:369-373).
+* spaces    : u in (P1)^3 on the mesh, psi in P1 on the submesh of contact facets (:211-216), degree 1 here.
+* residual  : (:236-249) with n_g = -e_z, g = x_z - gap, f = 0, facet quadrature degree 4 (:67-69,200-208):
+                R_u   = alpha (sigma(u), eps(v)) - alpha (f, v) - <psi - psi_k, v.n_g>_Gamma
+                R_psi = <u.n_g, w>_Gamma + <exp(psi), w>_Gamma - <g, w>_Gamma
+              sigma = 2 mu eps + lambda tr(eps) I, mu = E/(2(1+nu)), lambda = E nu/((1+nu)(1-2nu)) (:146-153,234-235).
+* Jacobian  : derivative: [[alpha A, +M_G (u_z, psi)], [-M_G (psi, u_z), D(psi)]], D = <exp(psi) N_a, N_b>.
+* BCs       : u = (0, 0, disp) on the displacement surface (:255-268), DOLFINx lifting / set_bc contract.
+* Newton    : SNES newtonls, linesearch none, atol = rtol = solver_tol (:331-332), PETSc defaults stol 1e-8, max_it 50
+              (`newton_max_its` is accepted but never handed to the solver).
+* outer     : it = 1..max_iterations; alpha = alpha_0 2^it (doubling) | alpha_0 + alpha_c it | constant (:323-328);
+              solver_tol = 10 newton_tol for it < 2 (:330); stop when ||u - u_prev||_2 <= tol (vector 2-norm, :337-341);
+              u_prev <- u, psi_k <- psi (:342-343).
+
+DOF layout: x = [u_x (nv) | u_y (nv) | u_z (nv) | psi (n_contact vertices, ordered by vertex id)].
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import pg_oracle as O
+
+
+def create_unit_cube_tets(nx, ny, nz):
+    xs, ys, zs = np.linspace(0, 1, nx + 1), np.linspace(0, 1, ny + 1), np.linspace(0, 1, nz + 1)
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (iz * (ny + 1) * (nx + 1) + iy * (nx + 1) + ix).ravel()
+    v1, v2 = v0 + 1, v0 + (nx + 1)
+    v3 = v1 + (nx + 1)
+    off = (nx + 1) * (ny + 1)
+    v4, v5, v6, v7 = v0 + off, v1 + off, v2 + off, v3 + off
+    tets = [(v0, v1, v3, v7), (v0, v1, v7, v5), (v0, v5, v7, v4), (v0, v3, v2, v7), (v0, v6, v4, v7), (v0, v2, v6, v7)]
+    cells = np.stack([np.stack(t, axis=1) for t in tets], axis=1).reshape(-1, 4).astype(np.int32)
+    return coords, cells
+
+
+def boundary_facets_where(coords, cells, pred):
+    """triangles (vertex triples) of cell faces whose three vertices satisfy pred(coords) - all such faces are exterior
+    for the planes z = 0 / z = 1 of the cube"""
+    on = pred(coords)
+    faces = np.concatenate([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]], cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]])
+    sel = faces[on[faces].all(axis=1)]
+    key = np.sort(sel, axis=1)
+    _, idx = np.unique(key, axis=0, return_index=True)
+    return sel[np.sort(idx)].astype(np.int32)
+
+
+class SignoriniP1:
+    def __init__(self, coords, cells, contact_facets, bc_vertices, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25,
+                 quadrature="tri_deg4_gj9"):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
+        self.nv, self.nc, self.nf = len(self.coords), len(self.cells), len(self.facets)
+        self.cverts = np.unique(self.facets.ravel()).astype(np.int32)  # psi dof -> vertex
+        self.npsi = len(self.cverts)
+        self.v2psi = np.full(self.nv, -1, dtype=np.int64)
+        self.v2psi[self.cverts] = np.arange(self.npsi)
+        self.ntot = 3 * self.nv + self.npsi
+        self.mu, self.lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+        self.gap, self.disp = float(gap), float(disp)
+        bv = np.asarray(bc_vertices, dtype=np.int64)
+        self.bc = np.concatenate([bv, self.nv + bv, 2 * self.nv + bv]).astype(np.int64)
+        self.bc_vals = np.concatenate([np.zeros(len(bv)), np.zeros(len(bv)), np.full(len(bv), self.disp)])
+        self.isbc = np.zeros(3 * self.nv, dtype=bool)
+        self.isbc[self.bc] = True
+        self.Xq, self.wq = O.load_quadrature(quadrature)
+        self.Lq = np.stack([1 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
+        # elasticity: constant-strain tetrahedra
+        x = self.coords[self.cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 3] - x[:, 0]], axis=2)  # columns
+        det = np.linalg.det(J)
+        invJ = np.linalg.inv(J)
+        gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+        G = np.einsum("ak,ckd->cad", gref, invJ)  # physical gradients (nc,4,3)
+        vol = np.abs(det) / 6.0
+        mu, lm = self.mu, self.lmbda
+        # A_e[(a,i),(b,j)] = vol * ( lambda G_ai G_bj + mu G_aj G_bi + mu delta_ij G_a.G_b )
+        GG = np.einsum("cad,cbd->cab", G, G)
+        Ae = (lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G)
+              + mu * np.einsum("cab,ij->caibj", GG, np.eye(3))) * vol[:, None, None, None, None]
+        rows = (self.cells[:, :, None, None, None] + self.nv * np.arange(3)[None, None, :, None, None])
+        cols = (self.cells[:, None, None, :, None] + self.nv * np.arange(3)[None, None, None, None, :])
+        rows, cols = np.broadcast_arrays(rows, cols)
+        self.A = sp.coo_matrix((Ae.ravel(), (rows.ravel(), cols.ravel())), shape=(3 * self.nv, 3 * self.nv)).tocsr()
+        # contact facets: area, mass matrix, g at quadrature points
+        xf = self.coords[self.facets]
+        self.farea2 = np.linalg.norm(np.cross(xf[:, 1] - xf[:, 0], xf[:, 2] - xf[:, 0]), axis=1)  # 2 * area
+        self.wdet = self.farea2[:, None] * self.wq[None]  # (nf,nq)
+        Mref = np.einsum("q,qa,qb->ab", self.wq, self.Lq, self.Lq)
+        Me = self.farea2[:, None, None] * Mref[None]
+        pf = self.v2psi[self.facets]
+        self.pf = pf
+        r = np.repeat(pf, 3, axis=1).ravel()
+        c = np.tile(self.facets, (1, 3)).ravel()
+        # MG[psi_a, vertex b] = <N_a, N_b>_Gamma  (npsi x nv)
+        self.MG = sp.coo_matrix((Me.ravel(), (r, c)), shape=(self.npsi, self.nv)).tocsr()
+        zq = np.einsum("qa,fa->fq", self.Lq, xf[:, :, 2])
+        self.b_g = np.bincount(pf.ravel(), weights=((self.wdet * (zq - self.gap)) @ self.Lq).ravel(), minlength=self.npsi)
+        self._rp = np.repeat(pf, 3, axis=1).ravel()
+        self._cp = np.tile(pf, (1, 3)).ravel()
+
+    def split(self, x):
+        return x[: 3 * self.nv], x[3 * self.nv:]
+
+    def exp_terms(self, psi, with_matrix=True):
+        pq = psi[self.pf] @ self.Lq.T
+        with np.errstate(over="ignore", under="ignore"):
+            wE = self.wdet * np.exp(pq)
+        b = np.bincount(self.pf.ravel(), weights=(wE @ self.Lq).ravel(), minlength=self.npsi)
+        if not with_matrix:
+            return b, None
+        De = np.einsum("fq,qa,qb->fab", wE, self.Lq, self.Lq)
+        return b, sp.coo_matrix((De.ravel(), (self._rp, self._cp)), shape=(self.npsi, self.npsi)).tocsr()
+
+    def residual(self, x, xk, alpha):
+        u, psi = self.split(x)
+        psik = xk[3 * self.nv:]
+        ut = u.copy()
+        ut[self.bc] = self.bc_vals
+        nv = self.nv
+        Fu = alpha * (self.A @ ut)
+        Fu[2 * nv:] += self.MG.T @ (psi - psik)  # -<psi - psi_k, v.n_g>, n_g = -e_z
+        b_exp, _ = self.exp_terms(psi, with_matrix=False)
+        Fp = -(self.MG @ ut[2 * nv:]) + b_exp - self.b_g
+        Fu[self.bc] = u[self.bc] - self.bc_vals
+        return np.concatenate([Fu, Fp])
+
+    def jacobian(self, x, alpha):
+        nv = self.nv
+        _, D = self.exp_terms(x[3 * nv:])
+        free = sp.diags((~self.isbc).astype(float))
+        A = free @ (alpha * self.A) @ free + sp.diags(self.isbc.astype(float))
+        Z = sp.csr_matrix((self.npsi, 2 * nv))
+        B = sp.hstack([Z, self.MG], format="csr") @ free  # (npsi, 3nv): <N_a, N_b> on the u_z columns
+        return sp.bmat([[A, (free @ B.T)], [-B, D]], format="csr")
+
+
+def solve_contact_problem(prob: SignoriniP1, newton_tol=1e-6, max_iterations=25, alpha_scheme="doubling", alpha_0=1.0,
+                          alpha_c=1.0, tol=1e-6, linear_solve=None, verbose=False, iterates=None):
+    """Mirror of signorini_dolfinx.solve_contact_problem's loop (:317-358). Returns (x, it, iterations)."""
+    x = np.zeros(prob.ntot)
+    xk = x.copy()
+    u_prev = np.zeros(3 * prob.nv)
+    iterations = []
+    it = 0
+    for it in range(1, max_iterations + 1):
+        alpha = alpha_0
+        if alpha_scheme == "linear":
+            alpha = alpha_0 + alpha_c * it
+        elif alpha_scheme == "doubling":
+            alpha = alpha_0 * 2**it
+        solver_tol = 10 * newton_tol if it < 2 else newton_tol
+        snes = O.SnesOptions(rtol=solver_tol, atol=solver_tol, stol=1e-8, max_it=50)
+        xn, reason, its = O.newton_solve(prob, x, xk, alpha, snes, linear_solve)
+        if reason <= 0:
+            raise RuntimeError(f"SNES diverged at LVPP step {it}: reason {reason} after {its} its")
+        x = xn
+        iterations.append(its)
+        nd = float(np.linalg.norm(x[: 3 * prob.nv] - u_prev))
+        if iterates is not None:
+            iterates.append(x.copy())
+        if verbose:
+            print(f"it={it} alpha={alpha:g} newton={its} reason={reason} |du|={nd:.3e} min psi {x[3 * prob.nv:].min():.2f}")
+        if nd <= tol:
+            break
+        u_prev = x[: 3 * prob.nv].copy()
+        xk = x.copy()
+    return x, it, iterations

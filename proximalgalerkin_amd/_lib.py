@@ -106,6 +106,31 @@ class pgx_gc_problem(C.Structure):  # include/pgx_gc.h
     ]
 
 
+class pgx_sg_mesh(C.Structure):  # include/pgx_sg.h
+    _fields_ = [
+        ("n_vertices", C.c_int32),
+        ("n_cells", C.c_int32),
+        ("coords", c_double_p),
+        ("cells", c_int32_p),
+        ("n_facets", C.c_int32),
+        ("facets", c_int32_p),
+    ]
+
+
+class pgx_sg_problem(C.Structure):
+    _fields_ = [
+        ("E", C.c_double),
+        ("nu", C.c_double),
+        ("gap", C.c_double),
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("n_bc", C.c_int32),
+        ("bc_dofs", c_int32_p),
+        ("bc_vals", c_double_p),
+    ]
+
+
 class pgx_partition(C.Structure):
     _fields_ = [
         ("rank", C.c_int32),
@@ -185,6 +210,26 @@ SYMBOLS = [
      [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pgx_gc_l2_increment", C.c_int, [_H, c_double_p]),
     ("pgx_gc_profile", C.c_int, [_H, C.c_int, c_double_p]),
+    # example 02: Signorini contact (include/pgx_sg.h)
+    ("pgx_sg_create", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_sg_destroy", None, [_H]),
+    ("pgx_sg_last_error", C.c_char_p, [_H]),
+    ("pgx_sg_num_dofs", C.c_int, [_H, c_int64_p, c_int64_p]),
+    ("pgx_sg_contact_vertices", C.c_int, [_H, c_int32_p]),
+    ("pgx_sg_set_state", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_get_state", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_set_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_get_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_advance_prev", C.c_int, [_H]),
+    ("pgx_sg_set_alpha", C.c_int, [_H, C.c_double]),
+    ("pgx_sg_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("pgx_sg_jacobian_fill", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_csr_export", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_double_p]),
+    ("pgx_sg_spmv", C.c_int, [_H, c_double_p, c_double_p]),
+    ("pgx_sg_newton_solve", C.c_int,
+     [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pgx_sg_u_increment", C.c_int, [_H, c_double_p]),
+    ("pgx_sg_profile", C.c_int, [_H, C.c_int, c_double_p]),
 ]
 
 _lib = None

@@ -6,20 +6,10 @@
 // per-cell destination tables are built once on the host; K and G are assembled once on the device, every Newton step
 // only rescales the K slots and re-assembles the 36 N entries per cell.  Linear solves: pgx_nd (sparse LU) + iterative
 // refinement on the exact operator.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
-#include <functional>
-#include <string>
-#include <thread>
-#include <vector>
 
 #include "../../include/pgx_gc.h"
-#include "../../include/pgx_nd.h"
+#include "pgx_mixed.h"
 
 #define GC_MAXQ 40
 struct GcQuad {
@@ -29,77 +19,25 @@ struct GcQuad {
 
 static thread_local std::string g_gc_error;
 
-struct pgx_gc_handle {
-  int device = 0;
-  hipStream_t st = nullptr;
-  std::string err;
+struct pgx_gc_handle : MixedBase {
   int nv = 0, nc = 0, n2 = 0;
-  int64_t ntot = 0, nnz = 0;
   GcQuad Q{};
   double alpha = 1.0;
-  // device data
   double *coords = nullptr, *phi = nullptr, *f = nullptr, *gbc = nullptr;
   int32_t* cdofs = nullptr;
   uint8_t* mask = nullptr;
-  int32_t *rowptr = nullptr, *col = nullptr, *dest36 = nullptr;
+  int32_t* dest36 = nullptr;
   uint8_t* kind = nullptr;
-  double *Jc = nullptr, *Jv = nullptr;
-  double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr, *r = nullptr, *z = nullptr;
-  double *partials = nullptr, *d_out = nullptr;
-  double* h_out = nullptr;  // pinned
-  std::vector<int32_t> h_rowptr, h_col;
-  pgx_nd* lu = nullptr;
-  bool jac_valid = false;
-  bool prof = false;
-  double ms[6] = {0, 0, 0, 0, 0, 0};
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  std::vector<void*> allocs;
+  double* Jc = nullptr;  // constant part of the Jacobian values (K and G slots), assembled once
+  void residual_dev(const double* xin, double* Fout) override;
+  void jacobian_dev(const double* xin) override;
 };
 
 extern "C" const char* pgx_gc_last_error(const pgx_gc_handle* h) { return h ? h->err.c_str() : g_gc_error.c_str(); }
 
-#define GCHIP(call)                                               \
-  do {                                                            \
-    hipError_t e_ = (call);                                       \
-    if (e_ != hipSuccess) {                                       \
-      h->err = std::string(#call) + ": " + hipGetErrorString(e_); \
-      return PGX_EHIP;                                            \
-    }                                                             \
-  } while (0)
-
-template <typename T>
-static int gc_alloc(pgx_gc_handle* h, T** p, size_t count) {
-  void* q = nullptr;
-  if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
-    h->err = "hipMalloc failed";
-    return PGX_ENOMEM;
-  }
-  h->allocs.push_back(q);
-  *p = (T*)q;
-  return PGX_OK;
-}
-#define GCALLOC(p, count)                        \
-  do {                                           \
-    int rc_ = gc_alloc(h, &(p), (size_t)(count)); \
-    if (rc_) return rc_;                         \
-  } while (0)
-
-struct GcTimer {
-  pgx_gc_handle* h;
-  int slot;
-  GcTimer(pgx_gc_handle* h_, int s) : h(h_), slot(s) {
-    if (h->prof) hipEventRecord(h->e0, h->st);
-  }
-  ~GcTimer() {
-    if (h->prof) {
-      hipEventRecord(h->e1, h->st);
-      hipEventSynchronize(h->e1);
-      float ms = 0;
-      hipEventElapsedTime(&ms, h->e0, h->e1);
-      h->ms[slot] += ms;
-    }
-  }
-};
+#define GCHIP MXHIP
+#define GCALLOC MXALLOC
+using GcTimer = MxTimer;
 
 // ------------------------------------------------------------------------------------------------------------------
 // element kernels (one thread per cell)
@@ -320,55 +258,7 @@ __global__ __launch_bounds__(128) void k_gc_jac_N(int nc, int n2, int nv, const 
     }
 }
 
-// y = A x, 16 lanes per row
-__global__ __launch_bounds__(256) void k_gc_spmv(int64_t nrows, const int32_t* __restrict__ rowptr,
-                                                 const int32_t* __restrict__ col, const double* __restrict__ vals,
-                                                 const double* __restrict__ x, double* __restrict__ y) {
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int lane = threadIdx.x & 15;
-  double a = 0.0;
-  if (row < nrows)
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 16) a += vals[k] * x[col[k]];
-  a += __shfl_xor(a, 8);
-  a += __shfl_xor(a, 4);
-  a += __shfl_xor(a, 2);
-  a += __shfl_xor(a, 1);
-  if (row < nrows && lane == 0) y[row] = a;
-}
-
-#define GC_RED 512
-// fixed-shape two-stage reductions (bitwise reproducible): partials[b] = sum over the block's slice
-__global__ __launch_bounds__(256) void k_gc_dot(int64_t len, const double* __restrict__ a, const double* __restrict__ b,
-                                                double* __restrict__ partials) {
-  __shared__ double sh[256];
-  double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)GC_RED * 256) s += a[i] * b[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
-}
-__global__ __launch_bounds__(256) void k_gc_final(int nb, const double* __restrict__ partials, double* __restrict__ out) {
-  __shared__ double sh[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = sh[0];
-}
-// y = a*x + b*y
-__global__ void k_gc_axpby(int64_t len, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < len) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
-}
-
+#define GC_RED MX_RED
 // int (u - uk)^2 with the problem's quadrature: per-block partial sums over cells
 __global__ __launch_bounds__(256) void k_gc_l2(int nc, const int32_t* __restrict__ cdofs, const double* __restrict__ coords,
                                                const double* __restrict__ x, const double* __restrict__ xk, GcQuad Q,
@@ -402,38 +292,9 @@ __global__ __launch_bounds__(256) void k_gc_l2(int nc, const int32_t* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // host: pattern, destination tables, create
 // ------------------------------------------------------------------------------------------------------------------
-static void par_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
-  unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (n < 20000) T = 1;
-  std::vector<std::thread> th;
-  const int64_t chunk = (n + T - 1) / T;
-  for (unsigned t = 0; t < T; ++t) {
-    const int64_t a = t * chunk, b = std::min<int64_t>(n, a + chunk);
-    if (a >= b) break;
-    th.emplace_back([=, &fn] { fn(a, b); });
-  }
-  for (auto& t : th) t.join();
-}
-
-static int gc_norm(pgx_gc_handle* h, const double* v, double* out) {
-  hipLaunchKernelGGL(k_gc_dot, dim3(GC_RED), dim3(256), 0, h->st, h->ntot, v, v, h->partials);
-  hipLaunchKernelGGL(k_gc_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
-  GCHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
-  GCHIP(hipStreamSynchronize(h->st));
-  *out = std::sqrt(h->h_out[0]);
-  return PGX_OK;
-}
-
 extern "C" void pgx_gc_destroy(pgx_gc_handle* h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  if (h->st) hipStreamSynchronize(h->st);
-  if (h->lu) pgx_nd_destroy(h->lu);
-  for (void* p : h->allocs) hipFree(p);
-  if (h->h_out) hipHostFree(h->h_out);
-  if (h->e0) hipEventDestroy(h->e0);
-  if (h->e1) hipEventDestroy(h->e1);
-  if (h->st) hipStreamDestroy(h->st);
+  mx_release(h);
   delete h;
 }
 
@@ -489,7 +350,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   std::vector<int32_t>& rowptr = h->h_rowptr;
   std::vector<int32_t>& col = h->h_col;
   rowptr.assign(ntot + 1, 0);
-  par_for(ntot, [&](int64_t a, int64_t b) {
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
     std::vector<int32_t> tmp;
     for (int64_t r = a; r < b; ++r) {
       tmp.clear();
@@ -513,7 +374,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   }
   h->nnz = tot;
   col.resize(tot);
-  par_for(ntot, [&](int64_t a, int64_t b) {
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
     std::vector<int32_t> tmp;
     for (int64_t r = a; r < b; ++r) {
       tmp.clear();
@@ -534,7 +395,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   };
   // slot kinds
   std::vector<uint8_t> kind(tot);
-  par_for(ntot, [&](int64_t a, int64_t b) {
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
     for (int64_t r = a; r < b; ++r)
       for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
         const int32_t c = col[k];
@@ -552,7 +413,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   });
   // destination tables
   std::vector<int32_t> d108((size_t)nc * 108), d36((size_t)nc * 36);
-  par_for(nc, [&](int64_t a0, int64_t b0) {
+  mx_par_for(nc, [&](int64_t a0, int64_t b0) {
     for (int64_t c = a0; c < b0; ++c) {
       int32_t md[12];
       mixed((int)c, md);
@@ -590,8 +451,6 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   for (int v = 0; v < nv; ++v) nod[n2 + v] = nod[(size_t)n2 + nv + v] = v;
   // device
   GCHIP(hipStreamCreate(&h->st));
-  hipEventCreate(&h->e0);
-  hipEventCreate(&h->e1);
   pgx_nd_matrix A{};
   A.n = ntot;
   A.rowptr = rowptr.data();
@@ -620,10 +479,10 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   GCALLOC(h->dest36, d36.size());
   GCALLOC(h->Jc, tot);
   GCALLOC(h->Jv, tot);
-  for (double** v : {&h->x, &h->xk, &h->F, &h->dx, &h->xw, &h->rhs, &h->r, &h->z}) GCALLOC(*v, ntot);
-  GCALLOC(h->partials, GC_RED);
-  GCALLOC(h->d_out, 2);
-  GCHIP(hipHostMalloc((void**)&h->h_out, 2 * sizeof(double)));
+  {
+    int rcs = mx_alloc_state(h);
+    if (rcs) return rcs;
+  }
   GCHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * nv, hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->cdofs, cd, sizeof(int32_t) * 6 * (size_t)nc, hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->mask, hmask.data(), n2, hipMemcpyHostToDevice));
@@ -634,8 +493,6 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   GCHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->dest36, d36.data(), sizeof(int32_t) * d36.size(), hipMemcpyHostToDevice));
-  GCHIP(hipMemsetAsync(h->x, 0, sizeof(double) * ntot, h->st));
-  GCHIP(hipMemsetAsync(h->xk, 0, sizeof(double) * ntot, h->st));
   GCHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
   int32_t* d_d108 = nullptr;
   if (hipMalloc((void**)&d_d108, sizeof(int32_t) * d108.size()) != hipSuccess) {
@@ -691,18 +548,8 @@ extern "C" int pgx_gc_num_dofs(const pgx_gc_handle* h, int64_t* ntot) {
   *ntot = h->ntot;
   return PGX_OK;
 }
-static int gc_in(pgx_gc_handle* h, double* dst, const double* src) {
-  if (!src) return PGX_EINVAL;
-  GCHIP(hipMemcpyAsync(dst, src, sizeof(double) * h->ntot, hipMemcpyHostToDevice, h->st));
-  GCHIP(hipStreamSynchronize(h->st));
-  return PGX_OK;
-}
-static int gc_out(pgx_gc_handle* h, double* dst, const double* src) {
-  if (!dst) return PGX_EINVAL;
-  GCHIP(hipMemcpyAsync(dst, src, sizeof(double) * h->ntot, hipMemcpyDeviceToHost, h->st));
-  GCHIP(hipStreamSynchronize(h->st));
-  return PGX_OK;
-}
+static int gc_in(pgx_gc_handle* h, double* dst, const double* src) { return mx_in(h, dst, src); }
+static int gc_out(pgx_gc_handle* h, double* dst, const double* src) { return mx_out(h, dst, src); }
 extern "C" int pgx_gc_set_state(pgx_gc_handle* h, const double* x) {
   GCNEED(h);
   return gc_in(h, h->x, x);
@@ -736,26 +583,27 @@ extern "C" int pgx_gc_set_alpha(pgx_gc_handle* h, double a) {
   return PGX_OK;
 }
 
-static void gc_residual_dev(pgx_gc_handle* h, const double* x, double* F) {
+void pgx_gc_handle::residual_dev(const double* xin, double* Fout) {
+  pgx_gc_handle* h = this;
   GcTimer t(h, 0);
-  hipMemsetAsync(F, 0, sizeof(double) * h->ntot, h->st);
+  hipMemsetAsync(Fout, 0, sizeof(double) * h->ntot, h->st);
   hipLaunchKernelGGL(k_gc_residual, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
-                     h->mask, h->gbc, h->phi, h->f, x, h->xk, h->alpha, h->Q, F);
-  hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, x, F);
+                     h->mask, h->gbc, h->phi, h->f, xin, h->xk, h->alpha, h->Q, Fout);
+  hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, xin, Fout);
 }
-static void gc_jacobian_dev(pgx_gc_handle* h, const double* x) {
+void pgx_gc_handle::jacobian_dev(const double* xin) {
+  pgx_gc_handle* h = this;
   GcTimer t(h, 1);
   hipLaunchKernelGGL(k_gc_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
   hipLaunchKernelGGL(k_gc_jac_N, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
-                     h->phi, x, h->dest36, h->Q, h->Jv);
+                     h->phi, xin, h->dest36, h->Q, h->Jv);
   h->jac_valid = true;
 }
-static void gc_spmv_dev(pgx_gc_handle* h, const double* x, double* y) {
-  GcTimer t(h, 4);
-  hipLaunchKernelGGL(k_gc_spmv, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, h->rowptr, h->col,
-                     h->Jv, x, y);
-}
+static void gc_residual_dev(pgx_gc_handle* h, const double* x, double* F) { h->residual_dev(x, F); }
+static void gc_jacobian_dev(pgx_gc_handle* h, const double* x) { h->jacobian_dev(x); }
+static void gc_spmv_dev(pgx_gc_handle* h, const double* x, double* y) { mx_spmv_dev(h, x, y); }
+static int gc_norm(pgx_gc_handle* h, const double* v, double* out) { return mx_norm(h, v, out); }
 
 extern "C" int pgx_gc_residual(pgx_gc_handle* h, const double* x, double* F, double* fnorm) {
   GCNEED(h);
@@ -823,7 +671,7 @@ extern "C" int pgx_gc_l2_increment(pgx_gc_handle* h, double* out) {
   GCNEED(h);
   if (!out) return PGX_EINVAL;
   hipLaunchKernelGGL(k_gc_l2, dim3(GC_RED), dim3(256), 0, h->st, h->nc, h->cdofs, h->coords, h->x, h->xk, h->Q, h->partials);
-  hipLaunchKernelGGL(k_gc_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
+  hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
   GCHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
   GCHIP(hipStreamSynchronize(h->st));
   *out = std::sqrt(std::max(h->h_out[0], 0.0));
@@ -832,136 +680,11 @@ extern "C" int pgx_gc_l2_increment(pgx_gc_handle* h, double* out) {
 
 extern "C" int pgx_gc_profile(pgx_gc_handle* h, int enable, double ms[6]) {
   GCNEED(h);
-  if (ms)
-    for (int i = 0; i < 6; ++i) ms[i] = h->ms[i];
-  for (int i = 0; i < 6; ++i) h->ms[i] = 0;
-  h->prof = enable != 0;
   pgx_nd_timing(h->lu, enable, nullptr, nullptr);
-  return PGX_OK;
-}
-
-// dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
-static int gc_linear_solve(pgx_gc_handle* h, const double* b, double* dx, const pgx_snes_opts* o, int* nsolves, double* relres) {
-  const auto axpby = [&](double a, const double* x, double bb, double* y) {
-    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, a, x, bb, y);
-  };
-  double bnorm = 0, rnorm = 0, prev = 1e300;
-  int rc = gc_norm(h, b, &bnorm);
-  if (rc) return rc;
-  *nsolves = 0;
-  if (bnorm == 0.0) {
-    GCHIP(hipMemsetAsync(dx, 0, sizeof(double) * h->ntot, h->st));
-    *relres = 0.0;
-    return PGX_OK;
-  }
-  const double tol = o->ksp_rtol > 0.0 ? o->ksp_rtol : 1e-12;
-  const int maxit = std::max(1, std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 6, 20));
-  auto lusolve = [&](const double* rhs, double* out) -> int {
-    GcTimer t(h, 3);
-    int r2 = pgx_nd_solve(h->lu, rhs, out, 1);
-    if (r2) h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
-    return r2;
-  };
-  if ((rc = lusolve(b, dx))) return rc;
-  ++*nsolves;
-  for (int it = 0;; ++it) {
-    gc_spmv_dev(h, dx, h->r);
-    axpby(1.0, b, -1.0, h->r);  // r = b - J dx
-    if ((rc = gc_norm(h, h->r, &rnorm))) return rc;
-    *relres = rnorm / bnorm;
-    if (o->monitor > 1) printf("      refinement %d  true rel residual %.3e\n", it, *relres);
-    if (!std::isfinite(*relres) || *relres <= tol || it + 1 >= maxit || *relres > 0.5 * prev) break;
-    prev = *relres;
-    if ((rc = lusolve(h->r, h->z))) return rc;
-    ++*nsolves;
-    axpby(1.0, h->z, 1.0, dx);
-  }
-  return PGX_OK;
+  return mx_profile(h, enable, ms);
 }
 
 extern "C" int pgx_gc_newton_solve(pgx_gc_handle* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   GCNEED(h);
-  if (!opts || !reason) return PGX_EINVAL;
-  hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (h->prof) {
-    hipEventCreate(&w0);
-    hipEventCreate(&w1);
-    hipEventRecord(w0, h->st);
-  }
-  const size_t bytes = sizeof(double) * h->ntot;
-  int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
-  double fnorm = 0, fnorm0 = 0;
-  GCHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
-  gc_residual_dev(h, h->xw, h->F);
-  if ((rc = gc_norm(h, h->F, &fnorm))) return rc;
-  fnorm0 = fnorm;
-  if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
-  if (!std::isfinite(fnorm))
-    rsn = PGX_SNES_DIVERGED_FNORM_NAN;
-  else if (fnorm < opts->snes_atol)
-    rsn = PGX_SNES_CONVERGED_FNORM_ABS;
-  const double ttol = fnorm * opts->snes_rtol;
-  while (rsn == 0) {
-    if (its >= opts->snes_max_it) {
-      rsn = PGX_SNES_DIVERGED_MAX_IT;
-      break;
-    }
-    gc_jacobian_dev(h, h->xw);
-    {
-      GcTimer t(h, 2);
-      rc = pgx_nd_factor(h->lu, h->Jv, 1);
-    }
-    if (rc) {
-      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
-      return rc;
-    }
-    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, -1.0, h->F, 0.0,
-                       h->rhs);
-    int ns = 0;
-    double relres = 0;
-    if ((rc = gc_linear_solve(h, h->rhs, h->dx, opts, &ns, &relres))) return rc;
-    lin += ns;
-    ++its;
-    if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
-    if (!(relres <= 1e-7) || !std::isfinite(relres)) {
-      rsn = PGX_SNES_DIVERGED_LINEAR_SOLVE;
-      break;
-    }
-    hipLaunchKernelGGL(k_gc_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, 1.0, h->dx, 1.0,
-                       h->xw);
-    gc_residual_dev(h, h->xw, h->F);
-    if ((rc = gc_norm(h, h->F, &fnorm))) return rc;
-    if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
-    if (!std::isfinite(fnorm)) {
-      rsn = PGX_SNES_DIVERGED_FNORM_NAN;
-    } else if (fnorm < opts->snes_atol) {
-      rsn = PGX_SNES_CONVERGED_FNORM_ABS;
-    } else if (fnorm <= ttol) {
-      rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
-    } else {
-      double snorm, xnorm;
-      if ((rc = gc_norm(h, h->dx, &snorm))) return rc;
-      if ((rc = gc_norm(h, h->xw, &xnorm))) return rc;
-      if (snorm < opts->snes_stol * xnorm)
-        rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
-      else if (fnorm > opts->snes_divtol * fnorm0)
-        rsn = PGX_SNES_DIVERGED_DTOL;
-    }
-  }
-  if (rsn > 0) GCHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
-  GCHIP(hipStreamSynchronize(h->st));
-  GCHIP(hipGetLastError());
-  if (h->prof) {
-    hipEventRecord(w1, h->st);
-    hipEventSynchronize(w1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, w0, w1);
-    h->ms[5] += ms;
-    hipEventDestroy(w0);
-    hipEventDestroy(w1);
-  }
-  *reason = rsn;
-  if (its_out) *its_out = its;
-  if (lin_out) *lin_out = lin;
-  return PGX_OK;
+  return mx_newton_solve(h, opts, reason, its_out, lin_out);
 }

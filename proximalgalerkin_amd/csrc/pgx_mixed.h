@@ -1,0 +1,334 @@
+// pgx_mixed.h - what the example-06 and example-02 handles share: a mixed CSR Newton matrix on the device, state vectors,
+// fixed-shape reductions, the SNES-mirroring Newton driver (newtonls, linesearch none) and its linear solve = sparse LU
+// (pgx_nd) + iterative refinement on the exact operator.  Included by pgx_gc.hip and pgx_sg.hip (static: one copy per TU).
+//
+// Reference for the driver: PETSc SNES newtonls with `snes_linesearch_type none` as configured at
+// examples/06_gradient_constraints/gradient_constraint_dolfinx.py:116-131 and examples/02_signorini/
+// signorini_dolfinx.py:271-291,331-335; callback contract src/lvpp/problem.py:54-77,114-124.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pgx.h"
+#include "../../include/pgx_nd.h"
+
+struct MixedBase {
+  int device = 0;
+  hipStream_t st = nullptr;
+  std::string err;
+  int64_t ntot = 0, nnz = 0;
+  int32_t *rowptr = nullptr, *col = nullptr;  // mixed CSR pattern (device)
+  double* Jv = nullptr;                        // values of the current Jacobian
+  double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr, *r = nullptr, *z = nullptr;
+  double *partials = nullptr, *d_out = nullptr;
+  double* h_out = nullptr;  // pinned
+  std::vector<int32_t> h_rowptr, h_col;
+  pgx_nd* lu = nullptr;
+  bool jac_valid = false;
+  bool prof = false;
+  double ms[6] = {0, 0, 0, 0, 0, 0};  // [0] residual [1] jacobian [2] LU factor [3] LU solves [4] spmv [5] Newton total
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<void*> allocs;
+  virtual void residual_dev(const double* xin, double* Fout) = 0;  // F(x) incl. the BC rows, asynchronous on st
+  virtual void jacobian_dev(const double* xin) = 0;                // fills Jv at x
+  virtual ~MixedBase() {}
+};
+
+#define MXHIP(call)                                               \
+  do {                                                            \
+    hipError_t e_ = (call);                                       \
+    if (e_ != hipSuccess) {                                       \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      return PGX_EHIP;                                            \
+    }                                                             \
+  } while (0)
+
+template <typename T>
+static int mx_alloc(MixedBase* h, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
+    h->err = "hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes failed";
+    return PGX_ENOMEM;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return PGX_OK;
+}
+#define MXALLOC(p, count)                        \
+  do {                                           \
+    int rc_ = mx_alloc(h, &(p), (size_t)(count)); \
+    if (rc_) return rc_;                         \
+  } while (0)
+
+struct MxTimer {
+  MixedBase* h;
+  int slot;
+  MxTimer(MixedBase* h_, int s) : h(h_), slot(s) {
+    if (h->prof) hipEventRecord(h->e0, h->st);
+  }
+  ~MxTimer() {
+    if (h->prof) {
+      hipEventRecord(h->e1, h->st);
+      hipEventSynchronize(h->e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, h->e0, h->e1);
+      h->ms[slot] += ms;
+    }
+  }
+};
+
+// y = A x, 16 lanes per row
+static __global__ __launch_bounds__(256) void k_mx_spmv(int64_t nrows, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const double* __restrict__ vals,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
+  double a = 0.0;
+  if (row < nrows)
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 16) a += vals[k] * x[col[k]];
+  a += __shfl_xor(a, 8);
+  a += __shfl_xor(a, 4);
+  a += __shfl_xor(a, 2);
+  a += __shfl_xor(a, 1);
+  if (row < nrows && lane == 0) y[row] = a;
+}
+
+#define MX_RED 512
+// fixed-shape two-stage reductions (bitwise reproducible): partials[b] = sum over the block's slice
+static __global__ __launch_bounds__(256) void k_mx_dot(int64_t len, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ partials) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)MX_RED * 256) s += a[i] * b[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+static __global__ __launch_bounds__(256) void k_mx_final(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// y = a*x + b*y   (b == 0: y is not read)
+static __global__ void k_mx_axpby(int64_t len, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+
+static void mx_par_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+  unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 20000) T = 1;
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + T - 1) / T;
+  for (unsigned t = 0; t < T; ++t) {
+    const int64_t a = t * chunk, b = std::min<int64_t>(n, a + chunk);
+    if (a >= b) break;
+    th.emplace_back([=, &fn] { fn(a, b); });
+  }
+  for (auto& t : th) t.join();
+}
+
+static int mx_norm(MixedBase* h, const double* v, double* out, int64_t len = 0) {
+  hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, len ? len : h->ntot, v, v, h->partials);
+  hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+  MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  *out = std::sqrt(h->h_out[0]);
+  return PGX_OK;
+}
+
+static void mx_axpby(MixedBase* h, double a, const double* x, double b, double* y, int64_t len = 0) {
+  const int64_t n = len ? len : h->ntot;
+  hipLaunchKernelGGL(k_mx_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, n, a, x, b, y);
+}
+
+static void mx_spmv_dev(MixedBase* h, const double* x, double* y) {
+  MxTimer t(h, 4);
+  hipLaunchKernelGGL(k_mx_spmv, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, h->rowptr, h->col,
+                     h->Jv, x, y);
+}
+
+// state vectors, reduction scratch, events; the stream must exist
+static int mx_alloc_state(MixedBase* h) {
+  for (double** v : {&h->x, &h->xk, &h->F, &h->dx, &h->xw, &h->rhs, &h->r, &h->z}) MXALLOC(*v, h->ntot);
+  MXALLOC(h->partials, MX_RED);
+  MXALLOC(h->d_out, 2);
+  MXHIP(hipHostMalloc((void**)&h->h_out, 2 * sizeof(double)));
+  MXHIP(hipMemsetAsync(h->x, 0, sizeof(double) * h->ntot, h->st));
+  MXHIP(hipMemsetAsync(h->xk, 0, sizeof(double) * h->ntot, h->st));
+  hipEventCreate(&h->e0);
+  hipEventCreate(&h->e1);
+  return PGX_OK;
+}
+
+static void mx_release(MixedBase* h) {
+  hipSetDevice(h->device);
+  if (h->st) hipStreamSynchronize(h->st);
+  if (h->lu) pgx_nd_destroy(h->lu);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_out) hipHostFree(h->h_out);
+  if (h->e0) hipEventDestroy(h->e0);
+  if (h->e1) hipEventDestroy(h->e1);
+  if (h->st) hipStreamDestroy(h->st);
+}
+
+static int mx_in(MixedBase* h, double* dst, const double* src, int64_t len = 0) {
+  if (!src) return PGX_EINVAL;
+  MXHIP(hipMemcpyAsync(dst, src, sizeof(double) * (len ? len : h->ntot), hipMemcpyHostToDevice, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+static int mx_out(MixedBase* h, double* dst, const double* src, int64_t len = 0) {
+  if (!dst) return PGX_EINVAL;
+  MXHIP(hipMemcpyAsync(dst, src, sizeof(double) * (len ? len : h->ntot), hipMemcpyDeviceToHost, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+
+// dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
+static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_snes_opts* o, int* nsolves, double* relres) {
+  double bnorm = 0, rnorm = 0, prev = 1e300;
+  int rc = mx_norm(h, b, &bnorm);
+  if (rc) return rc;
+  *nsolves = 0;
+  if (bnorm == 0.0) {
+    MXHIP(hipMemsetAsync(dx, 0, sizeof(double) * h->ntot, h->st));
+    *relres = 0.0;
+    return PGX_OK;
+  }
+  const double tol = o->ksp_rtol > 0.0 ? o->ksp_rtol : 1e-12;
+  const int maxit = std::max(1, std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 6, 20));
+  auto lusolve = [&](const double* rhs, double* out) -> int {
+    MxTimer t(h, 3);
+    int r2 = pgx_nd_solve(h->lu, rhs, out, 1);
+    if (r2) h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+    return r2;
+  };
+  if ((rc = lusolve(b, dx))) return rc;
+  ++*nsolves;
+  for (int it = 0;; ++it) {
+    mx_spmv_dev(h, dx, h->r);
+    mx_axpby(h, 1.0, b, -1.0, h->r);  // r = b - J dx
+    if ((rc = mx_norm(h, h->r, &rnorm))) return rc;
+    *relres = rnorm / bnorm;
+    if (o->monitor > 1) printf("      refinement %d  true rel residual %.3e\n", it, *relres);
+    if (!std::isfinite(*relres) || *relres <= tol || it + 1 >= maxit || *relres > 0.5 * prev) break;
+    prev = *relres;
+    if ((rc = lusolve(h->r, h->z))) return rc;
+    ++*nsolves;
+    mx_axpby(h, 1.0, h->z, 1.0, dx);
+  }
+  return PGX_OK;
+}
+
+// SNES newtonls + linesearch none on device `x` (replaced only when reason > 0: lvpp/problem.py:121-123)
+static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
+  if (!opts || !reason) return PGX_EINVAL;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  if (h->prof) {
+    hipEventCreate(&w0);
+    hipEventCreate(&w1);
+    hipEventRecord(w0, h->st);
+  }
+  const size_t bytes = sizeof(double) * h->ntot;
+  int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
+  double fnorm = 0, fnorm0 = 0;
+  MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
+  h->residual_dev(h->xw, h->F);
+  if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
+  fnorm0 = fnorm;
+  if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
+  if (!std::isfinite(fnorm))
+    rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+  else if (fnorm < opts->snes_atol)
+    rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+  const double ttol = fnorm * opts->snes_rtol;
+  while (rsn == 0) {
+    if (its >= opts->snes_max_it) {
+      rsn = PGX_SNES_DIVERGED_MAX_IT;
+      break;
+    }
+    h->jacobian_dev(h->xw);
+    {
+      MxTimer t(h, 2);
+      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+    }
+    if (rc) {
+      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+      return rc;
+    }
+    mx_axpby(h, -1.0, h->F, 0.0, h->rhs);
+    int ns = 0;
+    double relres = 0;
+    if ((rc = mx_linear_solve(h, h->rhs, h->dx, opts, &ns, &relres))) return rc;
+    lin += ns;
+    ++its;
+    if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
+    if (!(relres <= 1e-7) || !std::isfinite(relres)) {
+      rsn = PGX_SNES_DIVERGED_LINEAR_SOLVE;
+      break;
+    }
+    mx_axpby(h, 1.0, h->dx, 1.0, h->xw);
+    h->residual_dev(h->xw, h->F);
+    if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
+    if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
+    if (!std::isfinite(fnorm)) {
+      rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+    } else if (fnorm < opts->snes_atol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+    } else if (fnorm <= ttol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
+    } else {
+      double snorm, xnorm;
+      if ((rc = mx_norm(h, h->dx, &snorm))) return rc;
+      if ((rc = mx_norm(h, h->xw, &xnorm))) return rc;
+      if (snorm < opts->snes_stol * xnorm)
+        rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
+      else if (fnorm > opts->snes_divtol * fnorm0)
+        rsn = PGX_SNES_DIVERGED_DTOL;
+    }
+  }
+  if (rsn > 0) MXHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  MXHIP(hipGetLastError());
+  if (h->prof) {
+    hipEventRecord(w1, h->st);
+    hipEventSynchronize(w1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, w0, w1);
+    h->ms[5] += ms;
+    hipEventDestroy(w0);
+    hipEventDestroy(w1);
+  }
+  *reason = rsn;
+  if (its_out) *its_out = its;
+  if (lin_out) *lin_out = lin;
+  return PGX_OK;
+}
+
+static int mx_profile(MixedBase* h, int enable, double ms[6]) {
+  if (ms)
+    for (int i = 0; i < 6; ++i) ms[i] = h->ms[i];
+  for (int i = 0; i < 6; ++i) h->ms[i] = 0;
+  h->prof = enable != 0;
+  return PGX_OK;
+}

@@ -1,0 +1,610 @@
+// pgx_sg.hip - example 02 (Signorini contact, 3-D linear elasticity, latent variable on the contact facets) behind the
+// C ABI of include/pgx_sg.h.  Reference: examples/02_signorini/signorini_dolfinx.py (:146-153 sigma/eps, :199-249 spaces,
+// measure and residual, :255-291 BCs and solver, :317-358 outer loop).
+//
+// x = [u_x | u_y | u_z | psi].  Everything that does not depend on the iterate is assembled ONCE on the device into the
+// value array Jc of the mixed CSR pattern: the elasticity block A (constant-strain tetrahedra, 144 entries per cell) and
+// the facet mass coupling +-M_G.  A residual is then one row-parallel pass over Jc (deterministic, no atomics) plus a
+// facet kernel for the exp term; a Jacobian is "scale the A slots by alpha" plus 9 entries of D(psi) per contact facet.
+#include <cstring>
+
+#include "../../include/pgx_sg.h"
+#include "pgx_mixed.h"
+
+#define SG_MAXQ 16
+struct SgQuad {
+  double L[SG_MAXQ][3], w[SG_MAXQ];
+  int nq;
+};
+
+static thread_local std::string g_sg_error;
+
+struct pgx_sg_handle : MixedBase {
+  int nv = 0, nc = 0, nf = 0, npsi = 0;
+  SgQuad Q{};
+  double alpha = 1.0, gap = 0.0, mu = 0.0, lmbda = 0.0;
+  double *coords = nullptr, *gbc = nullptr, *bg = nullptr;
+  int32_t *facets = nullptr, *fpsi = nullptr, *destD = nullptr;
+  uint8_t *mask = nullptr, *kind = nullptr;
+  double* Jc = nullptr;
+  std::vector<int32_t> cverts;
+  void residual_dev(const double* xin, double* Fout) override;
+  void jacobian_dev(const double* xin) override;
+};
+
+extern "C" const char* pgx_sg_last_error(const pgx_sg_handle* h) { return h ? h->err.c_str() : g_sg_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+// elasticity block, once: A_e[(a,i),(b,j)] = vol (lambda G_ai G_bj + mu G_aj G_bi + mu delta_ij G_a.G_b)
+__global__ __launch_bounds__(128) void k_sg_const_cells(int nc, const int32_t* __restrict__ cells, const double* __restrict__ coords,
+                                                        double mu, double lmbda, const int32_t* __restrict__ dest144,
+                                                        double* __restrict__ Jc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cv = cells + 4 * (size_t)c;
+  double X[4][3];
+  for (int a = 0; a < 4; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)cv[a] + d];
+  double J[3][3];  // columns = edge vectors
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 3; ++k) J[d][k] = X[k + 1][d] - X[0][d];
+  const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+  double inv[3][3];
+  inv[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+  inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+  inv[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+  inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  inv[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+  inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+  inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+  // physical gradients G[a][d] = sum_k gref[a][k] inv[k][d], gref = [[-1,-1,-1],[1,0,0],[0,1,0],[0,0,1]]
+  double G[4][3];
+  for (int d = 0; d < 3; ++d) {
+    G[1][d] = inv[0][d];
+    G[2][d] = inv[1][d];
+    G[3][d] = inv[2][d];
+    G[0][d] = -(inv[0][d] + inv[1][d] + inv[2][d]);
+  }
+  const double vol = fabs(det) / 6.0;
+  const int32_t* D = dest144 + 144 * (size_t)c;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) {
+      const double gg = G[a][0] * G[b][0] + G[a][1] * G[b][1] + G[a][2] * G[b][2];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          const double v = vol * (lmbda * G[a][i] * G[b][j] + mu * G[a][j] * G[b][i] + (i == j ? mu * gg : 0.0));
+          atomicAdd(&Jc[D[(a * 3 + i) * 12 + (b * 3 + j)]], v);
+        }
+    }
+}
+
+// facet mass coupling (+M on (u_z, psi), -M on (psi, u_z)) and b_g = <g, w>, once
+__global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* __restrict__ facets, const int32_t* __restrict__ fpsi,
+                                                         const double* __restrict__ coords, double gap,
+                                                         const int32_t* __restrict__ dest18, SgQuad Q, double* __restrict__ Jc,
+                                                         double* __restrict__ bg) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int32_t* fv = facets + 3 * (size_t)f;
+  double X[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
+  const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
+  const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
+  const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+  const double area2 = sqrt(cx * cx + cy * cy + cz * cz);
+  double Me[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, g[3] = {0, 0, 0};
+  for (int q = 0; q < Q.nq; ++q) {
+    const double wd = Q.w[q] * area2;
+    const double zq = Q.L[q][0] * X[0][2] + Q.L[q][1] * X[1][2] + Q.L[q][2] * X[2][2];
+    for (int a = 0; a < 3; ++a) {
+      g[a] += wd * (zq - gap) * Q.L[q][a];
+      for (int b = 0; b < 3; ++b) Me[a][b] += wd * Q.L[q][a] * Q.L[q][b];
+    }
+  }
+  const int32_t* D = dest18 + 18 * (size_t)f;
+  for (int a = 0; a < 3; ++a) {
+    atomicAdd(&bg[fpsi[3 * (size_t)f + a]], g[a]);
+    for (int b = 0; b < 3; ++b) {
+      atomicAdd(&Jc[D[a * 3 + b]], Me[a][b]);       // row u_z(a), col psi(b)
+      atomicAdd(&Jc[D[9 + a * 3 + b]], -Me[a][b]);  // row psi(a), col u_z(b)
+    }
+  }
+}
+
+// kind: 0 = A slot (scaled by alpha), 1 = +-M_G slot, 2 = D slot (accumulated by k_sg_jac_D), 3 = BC diagonal, 4 = zeroed by BCs
+__global__ void k_sg_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, const double* __restrict__ Jc, double alpha,
+                              double* __restrict__ Jv) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const int t = kind[k];
+  Jv[k] = t == 0 ? alpha * Jc[k] : t == 1 ? Jc[k] : t == 3 ? 1.0 : 0.0;
+}
+
+// out (mode 0): D_e[a][b] = <exp(psi) N_a, N_b> into the Jacobian; (mode 1): b_exp[a] = <exp(psi), N_a> into the residual
+__global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const int32_t* __restrict__ facets,
+                                                const int32_t* __restrict__ fpsi, const double* __restrict__ coords,
+                                                const double* __restrict__ x, const int32_t* __restrict__ destD, SgQuad Q,
+                                                double* __restrict__ out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int32_t* fv = facets + 3 * (size_t)f;
+  const int32_t* fp = fpsi + 3 * (size_t)f;
+  double X[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
+  const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
+  const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
+  const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+  const double area2 = sqrt(cx * cx + cy * cy + cz * cz);
+  const double p0 = x[nu + fp[0]], p1 = x[nu + fp[1]], p2 = x[nu + fp[2]];
+  double De[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, be[3] = {0, 0, 0};
+  for (int q = 0; q < Q.nq; ++q) {
+    const double e = Q.w[q] * area2 * exp(p0 * Q.L[q][0] + p1 * Q.L[q][1] + p2 * Q.L[q][2]);
+    for (int a = 0; a < 3; ++a) {
+      be[a] += e * Q.L[q][a];
+      for (int b = 0; b < 3; ++b) De[a][b] += e * Q.L[q][a] * Q.L[q][b];
+    }
+  }
+  if (mode == 0) {
+    const int32_t* D = destD + 9 * (size_t)f;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) atomicAdd(&out[D[a * 3 + b]], De[a][b]);
+  } else {
+    for (int a = 0; a < 3; ++a) atomicAdd(&out[nu + fp[a]], be[a]);
+  }
+}
+
+// linear part of the residual from the constant values Jc (16 lanes per row), BC rows, - b_g
+__global__ __launch_bounds__(256) void k_sg_resid_rows(int64_t ntot, int nu, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, const double* __restrict__ Jc,
+                                                       const uint8_t* __restrict__ mask, const double* __restrict__ gbc,
+                                                       const double* __restrict__ bg, const double* __restrict__ x,
+                                                       const double* __restrict__ xk, double alpha, double* __restrict__ F) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
+  double a = 0.0;
+  if (row < ntot) {
+    const bool urow = row < nu;
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 16) {
+      const int c = col[k];
+      if (c < nu)
+        a += (urow ? alpha : 1.0) * Jc[k] * (mask[c] ? gbc[c] : x[c]);
+      else if (urow)
+        a += Jc[k] * (x[c] - xk[c]);
+    }
+  }
+  a += __shfl_xor(a, 8);
+  a += __shfl_xor(a, 4);
+  a += __shfl_xor(a, 2);
+  a += __shfl_xor(a, 1);
+  if (row < ntot && lane == 0) {
+    if (row < nu)
+      F[row] = mask[row] ? x[row] - gbc[row] : a;
+    else
+      F[row] = a - bg[row - nu];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void pgx_sg_destroy(pgx_sg_handle* h) {
+  if (!h) return;
+  mx_release(h);
+  delete h;
+}
+
+void pgx_sg_handle::residual_dev(const double* xin, double* Fout) {
+  pgx_sg_handle* h = this;
+  MxTimer t(h, 0);
+  const int nu = 3 * h->nv;
+  hipLaunchKernelGGL(k_sg_resid_rows, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, nu, h->rowptr,
+                     h->col, h->Jc, h->mask, h->gbc, h->bg, xin, h->xk, h->alpha, Fout);
+  hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                     h->destD, h->Q, Fout);
+}
+void pgx_sg_handle::jacobian_dev(const double* xin) {
+  pgx_sg_handle* h = this;
+  MxTimer t(h, 1);
+  hipLaunchKernelGGL(k_sg_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
+                     h->alpha, h->Jv);
+  hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi, h->coords,
+                     xin, h->destD, h->Q, h->Jv);
+  h->jac_valid = true;
+}
+
+static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_problem* p) {
+  const int nv = m->n_vertices, nc = m->n_cells, nf = m->n_facets;
+  const int nu = 3 * nv;
+  h->nv = nv, h->nc = nc, h->nf = nf;
+  h->gap = p->gap;
+  h->mu = p->E / (2.0 * (1.0 + p->nu));
+  h->lmbda = p->E * p->nu / ((1.0 + p->nu) * (1.0 - 2.0 * p->nu));
+  h->Q.nq = p->nq;
+  for (int q = 0; q < p->nq; ++q) {
+    const double X = p->qpts[2 * q], Y = p->qpts[2 * q + 1];
+    h->Q.L[q][0] = 1.0 - X - Y, h->Q.L[q][1] = X, h->Q.L[q][2] = Y, h->Q.w[q] = p->qwts[q];
+  }
+  for (size_t k = 0; k < 4 * (size_t)nc; ++k)
+    if (m->cells[k] < 0 || m->cells[k] >= nv) {
+      h->err = "cell vertex out of range";
+      return PGX_EINVAL;
+    }
+  // psi dofs = contact vertices ordered by vertex id
+  std::vector<int32_t> v2psi(nv, -1);
+  for (size_t k = 0; k < 3 * (size_t)nf; ++k) {
+    if (m->facets[k] < 0 || m->facets[k] >= nv) {
+      h->err = "facet vertex out of range";
+      return PGX_EINVAL;
+    }
+    v2psi[m->facets[k]] = 0;
+  }
+  h->cverts.clear();
+  for (int v = 0; v < nv; ++v)
+    if (v2psi[v] == 0) v2psi[v] = (int32_t)h->cverts.size(), h->cverts.push_back(v);
+  const int npsi = (int)h->cverts.size();
+  h->npsi = npsi;
+  const int64_t ntot = (int64_t)nu + npsi;
+  h->ntot = ntot;
+  std::vector<uint8_t> hmask(nu, 0);
+  std::vector<double> hg(nu, 0.0);
+  for (int k = 0; k < p->n_bc; ++k) {
+    const int d = p->bc_dofs[k];
+    if (d < 0 || d >= nu) {
+      h->err = "bc dof out of range";
+      return PGX_EINVAL;
+    }
+    hmask[d] = 1;
+    hg[d] = p->bc_vals ? p->bc_vals[k] : 0.0;
+  }
+  std::vector<int32_t> fpsi(3 * (size_t)nf);
+  for (size_t k = 0; k < fpsi.size(); ++k) fpsi[k] = v2psi[m->facets[k]];
+  // entities: cells (12 mixed dofs: (a,i) -> i*nv + vertex a) and facets (6: u_z of 3 vertices, psi of 3 vertices)
+  auto cell_dofs = [&](int c, int32_t md[12]) {
+    for (int a = 0; a < 4; ++a)
+      for (int i = 0; i < 3; ++i) md[a * 3 + i] = i * nv + m->cells[4 * (size_t)c + a];
+  };
+  auto facet_dofs = [&](int f, int32_t md[6]) {
+    for (int a = 0; a < 3; ++a) md[a] = 2 * nv + m->facets[3 * (size_t)f + a], md[3 + a] = nu + fpsi[3 * (size_t)f + a];
+  };
+  const int64_t nent = (int64_t)nc + nf;
+  std::vector<int64_t> dptr(ntot + 1, 0);
+  for (int c = 0; c < nc; ++c) {
+    int32_t md[12];
+    cell_dofs(c, md);
+    for (int a = 0; a < 12; ++a) dptr[md[a] + 1]++;
+  }
+  for (int f = 0; f < nf; ++f) {
+    int32_t md[6];
+    facet_dofs(f, md);
+    for (int a = 0; a < 6; ++a) dptr[md[a] + 1]++;
+  }
+  for (int64_t i = 0; i < ntot; ++i) dptr[i + 1] += dptr[i];
+  std::vector<int64_t> dent(dptr[ntot]);  // entity id: cells [0,nc), facets [nc, nc+nf)
+  {
+    std::vector<int64_t> fill(dptr.begin(), dptr.end() - 1);
+    for (int c = 0; c < nc; ++c) {
+      int32_t md[12];
+      cell_dofs(c, md);
+      for (int a = 0; a < 12; ++a) dent[fill[md[a]]++] = c;
+    }
+    for (int f = 0; f < nf; ++f) {
+      int32_t md[6];
+      facet_dofs(f, md);
+      for (int a = 0; a < 6; ++a) dent[fill[md[a]]++] = (int64_t)nc + f;
+    }
+  }
+  (void)nent;
+  auto gather_row = [&](int64_t r, std::vector<int32_t>& tmp) {
+    tmp.clear();
+    for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
+      const int64_t e = dent[q];
+      if (e < nc) {
+        int32_t md[12];
+        cell_dofs((int)e, md);
+        tmp.insert(tmp.end(), md, md + 12);
+      } else {
+        int32_t md[6];
+        facet_dofs((int)(e - nc), md);
+        tmp.insert(tmp.end(), md, md + 6);
+      }
+    }
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+  };
+  std::vector<int32_t>& rowptr = h->h_rowptr;
+  std::vector<int32_t>& col = h->h_col;
+  rowptr.assign(ntot + 1, 0);
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp;
+    for (int64_t r = a; r < b; ++r) {
+      gather_row(r, tmp);
+      rowptr[r + 1] = (int32_t)tmp.size();
+    }
+  });
+  int64_t tot = 0;
+  for (int64_t r = 0; r < ntot; ++r) {
+    tot += rowptr[r + 1];
+    if (tot > 0x7fffffff) {
+      h->err = "mixed matrix exceeds int32 nnz";
+      return PGX_EINVAL;
+    }
+    rowptr[r + 1] = (int32_t)tot;
+  }
+  h->nnz = tot;
+  col.resize(tot);
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp;
+    for (int64_t r = a; r < b; ++r) {
+      gather_row(r, tmp);
+      std::copy(tmp.begin(), tmp.end(), col.begin() + rowptr[r]);
+    }
+  });
+  auto find = [&](int32_t r, int32_t c) -> int32_t {
+    const int32_t* b = col.data() + rowptr[r];
+    const int32_t* e = col.data() + rowptr[r + 1];
+    return (int32_t)(std::lower_bound(b, e, c) - col.data());
+  };
+  std::vector<uint8_t> kind(tot);
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r)
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = col[k];
+        uint8_t t;
+        if (r < nu && c < nu)
+          t = (hmask[r] || hmask[c]) ? ((r == c && hmask[r]) ? 3 : 4) : 0;
+        else if (r < nu)
+          t = hmask[r] ? 4 : 1;
+        else if (c < nu)
+          t = hmask[c] ? 4 : 1;
+        else
+          t = 2;
+        kind[k] = t;
+      }
+  });
+  std::vector<int32_t> d144((size_t)nc * 144), d18((size_t)nf * 18), dD((size_t)nf * 9);
+  mx_par_for(nc, [&](int64_t a0, int64_t b0) {
+    for (int64_t c = a0; c < b0; ++c) {
+      int32_t md[12];
+      cell_dofs((int)c, md);
+      int32_t* D = d144.data() + 144 * (size_t)c;
+      for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 12; ++b) D[a * 12 + b] = find(md[a], md[b]);
+    }
+  });
+  for (int f = 0; f < nf; ++f) {
+    int32_t md[6];
+    facet_dofs(f, md);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        d18[18 * (size_t)f + a * 3 + b] = find(md[a], md[3 + b]);
+        d18[18 * (size_t)f + 9 + a * 3 + b] = find(md[3 + a], md[b]);
+        dD[9 * (size_t)f + a * 3 + b] = find(md[3 + a], md[3 + b]);
+      }
+  }
+  std::vector<int32_t> nod(ntot);
+  for (int v = 0; v < nv; ++v) nod[v] = nod[(size_t)nv + v] = nod[2 * (size_t)nv + v] = v;
+  for (int k = 0; k < npsi; ++k) nod[(size_t)nu + k] = h->cverts[k];
+  // device
+  MXHIP(hipStreamCreate(&h->st));
+  pgx_nd_matrix A{};
+  A.n = ntot;
+  A.rowptr = rowptr.data();
+  A.col = col.data();
+  A.n_nodes = nv;
+  A.node_of_dof = nod.data();
+  A.dim = 3;
+  A.node_coords = m->coords;
+  A.leaf_nodes = 0;
+  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  if (rc) {
+    h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
+    h->lu = nullptr;
+    return rc;
+  }
+  int32_t* d_cells = nullptr;
+  MXALLOC(h->coords, 3 * (size_t)nv);
+  MXALLOC(h->facets, 3 * (size_t)nf);
+  MXALLOC(h->fpsi, 3 * (size_t)nf);
+  MXALLOC(h->destD, dD.size());
+  MXALLOC(h->mask, nu);
+  MXALLOC(h->gbc, nu);
+  MXALLOC(h->bg, npsi);
+  MXALLOC(h->rowptr, ntot + 1);
+  MXALLOC(h->col, tot);
+  MXALLOC(h->kind, tot);
+  MXALLOC(h->Jc, tot);
+  MXALLOC(h->Jv, tot);
+  if ((rc = mx_alloc_state(h))) return rc;
+  MXHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 3 * nv, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->facets, m->facets, sizeof(int32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->fpsi, fpsi.data(), sizeof(int32_t) * fpsi.size(), hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->destD, dD.data(), sizeof(int32_t) * dD.size(), hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->mask, hmask.data(), nu, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nu, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
+  MXHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
+  MXHIP(hipMemsetAsync(h->bg, 0, sizeof(double) * npsi, h->st));
+  int32_t *d_d144 = nullptr, *d_d18 = nullptr;
+  hipError_t e = hipMalloc((void**)&d_cells, sizeof(int32_t) * 4 * (size_t)nc);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_d144, sizeof(int32_t) * d144.size());
+  if (e == hipSuccess) e = hipMalloc((void**)&d_d18, sizeof(int32_t) * std::max<size_t>(d18.size(), 1));
+  if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * 4 * (size_t)nc, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_d144, d144.data(), sizeof(int32_t) * d144.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !d18.empty()) e = hipMemcpy(d_d18, d18.data(), sizeof(int32_t) * d18.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda,
+                       d_d144, h->Jc);
+    if (nf > 0)
+      hipLaunchKernelGGL(k_sg_const_facets, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
+                         d_d18, h->Q, h->Jc, h->bg);
+    e = hipStreamSynchronize(h->st);
+  }
+  hipFree(d_cells);
+  hipFree(d_d144);
+  hipFree(d_d18);
+  if (e != hipSuccess) {
+    h->err = std::string("constant Jacobian blocks: ") + hipGetErrorString(e);
+    return PGX_EHIP;
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
+  if (!m || !p || !out || !m->coords || !m->cells || m->n_vertices <= 0 || m->n_cells <= 0 || m->n_facets < 0 ||
+      (m->n_facets > 0 && !m->facets) || !p->qpts || !p->qwts || p->nq <= 0 || p->nq > SG_MAXQ ||
+      (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5)) {
+    g_sg_error = "pgx_sg_create: bad arguments";
+    return PGX_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    g_sg_error = "pgx_sg_create: no usable GPU (there is no CPU fallback)";
+    return PGX_ENODEV;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_sg_error = "hipSetDevice failed";
+    return PGX_EHIP;
+  }
+  pgx_sg_handle* h = new pgx_sg_handle();
+  h->device = device;
+  int rc = sg_create_impl(h, m, p);
+  if (rc) {
+    g_sg_error = h->err;
+    pgx_sg_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return PGX_OK;
+}
+
+#define SGNEED(h)              \
+  if (!(h)) return PGX_EINVAL; \
+  if (hipSetDevice((h)->device) != hipSuccess) return PGX_EHIP
+
+extern "C" int pgx_sg_num_dofs(const pgx_sg_handle* h, int64_t* ntot, int64_t* npsi) {
+  if (!h) return PGX_EINVAL;
+  if (ntot) *ntot = h->ntot;
+  if (npsi) *npsi = h->npsi;
+  return PGX_OK;
+}
+extern "C" int pgx_sg_contact_vertices(const pgx_sg_handle* h, int32_t* verts) {
+  if (!h || !verts) return PGX_EINVAL;
+  std::copy(h->cverts.begin(), h->cverts.end(), verts);
+  return PGX_OK;
+}
+extern "C" int pgx_sg_set_state(pgx_sg_handle* h, const double* x) {
+  SGNEED(h);
+  return mx_in(h, h->x, x);
+}
+extern "C" int pgx_sg_get_state(pgx_sg_handle* h, double* x) {
+  SGNEED(h);
+  return mx_out(h, x, h->x);
+}
+extern "C" int pgx_sg_set_prev(pgx_sg_handle* h, const double* x) {
+  SGNEED(h);
+  return mx_in(h, h->xk, x);
+}
+extern "C" int pgx_sg_get_prev(pgx_sg_handle* h, double* x) {
+  SGNEED(h);
+  return mx_out(h, x, h->xk);
+}
+extern "C" int pgx_sg_advance_prev(pgx_sg_handle* h) {
+  SGNEED(h);
+  MXHIP(hipMemcpyAsync(h->xk, h->x, sizeof(double) * h->ntot, hipMemcpyDeviceToDevice, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+extern "C" int pgx_sg_set_alpha(pgx_sg_handle* h, double a) {
+  SGNEED(h);
+  if (!(a > 0.0) || !std::isfinite(a)) {
+    h->err = "alpha must be positive and finite";
+    return PGX_EINVAL;
+  }
+  h->alpha = a;
+  h->jac_valid = false;
+  return PGX_OK;
+}
+extern "C" int pgx_sg_residual(pgx_sg_handle* h, const double* x, double* F, double* fnorm) {
+  SGNEED(h);
+  const double* xd = h->x;
+  if (x) {
+    int rc = mx_in(h, h->xw, x);
+    if (rc) return rc;
+    xd = h->xw;
+  }
+  h->residual_dev(xd, h->F);
+  if (fnorm) {
+    int rc = mx_norm(h, h->F, fnorm);
+    if (rc) return rc;
+  }
+  if (F) return mx_out(h, F, h->F);
+  MXHIP(hipStreamSynchronize(h->st));
+  return PGX_OK;
+}
+extern "C" int pgx_sg_jacobian_fill(pgx_sg_handle* h, const double* x) {
+  SGNEED(h);
+  const double* xd = h->x;
+  if (x) {
+    int rc = mx_in(h, h->xw, x);
+    if (rc) return rc;
+    xd = h->xw;
+  }
+  h->jacobian_dev(xd);
+  MXHIP(hipStreamSynchronize(h->st));
+  MXHIP(hipGetLastError());
+  return PGX_OK;
+}
+extern "C" int pgx_sg_csr_export(pgx_sg_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col,
+                                 double* vals) {
+  SGNEED(h);
+  if (nrows) *nrows = h->ntot;
+  if (nnz) *nnz = h->nnz;
+  if (rowptr) std::copy(h->h_rowptr.begin(), h->h_rowptr.end(), rowptr);
+  if (col) std::copy(h->h_col.begin(), h->h_col.end(), col);
+  if (vals) {
+    if (!h->jac_valid) {
+      h->err = "pgx_sg_csr_export: no Jacobian has been filled";
+      return PGX_ESTATE;
+    }
+    MXHIP(hipMemcpy(vals, h->Jv, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
+  }
+  return PGX_OK;
+}
+extern "C" int pgx_sg_spmv(pgx_sg_handle* h, const double* x, double* y) {
+  SGNEED(h);
+  if (!x || !y) return PGX_EINVAL;
+  if (!h->jac_valid) {
+    h->err = "pgx_sg_spmv: no Jacobian has been filled";
+    return PGX_ESTATE;
+  }
+  int rc = mx_in(h, h->r, x);
+  if (rc) return rc;
+  mx_spmv_dev(h, h->r, h->z);
+  return mx_out(h, y, h->z);
+}
+extern "C" int pgx_sg_newton_solve(pgx_sg_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its) {
+  SGNEED(h);
+  return mx_newton_solve(h, opts, reason, its, lin_its);
+}
+extern "C" int pgx_sg_u_increment(pgx_sg_handle* h, double* out) {
+  SGNEED(h);
+  if (!out) return PGX_EINVAL;
+  mx_axpby(h, 1.0, h->x, 0.0, h->r);
+  mx_axpby(h, -1.0, h->xk, 1.0, h->r);
+  return mx_norm(h, h->r, out, 3 * (int64_t)h->nv);
+}
+extern "C" int pgx_sg_profile(pgx_sg_handle* h, int enable, double ms[6]) {
+  SGNEED(h);
+  pgx_nd_timing(h->lu, enable, nullptr, nullptr);
+  return mx_profile(h, enable, ms);
+}

@@ -1,0 +1,242 @@
+"""Example 02 - Signorini contact of a linear-elastic body with a rigid plane - on the HIP backend.
+
+Host-side mirror of /root/reference/examples/02_signorini/signorini_dolfinx.py: `solve_contact_problem` keeps the
+reference's signature (:156-174) and loop (:317-358); `SignoriniProblem` stands where the script builds the blocked
+`dolfinx.fem.petsc.NonlinearProblem(F, [u, psi], bcs=bcs, entity_maps=..., petsc_options=...)` (:281-291) and exposes
+`.solve()`, `.solver.setTolerances(atol=, rtol=)`, `.solver.getIterationNumber()`, `.solver.getConvergedReason()`
+(:331-335).  Everything below `.solve()` runs in libpgx.so (include/pgx_sg.h).  No CPU fallback.
+
+Degree 1 on tetrahedra (BASELINE.json config 5); the reference's default degree 2 and its hexahedral native mesh are not
+implemented.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Literal
+
+import numpy as np
+
+from . import _lib, fem
+from .problem import ConvergenceError, _SNES
+
+AlphaScheme = Literal["constant", "linear", "doubling"]
+
+
+@dataclass
+class TetMesh:
+    geometry: np.ndarray  # (nv,3)
+    cells: np.ndarray  # (nc,4)
+
+    def facets_where(self, pred):
+        """Exterior triangles (vertex triples) whose three vertices satisfy pred(x) (locate_entities_boundary, :369-373)."""
+        on = pred(self.geometry.T)
+        c = self.cells
+        faces = np.concatenate([c[:, [1, 2, 3]], c[:, [0, 2, 3]], c[:, [0, 1, 3]], c[:, [0, 1, 2]]])
+        sel = faces[on[faces].all(axis=1)]
+        key = np.sort(sel, axis=1)
+        _, idx, cnt = np.unique(key, axis=0, return_index=True, return_counts=True)
+        idx = idx[cnt == 1]  # exterior: the face belongs to exactly one cell
+        return np.ascontiguousarray(sel[np.sort(idx)], dtype=np.int32)
+
+
+class MeshTags:
+    """facet_tag of the reference (:384-385): tag -> facets (vertex triples); `.find(tag)` as dolfinx.mesh.MeshTags."""
+
+    def __init__(self, tagged: dict):
+        self._t = {int(k): np.ascontiguousarray(v, dtype=np.int32) for k, v in tagged.items()}
+
+    def find(self, tag):
+        return self._t.get(int(tag), np.zeros((0, 3), dtype=np.int32))
+
+
+def create_unit_cube(nx, ny, nz) -> TetMesh:
+    """nx x ny x nz cubes, six tetrahedra each around the diagonal v0-v7 (dolfinx.mesh.create_unit_cube with
+    CellType.tetrahedron [split pattern recalled, not verifiable offline])."""
+    xs, ys, zs = np.linspace(0, 1, nx + 1), np.linspace(0, 1, ny + 1), np.linspace(0, 1, nz + 1)
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    coords = np.ascontiguousarray(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+    iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (iz * (ny + 1) * (nx + 1) + iy * (nx + 1) + ix).ravel()
+    v1, v2 = v0 + 1, v0 + (nx + 1)
+    v3 = v1 + (nx + 1)
+    off = (nx + 1) * (ny + 1)
+    v4, v5, v6, v7 = v0 + off, v1 + off, v2 + off, v3 + off
+    tets = [(v0, v1, v3, v7), (v0, v1, v7, v5), (v0, v5, v7, v4), (v0, v3, v2, v7), (v0, v6, v4, v7), (v0, v2, v6, v7)]
+    cells = np.stack([np.stack(t, axis=1) for t in tets], axis=1).reshape(-1, 4)
+    return TetMesh(coords, np.ascontiguousarray(cells, dtype=np.int32))
+
+
+def native_tags(mesh: TetMesh) -> tuple[MeshTags, dict]:
+    """The `native` branch of the reference's __main__ (:365-386): top (z = 1) tagged 1, bottom (z = 0) tagged 2."""
+    top = mesh.facets_where(lambda x: np.isclose(x[2], 1.0))
+    bottom = mesh.facets_where(lambda x: np.isclose(x[2], 0.0))
+    return MeshTags({1: top, 2: bottom}), {"contact": (2,), "displacement": (1,)}
+
+
+class SignoriniProblem:
+    """x = [u_x | u_y | u_z | psi (contact vertices ordered by vertex id)]."""
+
+    def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0):
+        self._lib = lib = _lib.load()
+        self.mesh = mesh
+        nv = mesh.geometry.shape[0]
+        pts, wts = fem.quadrature_rule("triangle", quadrature_degree)
+        facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
+        bv = np.asarray(bc_vertices, dtype=np.int64)
+        bc = np.ascontiguousarray(np.concatenate([bv, nv + bv, 2 * nv + bv]), dtype=np.int32)  # all components (:267)
+        vals = np.ascontiguousarray(np.concatenate([np.zeros(len(bv)), np.zeros(len(bv)), np.full(len(bv), float(disp))]))
+        self._keep = (mesh.geometry, mesh.cells, facets, pts, wts, bc, vals)
+        pm = _lib.pgx_sg_mesh(nv, mesh.cells.shape[0], _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), facets.shape[0],
+                              _lib.iptr(facets))
+        pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
+                                 _lib.iptr(bc), _lib.dptr(vals))
+        self._h = C.c_void_p()
+        rc = lib.pgx_sg_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+        if rc:
+            msg = lib.pgx_sg_last_error(None)
+            raise _lib.PgxError(f"pgx_sg_create failed (code {rc}): {msg.decode() if msg else ''}")
+        nt, npsi = C.c_int64(0), C.c_int64(0)
+        lib.pgx_sg_num_dofs(self._h, C.byref(nt), C.byref(npsi))
+        self.ndofs, self.npsi, self.nv = nt.value, npsi.value, nv
+        self.contact_vertices = np.zeros(self.npsi, dtype=np.int32)
+        lib.pgx_sg_contact_vertices(self._h, _lib.iptr(self.contact_vertices))
+        self._opts = _lib.pgx_snes_opts()
+        lib.pgx_default_opts(C.byref(self._opts))  # PETSc defaults: stol 1e-8, max_it 50 (the script sets atol/rtol only)
+        self._opts.ksp_max_it = 6
+        self._flags = {"snes_error_if_not_converged": True}  # :278
+        self.solver = _SNES(self._opts)
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self._lib.pgx_sg_last_error(self._h)
+            raise _lib.PgxError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+    def get_state(self):
+        x = np.empty(self.ndofs)
+        self._check(self._lib.pgx_sg_get_state(self._h, _lib.dptr(x)), "pgx_sg_get_state")
+        return x
+
+    def set_state(self, x):
+        self._check(self._lib.pgx_sg_set_state(self._h, _lib.dptr(np.ascontiguousarray(x, dtype=np.float64))), "set_state")
+
+    def set_prev(self, x):
+        self._check(self._lib.pgx_sg_set_prev(self._h, _lib.dptr(np.ascontiguousarray(x, dtype=np.float64))), "set_prev")
+
+    def advance_prev(self):
+        """u_prev.x.array[:] = u.x.array; psi_k.x.array[:] = psi.x.array (:342-343), on the device"""
+        self._check(self._lib.pgx_sg_advance_prev(self._h), "pgx_sg_advance_prev")
+
+    def set_alpha(self, a):
+        self._check(self._lib.pgx_sg_set_alpha(self._h, float(a)), "pgx_sg_set_alpha")
+
+    def solve(self):
+        reason, its, lin = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.pgx_sg_newton_solve(self._h, C.byref(self._opts), C.byref(reason), C.byref(its),
+                                                  C.byref(lin)), "pgx_sg_newton_solve")
+        s = self.solver
+        s._reason, s._its = reason.value, its.value
+        s.ksp._its, s.ksp._reason = lin.value, (-3 if reason.value == -3 else 4)
+        if reason.value <= 0 and self._flags["snes_error_if_not_converged"]:
+            raise ConvergenceError(f"SNES did not converge: reason {reason.value} after {its.value} iterations")
+        return reason.value, its.value
+
+    def u_increment(self):
+        out = C.c_double(0)
+        self._check(self._lib.pgx_sg_u_increment(self._h, C.byref(out)), "pgx_sg_u_increment")
+        return out.value
+
+    def residual(self, x=None):
+        out = np.empty(self.ndofs)
+        nrm = C.c_double(0)
+        xx = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        self._check(self._lib.pgx_sg_residual(self._h, _lib.dptr(xx), _lib.dptr(out), C.byref(nrm)), "pgx_sg_residual")
+        return out, nrm.value
+
+    def jacobian(self, x=None):
+        import scipy.sparse as sp
+
+        xx = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        self._check(self._lib.pgx_sg_jacobian_fill(self._h, _lib.dptr(xx)), "pgx_sg_jacobian_fill")
+        nr, nnz = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.pgx_sg_csr_export(self._h, C.byref(nr), C.byref(nnz), None, None, None), "csr_export")
+        rp, col, val = np.empty(nr.value + 1, np.int32), np.empty(nnz.value, np.int32), np.empty(nnz.value)
+        self._check(self._lib.pgx_sg_csr_export(self._h, None, None, _lib.iptr(rp), _lib.iptr(col), _lib.dptr(val)),
+                    "csr_export")
+        return sp.csr_matrix((val, col, rp), shape=(nr.value, nr.value))
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._check(self._lib.pgx_sg_spmv(self._h, _lib.dptr(x), _lib.dptr(y)), "pgx_sg_spmv")
+        return y
+
+    def profile(self, enable=True):
+        ms = (C.c_double * 6)()
+        self._check(self._lib.pgx_sg_profile(self._h, int(enable), ms), "pgx_sg_profile")
+        return dict(zip(("residual", "jacobian", "lu_factor", "lu_solve", "spmv", "newton_total"), ms))
+
+    def close(self):
+        if self._h:
+            self._lib.pgx_sg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_conditions: dict, degree: int = 1, E: float = 2.0e4,
+                          nu: float = 0.3, gap: float = 0.0, disp: float = -0.25, newton_max_its: int = 250,
+                          newton_tol: float = 1e-6, max_iterations: int = 25, alpha_scheme: AlphaScheme = "doubling",
+                          alpha_0: float = 1.0, alpha_c: float = 1.0, tol: float = 1e-6, output: Path | None = None,
+                          quadrature_degree: int = 4, verbose: bool = True, return_solution: bool = False, device: int = 0):
+    """signorini_dolfinx.solve_contact_problem (:156-360): returns (it, iterations) [, final state, problem data]."""
+    if degree != 1:
+        raise NotImplementedError("HIP backend: degree 1 (BASELINE.json config 5); the reference's default is 2")
+    contact = np.concatenate([facet_tag.find(t) for t in boundary_conditions["contact"]])  # :186-189
+    bc_facets = np.concatenate([facet_tag.find(t) for t in boundary_conditions["displacement"]])  # :265-266
+    bc_vertices = np.unique(bc_facets.ravel())
+    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device)
+    iterations = []
+    normed_diff = -1.0
+    it = 0
+    for it in range(1, max_iterations + 1):
+        if verbose:
+            print(f"{it=}/{max_iterations} {normed_diff:.2e}")
+        alpha = alpha_0
+        if alpha_scheme == "linear":
+            alpha = alpha_0 + alpha_c * it
+        elif alpha_scheme == "doubling":
+            alpha = alpha_0 * 2**it
+        problem.set_alpha(alpha)
+        solver_tol = 10 * newton_tol if it < 2 else newton_tol  # :330
+        problem.solver.setTolerances(atol=solver_tol, rtol=solver_tol)  # :331-332
+        problem.solve()  # :333
+        num_its = problem.solver.getIterationNumber()
+        converged = problem.solver.getConvergedReason() > 0
+        iterations.append(num_its)
+        normed_diff = problem.u_increment()  # :336-339
+        if normed_diff <= tol:
+            if verbose:
+                print(f"Converged at {it=} with increment norm {normed_diff:.2e}<{tol:.2e}")
+            break
+        problem.advance_prev()  # :342-343
+        if not converged:
+            break
+    if output is not None:
+        output = Path(output)
+        output.mkdir(parents=True, exist_ok=True)
+        np.savetxt(output / "lvpp_history.csv", np.asarray(iterations, dtype=np.int64), header="newton")
+    if verbose:
+        print(f"num_dofs_u={3 * problem.nv}, num_cells={mesh.cells.shape[0]}")
+    if return_solution:
+        x = problem.get_state()
+        cv = problem.contact_vertices.copy()
+        problem.close()
+        return it, iterations, x, cv
+    problem.close()
+    return it, iterations

@@ -1,0 +1,71 @@
+"""Example 02 (Signorini contact, 3-D elasticity) HIP path vs the CPU oracle (oracle/sg_oracle.py), through the C ABI of
+include/pgx_sg.h.  Tolerances: kernels 1e-12 relative; full LVPP run: identical Newton counts, final displacement field
+<= 1e-10 relative L2."""
+import numpy as np
+import pytest
+
+from oracle import sg_oracle as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _setup(nx, ny, nz, gap=0.0, disp=-0.25):
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube(nx, ny, nz)
+    mt, bcs = G.native_tags(mesh)
+    contact = mt.find(2)
+    bcv = np.unique(mt.find(1).ravel())
+    problem = G.SignoriniProblem(mesh, contact, bcv, 2.0e4, 0.3, gap, disp)
+    coords, cells = S.create_unit_cube_tets(nx, ny, nz)
+    assert np.array_equal(coords, mesh.geometry) and np.array_equal(cells, mesh.cells)
+    cf = S.boundary_facets_where(coords, cells, lambda c: np.isclose(c[:, 2], 0.0))
+    prob = S.SignoriniP1(coords, cells, cf, np.flatnonzero(np.isclose(coords[:, 2], 1.0)), gap=gap, disp=disp)
+    assert problem.ndofs == prob.ntot and np.array_equal(problem.contact_vertices, prob.cverts)
+    return problem, prob
+
+
+@pytest.mark.parametrize("n", [(2, 2, 2), (5, 3, 4), (9, 9, 9)])
+def test_kernels_match_oracle(require_gpu, n):
+    problem, prob = _setup(*n, gap=0.01)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(prob.ntot) * 0.05
+    x[3 * prob.nv:] = -np.abs(rng.standard_normal(prob.npsi)) * np.where(rng.random(prob.npsi) < 0.4, 400.0, 2.0)
+    xk = rng.standard_normal(prob.ntot) * 0.05
+    for alpha in (2.0, 64.0):
+        problem.set_alpha(alpha)
+        problem.set_prev(xk)
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, alpha)
+        assert _rel(F, Fr) < 1e-12 and abs(fn - np.linalg.norm(Fr)) <= 1e-12 * np.linalg.norm(Fr)
+        J = problem.jacobian(x)
+        Jr = prob.jacobian(x, alpha).tocsr()
+        assert abs(J - Jr).max() <= 1e-12 * abs(Jr).max()
+        nu3 = 3 * prob.nv
+        assert abs(J[nu3:, nu3:] - Jr[nu3:, nu3:]).max() <= 1e-12 * abs(Jr[nu3:, nu3:]).max()
+        v = rng.standard_normal(prob.ntot)
+        assert _rel(problem.spmv(v), Jr @ v) < 1e-12
+    problem.set_state(x)
+    problem.set_prev(xk)
+    assert abs(problem.u_increment() - np.linalg.norm((x - xk)[: 3 * prob.nv])) < 1e-12
+    problem.close()
+
+
+@pytest.mark.parametrize("n,gap", [((4, 4, 4), 0.0), ((8, 6, 5), 0.0), ((6, 6, 6), -0.1)])
+def test_full_lvpp_run_matches_oracle(require_gpu, n, gap):
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube(*n)
+    mt, bcs = G.native_tags(mesh)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, gap=gap, verbose=False, return_solution=True)
+    coords, cells = S.create_unit_cube_tets(*n)
+    cf = S.boundary_facets_where(coords, cells, lambda c: np.isclose(c[:, 2], 0.0))
+    prob = S.SignoriniP1(coords, cells, cf, np.flatnonzero(np.isclose(coords[:, 2], 1.0)), gap=gap)
+    x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
+    assert it == it_ref and list(iterations) == list(its_ref)
+    nu3 = 3 * prob.nv
+    assert _rel(x[:nu3], x_ref[:nu3]) < 1e-10

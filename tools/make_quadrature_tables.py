@@ -88,8 +88,12 @@ def gauss_jacobi_01(m, a):
     import numpy as np
     from scipy.special import roots_jacobi
 
+    def jac(t):  # P_m^{(a,0)}(t) by its finite sum (mpmath's hypergeometric form fails to converge at t = 0)
+        return sum(mp.binomial(m + a, m - s) * mp.binomial(m, s) * ((t - 1) / 2) ** s * ((t + 1) / 2) ** (m - s)
+                   for s in range(m + 1))
+
     guess, _ = roots_jacobi(m, a, 0)
-    nodes = [mp.findroot(lambda t: mp.jacobi(m, a, 0, t), mp.mpf(float(g)), tol=1e-45) for g in guess]
+    nodes = [mp.findroot(jac, mp.mpf(float(g)) + mp.mpf("1e-20"), tol=1e-45) for g in guess]
     nodes = [(1 + t) / 2 for t in nodes]  # [-1,1] -> [0,1]; weight (1-t)^a keeps its form up to a constant
     A = mp.matrix(m, m)
     b = mp.matrix(m, 1)
@@ -159,6 +163,22 @@ def main():
         "source": "collapsed Gauss-Jacobi(1,0) x Gauss-Legendre, 6 x 6 points (exact to degree 11); tools/make_quadrature_tables.py",
         "points": [[float(x), float(y)] for (x, y) in pts10],
         "weights": [float(w) for w in wts10],
+    }
+    # facet rule of example 02 (quadrature_degree 4 on the contact triangles, signorini_dolfinx.py:67-69,211-218): same
+    # derivable family, m = (4+2)//2 = 3 points per direction, exact to degree 5
+    pts4, wts4 = collapsed_rule(3)
+    worst4 = mp.mpf(0)
+    for p in range(6):
+        for q in range(6 - p):
+            s = sum(w * x**p * y**q for (x, y), w in zip(pts4, wts4))
+            worst4 = max(worst4, abs(s - moments_exact(p, q)))
+    assert worst4 < mp.mpf(10) ** (-35), worst4
+    table["tri_deg4_gj9"] = {
+        "cell": "triangle",
+        "degree": 4,
+        "source": "collapsed Gauss-Jacobi(1,0) x Gauss-Legendre, 3 x 3 points (exact to degree 5); tools/make_quadrature_tables.py",
+        "points": [[float(x), float(y)] for (x, y) in pts4],
+        "weights": [float(w) for w in wts4],
     }
     out = pathlib.Path(__file__).resolve().parents[1] / "proximalgalerkin_amd" / "tables" / "quadrature.json"
     out.write_text(json.dumps(table, indent=1) + "\n")
