@@ -57,3 +57,34 @@ def test_p2_auto_lu_matches_oracle_where_multigrid_failed(require_gpu):
     x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
     assert hist["Newton steps"] == h_ref["Newton steps"]
     assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
+
+
+def test_p2_n256_reproduces_the_oracles_newton_divergence(require_gpu):
+    """P2, N = 256, settings B: the exact-Newton CPU oracle (SuperLU) itself ends with SNES_DIVERGED_DTOL (-9) at the
+    alpha 16 -> 85 step (tests/golden/obstacle_p2_n256_settingsB_divergence.json, tools/p2_divergence_oracle.py) - the
+    reference's undamped Newton overshoots there.  Parity means reproducing that: same Newton counts up to the step, same
+    reason, same residual history."""
+    import json
+    import pathlib
+
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import alpha_update, setup_problem
+
+    z = json.loads((pathlib.Path(__file__).resolve().parent / "golden" / "obstacle_p2_n256_settingsB_divergence.json").read_text())
+    msh = fem.create_rectangle(DOMAIN, (256, 256))
+    problem, sol, sol_k, alpha = setup_problem(msh, 2, petsc_options={"snes_linesearch_type": "none", "snes_rtol": 1e-6,
+                                                                     "snes_max_it": 100})
+    problem.zero_state()
+    alpha_k, counts, reason = 1, [], None
+    for k in range(20):
+        alpha.value, alpha_k = alpha_update("double_exponential", k, alpha_k, 1e2, current=alpha.value)
+        problem.solve()
+        reason = problem.solver.getConvergedReason()
+        if reason <= 0:
+            assert k == z["failed_outer_step_0based"] and reason == z["failed_reason"]
+            assert problem.solver.getIterationNumber() == z["failed_after_its"]
+            break
+        counts.append(problem.solver.getIterationNumber())
+        sol_k.x.assign_from(sol.x)
+    assert reason == -9 and counts == z["newton_steps_converged"][: len(counts)] and len(counts) == 7
+    problem.close()
