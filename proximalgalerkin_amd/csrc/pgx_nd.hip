@@ -507,6 +507,7 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 #define ND_TS 64   // panel chunk
 #define ND_KC 16   // GEMM k-chunk staged in LDS
 #define ND_SLAB 256 // pivots per triangular-solve launch in the solve phase
+#define ND_OUTER 256 // pivots per outer block of the factorisation (rank of the big trailing updates)
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 // LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level.  Blocked by 8 columns:
@@ -710,24 +711,19 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
   }
 }
 
-// C -= A B with A = F[rows, k0:k1), B = F[k0:k1, cols) on (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of
-// v_mfma_f64_16x16x4_f64, operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous
-// bytes of C.  The next k-chunk is prefetched into registers while the current one feeds the matrix cores.
-// Tiles never straddle P: row/col blocks are laid out as [s, P) then [P, M).  mode 0: all tiles of the trailing matrix
-// EXCEPT the Schur block (rows >= P and cols >= P); mode 1 (s == P): the Schur block only.
+// C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
+// B = F[k0:k1, cols); (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of v_mfma_f64_16x16x4_f64, operands swapped
+// (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
+// into registers while the current one feeds the matrix cores.
 template <int WT>
-__global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int P, int s, int k0,
-                                                 int k1, int mode) {
+__global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
+                                                 int c0g, int c1g, int k0, int k1) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
-  const int nb1 = s < P ? (P - s + TS - 1) / TS : 0;
-  const int bi = blockIdx.y, bj = blockIdx.z;
-  if (mode == 0 && bi >= nb1 && bj >= nb1) return;
-  int r0, rmax, c0, cmax;
-  if (bi < nb1) r0 = s + TS * bi, rmax = P; else r0 = P + TS * (bi - nb1), rmax = M;
-  if (bj < nb1) c0 = s + TS * bj, cmax = P; else c0 = P + TS * (bj - nb1), cmax = M;
+  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
+  const int rmax = r1g, cmax = c1g;
   if (r0 >= rmax || c0 >= cmax) return;
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
@@ -1008,17 +1004,17 @@ extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* s
   return PGX_OK;
 }
 
-// trailing / Schur update of one level: 128 x 128 tiles where the fronts are large, 64 x 64 otherwise
-static void nd_launch_gemm(pgx_nd* s, const NdLevel& Lv, int sfirst, int k0, int k1, int mode) {
-  const int P = Lv.P, B = Lv.B, M = P + B;
-  const bool big = (M - sfirst) >= 512;
+// C -= A B on one rectangle of every front of a level: 128 x 128 tiles where both sides are long, 64 x 64 otherwise
+static void nd_launch_gemm(pgx_nd* s, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1) {
+  if (r1 <= r0 || c1 <= c0 || k1 <= k0) return;
+  const int M = Lv.P + Lv.B;
+  const bool big = (r1 - r0) >= 256 && (c1 - c0) >= 256;
   const int TS = big ? 128 : 64;
-  const unsigned nb1 = sfirst < P ? (unsigned)((P - sfirst + TS - 1) / TS) : 0u, nb2 = (unsigned)((B + TS - 1) / TS);
-  const dim3 grid((unsigned)Lv.count, nb1 + nb2, nb1 + nb2);
+  const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   if (big)
-    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, P, sfirst, k0, k1, mode);
+    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
   else
-    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, P, sfirst, k0, k1, mode);
+    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -1059,22 +1055,34 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
                              s->arena);
       }
     }
-    // partial left-looking LU of the level: pivot block + both panels step by step, Schur block once at the end
-    const int nsteps = (P + ND_NB - 1) / ND_NB;
-    int kb = 0;
-    for (int st = 0; st < nsteps; ++st) {
-      const int nb = P / nsteps + (st < P % nsteps ? 1 : 0);
-      hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb, s->d_info);
-      const int R = M - kb - nb;
-      if (R > 0) {
-        const unsigned nch = (unsigned)((R + ND_TS - 1) / ND_TS);
-        hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
-        const int sfirst = kb + nb;
-        if (sfirst < P) nd_launch_gemm(s, Lv, sfirst, kb, kb + nb, 0);
+    // Two-level blocked partial LU of the level.  Outer blocks of <= ND_OUTER pivots; inside one, <= 64-wide panels:
+    // diagonal block, both panel solves, then rank-64 updates of the outer block's row and column STRIPS only.  The rest
+    // of the trailing pivot block and panels gets ONE rank-ND_OUTER update per outer block (arithmetic intensity
+    // ND_OUTER/8 flop/byte: MFMA-bound instead of HBM-bound), the Schur block F22 ONE update with K = P at the end.
+    const int nouter = (P + ND_OUTER - 1) / ND_OUTER;
+    int ob = 0;
+    for (int ou = 0; ou < nouter; ++ou) {
+      const int W = P / nouter + (ou < P % nouter ? 1 : 0), oe = ob + W;
+      const int nsteps = (W + ND_NB - 1) / ND_NB;
+      int kb = ob;
+      for (int st = 0; st < nsteps; ++st) {
+        const int nb = W / nsteps + (st < W % nsteps ? 1 : 0), ke = kb + nb;
+        hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb, s->d_info);
+        if (M - ke > 0) {
+          const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
+          hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
+          nd_launch_gemm(s, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
+          nd_launch_gemm(s, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
+        }
+        kb = ke;
       }
-      kb += nb;
+      // trailing matrix beyond the outer block, without the Schur block
+      nd_launch_gemm(s, Lv, oe, P, oe, P, ob, oe);
+      nd_launch_gemm(s, Lv, oe, P, P, M, ob, oe);
+      nd_launch_gemm(s, Lv, P, M, oe, P, ob, oe);
+      ob = oe;
     }
-    if (B > 0) nd_launch_gemm(s, Lv, P, 0, P, 1);
+    if (B > 0) nd_launch_gemm(s, Lv, P, M, P, M, 0, P);
   }
   if (s->timing) {
     hipEventRecord(s->e1, s->st);
