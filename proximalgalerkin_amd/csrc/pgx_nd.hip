@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
 // (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
 // into registers while the current one feeds the matrix cores.
 template <int WT>
-__global__ __launch_bounds__(256) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
+__global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
                                                  int c0g, int c1g, int k0, int k1) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
