@@ -107,7 +107,8 @@ typedef struct {
   int32_t mg_nu;      /* pre/post smoothing sweeps, default 6 (even values run as fused double sweeps) */
   double mg_omega;    /* collective-Jacobi damping, default 0.8 */
   int32_t monitor;    /* 1 = print per-Newton-step residuals (snes_monitor/ksp_monitor) */
-  int32_t pc_type;    /* preconditioner of the FGMRES Newton solve: 0 = auto (1 for P1, 2 for P2), 1 = multigrid V-cycle,
+  int32_t pc_type;    /* preconditioner of the FGMRES Newton solve: 0 = auto (1 for P1 on a structured mesh, 2 for P2 and for general
+                         meshes), 1 = multigrid V-cycle (single-level smoother on general meshes),
                          2 = sparse LU (nested-dissection multifrontal, include/pgx_nd.h) - what the reference's
                          "pc_type": "lu" (obstacle_pg.py:130) asks for; FGMRES then acts as iterative refinement */
 } pgx_snes_opts;

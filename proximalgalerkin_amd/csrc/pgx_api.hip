@@ -1819,9 +1819,10 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // (tools/lu_accuracy_check.py, tools/tolerance_sweep.py): small / unstructured meshes are the sensitive ones
   if (!(optv.ksp_rtol > 0.0)) optv.ksp_rtol = (h->degree == 2) ? 1e-11 : 1e-10;
   opts = &optv;
-  // pc_type: 0 auto (multigrid for P1; sparse LU for P2, whose two-level cycle is not robust on the late large-alpha
-  // systems), 1 multigrid V-cycle, 2 sparse LU (what the reference asks PETSc/MUMPS for)
-  const bool use_lu = optv.pc_type == 2 || (optv.pc_type == 0 && h->degree == 2 && !h->dist.on);
+  // pc_type: 0 auto (geometric multigrid for P1 on a structured mesh; sparse LU for P2, whose two-level cycle is not robust
+  // on the late large-alpha systems, and for general meshes, which have no grid hierarchy - e.g. the reference's own gmsh
+  // disk, obstacle_pg.py:64-65), 1 multigrid V-cycle, 2 sparse LU (what the reference asks PETSc/MUMPS for)
+  const bool use_lu = optv.pc_type == 2 || (optv.pc_type == 0 && (h->degree == 2 || !h->structured) && !h->dist.on);
   h->lu_active = false;
   if (use_lu) {
     int rcl = ensure_lu(h);
