@@ -111,6 +111,9 @@ typedef struct {
                          meshes), 1 = multigrid V-cycle (single-level smoother on general meshes),
                          2 = sparse LU (nested-dissection multifrontal, include/pgx_nd.h) - what the reference's
                          "pc_type": "lu" (obstacle_pg.py:130) asks for; FGMRES then acts as iterative refinement */
+  int32_t linesearch; /* snes_linesearch_type: 0 = none / basic (full step: examples 01, 02, 06), 1 = bt of order 2
+                         (quadratic backtracking, examples/05_obstacle_type_qvi/thermoforming_dolfinx.py:104,111); honoured by
+                         the handles of pgx_qvi.h, pgx_gc.h and pgx_sg.h (pgx_newton_solve of example 01 takes the full step) */
 } pgx_snes_opts;
 
 void pgx_default_opts(pgx_snes_opts* o);

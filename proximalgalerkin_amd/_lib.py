@@ -65,6 +65,7 @@ class pgx_snes_opts(C.Structure):
         ("mg_omega", C.c_double),
         ("monitor", C.c_int32),
         ("pc_type", C.c_int32),
+        ("linesearch", C.c_int32),
     ]
 
 
@@ -128,6 +129,20 @@ class pgx_sg_problem(C.Structure):
         ("n_bc", C.c_int32),
         ("bc_dofs", c_int32_p),
         ("bc_vals", c_double_p),
+    ]
+
+
+class pgx_qvi_problem(C.Structure):  # include/pgx_qvi.h
+    _fields_ = [
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("beta", C.c_double),
+        ("f", C.c_double),
+        ("knee", C.c_double),
+        ("eps_mod", C.c_double),
+        ("n_bc", C.c_int32),
+        ("bc_dofs", c_int32_p),
     ]
 
 
@@ -230,6 +245,25 @@ SYMBOLS = [
      [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pgx_sg_u_increment", C.c_int, [_H, c_double_p]),
     ("pgx_sg_profile", C.c_int, [_H, C.c_int, c_double_p]),
+    # example 05: thermoforming QVI (include/pgx_qvi.h)
+    ("pgx_qvi_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_qvi_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_qvi_destroy", None, [_H]),
+    ("pgx_qvi_last_error", C.c_char_p, [_H]),
+    ("pgx_qvi_num_dofs", C.c_int, [_H, c_int64_p]),
+    ("pgx_qvi_set_state", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_get_state", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_set_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_get_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_advance_prev", C.c_int, [_H]),
+    ("pgx_qvi_set_alpha", C.c_int, [_H, C.c_double]),
+    ("pgx_qvi_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("pgx_qvi_jacobian_fill", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_csr_export", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_double_p]),
+    ("pgx_qvi_spmv", C.c_int, [_H, c_double_p, c_double_p]),
+    ("pgx_qvi_newton_solve", C.c_int,
+     [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pgx_qvi_h1_increment", C.c_int, [_H, c_double_p]),
+    ("pgx_qvi_profile", C.c_int, [_H, C.c_int, c_double_p]),
 ]
 
 _lib = None

@@ -160,6 +160,7 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->mg_omega = 0.8;
   o->monitor = 0;
   o->pc_type = 0;  // auto: multigrid for P1, sparse LU for P2
+  o->linesearch = 0;
 }
 
 extern "C" const char* pgx_last_error(const pgx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }

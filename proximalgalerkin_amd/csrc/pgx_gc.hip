@@ -686,5 +686,7 @@ extern "C" int pgx_gc_profile(pgx_gc_handle* h, int enable, double ms[6]) {
 
 extern "C" int pgx_gc_newton_solve(pgx_gc_handle* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   GCNEED(h);
-  return mx_newton_solve(h, opts, reason, its_out, lin_out);
+  if (!opts) return PGX_EINVAL;
+  return opts->linesearch == 1 ? mx_newton_solve_bt(h, opts, reason, its_out, lin_out)
+                               : mx_newton_solve(h, opts, reason, its_out, lin_out);
 }

@@ -325,6 +325,191 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
   return PGX_OK;
 }
 
+
+#define PGX_SNES_DIVERGED_LINE_SEARCH (-6)
+
+// max_i |y_i| / max(|x_i|, 1)  (VecMaxPointwiseDivide of the line search), fixed-shape two-stage reduction
+static __global__ __launch_bounds__(256) void k_mx_relmax(int64_t len, const double* __restrict__ y, const double* __restrict__ x,
+                                                          double* __restrict__ partials) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)MX_RED * 256)
+    s = fmax(s, fabs(y[i]) / fmax(fabs(x[i]), 1.0));
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+static __global__ __launch_bounds__(256) void k_mx_final_max(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s = fmax(s, partials[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+static int mx_dot(MixedBase* h, const double* a, const double* b, double* out) {
+  hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, h->ntot, a, b, h->partials);
+  hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+  MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  *out = h->h_out[0];
+  return PGX_OK;
+}
+
+// SNES newtonls with the backtracking line search `bt` of order 2 (quadratic): restates PETSc's SNESLineSearchApply_BT
+// [upstream, recalled; the same restatement as oracle/qvi_oracle.py::newton_bt] - Armijo parameter 1e-4, maxstep 1e8,
+// steptol 1e-12, at most 40 backtracking steps; a non-finite trial residual counts as "no sufficient decrease" and
+// shrinks lambda tenfold.  The Jacobian may be a MODIFIED one (J != dF/dx, thermoforming_dolfinx.py:69-71): the initial
+// slope uses the same matrix the direction was computed with, as PETSc's MatMult(jac, Y, W) does.
+static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
+  if (!opts || !reason) return PGX_EINVAL;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  if (h->prof) {
+    hipEventCreate(&w0);
+    hipEventCreate(&w1);
+    hipEventRecord(w0, h->st);
+  }
+  const size_t bytes = sizeof(double) * h->ntot;
+  int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
+  double fnorm = 0, fnorm0 = 0;
+  MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
+  h->residual_dev(h->xw, h->F);
+  if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
+  fnorm0 = fnorm;
+  if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
+  if (!std::isfinite(fnorm))
+    rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+  else if (fnorm < opts->snes_atol)
+    rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+  const double ttol = fnorm * opts->snes_rtol;
+  while (rsn == 0) {
+    if (its >= opts->snes_max_it) {
+      rsn = PGX_SNES_DIVERGED_MAX_IT;
+      break;
+    }
+    h->jacobian_dev(h->xw);
+    {
+      MxTimer t(h, 2);
+      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+    }
+    if (rc) {
+      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+      return rc;
+    }
+    // dx = y = J^{-1} F (PETSc's direction; the update is x - lambda y)
+    int ns = 0;
+    double relres = 0;
+    if ((rc = mx_linear_solve(h, h->F, h->dx, opts, &ns, &relres))) return rc;
+    lin += ns;
+    ++its;
+    if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
+    if (!(relres <= 1e-7) || !std::isfinite(relres)) {
+      rsn = PGX_SNES_DIVERGED_LINEAR_SOLVE;
+      break;
+    }
+    double ynorm = 0, initslope = 0, rellength = 0, g = 0;
+    if ((rc = mx_norm(h, h->dx, &ynorm))) return rc;
+    if (ynorm > 1e8) {
+      mx_axpby(h, 0.0, h->dx, 1e8 / ynorm, h->dx);
+      ynorm = 1e8;
+    }
+    mx_spmv_dev(h, h->dx, h->rhs);  // J y
+    if ((rc = mx_dot(h, h->F, h->rhs, &initslope))) return rc;
+    if (initslope > 0.0) initslope = -initslope;
+    if (initslope == 0.0) initslope = -1.0;
+    hipLaunchKernelGGL(k_mx_relmax, dim3(MX_RED), dim3(256), 0, h->st, h->ntot, h->dx, h->xw, h->partials);
+    hipLaunchKernelGGL(k_mx_final_max, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+    MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    MXHIP(hipStreamSynchronize(h->st));
+    rellength = h->h_out[0];
+    const double minlambda = 1e-12 / rellength;
+    const double f = fnorm * fnorm;
+    double lam = 1.0;
+    auto trial = [&](double l) -> int {  // z = xw - l y ; r = F(z) ; g = |r|^2
+      mx_axpby(h, 1.0, h->xw, 0.0, h->z);
+      mx_axpby(h, -l, h->dx, 1.0, h->z);
+      h->residual_dev(h->z, h->r);
+      double gn = 0;
+      int r2 = mx_norm(h, h->r, &gn);
+      g = gn * gn;
+      return r2;
+    };
+    auto shrink = [&](double l, bool with_lam) {
+      if (!std::isfinite(g)) return 0.1 * l;
+      double lt = -initslope / (g - f - 2.0 * (with_lam ? l : 1.0) * initslope);
+      lt = std::min(lt, 0.5 * l);
+      return lt <= 0.1 * l ? 0.1 * l : lt;
+    };
+    bool ok = true;
+    if ((rc = trial(lam))) return rc;
+    if (!(std::isfinite(g) && 0.5 * g <= 0.5 * f + lam * 1e-4 * initslope)) {
+      lam = shrink(lam, true);
+      if ((rc = trial(lam))) return rc;
+      if (!(std::isfinite(g) && 0.5 * g < 0.5 * f + lam * 1e-4 * initslope)) {
+        int count = 0;
+        while (true) {
+          if (lam <= minlambda) {
+            ok = false;
+            break;
+          }
+          lam = shrink(lam, false);
+          if ((rc = trial(lam))) return rc;
+          if (std::isfinite(g) && 0.5 * g < 0.5 * f + lam * 1e-4 * initslope) break;
+          if (++count > 40) {
+            ok = false;
+            break;
+          }
+        }
+      }
+    }
+    if (opts->monitor > 1) printf("      line search: lambda %.6e  gnorm %.12e\n", lam, std::sqrt(g));
+    if (!ok) {
+      rsn = PGX_SNES_DIVERGED_LINE_SEARCH;
+      break;
+    }
+    MXHIP(hipMemcpyAsync(h->xw, h->z, bytes, hipMemcpyDeviceToDevice, h->st));
+    MXHIP(hipMemcpyAsync(h->F, h->r, bytes, hipMemcpyDeviceToDevice, h->st));
+    fnorm = std::sqrt(g);
+    if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
+    if (fnorm < opts->snes_atol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+    } else if (fnorm <= ttol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
+    } else {
+      double xnorm;
+      if ((rc = mx_norm(h, h->xw, &xnorm))) return rc;
+      if (lam * ynorm < opts->snes_stol * xnorm)
+        rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
+      else if (fnorm > opts->snes_divtol * fnorm0)
+        rsn = PGX_SNES_DIVERGED_DTOL;
+    }
+  }
+  if (rsn > 0) MXHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  MXHIP(hipGetLastError());
+  if (h->prof) {
+    hipEventRecord(w1, h->st);
+    hipEventSynchronize(w1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, w0, w1);
+    h->ms[5] += ms;
+    hipEventDestroy(w0);
+    hipEventDestroy(w1);
+  }
+  *reason = rsn;
+  if (its_out) *its_out = its;
+  if (lin_out) *lin_out = lin;
+  return PGX_OK;
+}
+
 static int mx_profile(MixedBase* h, int enable, double ms[6]) {
   if (ms)
     for (int i = 0; i < 6; ++i) ms[i] = h->ms[i];

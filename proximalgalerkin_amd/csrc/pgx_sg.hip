@@ -594,7 +594,8 @@ extern "C" int pgx_sg_spmv(pgx_sg_handle* h, const double* x, double* y) {
 }
 extern "C" int pgx_sg_newton_solve(pgx_sg_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its) {
   SGNEED(h);
-  return mx_newton_solve(h, opts, reason, its, lin_its);
+  if (!opts) return PGX_EINVAL;
+  return opts->linesearch == 1 ? mx_newton_solve_bt(h, opts, reason, its, lin_its) : mx_newton_solve(h, opts, reason, its, lin_its);
 }
 extern "C" int pgx_sg_u_increment(pgx_sg_handle* h, double* out) {
   SGNEED(h);
