@@ -77,10 +77,10 @@ class Thermoforming:
         pq = psi[self.cells] @ self.Nq.T
         with np.errstate(over="ignore", under="ignore", invalid="ignore"):
             s = np.exp(-pq)
-        gval = np.where(s < Q_KNEE, 1.0 - s / Q_KNEE, 0.0)  # s > 0 always: the branch s < 0 of :42-47 is never taken
-        cb = self.cells.ravel()
-        b_g = np.bincount(cb, weights=((self.wdet * gval) @ self.Nq).ravel(), minlength=self.nv)
-        b_e = np.bincount(cb, weights=((self.wdet * s) @ self.Nq).ravel(), minlength=self.nv)
+            gval = np.where(s < Q_KNEE, 1.0 - s / Q_KNEE, 0.0)  # s > 0 always: the branch s < 0 of :42-47 is never taken
+            cb = self.cells.ravel()
+            b_g = np.bincount(cb, weights=((self.wdet * gval) @ self.Nq).ravel(), minlength=self.nv)
+            b_e = np.bincount(cb, weights=((self.wdet * s) @ self.Nq).ravel(), minlength=self.nv)  # inf/nan if a trial overshoots
         if not with_matrix:
             return b_g, b_e, None, None
         D = self._mk(np.einsum("cq,qa,qb->cab", self.wdet * s, self.Nq, self.Nq))
@@ -150,7 +150,8 @@ def newton_bt(prob, x0, xk, alpha, rtol=1e-5, atol=1e-5, stol=10 * np.finfo(floa
         lam = 1.0
         w = x - lam * y
         G = prob.residual(w, xk, alpha)
-        g = float(G @ G)
+        with np.errstate(over="ignore", invalid="ignore"):
+            g = float(G @ G)
         ok = True
         # a non-finite trial residual (exp(-psi) overflows when a full step throws psi far negative) counts as "no
         # sufficient decrease" and shrinks lambda by the largest allowed factor (PETSc guards its acceptance test with
@@ -166,7 +167,8 @@ def newton_bt(prob, x0, xk, alpha, rtol=1e-5, atol=1e-5, stol=10 * np.finfo(floa
             lam = shrink(lam, g, True)
             w = x - lam * y
             G = prob.residual(w, xk, alpha)
-            g = float(G @ G)
+            with np.errstate(over="ignore", invalid="ignore"):
+                g = float(G @ G)
             if not (np.isfinite(g) and 0.5 * g < 0.5 * f + lam * 1e-4 * initslope):
                 count = 0
                 while True:
@@ -176,7 +178,8 @@ def newton_bt(prob, x0, xk, alpha, rtol=1e-5, atol=1e-5, stol=10 * np.finfo(floa
                     lam = shrink(lam, g, False)
                     w = x - lam * y
                     G = prob.residual(w, xk, alpha)
-                    g = float(G @ G)
+                    with np.errstate(over="ignore", invalid="ignore"):
+                        g = float(G @ G)
                     if np.isfinite(g) and 0.5 * g < 0.5 * f + lam * 1e-4 * initslope:
                         break
                     count += 1
