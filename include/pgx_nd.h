@@ -48,6 +48,14 @@ typedef struct {
 
 /* device < 0: symbolic phase only (no GPU touched) - for pgx_nd_get_stats / pgx_nd_export_* on CPU-only machines. */
 int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream /* may be NULL: own stream */, pgx_nd** out);
+/* Distributed factorisation over the ranks of a pgx_comm (include/pgx.h: pgx_comm_rccl_init / pgx_comm_local_group; size a
+ * power of two): the dissection tree is cut at depth log2(size); every rank factorises one subtree in its own HBM, rank 0
+ * also the levels above, receiving the subtree roots' Schur blocks (one grouped ncclSend/ncclRecv per factorisation, one
+ * small pair per solve, one all-reduce of the solution).  Every rank passes the SAME matrix (pattern at create, values at
+ * factor, right-hand side at solve) and receives the full solution; all calls are collective.  Replaces what MUMPS does
+ * over MPI in the reference (`mpirun -n N` + "pc_factor_mat_solver_type": "mumps"). */
+struct pgx_comm;
+int pgx_nd_create_dist(const pgx_nd_matrix* A, struct pgx_comm* comm, int device, void* hip_stream, pgx_nd** out);
 void pgx_nd_destroy(pgx_nd* s);
 const char* pgx_nd_last_error(const pgx_nd* s);
 int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st);

@@ -50,6 +50,11 @@ typedef struct {
 } pgx_sg_problem;
 
 int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int device, pgx_sg_handle** out);
+/* One handle per GPU over a pgx_comm (BASELINE.json config 5: 4 GPUs): every rank holds the whole (small) mesh and the
+ * replicated iterate and assembles redundantly - assembly is < 1 % of a Newton step here - while the sparse LU, 94 % of it,
+ * is distributed (pgx_nd_create_dist).  Replaces `mpirun -n N python signorini_dolfinx.py`; all calls are collective and
+ * return identical results on every rank. */
+int pgx_sg_create_dist(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, pgx_comm* comm, int device, pgx_sg_handle** out);
 void pgx_sg_destroy(pgx_sg_handle* h);
 const char* pgx_sg_last_error(const pgx_sg_handle* h);
 int pgx_sg_num_dofs(const pgx_sg_handle* h, int64_t* ntot, int64_t* npsi);

@@ -196,6 +196,7 @@ SYMBOLS = [
     ("pgx_sync_ghosts", C.c_int, [_H]),
     # sparse direct solver (include/pgx_nd.h)
     ("pgx_nd_create", C.c_int, [C.POINTER(pgx_nd_matrix), C.c_int, C.c_void_p, C.POINTER(_H)]),
+    ("pgx_nd_create_dist", C.c_int, [C.POINTER(pgx_nd_matrix), _COMM, C.c_int, C.c_void_p, C.POINTER(_H)]),
     ("pgx_nd_destroy", None, [_H]),
     ("pgx_nd_last_error", C.c_char_p, [_H]),
     ("pgx_nd_get_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
@@ -227,6 +228,7 @@ SYMBOLS = [
     ("pgx_gc_profile", C.c_int, [_H, C.c_int, c_double_p]),
     # example 02: Signorini contact (include/pgx_sg.h)
     ("pgx_sg_create", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_sg_create_dist", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_sg_destroy", None, [_H]),
     ("pgx_sg_last_error", C.c_char_p, [_H]),
     ("pgx_sg_num_dofs", C.c_int, [_H, c_int64_p, c_int64_p]),

@@ -17,4 +17,8 @@ struct pgx_comm {
                    size_t n_recv_lo, size_t send_hi, size_t n_send_hi, size_t recv_hi, size_t n_recv_hi) = 0;
   // in-place sum over all ranks of n doubles in device memory; identical result on every rank
   virtual int allreduce(hipStream_t st, double* dev, size_t n) = 0;
+  // rank r > 0 sends n doubles to rank 0, which receives them at recv0 + r*n (slot 0 of recv0 is not touched)
+  virtual int gather0(hipStream_t st, const double* send, size_t n, double* recv0) = 0;
+  // rank 0 sends send0 + r*n to every rank r > 0, which receives n doubles at recv
+  virtual int scatter0(hipStream_t st, const double* send0, size_t n, double* recv) = 0;
 };

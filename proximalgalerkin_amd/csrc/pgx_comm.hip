@@ -112,6 +112,34 @@ struct RcclComm : pgx_comm {
     if (r != ncclSuccess) return fail("ncclAllReduce", r);
     return PGX_OK;
   }
+  int gather0(hipStream_t st, const double* send, size_t n, double* recv0) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    ncclResult_t r = a->GroupStart();
+    if (r != ncclSuccess) return fail("ncclGroupStart", r);
+    if (rank == 0) {
+      for (int q = 1; q < size && r == ncclSuccess; ++q) r = a->Recv(recv0 + (size_t)q * n, n, ncclDouble, q, c, st);
+    } else {
+      r = a->Send(send, n, ncclDouble, 0, c, st);
+    }
+    const ncclResult_t r2 = a->GroupEnd();
+    if (r != ncclSuccess) return fail("ncclSend/ncclRecv (gather0)", r);
+    if (r2 != ncclSuccess) return fail("ncclGroupEnd", r2);
+    return PGX_OK;
+  }
+  int scatter0(hipStream_t st, const double* send0, size_t n, double* recv) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    ncclResult_t r = a->GroupStart();
+    if (r != ncclSuccess) return fail("ncclGroupStart", r);
+    if (rank == 0) {
+      for (int q = 1; q < size && r == ncclSuccess; ++q) r = a->Send(send0 + (size_t)q * n, n, ncclDouble, q, c, st);
+    } else {
+      r = a->Recv(recv, n, ncclDouble, 0, c, st);
+    }
+    const ncclResult_t r2 = a->GroupEnd();
+    if (r != ncclSuccess) return fail("ncclSend/ncclRecv (scatter0)", r);
+    if (r2 != ncclSuccess) return fail("ncclGroupEnd", r2);
+    return PGX_OK;
+  }
 };
 }  // namespace
 
@@ -180,6 +208,9 @@ struct LocalShared {
     int nf = 0;
     size_t send_lo = 0, n_send_lo = 0, send_hi = 0, n_send_hi = 0;
     std::vector<double> red;
+    const double* p2p_src = nullptr;  // gather0: a rank's send buffer; scatter0: rank 0's send0
+    double* p2p_dst = nullptr;        // scatter0: a rank's receive buffer
+    size_t p2p_n = 0;
   };
   std::vector<Pub> pub;
   // all ranks arrive or the group is declared broken (a peer returned early with an error): no silent hang
@@ -280,6 +311,52 @@ struct LocalComm : pgx_comm {
 };
 }  // namespace
 
+namespace {
+struct LocalCommP2P : LocalComm {
+  int gather0(hipStream_t st, const double* send, size_t n, double* recv0) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    hipError_t e = hipStreamSynchronize(st);  // my buffer is final before rank 0 reads it
+    if (e != hipSuccess) return hipfail(e);
+    s->pub[rank].p2p_src = send;
+    s->pub[rank].p2p_n = n;
+    if (!s->barrier()) return dead();
+    if (rank == 0) {
+      for (int q = 1; q < size && e == hipSuccess; ++q) {
+        if (s->pub[q].p2p_n != n) {
+          err = "local group: gather0 lengths of the ranks disagree";
+          return PGX_ECOMM;
+        }
+        e = hipMemcpyAsync(recv0 + (size_t)q * n, s->pub[q].p2p_src, n * sizeof(double), hipMemcpyDefault, st);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return hipfail(e);
+    }
+    if (!s->barrier()) return dead();  // rank 0 has read every buffer
+    return PGX_OK;
+  }
+  int scatter0(hipStream_t st, const double* send0, size_t n, double* recv) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(e);
+    s->pub[rank].p2p_src = send0;
+    s->pub[rank].p2p_dst = recv;
+    s->pub[rank].p2p_n = n;
+    if (!s->barrier()) return dead();
+    if (rank != 0) {
+      if (s->pub[0].p2p_n != n) {
+        err = "local group: scatter0 lengths of the ranks disagree";
+        return PGX_ECOMM;
+      }
+      e = hipMemcpyAsync(recv, s->pub[0].p2p_src + (size_t)rank * n, n * sizeof(double), hipMemcpyDefault, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return hipfail(e);
+    }
+    if (!s->barrier()) return dead();
+    return PGX_OK;
+  }
+};
+}  // namespace
+
 extern "C" int pgx_comm_local_group(int size, pgx_comm** out) {
   if (size < 1 || !out) {
     g_comm_error = "pgx_comm_local_group: bad argument";
@@ -289,7 +366,7 @@ extern "C" int pgx_comm_local_group(int size, pgx_comm** out) {
   s->n = size;
   s->pub.resize(size);
   for (int r = 0; r < size; ++r) {
-    LocalComm* c = new LocalComm();
+    LocalComm* c = new LocalCommP2P();
     c->rank = r;
     c->size = size;
     c->s = s;

@@ -19,6 +19,7 @@
 
 #include "../../include/pgx.h"
 #include "../../include/pgx_nd.h"
+#include "pgx_comm.h"
 
 struct MixedBase {
   int device = 0;
@@ -32,6 +33,10 @@ struct MixedBase {
   double* h_out = nullptr;  // pinned
   std::vector<int32_t> h_rowptr, h_col;
   pgx_nd* lu = nullptr;
+  // distributed handles (one per GPU, replicated iterate, distributed LU): every scalar that steers control flow - norms,
+  // dot products of the line search - is taken from rank 0, so that all ranks make the same collective calls even though
+  // their redundantly assembled residuals differ in the last bits (atomics)
+  pgx_comm* comm = nullptr;
   bool jac_valid = false;
   bool prof = false;
   double ms[6] = {0, 0, 0, 0, 0, 0};  // [0] residual [1] jacobian [2] LU factor [3] LU solves [4] spmv [5] Newton total
@@ -147,9 +152,22 @@ static void mx_par_for(int64_t n, const std::function<void(int64_t, int64_t)>& f
   for (auto& t : th) t.join();
 }
 
+// d_out[0] <- rank 0's value on every rank (no-op on a single handle)
+static int mx_sync_scalar(MixedBase* h) {
+  if (!h->comm || h->comm->size == 1) return PGX_OK;
+  if (h->comm->rank != 0) MXHIP(hipMemsetAsync(h->d_out, 0, sizeof(double), h->st));
+  const int rc = h->comm->allreduce(h->st, h->d_out, 1);
+  if (rc) h->err = "scalar synchronisation: " + h->comm->err;
+  return rc;
+}
+
 static int mx_norm(MixedBase* h, const double* v, double* out, int64_t len = 0) {
   hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, len ? len : h->ntot, v, v, h->partials);
   hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+  {
+    const int rcs = mx_sync_scalar(h);
+    if (rcs) return rcs;
+  }
   MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
   MXHIP(hipStreamSynchronize(h->st));
   *out = std::sqrt(h->h_out[0]);
@@ -358,6 +376,10 @@ static __global__ __launch_bounds__(256) void k_mx_final_max(int nb, const doubl
 static int mx_dot(MixedBase* h, const double* a, const double* b, double* out) {
   hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, h->ntot, a, b, h->partials);
   hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+  {
+    const int rcs = mx_sync_scalar(h);
+    if (rcs) return rcs;
+  }
   MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
   MXHIP(hipStreamSynchronize(h->st));
   *out = h->h_out[0];
@@ -427,6 +449,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
     if (initslope == 0.0) initslope = -1.0;
     hipLaunchKernelGGL(k_mx_relmax, dim3(MX_RED), dim3(256), 0, h->st, h->ntot, h->dx, h->xw, h->partials);
     hipLaunchKernelGGL(k_mx_final_max, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+    if ((rc = mx_sync_scalar(h))) return rc;
     MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
     MXHIP(hipStreamSynchronize(h->st));
     rellength = h->h_out[0];

@@ -34,6 +34,7 @@
 
 #include "../../include/pgx.h"
 #include "../../include/pgx_nd.h"
+#include "pgx_comm.h"
 
 static thread_local std::string g_nd_error;
 
@@ -62,6 +63,14 @@ struct pgx_nd {
   int32_t *d_fp = nullptr, *d_fb = nullptr, *d_parent = nullptr, *d_slot01 = nullptr, *d_child0 = nullptr,
           *d_child1 = nullptr, *d_own_dofs = nullptr, *d_rel = nullptr, *d_fM = nullptr, *d_fP = nullptr;
   int* d_info = nullptr;  // [0] = number of (near-)zero pivots met by the last factorisation
+  // distributed factorisation (pgx_nd_create_dist): the 2^kdist subtrees below tree depth kdist live on one rank each,
+  // the levels above on rank 0, which also holds GHOST copies of the other ranks' subtree-root fronts (identity pivot
+  // block; their Schur block / border vector arrives through pgx_comm::gather0, leaves through scatter0)
+  pgx_comm* comm = nullptr;
+  int rank = 0, size = 1, kdist = 0;
+  int root_slot = -1;             // this rank's subtree-root front (depth kdist)
+  std::vector<int> ghost_slot;    // rank 0: slot of rank j's subtree-root front (index j; [0] unused)
+  double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
   double factor_ms = 0, solve_ms = 0;
@@ -195,6 +204,7 @@ struct Symbolic {
 }  // namespace
 
 static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
+  const int drank = s->rank, dsize = s->size;
   Symbolic S;
   S.A = A;
   S.n = A->n;
@@ -264,21 +274,58 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
       std::sort(b.begin(), b.end(), [&](int32_t a, int32_t c) { return node_pos[a] < node_pos[c]; });
     }
   }
-  // levels by depth; slots ordered by postorder inside a level
+  // distribution: state[t] = 0 not on this rank, 1 owned, 2 ghost (rank 0's copy of another rank's subtree root)
+  int kd = 0;
+  while ((1 << kd) < dsize) ++kd;
+  if ((1 << kd) != dsize) {
+    s->err = "distributed factorisation needs a power-of-two number of ranks";
+    return PGX_EINVAL;
+  }
+  s->kdist = kd;
+  std::vector<uint8_t> state(nt, 1);
+  if (dsize > 1) {
+    std::vector<int> owner(nt, -1);
+    int next_sub = 0;
+    for (int t : post) {  // postorder visits the depth-kd nodes left to right
+      if (T[t].depth < kd && (T[t].child[0] < 0 || T[t].child[1] < 0)) {
+        s->err = "matrix too small to distribute over this many ranks (the dissection tree is shallower than log2(size))";
+        return PGX_EINVAL;
+      }
+      if (T[t].depth == kd) owner[t] = next_sub++;
+    }
+    if (next_sub != dsize) {
+      s->err = "distributed factorisation: unexpected number of subtrees";
+      return PGX_EINVAL;
+    }
+    for (int t = 0; t < nt; ++t)  // tree ids are assigned parent-before-child
+      if (T[t].depth > kd) owner[t] = owner[T[t].parent];
+    s->ghost_slot.assign(dsize, -1);
+    for (int t = 0; t < nt; ++t) {
+      if (T[t].depth < kd)
+        state[t] = drank == 0 ? 1 : 0;
+      else if (owner[t] == drank)
+        state[t] = 1;
+      else
+        state[t] = (drank == 0 && T[t].depth == kd) ? 2 : 0;
+    }
+  }
+  // levels by depth; slots ordered by postorder inside a level; only the fronts living on this rank get a slot
   int maxd = 0;
   for (auto& t : T) maxd = std::max(maxd, t.depth);
   const int L = maxd + 1;
   s->lev.assign(L, NdLevel());
-  std::vector<int> slot_of(nt);
+  std::vector<int> slot_of(nt, -1);
   auto ndofs = [&](int32_t g) { return (int)(S.nd_ptr[g + 1] - S.nd_ptr[g]); };
   std::vector<int> tp(nt), tb(nt);
+  int nloc = 0;
   for (int t = 0; t < nt; ++t) {
     int p = 0, b = 0;
     for (int32_t g : T[t].own) p += ndofs(g);
     for (int32_t g : T[t].border) b += ndofs(g);
-    tp[t] = p, tb[t] = b;
-    s->lev[T[t].depth].count++;
-    s->lev[T[t].depth].P = std::max(s->lev[T[t].depth].P, p);
+    tp[t] = state[t] == 2 ? 0 : p;  // a ghost eliminates nothing here
+    tb[t] = b;
+    if (state[t]) s->lev[T[t].depth].count++, ++nloc;
+    s->lev[T[t].depth].P = std::max(s->lev[T[t].depth].P, p);  // padding is the same on every rank
     s->lev[T[t].depth].B = std::max(s->lev[T[t].depth].B, b);
   }
   int64_t off = 0, voff = 0, start = 0;
@@ -295,30 +342,33 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     start += Lv.count;
     double P = Lv.P, B = Lv.B;
     s->stats.flops_padded += Lv.count * (2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B);
-    s->stats.max_front = std::max<int64_t>(s->stats.max_front, M);
+    if (Lv.count) s->stats.max_front = std::max<int64_t>(s->stats.max_front, M);
   }
   s->arena_len = off;
   s->vec_len = voff;
-  s->nfronts = nt;
-  s->stats.n_fronts = nt;
+  s->nfronts = nloc;
+  s->stats.n_fronts = nloc;
   s->stats.n_levels = L;
   s->stats.arena_doubles = off;
   {
     std::vector<int64_t> next(L);
     for (int l = 0; l < L; ++l) next[l] = s->lev[l].start;
-    for (int t : post) slot_of[t] = (int)next[T[t].depth]++;
+    for (int t : post)
+      if (state[t]) slot_of[t] = (int)next[T[t].depth]++;
   }
-  s->fp.assign(nt, 0);
-  s->fb.assign(nt, 0);
-  s->parent.assign(nt, -1);
-  s->slot01.assign(nt, 0);
-  s->child0.assign(nt, -1);
-  s->child1.assign(nt, -1);
-  s->flevel.assign(nt, 0);
-  s->fbase.assign(nt, 0);
-  s->dof_ptr.assign(nt + 1, 0);
-  s->rel_ptr.assign(nt + 1, 0);
-  for (int t = 0; t < nt; ++t) {
+  const int nt_all = nt;
+  s->fp.assign(nloc, 0);
+  s->fb.assign(nloc, 0);
+  s->parent.assign(nloc, -1);
+  s->slot01.assign(nloc, 0);
+  s->child0.assign(nloc, -1);
+  s->child1.assign(nloc, -1);
+  s->flevel.assign(nloc, 0);
+  s->fbase.assign(nloc, 0);
+  s->dof_ptr.assign(nloc + 1, 0);
+  s->rel_ptr.assign(nloc + 1, 0);
+  for (int t = 0; t < nt_all; ++t) {
+    if (!state[t]) continue;
     int f = slot_of[t];
     s->fp[f] = tp[t];
     s->fb[f] = tb[t];
@@ -326,21 +376,34 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     const NdLevel& Lv = s->lev[T[t].depth];
     int64_t M = Lv.P + Lv.B;
     s->fbase[f] = Lv.off + (f - Lv.start) * M * M;
-    if (T[t].parent >= 0) s->parent[f] = slot_of[T[t].parent];
+    if (T[t].parent >= 0 && slot_of[T[t].parent] >= 0) s->parent[f] = slot_of[T[t].parent];
     for (int c = 0; c < 2; ++c)
-      if (T[t].child[c] >= 0) {
+      if (T[t].child[c] >= 0 && slot_of[T[t].child[c]] >= 0) {
         (c == 0 ? s->child0 : s->child1)[f] = slot_of[T[t].child[c]];
         s->slot01[slot_of[T[t].child[c]]] = c;
       }
     s->dof_ptr[f + 1] = tp[t];
     s->rel_ptr[f + 1] = tb[t];
-    double p = tp[t], b = tb[t];
-    s->stats.flops += 2.0 / 3 * p * p * p + 2 * p * p * b + 2 * p * b * b;
-    s->stats.factor_nnz += (int64_t)(p * p + 2 * p * b);
+    if (dsize > 1 && T[t].depth == kd) {
+      if (state[t] == 1) s->root_slot = f;
+      // ghost_slot[j]: which rank owns this subtree root?  depth-kd nodes were numbered left to right above
+    }
+    if (state[t] == 1) {
+      double p = tp[t], b = tb[t];
+      s->stats.flops += 2.0 / 3 * p * p * p + 2 * p * p * b + 2 * p * b * b;
+      s->stats.factor_nnz += (int64_t)(p * p + 2 * p * b);
+    }
   }
-  for (int f = 0; f < nt; ++f) s->dof_ptr[f + 1] += s->dof_ptr[f], s->rel_ptr[f + 1] += s->rel_ptr[f];
-  s->own_dofs.resize(s->dof_ptr[nt]);
-  s->rel.resize(s->rel_ptr[nt]);
+  if (dsize > 1 && drank == 0) {
+    int j = 0;
+    for (int t : post)
+      if (T[t].depth == kd) s->ghost_slot[j++] = slot_of[t];
+  }
+  const int nt_loop = nloc;
+  (void)nt_loop;
+  for (int f = 0; f < nloc; ++f) s->dof_ptr[f + 1] += s->dof_ptr[f], s->rel_ptr[f + 1] += s->rel_ptr[f];
+  s->own_dofs.resize(s->dof_ptr[nloc]);
+  s->rel.resize(s->rel_ptr[nloc]);
   s->nnz = A->rowptr[n];
   s->dest.assign(s->nnz, -1);
   // local indices, child -> parent maps, assembly destinations
@@ -352,6 +415,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     return (it != e && *it == colv) ? (int64_t)(it - A->col) : -1;
   };
   for (int t : post) {
+    if (state[t] != 1) continue;  // ghosts are neither assembled nor eliminated here; their maps into the parent are built below
     const int f = slot_of[t];
     const NdLevel& Lv = s->lev[T[t].depth];
     const int64_t M = Lv.P + Lv.B;
@@ -373,7 +437,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
       }
     for (int c = 0; c < 2; ++c) {
       int ct = T[t].child[c];
-      if (ct < 0) continue;
+      if (ct < 0 || slot_of[ct] < 0) continue;
       int64_t r = s->rel_ptr[slot_of[ct]];
       for (int32_t g : T[ct].border)
         for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
@@ -406,11 +470,12 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
         }
       }
   }
-  for (int64_t e = 0; e < s->nnz; ++e)
-    if (s->dest[e] < 0) {
-      s->err = "matrix pattern is not structurally symmetric (or columns are not sorted)";
-      return PGX_EINVAL;
-    }
+  if (dsize == 1)  // (on a distributed handle the entries of other ranks' fronts legitimately stay unassigned)
+    for (int64_t e = 0; e < s->nnz; ++e)
+      if (s->dest[e] < 0) {
+        s->err = "matrix pattern is not structurally symmetric (or columns are not sorted)";
+        return PGX_EINVAL;
+      }
   return PGX_OK;
 }
 
@@ -421,7 +486,10 @@ __global__ void k_nd_scatter(int64_t nnz, const int64_t* __restrict__ dest, cons
                              double* __restrict__ arena) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; k < nnz; k += stride) arena[dest[k]] = __builtin_nontemporal_load(vals + k);
+  for (; k < nnz; k += stride) {
+    const int64_t d = dest[k];
+    if (d >= 0) arena[d] = __builtin_nontemporal_load(vals + k);  // < 0: the entry lives in another rank's front
+  }
 }
 
 // identity on the padded part of every pivot block
@@ -455,6 +523,19 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
   }
 }
 
+// Schur block of one front <-> contiguous B x B buffer (exchange between ranks)
+__global__ void k_nd_pack(const double* __restrict__ F, int M, int P, int B, double* __restrict__ buf, int unpack) {
+  const int64_t total = (int64_t)B * B;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / B), r = (int)(idx - (int64_t)c * B);
+    double* e = const_cast<double*>(F) + (int64_t)(P + c) * M + P + r;
+    if (unpack)
+      *e = buf[idx];
+    else
+      buf[idx] = *e;
+  }
+}
+
 // forward assembly of the per-front vectors of one level: own part from the right-hand side, border part from the children
 __global__ void k_nd_fwd_assemble(int64_t f0, int P, int M, const int32_t* __restrict__ fp, const int32_t* __restrict__ fb,
                                   const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
@@ -483,6 +564,7 @@ __global__ void k_nd_bwd_gather(int64_t f0, int P, const int32_t* __restrict__ f
                                 const int64_t* __restrict__ vbase, const int64_t* __restrict__ rel_ptr,
                                 const int32_t* __restrict__ rel, double* __restrict__ vec) {
   const int64_t f = f0 + blockIdx.x;
+  if (parent[f] < 0) return;  // subtree root of a distributed factorisation: its border values arrive from rank 0
   double* w = vec + vbase[f] + P;
   const double* wp = vec + vbase[parent[f]];
   const int32_t* R = rel + rel_ptr[f];
@@ -905,7 +987,7 @@ static int nd_alloc(pgx_nd* s, T** d, size_t count) {
   return PGX_OK;
 }
 
-extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream, pgx_nd** out) {
+static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, void* hip_stream, pgx_nd** out) {
   if (!A || !out || A->n <= 0 || !A->rowptr || !A->col || !A->node_of_dof || !A->node_coords || A->n_nodes <= 0 ||
       (A->dim != 2 && A->dim != 3)) {
     g_nd_error = "pgx_nd_create: bad arguments";
@@ -913,6 +995,7 @@ extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_strea
   }
   pgx_nd* s = new pgx_nd();
   s->n = A->n;
+  if (comm) s->comm = comm, s->rank = comm->rank, s->size = comm->size;
   int rc = nd_symbolic(s, A);
   if (rc) {
     g_nd_error = s->err;
@@ -971,9 +1054,29 @@ extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_strea
   if ((rc = nd_alloc(s, &s->d_info, (size_t)maxbatch))) return fail(rc);
   hipEventCreate(&s->e0);
   hipEventCreate(&s->e1);
-  // the dest map is only needed on the device from here on
+  if (s->size > 1) {  // exchange buffers: one Schur block / border vector per rank on rank 0, one on the others
+    const NdLevel& Lk = s->lev[s->kdist];
+    const size_t nb = (size_t)Lk.B * Lk.B, mult = s->rank == 0 ? (size_t)s->size : 1;
+    if ((rc = nd_alloc(s, &s->d_xbuf, mult * nb)) || (rc = nd_alloc(s, &s->d_vbuf, mult * (size_t)Lk.B))) return fail(rc);
+  }
   *out = s;
   return PGX_OK;
+}
+
+extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream, pgx_nd** out) {
+  return nd_create_impl(A, nullptr, device, hip_stream, out);
+}
+
+extern "C" int pgx_nd_create_dist(const pgx_nd_matrix* A, pgx_comm* comm, int device, void* hip_stream, pgx_nd** out) {
+  if (!comm) {
+    g_nd_error = "pgx_nd_create_dist: null communicator";
+    return PGX_EINVAL;
+  }
+  if (device < 0) {
+    g_nd_error = "pgx_nd_create_dist needs a device";
+    return PGX_EINVAL;
+  }
+  return nd_create_impl(A, comm, device, hip_stream, out);
 }
 
 extern "C" void pgx_nd_destroy(pgx_nd* s) {
@@ -1042,7 +1145,8 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   for (int l = L - 1; l >= 0; --l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
-    if (l + 1 < L) {
+    if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
+    if (l + 1 < L && s->lev[l + 1].count > 0) {
       const NdLevel& C = s->lev[l + 1];
       if (C.B > 0) {
         int64_t per = (int64_t)C.B * C.B;
@@ -1083,6 +1187,21 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       ob = oe;
     }
     if (B > 0) nd_launch_gemm(s, Lv, P, M, P, M, 0, P);
+    if (s->size > 1 && l == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
+      const size_t nb = (size_t)B * B;
+      const unsigned pb = (unsigned)std::min<size_t>((nb + 255) / 256, 65535);
+      if (s->rank != 0)
+        hipLaunchKernelGGL(k_nd_pack, dim3(pb), dim3(256), 0, s->st, s->arena + s->fbase[s->root_slot], M, P, B, s->d_xbuf, 0);
+      int rcx = s->comm->gather0(s->st, s->d_xbuf, nb, s->d_xbuf);
+      if (rcx) {
+        s->err = "distributed factorisation: " + s->comm->err;
+        return rcx;
+      }
+      if (s->rank == 0)
+        for (int j = 1; j < s->size; ++j)
+          hipLaunchKernelGGL(k_nd_pack, dim3(pb), dim3(256), 0, s->st, s->arena + s->fbase[s->ghost_slot[j]], M, P, B,
+                             s->d_xbuf + (size_t)j * nb, 1);
+    }
   }
   if (s->timing) {
     hipEventRecord(s->e1, s->st);
@@ -1120,6 +1239,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
   for (int l = L - 1; l >= 0; --l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
+    if (Lv.count == 0) continue;
     hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, M, s->d_fp, s->d_fb,
                        s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
                        db, s->vec);
@@ -1132,13 +1252,38 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
         hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + 255) / 256)), dim3(256), 0, s->st, s->arena,
                            Lv.off, s->vec, Lv.voff, M, k1, M, k0, k1);
     }
+    if (s->size > 1 && l == s->kdist && B > 0) {  // border contributions of the subtree roots -> rank 0's ghost fronts
+      const int64_t vb = Lv.voff + (int64_t)(s->root_slot - Lv.start) * M + P;
+      int rcx = s->comm->gather0(s->st, s->vec + vb, (size_t)B, s->d_vbuf);
+      if (rcx) {
+        s->err = "distributed solve: " + s->comm->err;
+        return rcx;
+      }
+      if (s->rank == 0)
+        for (int j = 1; j < s->size; ++j)
+          NDHIP(hipMemcpyAsync(s->vec + Lv.voff + (int64_t)(s->ghost_slot[j] - Lv.start) * M + P, s->d_vbuf + (size_t)j * B,
+                               sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
+    }
   }
   for (int l = 0; l < L; ++l) {
     const NdLevel& Lv = s->lev[l];
     const int P = Lv.P, B = Lv.B, M = P + B;
+    if (Lv.count == 0) continue;
     if (B > 0) {
       hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
                          s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
+      if (s->size > 1 && l == s->kdist) {  // border values of the other ranks' subtree roots leave rank 0
+        if (s->rank == 0)
+          for (int j = 1; j < s->size; ++j)
+            NDHIP(hipMemcpyAsync(s->d_vbuf + (size_t)j * B, s->vec + Lv.voff + (int64_t)(s->ghost_slot[j] - Lv.start) * M + P,
+                                 sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
+        const int64_t vb = Lv.voff + (int64_t)(s->root_slot - Lv.start) * M + P;
+        int rcx = s->comm->scatter0(s->st, s->d_vbuf, (size_t)B, s->vec + vb);
+        if (rcx) {
+          s->err = "distributed solve: " + s->comm->err;
+          return rcx;
+        }
+      }
       hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, s->st, s->arena,
                          Lv.off, s->vec, Lv.voff, M, 0, P, P, M);
     }
@@ -1151,8 +1296,16 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
                            Lv.off, s->vec, Lv.voff, M, 0, k0, k0, k1);
     }
   }
+  if (s->size > 1) NDHIP(hipMemsetAsync(dx, 0, sizeof(double) * s->n, s->st));  // every rank writes its own dofs only
   hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
                      s->d_dof_ptr, s->d_own_dofs, s->vec, dx);
+  if (s->size > 1) {
+    int rcx = s->comm->allreduce(s->st, dx, (size_t)s->n);
+    if (rcx) {
+      s->err = "distributed solve: " + s->comm->err;
+      return rcx;
+    }
+  }
   if (s->timing) {
     hipEventRecord(s->e1, s->st);
     hipEventSynchronize(s->e1);

@@ -219,10 +219,11 @@ void pgx_sg_handle::jacobian_dev(const double* xin) {
   h->jac_valid = true;
 }
 
-static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_problem* p) {
+static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm) {
   const int nv = m->n_vertices, nc = m->n_cells, nf = m->n_facets;
   const int nu = 3 * nv;
   h->nv = nv, h->nc = nc, h->nf = nf;
+  h->comm = comm;
   h->gap = p->gap;
   h->mu = p->E / (2.0 * (1.0 + p->nu));
   h->lmbda = p->E * p->nu / ((1.0 + p->nu) * (1.0 - 2.0 * p->nu));
@@ -403,7 +404,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   A.node_coords = m->coords;
   A.leaf_nodes = 0;
   if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
-  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  int rc = comm ? pgx_nd_create_dist(&A, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
     h->lu = nullptr;
@@ -459,7 +460,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   return PGX_OK;
 }
 
-extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
+static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device, pgx_sg_handle** out) {
   if (!m || !p || !out || !m->coords || !m->cells || m->n_vertices <= 0 || m->n_cells <= 0 || m->n_facets < 0 ||
       (m->n_facets > 0 && !m->facets) || !p->qpts || !p->qwts || p->nq <= 0 || p->nq > SG_MAXQ ||
       (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5)) {
@@ -477,7 +478,7 @@ extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int 
   }
   pgx_sg_handle* h = new pgx_sg_handle();
   h->device = device;
-  int rc = sg_create_impl(h, m, p);
+  int rc = sg_create_impl(h, m, p, comm);
   if (rc) {
     g_sg_error = h->err;
     pgx_sg_destroy(h);
@@ -485,6 +486,18 @@ extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int 
   }
   *out = h;
   return PGX_OK;
+}
+
+extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
+  return sg_create(m, p, nullptr, device, out);
+}
+extern "C" int pgx_sg_create_dist(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device,
+                                  pgx_sg_handle** out) {
+  if (!comm) {
+    g_sg_error = "pgx_sg_create_dist: null communicator";
+    return PGX_EINVAL;
+  }
+  return sg_create(m, p, comm, device, out);
 }
 
 #define SGNEED(h)              \

@@ -15,7 +15,9 @@ from . import _lib as L
 
 
 class DirectSolver:
-    def __init__(self, indptr, indices, node_of_dof, node_coords, leaf_nodes: int = 0, device: int = 0):
+    def __init__(self, indptr, indices, node_of_dof, node_coords, leaf_nodes: int = 0, device: int = 0, comm=None):
+        """comm: a proximalgalerkin_amd.comm.Communicator -> distributed factorisation (pgx_nd_create_dist): one subtree of
+        the dissection tree per rank; every rank passes the same matrix / right-hand sides, all calls are collective."""
         self._lib = L.load()
         self._h = L._H()
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
@@ -26,7 +28,11 @@ class DirectSolver:
         m = L.pgx_nd_matrix(self.n, L.iptr(self.indptr), L.iptr(self.indices), int(self.node_coords.shape[0]),
                             L.iptr(self.node_of_dof), int(self.node_coords.shape[1]), L.dptr(self.node_coords),
                             int(leaf_nodes))
-        rc = self._lib.pgx_nd_create(C.byref(m), int(device), None, C.byref(self._h))
+        if comm is None:
+            rc = self._lib.pgx_nd_create(C.byref(m), int(device), None, C.byref(self._h))
+        else:
+            self._comm = comm  # keep the communicator alive
+            rc = self._lib.pgx_nd_create_dist(C.byref(m), comm._c, int(device), None, C.byref(self._h))
         if rc:
             msg = self._lib.pgx_nd_last_error(None)
             raise L.PgxError(f"pgx_nd_create failed (code {rc}): {msg.decode() if msg else ''}")

@@ -78,7 +78,7 @@ def native_tags(mesh: TetMesh) -> tuple[MeshTags, dict]:
 class SignoriniProblem:
     """x = [u_x | u_y | u_z | psi (contact vertices ordered by vertex id)]."""
 
-    def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0):
+    def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None):
         self._lib = lib = _lib.load()
         self.mesh = mesh
         nv = mesh.geometry.shape[0]
@@ -93,7 +93,11 @@ class SignoriniProblem:
         pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
                                  _lib.iptr(bc), _lib.dptr(vals))
         self._h = C.c_void_p()
-        rc = lib.pgx_sg_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+        if comm is None:
+            rc = lib.pgx_sg_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+        else:  # one handle per GPU, distributed sparse LU (include/pgx_sg.h); every call below is collective
+            self._comm = comm
+            rc = lib.pgx_sg_create_dist(C.byref(pm), C.byref(pp), comm._c, int(device), C.byref(self._h))
         if rc:
             msg = lib.pgx_sg_last_error(None)
             raise _lib.PgxError(f"pgx_sg_create failed (code {rc}): {msg.decode() if msg else ''}")
@@ -193,14 +197,15 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
                           nu: float = 0.3, gap: float = 0.0, disp: float = -0.25, newton_max_its: int = 250,
                           newton_tol: float = 1e-6, max_iterations: int = 25, alpha_scheme: AlphaScheme = "doubling",
                           alpha_0: float = 1.0, alpha_c: float = 1.0, tol: float = 1e-6, output: Path | None = None,
-                          quadrature_degree: int = 4, verbose: bool = True, return_solution: bool = False, device: int = 0):
+                          quadrature_degree: int = 4, verbose: bool = True, return_solution: bool = False, device: int = 0,
+                          comm=None):
     """signorini_dolfinx.solve_contact_problem (:156-360): returns (it, iterations) [, final state, problem data]."""
     if degree != 1:
         raise NotImplementedError("HIP backend: degree 1 (BASELINE.json config 5); the reference's default is 2")
     contact = np.concatenate([facet_tag.find(t) for t in boundary_conditions["contact"]])  # :186-189
     bc_facets = np.concatenate([facet_tag.find(t) for t in boundary_conditions["displacement"]])  # :265-266
     bc_vertices = np.unique(bc_facets.ravel())
-    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device)
+    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device, comm=comm)
     iterations = []
     normed_diff = -1.0
     it = 0

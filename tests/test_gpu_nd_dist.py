@@ -1,0 +1,116 @@
+"""Distributed sparse LU (pgx_nd_create_dist) and the distributed example-02 handle (pgx_sg_create_dist), driven on ONE
+GPU through the in-process transport (pgx_comm_local_group: one host thread per rank; gpurun boxes have a single GPU and
+RCCL refuses two ranks on one device).  The same code path runs over RCCL with one process per GPU.
+Checks: every rank returns the solution of the single-handle factorisation to rounding; example 02 on 2 and 4 ranks
+reproduces the single-GPU LVPP run (Newton counts, displacement <= 1e-10)."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import pg_oracle as O
+from oracle import sg_oracle as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(comms, fn):
+    out, err = [None] * len(comms), [None] * len(comms)
+
+    def work(r):
+        try:
+            out[r] = fn(comms[r])
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(comms))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_distributed_lu_matches_superlu(require_gpu, R):
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    N = 40
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    its = []
+    O.solve_problem(p1, 500, "double_exponential", 1e2, 1e-4, iterates=its)
+    J = p1.jacobian(its[-2], 100.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p1.n)] * 2)
+    rng = np.random.default_rng(2)
+    bs = [rng.standard_normal(J.shape[0]) for _ in range(2)]
+    lu = spla.splu(J.tocsc())
+
+    def rank_main(c):
+        ds = DirectSolver(J.indptr, J.indices, nod, p1.coords, leaf_nodes=8, device=0, comm=c)
+        ds.factor(J.data)
+        xs = [ds.solve(b) for b in bs]
+        ds.factor(J.data * 2.0)  # refactorisation with new values on the same pattern
+        xs.append(ds.solve(bs[0]))
+        ds.close()
+        return xs
+
+    res = _run_ranks(pcomm.local_group(R), rank_main)
+    for xs in res:
+        for x, b in zip(xs[:2], bs):
+            xr = lu.solve(b)
+            assert np.linalg.norm(J @ x - b) <= 1e-13 * (abs(J).sum(axis=0).max() * np.linalg.norm(x) + np.linalg.norm(b))
+            assert np.linalg.norm(x - xr) <= 1e-7 * np.linalg.norm(xr)
+        assert np.linalg.norm(2.0 * xs[2] - xs[0]) <= 1e-12 * np.linalg.norm(xs[0])
+    for xs in res[1:]:  # every rank returns the same vectors
+        for a, b in zip(xs, res[0]):
+            assert np.array_equal(a, b)
+
+
+def test_too_few_levels_is_an_error(require_gpu):
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd._lib import PgxError
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    coords, cells = O.create_rectangle(2, 2)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(2, 2))
+    J = p1.jacobian(np.zeros(2 * p1.n), 1.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p1.n)] * 2)
+
+    def rank_main(c):
+        with pytest.raises(PgxError):
+            DirectSolver(J.indptr, J.indices, nod, p1.coords, leaf_nodes=64, device=0, comm=c)
+        return True
+
+    assert all(_run_ranks(pcomm.local_group(4), rank_main))
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_example02_distributed_run_matches_single_gpu(require_gpu, R):
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import signorini as G
+
+    n = (6, 6, 6)
+    mesh = G.create_unit_cube(*n)
+    mt, bcs = G.native_tags(mesh)
+    it1, its1, x1, _ = G.solve_contact_problem(mesh, mt, bcs, verbose=False, return_solution=True)
+
+    def rank_main(c):
+        return G.solve_contact_problem(mesh, mt, bcs, verbose=False, return_solution=True, comm=c)
+
+    for it, its, x, _ in _run_ranks(pcomm.local_group(R), rank_main):
+        assert it == it1 and list(its) == list(its1)
+        nu3 = 3 * mesh.geometry.shape[0]
+        assert np.linalg.norm(x[:nu3] - x1[:nu3]) <= 1e-10 * np.linalg.norm(x1[:nu3])
+    coords, cells = S.create_unit_cube_tets(*n)
+    prob = S.SignoriniP1(coords, cells, S.boundary_facets_where(coords, cells, lambda c: np.isclose(c[:, 2], 0.0)),
+                         np.flatnonzero(np.isclose(coords[:, 2], 1.0)))
+    x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
+    assert list(its1) == list(its_ref)

@@ -8,11 +8,25 @@ import numpy as np  # noqa: E402
 
 from proximalgalerkin_amd import signorini as G  # noqa: E402
 
+import os  # noqa: E402
+
 n = int(sys.argv[1])
 mesh = G.create_unit_cube(n, n, n)
 mt, bcs = G.native_tags(mesh)
+comm, device = None, 0
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 tools/sg_scaling.py 70
+    # one process per GPU, distributed sparse LU over RCCL (pgx_sg_create_dist); NOT executed on this pool's one-GPU
+    # boxes - the same code path runs in tests/test_gpu_nd_dist.py through the in-process transport
+    import torch.distributed as dist
+
+    from proximalgalerkin_amd import comm as pcomm
+
+    device = int(os.environ.get("LOCAL_RANK", "0"))
+    dist.init_process_group("gloo")
+    comm = pcomm.rccl_from_torch_distributed(device)
 t = time.perf_counter()
-problem = G.SignoriniProblem(mesh, mt.find(2), np.unique(mt.find(1).ravel()), 2.0e4, 0.3, 0.0, -0.25)
+problem = G.SignoriniProblem(mesh, mt.find(2), np.unique(mt.find(1).ravel()), 2.0e4, 0.3, 0.0, -0.25, device=device, comm=comm)
 print(f"n={n} tets={mesh.cells.shape[0]} dofs u={3 * problem.nv} psi={problem.npsi} setup {time.perf_counter() - t:.2f}s", flush=True)
 problem.profile(True)
 t = time.perf_counter()
