@@ -9,6 +9,10 @@ with its Newton iterations, observables and stopping test) from the zero state, 
 already resident in HBM.  `value` = Newton iterations per second over the timed K steps
 (BASELINE.json metric "proximal-Newton iterations/sec"); proximal iterations/s is reported beside it.
 
+`--workload ex06` / `--workload ex02` time BASELINE configs 4 and 5 instead (example 06 at --cells 1024, example 02 on
+--cells 70 cubes of 6 tetrahedra): same contract, `roofline` then describes the fp64-MFMA GEMM of the sparse LU
+(bound "mfma"); with N>1 example 02 runs ONE solve with the factorisation distributed over the ranks.
+
 N>1: one process per GPU under torch.distributed.run.  The SAME problem is cut into N horizontal strips (sharded
 path of include/pgx.h: RCCL halo exchange of ghost vertex rows + packed all-reduces), so the numbers at N = 1, 2, 4, 8
 are a strong-scaling series of one fixed workload; `--replicas` runs N independent solves instead (and says so).
@@ -68,6 +72,146 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
     return steps / dt, steps, dt
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (dense)
+
+
+def bench_lu_workload(args, rank, world, local_rank, dist, backend):
+    """BASELINE configs 4 (ex 06, gradient constraint) and 5 (ex 02, Signorini): a step = one full LVPP solve from the
+    zero state with the reference's default settings; the linear solves are the sparse LU of include/pgx_nd.h."""
+    import torch
+
+    comm = None
+    if world > 1:
+        from proximalgalerkin_amd.comm import rccl_from_torch_distributed
+
+        comm = rccl_from_torch_distributed(local_rank)
+    t_setup = time.perf_counter()
+    if args.workload == "ex06":
+        from proximalgalerkin_amd import fem
+        from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default
+
+        N = args.n if args.n != 2048 else 1024
+        problem = GradientConstraintProblem(fem.create_unit_square(N, N), phi_default, f_default, device=local_rank, comm=comm)
+        workload = (f"examples/06_gradient_constraints: {N}x{N} unit square, primal P2 / latent vector-P1 ({problem.ndofs} unknowns), "
+                    "phi = 0.1+0.2x+0.4y, f = 15 sin^2(pi x), alpha doubling from 1, tol 1e-8, SNES atol=rtol=stol=1e-9")
+
+        def one_step():
+            problem.set_state(np.zeros(problem.ndofs))
+            problem.set_prev(np.zeros(problem.ndofs))
+            its = []
+            for i in range(25):
+                problem.set_alpha(2.0**i)
+                its.append(problem.solve()[1])
+                if problem.l2_increment() < 1e-8:
+                    break
+                problem.advance_prev()
+            return its
+
+        def cpu_leg(budget):
+            from oracle import gc_oracle as G
+            from oracle import pg_oracle as O
+
+            c, e = O.create_rectangle(args.cpu_n // 8, args.cpu_n // 8, (0.0, 0.0), (1.0, 1.0))
+            prob = G.GradientConstraintP2(c, e)
+            t0 = time.perf_counter()
+            _, its, _ = G.solve_problem(prob)
+            return int(its.sum()), time.perf_counter() - t0, f"the full LVPP run on a {args.cpu_n // 8}x{args.cpu_n // 8} mesh ({prob.ntot} unknowns)"
+    else:
+        from proximalgalerkin_amd import signorini as G
+
+        n = args.n if args.n != 2048 else 70
+        mesh = G.create_unit_cube(n, n, n)
+        mt, _ = G.native_tags(mesh)
+        problem = G.SignoriniProblem(mesh, mt.find(2), np.unique(mt.find(1).ravel()), 2.0e4, 0.3, 0.0, -0.25, device=local_rank,
+                                     comm=comm)
+        workload = (f"examples/02_signorini: unit cube, {n}^3 x 6 = {mesh.cells.shape[0]} P1 tetrahedra ({problem.ndofs} unknowns), "
+                    "E 2e4, nu 0.3, disp -0.25, gap 0, alpha doubling, Newton tol 1e-6 (1e-5 first step), LVPP tol 1e-6")
+
+        def one_step():
+            problem.set_state(np.zeros(problem.ndofs))
+            problem.set_prev(np.zeros(problem.ndofs))
+            its = []
+            for it in range(1, 26):
+                problem.set_alpha(2.0**it)
+                tol = 1e-5 if it < 2 else 1e-6
+                problem.solver.setTolerances(atol=tol, rtol=tol)
+                its.append(problem.solve()[1])
+                if problem.u_increment() <= 1e-6:
+                    break
+                problem.advance_prev()
+            return its
+
+        def cpu_leg(budget):
+            from oracle import sg_oracle as S
+
+            m = 14
+            c, t = S.create_unit_cube_tets(m, m, m)
+            prob = S.SignoriniP1(c, t, S.boundary_facets_where(c, t, lambda x: np.isclose(x[:, 2], 0.0)),
+                                 np.flatnonzero(np.isclose(c[:, 2], 1.0)))
+            t0 = time.perf_counter()
+            _, _, its = S.solve_contact_problem(prob)
+            return int(sum(its)), time.perf_counter() - t0, f"the full LVPP run on {m}^3 x 6 tetrahedra ({prob.ntot} unknowns)"
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        its = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    newton_total = 0
+    for _ in range(args.steps):
+        its = one_step()
+        newton_total += int(sum(its))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dt, _, _ = reduce_over_ranks(dist, dt, newton_total, 0, "cuda" if backend == "nccl" else "cpu")
+    # roofline of the dominant kernel: one more solve with per-phase HIP-event timing (adds syncs: not part of `value`)
+    problem.profile(True)
+    its_p = one_step()
+    prof = problem.profile(False)
+    st = problem.lu_stats()
+    tflops = st["flops_padded"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
+    out = None
+    if rank == 0:
+        out = {
+            "metric": f"proximal-Newton iterations/sec, {args.workload} (LVPP Newton inner loop, sparse-LU linear solves)",
+            "value": newton_total / dt, "unit": "Newton iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "step": "one full LVPP solve from the zero state",
+                       "newton_iterations_per_step": newton_total / args.steps, "newton_per_lvpp_step": [int(i) for i in its],
+                       "parallelism": "single" if world == 1 else f"replicated iterate, sparse LU distributed over {world} ranks "
+                                                                   "(one dissection subtree each, RCCL gather/scatter + all-reduce)"},
+            "setup_s": t_setup,
+            "roofline": {"kernel": "k_nd_gemm<4>/<2> inside pgx_nd_factor (fp64 MFMA GEMM of the multifrontal LU; the figure is the "
+                                   "WHOLE factorisation: padded flops of this rank / its device time, panels and extend-add included)",
+                         "bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_padded_per_factorisation": st["flops_padded"], "arena_GB": st["arena_doubles"] * 8 / 1e9,
+                         "lu_factor_ms_per_newton_step": prof["lu_factor"] / max(sum(its_p), 1),
+                         "lu_solve_ms_per_newton_step": prof["lu_solve"] / max(sum(its_p), 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            steps, secs, what = cpu_leg(25.0)
+            out["cpu_baseline"] = {"value": steps / secs, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{steps} Newton steps ({secs:.1f} s) of {what}: numpy assembly + SuperLU exact "
+                                             "Newton, 1 thread (the oracle; a stand-in for, not a measurement of, FEniCSx+MUMPS)"}
+    problem.close()
+    if comm is not None:
+        comm.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def reduce_over_ranks(dist, dt, newton_total, outer_total, device):
     """Launch-contract aggregation: wall time = MAX over ranks, work counts = SUM over ranks (whole-job value)."""
     import torch
@@ -95,6 +239,8 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N>1: N independent solves instead of one sharded solve")
     ap.add_argument("--dist-levels", type=int, default=0, help="sharded: multigrid levels kept distributed (0 = auto)")
     ap.add_argument("--watchdog", type=float, default=900.0, help="N>1: abort the process after this many seconds")
+    ap.add_argument("--workload", choices=["ex01", "ex06", "ex02"], default="ex01",
+                    help="ex01 = BASELINE metric (config 2); ex06 / ex02 = configs 4 / 5 through the sparse LU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +266,9 @@ def main():
             dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+
+    if args.workload != "ex01":
+        return bench_lu_workload(args, rank, world, local_rank, dist, backend)
 
     from proximalgalerkin_amd import fem
     from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem

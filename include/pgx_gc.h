@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "pgx.h"
+#include "pgx_nd.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -48,6 +49,10 @@ typedef struct {
 
 /* mesh: pgx_mesh with cell_dofs / n_dofs set (P2); structured_nx/ny are ignored */
 int pgx_gc_create(const pgx_mesh* mesh, const pgx_gc_problem* prob, int device, pgx_gc_handle** out);
+/* one handle per GPU over a pgx_comm: replicated iterate and assembly, distributed sparse LU (see pgx_sg_create_dist) */
+int pgx_gc_create_dist(const pgx_mesh* mesh, const pgx_gc_problem* prob, pgx_comm* comm, int device, pgx_gc_handle** out);
+/* symbolic statistics of the handle's sparse LU (flop counts, arena size: include/pgx_nd.h) */
+int pgx_gc_lu_stats(const pgx_gc_handle* h, pgx_nd_stats* st);
 void pgx_gc_destroy(pgx_gc_handle* h);
 const char* pgx_gc_last_error(const pgx_gc_handle* h);
 int pgx_gc_num_dofs(const pgx_gc_handle* h, int64_t* ntot);

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "pgx.h"
+#include "pgx_nd.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -55,6 +56,8 @@ int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int devic
  * is distributed (pgx_nd_create_dist).  Replaces `mpirun -n N python signorini_dolfinx.py`; all calls are collective and
  * return identical results on every rank. */
 int pgx_sg_create_dist(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, pgx_comm* comm, int device, pgx_sg_handle** out);
+/* symbolic statistics of the handle's sparse LU (flop counts, arena size: include/pgx_nd.h) */
+int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st);
 void pgx_sg_destroy(pgx_sg_handle* h);
 const char* pgx_sg_last_error(const pgx_sg_handle* h);
 int pgx_sg_num_dofs(const pgx_sg_handle* h, int64_t* ntot, int64_t* npsi);

@@ -209,6 +209,8 @@ SYMBOLS = [
     ("pgx_nd_export_dest", C.c_int, [_H, c_int64_p, c_int64_p]),
     # example 06: gradient constraint, vector latent variable (include/pgx_gc.h)
     ("pgx_gc_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_gc_create_dist", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_gc_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
     ("pgx_gc_destroy", None, [_H]),
     ("pgx_gc_last_error", C.c_char_p, [_H]),
     ("pgx_gc_num_dofs", C.c_int, [_H, c_int64_p]),
@@ -229,6 +231,7 @@ SYMBOLS = [
     # example 02: Signorini contact (include/pgx_sg.h)
     ("pgx_sg_create", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.c_int, C.POINTER(_H)]),
     ("pgx_sg_create_dist", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_sg_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
     ("pgx_sg_destroy", None, [_H]),
     ("pgx_sg_last_error", C.c_char_p, [_H]),
     ("pgx_sg_num_dofs", C.c_int, [_H, c_int64_p, c_int64_p]),

@@ -298,7 +298,8 @@ extern "C" void pgx_gc_destroy(pgx_gc_handle* h) {
   delete h;
 }
 
-static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_problem* p) {
+static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_problem* p, pgx_comm* comm) {
+  h->comm = comm;
   const int nv = m->n_vertices, nc = m->n_cells, n2 = m->n_dofs;
   const int64_t ntot = (int64_t)n2 + 2 * (int64_t)nv;
   h->nv = nv, h->nc = nc, h->n2 = n2, h->ntot = ntot;
@@ -461,7 +462,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   A.node_coords = xy.data();
   A.leaf_nodes = 0;
   if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
-  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  int rc = comm ? pgx_nd_create_dist(&A, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
     h->lu = nullptr;
@@ -512,7 +513,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   return PGX_OK;
 }
 
-extern "C" int pgx_gc_create(const pgx_mesh* m, const pgx_gc_problem* p, int device, pgx_gc_handle** out) {
+static int gc_create(const pgx_mesh* m, const pgx_gc_problem* p, pgx_comm* comm, int device, pgx_gc_handle** out) {
   if (!m || !p || !out || !m->coords || !m->cells || !m->cell_dofs || m->n_dofs <= m->n_vertices || !p->qpts || !p->qwts ||
       !p->phi_dofs || !p->f_dofs || p->nq <= 0 || p->nq > GC_MAXQ || (p->n_bc > 0 && !p->bc_dofs)) {
     g_gc_error = "pgx_gc_create: bad arguments";
@@ -529,7 +530,7 @@ extern "C" int pgx_gc_create(const pgx_mesh* m, const pgx_gc_problem* p, int dev
   }
   pgx_gc_handle* h = new pgx_gc_handle();
   h->device = device;
-  int rc = gc_create_impl(h, m, p);
+  int rc = gc_create_impl(h, m, p, comm);
   if (rc) {
     g_gc_error = h->err;
     pgx_gc_destroy(h);
@@ -538,6 +539,18 @@ extern "C" int pgx_gc_create(const pgx_mesh* m, const pgx_gc_problem* p, int dev
   *out = h;
   return PGX_OK;
 }
+
+extern "C" int pgx_gc_create(const pgx_mesh* m, const pgx_gc_problem* p, int device, pgx_gc_handle** out) {
+  return gc_create(m, p, nullptr, device, out);
+}
+extern "C" int pgx_gc_create_dist(const pgx_mesh* m, const pgx_gc_problem* p, pgx_comm* comm, int device, pgx_gc_handle** out) {
+  if (!comm) {
+    g_gc_error = "pgx_gc_create_dist: null communicator";
+    return PGX_EINVAL;
+  }
+  return gc_create(m, p, comm, device, out);
+}
+extern "C" int pgx_gc_lu_stats(const pgx_gc_handle* h, pgx_nd_stats* st) { return h ? pgx_nd_get_stats(h->lu, st) : PGX_EINVAL; }
 
 #define GCNEED(h)                  \
   if (!(h)) return PGX_EINVAL;     \
@@ -672,6 +685,10 @@ extern "C" int pgx_gc_l2_increment(pgx_gc_handle* h, double* out) {
   if (!out) return PGX_EINVAL;
   hipLaunchKernelGGL(k_gc_l2, dim3(GC_RED), dim3(256), 0, h->st, h->nc, h->cdofs, h->coords, h->x, h->xk, h->Q, h->partials);
   hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
+  {
+    const int rcs = mx_sync_scalar(h);  // distributed handles: the loop's stopping test must agree on every rank
+    if (rcs) return rcs;
+  }
   GCHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
   GCHIP(hipStreamSynchronize(h->st));
   *out = std::sqrt(std::max(h->h_out[0], 0.0));

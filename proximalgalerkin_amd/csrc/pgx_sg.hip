@@ -491,6 +491,7 @@ static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* co
 extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
   return sg_create(m, p, nullptr, device, out);
 }
+extern "C" int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st) { return h ? pgx_nd_get_stats(h->lu, st) : PGX_EINVAL; }
 extern "C" int pgx_sg_create_dist(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device,
                                   pgx_sg_handle** out) {
   if (!comm) {

@@ -39,7 +39,7 @@ class GradientConstraintProblem:
     """Mixed space [P2, (P1)^2] on `mesh`; state layout x = [u (P2 dofs: vertices | edges) | psi_x | psi_y]."""
 
     def __init__(self, mesh: fem.Mesh, phi_func: Callable, f_func: Callable, petsc_options: dict | None = None,
-                 quadrature_degree: int = 10, device: int = 0):
+                 quadrature_degree: int = 10, device: int = 0, comm=None):
         self._lib = lib = _lib.load()
         self.mesh = mesh
         U = fem.FunctionSpace(mesh, 2, 1)  # primal space (collapsed sub(0), :54)
@@ -58,7 +58,11 @@ class GradientConstraintProblem:
         pp = _lib.pgx_gc_problem(len(wts), _lib.dptr(pts), _lib.dptr(wts), _lib.dptr(phi), _lib.dptr(f), len(bc),
                                  _lib.iptr(bc), None)
         self._h = C.c_void_p()
-        rc = lib.pgx_gc_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+        if comm is None:
+            rc = lib.pgx_gc_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+        else:  # one handle per GPU: replicated iterate, distributed sparse LU; every call below is collective
+            self._comm = comm
+            rc = lib.pgx_gc_create_dist(C.byref(pm), C.byref(pp), comm._c, int(device), C.byref(self._h))
         if rc:
             msg = lib.pgx_gc_last_error(None)
             raise _lib.PgxError(f"pgx_gc_create failed (code {rc}): {msg.decode() if msg else ''}")
@@ -155,6 +159,11 @@ class GradientConstraintProblem:
         self._check(self._lib.pgx_gc_spmv(self._h, _lib.dptr(x), _lib.dptr(y)), "pgx_gc_spmv")
         return y
 
+    def lu_stats(self) -> dict:
+        st = _lib.pgx_nd_stats()
+        self._check(self._lib.pgx_gc_lu_stats(self._h, C.byref(st)), "pgx_gc_lu_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def profile(self, enable=True):
         ms = (C.c_double * 6)()
         self._check(self._lib.pgx_gc_profile(self._h, int(enable), ms), "pgx_gc_profile")
@@ -176,14 +185,14 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
                   alpha_scheme: AlphaScheme = "doubling", alpha_0: float = 1.0, alpha_c: float = 1.0,
                   max_iterations: int = 25, stopping_tol: float = 1e-8, result_dir: Path | None = None,
                   phi_func: Callable = phi_default, f_func: Callable = f_default, warm_start: bool = False,
-                  verbose: bool = True, return_solution: bool = False, device: int = 0):
+                  verbose: bool = True, return_solution: bool = False, device: int = 0, comm=None):
     """gradient_constraint_dolfinx.solve_problem (:18-205): returns (newton_iterations, L2_diff) [, final state]."""
     if primal_space not in ("Lagrange", "P", "CG") or primal_degree != 2 or cell_type != "triangle":
         raise NotImplementedError("HIP backend: primal Lagrange degree 2 on triangles (the reference's defaults)")
     if warm_start:
         raise NotImplementedError("warm_start (a Poisson pre-solve, :71-98) is not implemented")
     mesh = fem.create_unit_square(N, M)  # :36
-    problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device)
+    problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device, comm=comm)
     if verbose:
         print(f"Number of dofs: {problem.n2}")  # :112
     newton_iterations = np.zeros(max_iterations, dtype=np.int32)

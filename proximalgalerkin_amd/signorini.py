@@ -176,6 +176,11 @@ class SignoriniProblem:
         self._check(self._lib.pgx_sg_spmv(self._h, _lib.dptr(x), _lib.dptr(y)), "pgx_sg_spmv")
         return y
 
+    def lu_stats(self) -> dict:
+        st = _lib.pgx_nd_stats()
+        self._check(self._lib.pgx_sg_lu_stats(self._h, C.byref(st)), "pgx_sg_lu_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def profile(self, enable=True):
         ms = (C.c_double * 6)()
         self._check(self._lib.pgx_sg_profile(self._h, int(enable), ms), "pgx_sg_profile")

@@ -114,3 +114,19 @@ def test_example02_distributed_run_matches_single_gpu(require_gpu, R):
                          np.flatnonzero(np.isclose(coords[:, 2], 1.0)))
     x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
     assert list(its1) == list(its_ref)
+
+
+def test_example06_distributed_run_matches_single_gpu(require_gpu):
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    N = 12
+    its1, d1, x1 = solve_problem(N, N, verbose=False, return_solution=True)
+
+    def rank_main(c):
+        return solve_problem(N, N, verbose=False, return_solution=True, comm=c)
+
+    n2 = (2 * N + 1) ** 2
+    for its, d, x in _run_ranks(pcomm.local_group(2), rank_main):
+        assert list(its) == list(its1)
+        assert np.linalg.norm(x[:n2] - x1[:n2]) <= 1e-10 * np.linalg.norm(x1[:n2])
