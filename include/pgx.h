@@ -200,6 +200,13 @@ const char* pgx_comm_last_error(void);
 
 int pgx_create_sharded(const pgx_mesh* local_mesh, const pgx_problem* local_prob, const pgx_partition* part,
                        pgx_comm* comm, int device, pgx_handle** out);
+/* Replicated handles with a DISTRIBUTED sparse LU (BASELINE.json config 3: P2 on 8 GPUs, where the multigrid path is not
+ * robust and one GPU cannot hold the factor): every rank passes the WHOLE mesh / problem and keeps the whole iterate;
+ * assembly, SpMV and the Krylov vectors are replicated, the LU preconditioner - the dominant cost - is factorised with one
+ * dissection subtree per rank (include/pgx_nd.h: pgx_nd_create_dist).  Residuals and observables are broadcast from rank 0
+ * so that the replicas stay bitwise identical.  All calls are collective; results are identical on every rank.  Replaces
+ * `mpirun -n N python obstacle_pg.py` with MUMPS distributing the factorisation (obstacle_pg.py:129-131). */
+int pgx_create_lu_dist(const pgx_mesh* mesh, const pgx_problem* prob, pgx_comm* comm, int device, pgx_handle** out);
 /* owned entries of a local vector: fields [0,n) and [n,2n) each hold owned entries at [offset, offset+count) */
 int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count);
 /* refresh the ghost entries of device `sol` and `sol_k` from their owners (after pgx_set_state / pgx_set_prev

@@ -192,6 +192,7 @@ SYMBOLS = [
     ("pgx_comm_last_error", C.c_char_p, []),
     ("pgx_create_sharded", C.c_int,
      [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.POINTER(pgx_partition), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_create_lu_dist", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_owned_range", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("pgx_sync_ghosts", C.c_int, [_H]),
     # sparse direct solver (include/pgx_nd.h)

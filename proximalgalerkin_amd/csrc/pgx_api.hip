@@ -90,6 +90,10 @@ struct pgx_handle {
   TailArgs tail{};
   // sparse direct preconditioner (pc_type lu): nested-dissection multifrontal LU of the mixed Newton matrix (pgx_nd.hip)
   pgx_nd* lu = nullptr;
+  // pgx_create_lu_dist: this handle is one of `size` REPLICAS (whole mesh, whole iterate on every rank) whose sparse LU is
+  // distributed over the ranks (pgx_nd_create_dist).  Residuals and observables are broadcast from rank 0 so that the
+  // replicas stay bitwise identical (the P2 assembly uses atomics) and issue the same collectives.
+  pgx_comm* lu_comm = nullptr;
   double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
   // observables
@@ -960,8 +964,12 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     // up to 300 basis vectors within a 96 GB budget (V and Z) - HBM capacity is what MI355X has plenty of.
     h->restart = 50;
     if (p->degree == 2) {
+      // PGX_P2_BASIS_GB (default 24): the sparse LU is the default P2 preconditioner (1-2 iterations per Newton step), the
+      // long basis only matters for "pc_type": "pgx_mg"; 96 GB reproduces the pre-LU behaviour
+      double budget = 24e9;
+      if (const char* e = getenv("PGX_P2_BASIS_GB")) budget = 1e9 * atof(e);
       const double per_vec = 2.0 * (double)n2 * sizeof(double);
-      h->restart = (int)std::max(50.0, std::min(300.0, 96e9 / per_vec));
+      h->restart = (int)std::max(50.0, std::min(300.0, budget / per_vec));
     }
     DALLOC(h->V, (size_t)(h->restart + 1) * n2);
     DALLOC(h->Z, (size_t)h->restart * n2);
@@ -994,6 +1002,16 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
 
 extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, pgx_handle** out) {
   return create_impl(m, p, device, nullptr, nullptr, out);
+}
+extern "C" int pgx_create_lu_dist(const pgx_mesh* m, const pgx_problem* p, pgx_comm* comm, int device, pgx_handle** out) {
+  if (!comm) {
+    g_create_error = "pgx_create_lu_dist: null communicator";
+    return PGX_EINVAL;
+  }
+  int rc = create_impl(m, p, device, nullptr, nullptr, out);
+  if (rc) return rc;
+  (*out)->lu_comm = comm;
+  return PGX_OK;
 }
 extern "C" int pgx_create_sharded(const pgx_mesh* m, const pgx_problem* p, const pgx_partition* part, pgx_comm* comm,
                                   int device, pgx_handle** out) {
@@ -1460,7 +1478,8 @@ static int ensure_lu(pgx_handle* h) {
   A.node_coords = xy.data();
   A.leaf_nodes = 0;
   if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
-  int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
+  int rc = h->lu_comm ? pgx_nd_create_dist(&A, h->lu_comm, h->device, (void*)h->st, &h->lu)
+                      : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("pc_type lu: ") + pgx_nd_last_error(nullptr);
     h->lu = nullptr;
@@ -1468,6 +1487,15 @@ static int ensure_lu(pgx_handle* h) {
   }
   DALLOC(h->Jmix, 4 * (size_t)nnz);
   return PGX_OK;
+}
+
+// replicas of pgx_create_lu_dist: overwrite dev[0:n) with rank 0's copy (all-reduce of "mine if rank 0 else zero")
+static int replica_bcast(pgx_handle* h, double* dev, size_t n) {
+  if (!h->lu_comm || h->lu_comm->size == 1) return PGX_OK;
+  if (h->lu_comm->rank != 0) HIPCHK(hipMemsetAsync(dev, 0, n * sizeof(double), h->st));
+  const int rc = h->lu_comm->allreduce(h->st, dev, n);
+  if (rc) h->err = "replica broadcast: " + h->lu_comm->err;
+  return rc;
 }
 
 static int lu_factor(pgx_handle* h) {
@@ -1784,6 +1812,10 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
                        h->obs_blocks, h->d_out6);
     }
   }
+  {
+    const int rcb = replica_bcast(h, h->d_out6, 6);  // the loop's stopping test must agree on every replica
+    if (rcb) return rcb;
+  }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_out6, sizeof(double) * 6, hipMemcpyDeviceToHost, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   for (int k = 0; k < 6; ++k) out[k] = h->h_small[k];
@@ -1823,7 +1855,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // pc_type: 0 auto (geometric multigrid for P1 on a structured mesh; sparse LU for P2, whose two-level cycle is not robust
   // on the late large-alpha systems, and for general meshes, which have no grid hierarchy - e.g. the reference's own gmsh
   // disk, obstacle_pg.py:64-65), 1 multigrid V-cycle, 2 sparse LU (what the reference asks PETSc/MUMPS for)
-  const bool use_lu = optv.pc_type == 2 || (optv.pc_type == 0 && (h->degree == 2 || !h->structured) && !h->dist.on);
+  const bool use_lu = h->lu_comm || optv.pc_type == 2 || (optv.pc_type == 0 && (h->degree == 2 || !h->structured) && !h->dist.on);
   h->lu_active = false;
   if (use_lu) {
     int rcl = ensure_lu(h);
@@ -1851,6 +1883,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   };
   HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   residual_dev(h, h->xw, h->F, 1);
+  if ((rc = replica_bcast(h, h->F, n2))) return rc;
   if (dist) {
     gather_owned(h, h->F, h->rhs);
     rc = dev_norm(h, h->rhs, &fnorm, nk);
@@ -1891,6 +1924,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
     if (dist && (rc = halo_level(h, 0, h->xw, h->xw + h->n))) return rc;
     residual_dev(h, h->xw, h->F, 1);
+    if ((rc = replica_bcast(h, h->F, n2))) return rc;
     if (dist) {
       gather_owned(h, h->F, h->rhs);
       rc = dev_norm(h, h->rhs, &fnorm, nk);

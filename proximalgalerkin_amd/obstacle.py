@@ -37,7 +37,7 @@ COLUMNS = ["Energy", "Complementarity", "Feasibility", "Dual Feasibility", "Newt
 
 
 def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict | None = None, device: int = 0,
-                  phi=phi_set):
+                  phi=phi_set, lu_comm=None):
     """Everything obstacle_pg.py does before the loop (:66-152). Returns (problem, sol, sol_k, alpha)."""
     V = fem.functionspace(msh, ("Lagrange", polynomial_order), ncomp=2)  # :68-70
     alpha = fem.Constant(msh, 1.0)  # :73
@@ -61,7 +61,7 @@ def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict 
             "snes_max_it": 100,
         }
     problem = NonlinearProblem(F, u=sol, bcs=[bcs], J=J, petsc_options=petsc_options,
-                               petsc_options_prefix="obstacle_", device=device)  # :140-142
+                               petsc_options_prefix="obstacle_", device=device, lu_comm=lu_comm)  # :140-142
     return problem, sol, sol_k, alpha
 
 

@@ -149,7 +149,9 @@ class _SNES:
 
 
 class NonlinearProblem:
-    def __init__(self, F, u: Function, bcs=None, J=None, petsc_options=None, petsc_options_prefix="", device=0):
+    def __init__(self, F, u: Function, bcs=None, J=None, petsc_options=None, petsc_options_prefix="", device=0, lu_comm=None):
+        """lu_comm: a comm.Communicator -> this handle is one of several REPLICAS (whole mesh on every rank) whose sparse-LU
+        preconditioner is distributed over the ranks (include/pgx.h: pgx_create_lu_dist); every call is collective."""
         if not isinstance(F, ObstacleResidual):
             raise TypeError("F must be an ObstacleResidual form description")
         if J is not None and not (isinstance(J, Derivative) and J.form is F):
@@ -185,7 +187,11 @@ class NonlinearProblem:
                               _lib.dptr(self._keep[6]))
         h = C.c_void_p()
         self.partition = part = getattr(mesh, "partition", None)
-        if part is None:
+        if part is None and lu_comm is not None:
+            self._lu_comm = lu_comm
+            rc = lib.pgx_create_lu_dist(C.byref(pm), C.byref(pp), lu_comm._c, int(device), C.byref(h))
+            _lib.check(lib, None, rc, "pgx_create_lu_dist")
+        elif part is None:
             rc = lib.pgx_create(C.byref(pm), C.byref(pp), int(device), C.byref(h))
             _lib.check(lib, None, rc, "pgx_create")
         else:  # this mesh is one rank's strip: every call below is collective over part.comm (include/pgx.h)

@@ -130,3 +130,28 @@ def test_example06_distributed_run_matches_single_gpu(require_gpu):
     for its, d, x in _run_ranks(pcomm.local_group(2), rank_main):
         assert list(its) == list(its1)
         assert np.linalg.norm(x[:n2] - x1[:n2]) <= 1e-10 * np.linalg.norm(x1[:n2])
+
+
+@pytest.mark.parametrize("degree,N", [(2, 24), (1, 40)])
+def test_example01_replicas_with_distributed_lu(require_gpu, degree, N):
+    """pgx_create_lu_dist (BASELINE config 3: P2, multi-GPU): replicated handles, distributed LU preconditioner."""
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    def run(c):
+        msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+        problem, sol, sol_k, alpha = setup_problem(msh, degree, lu_comm=c)
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4)
+        x = sol.x.array.copy()
+        problem.close()
+        return x, hist
+
+    x1, h1 = run(None)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, degree)
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert h1["Newton steps"] == h_ref["Newton steps"]
+    for x, h in _run_ranks(pcomm.local_group(2), run):
+        assert h["Newton steps"] == h_ref["Newton steps"]
+        assert np.linalg.norm(x[: prob.n] - x_ref[: prob.n]) <= 1e-10 * np.linalg.norm(x_ref[: prob.n])
