@@ -18,6 +18,9 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="Run examples from paper",
                                      formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument("-N", dest="N", type=int, default=64, help="cells per side of the square mesh")
+    parser.add_argument("--disk", dest="disk_h", type=float, default=0.0,
+                        help="mesh size of a unit-DISK mesh (the reference's own domain, generate_mesh_gmsh.py:23) instead of "
+                             "the square; general mesh -> sparse-LU preconditioner")
     parser.add_argument("--polynomial_order", "-p", dest="polynomial_order", type=int, default=1, choices=[1, 2],
                         help="Polynomial order of primal space")
     parser.add_argument("--alpha-scheme", dest="alpha_scheme", type=str, default="constant",
@@ -28,7 +31,8 @@ if __name__ == "__main__":
     parser.add_argument("--tol", "-t", dest="tol_exit", type=float, default=1e-6,
                         help="Tolerance for exiting Newton iteration")
     args = parser.parse_args()
-    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N))
+    msh = (fem.create_disk(args.disk_h) if args.disk_h > 0.0 else
+           fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N)))
     sol, newton_steps = solve_problem(msh, args.polynomial_order, args.maximum_number_of_outer_loop_iterations,
                                       args.alpha_scheme, args.alpha_max, args.tol_exit,
                                       output_dir=Path.cwd() / "output")

@@ -4,12 +4,12 @@ Host-side mirror of the reference's solver surface (lvpp.SNESProblem / SNESSolve
 dolfinx NonlinearProblem call shape) over the C ABI of include/pgx.h -> hand-written HIP (gfx950).
 """
 from . import fem
-from .fem import (Constant, Function, Mesh, QuadratureFunction, create_rectangle, create_unit_square, dirichletbc,
+from .fem import (Constant, Function, Mesh, QuadratureFunction, create_disk, create_rectangle, create_unit_square, dirichletbc,
                   functionspace)
 from .problem import (ConvergenceError, NonlinearProblem, ObstacleResidual, SNESProblem, SNESSolver, derivative)
 
 __all__ = [
     "SNESProblem", "SNESSolver", "NonlinearProblem", "ObstacleResidual", "derivative", "ConvergenceError", "fem",
-    "Mesh", "Function", "Constant", "QuadratureFunction", "create_rectangle", "create_unit_square", "dirichletbc",
+    "Mesh", "Function", "Constant", "QuadratureFunction", "create_disk", "create_rectangle", "create_unit_square", "dirichletbc",
     "functionspace",
 ]

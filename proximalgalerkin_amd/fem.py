@@ -160,6 +160,28 @@ def create_rectangle(points, n, diagonal="right", comm=None, dist_levels=0):
     return Mesh(coords, cells, structured=(nx, ny), partition=part)
 
 
+def create_disk(h: float, radius: float = 1.0):
+    """Delaunay triangulation of a disk with mesh size ~h: concentric rings, staggered - the reference's example-01 domain is
+    a gmsh disk of radius 1 (examples/01_obstacle_problem/generate_mesh_gmsh.py:23); gmsh itself is not available here.
+    A general (unstructured) mesh: the solver preconditions with the sparse LU."""
+    from scipy.spatial import Delaunay
+
+    pts = [(0.0, 0.0)]
+    nr = max(1, int(round(radius / h)))
+    for k in range(1, nr + 1):
+        r = radius * k / nr
+        m = max(6, int(round(2 * np.pi * r / h)))
+        th = 2 * np.pi * (np.arange(m) + 0.5 * (k % 2)) / m
+        pts += list(zip(r * np.cos(th), r * np.sin(th)))
+    pts = np.array(pts)
+    tri = Delaunay(pts).simplices.astype(np.int32)
+    # consistent (counter-clockwise) orientation
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    neg = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) < 0
+    tri[neg] = tri[neg][:, [0, 2, 1]]
+    return Mesh(pts, tri)
+
+
 def create_unit_square(nx, ny):
     return create_rectangle(((0.0, 0.0), (1.0, 1.0)), (nx, ny))
 

@@ -138,3 +138,30 @@ def test_graded_structured_mesh_uses_explicit_stencils(require_gpu):
     prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
     _outer(problem, sol, sol_k, alpha, prob)
     problem.close()
+
+
+def test_disk_solution_converges_to_the_closed_form(require_gpu):
+    """Independent of the oracle: on the reference's own domain (unit disk, generate_mesh_gmsh.py:23) the obstacle problem
+    has the closed-form solution of SURVEY.md App. A.6 (u = phi for r <= a, -c ln r beyond, a^2 (1 - ln a) = r0^2,
+    a = 0.34898...).  The HIP path (general mesh -> sparse-LU preconditioner) must converge to it at O(h^2)."""
+    from scipy.optimize import brentq
+
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    r0 = 0.5
+    a = brentq(lambda a: a * a * (1 - np.log(a)) - r0 * r0, 0.1, 0.45)
+    assert abs(a - 0.3489825741) < 1e-9
+    c = a * a / np.sqrt(r0 * r0 - a * a)
+    errs = []
+    for h in (0.05, 0.025, 0.0125):
+        msh = fem.create_disk(h)
+        problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options={"snes_linesearch_type": "none", "snes_rtol": 1e-6,
+                                                                         "snes_max_it": 100})
+        run_outer_loop(problem, sol, sol_k, alpha, 500, "double_exponential", 1e2, 1e-7)
+        x = msh.geometry
+        r = np.hypot(x[:, 0], x[:, 1])
+        exact = np.where(r <= a, np.sqrt(np.maximum(r0 * r0 - r * r, 0.0)), -c * np.log(np.maximum(r, 1e-300)))
+        errs.append(np.abs(sol.x.array[: msh.num_vertices] - exact).max())
+        problem.close()
+    assert errs[2] < 2.5e-4 and errs[0] / errs[1] > 3.0 and errs[1] / errs[2] > 3.0, errs
