@@ -356,7 +356,6 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     for (int t : post)
       if (state[t]) slot_of[t] = (int)next[T[t].depth]++;
   }
-  const int nt_all = nt;
   s->fp.assign(nloc, 0);
   s->fb.assign(nloc, 0);
   s->parent.assign(nloc, -1);
@@ -367,7 +366,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   s->fbase.assign(nloc, 0);
   s->dof_ptr.assign(nloc + 1, 0);
   s->rel_ptr.assign(nloc + 1, 0);
-  for (int t = 0; t < nt_all; ++t) {
+  for (int t = 0; t < nt; ++t) {
     if (!state[t]) continue;
     int f = slot_of[t];
     s->fp[f] = tp[t];
@@ -384,10 +383,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
       }
     s->dof_ptr[f + 1] = tp[t];
     s->rel_ptr[f + 1] = tb[t];
-    if (dsize > 1 && T[t].depth == kd) {
-      if (state[t] == 1) s->root_slot = f;
-      // ghost_slot[j]: which rank owns this subtree root?  depth-kd nodes were numbered left to right above
-    }
+    if (dsize > 1 && T[t].depth == kd && state[t] == 1) s->root_slot = f;
     if (state[t] == 1) {
       double p = tp[t], b = tb[t];
       s->stats.flops += 2.0 / 3 * p * p * p + 2 * p * p * b + 2 * p * b * b;
@@ -399,8 +395,6 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     for (int t : post)
       if (T[t].depth == kd) s->ghost_slot[j++] = slot_of[t];
   }
-  const int nt_loop = nloc;
-  (void)nt_loop;
   for (int f = 0; f < nloc; ++f) s->dof_ptr[f + 1] += s->dof_ptr[f], s->rel_ptr[f + 1] += s->rel_ptr[f];
   s->own_dofs.resize(s->dof_ptr[nloc]);
   s->rel.resize(s->rel_ptr[nloc]);

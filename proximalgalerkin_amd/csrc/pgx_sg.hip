@@ -274,7 +274,6 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   auto facet_dofs = [&](int f, int32_t md[6]) {
     for (int a = 0; a < 3; ++a) md[a] = 2 * nv + m->facets[3 * (size_t)f + a], md[3 + a] = nu + fpsi[3 * (size_t)f + a];
   };
-  const int64_t nent = (int64_t)nc + nf;
   std::vector<int64_t> dptr(ntot + 1, 0);
   for (int c = 0; c < nc; ++c) {
     int32_t md[12];
@@ -301,7 +300,6 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
       for (int a = 0; a < 6; ++a) dent[fill[md[a]]++] = (int64_t)nc + f;
     }
   }
-  (void)nent;
   auto gather_row = [&](int64_t r, std::vector<int32_t>& tmp) {
     tmp.clear();
     for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
