@@ -18,6 +18,9 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="Run examples from paper",
                                      formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument("-N", dest="N", type=int, default=64, help="cells per side of the square mesh")
+    parser.add_argument("--path", "-f", dest="filename", type=Path, default=None,
+                        help="gmsh MSH (2.2 / 4.1 ASCII) file with a triangle mesh - the reference's -f takes the XDMF file its "
+                             "gmsh script writes (obstacle_pg.py:276-280); HDF5 is not available offline")
     parser.add_argument("--disk", dest="disk_h", type=float, default=0.0,
                         help="mesh size of a unit-DISK mesh (the reference's own domain, generate_mesh_gmsh.py:23) instead of "
                              "the square; general mesh -> sparse-LU preconditioner")
@@ -31,9 +34,21 @@ if __name__ == "__main__":
     parser.add_argument("--tol", "-t", dest="tol_exit", type=float, default=1e-6,
                         help="Tolerance for exiting Newton iteration")
     args = parser.parse_args()
-    msh = (fem.create_disk(args.disk_h) if args.disk_h > 0.0 else
-           fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N)))
+    if args.filename is not None:
+        from proximalgalerkin_amd.io import mesh_from_msh
+
+        msh = mesh_from_msh(args.filename)
+    else:
+        msh = (fem.create_disk(args.disk_h) if args.disk_h > 0.0 else
+               fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N)))
     sol, newton_steps = solve_problem(msh, args.polynomial_order, args.maximum_number_of_outer_loop_iterations,
                                       args.alpha_scheme, args.alpha_max, args.tol_exit,
                                       output_dir=Path.cwd() / "output")
     print(f"total Newton steps: {newton_steps}")
+    # fields for ParaView (the reference writes u and psi with VTXWriter, obstacle_pg.py:239-243)
+    from proximalgalerkin_amd.io import write_vtu
+
+    V = sol.function_space
+    n = V.block_size
+    write_vtu(Path.cwd() / "output" / "obstacle.vtu", V.dof_coordinates(), V.cell_dofs(),
+              {"u": sol.x.array[:n], "psi": sol.x.array[n:]})

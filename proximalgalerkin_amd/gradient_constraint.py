@@ -225,6 +225,13 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
         result_dir = Path(result_dir)
         result_dir.mkdir(parents=True, exist_ok=True)
         np.savetxt(result_dir / "lvpp_history.csv", np.stack(out, axis=1), delimiter=",", header="newton,L2_diff")
+        from .io import write_vtu  # u (P2) for ParaView - the reference writes u.bp / grad_u.bp with VTXWriter (:145-158)
+
+        xs = problem.get_state()
+        write_vtu(result_dir / "u.vtu", problem.U.dof_coordinates(), problem.U.cell_dofs(), {"u": xs[: problem.n2]})
+        nv, n2 = problem.nv, problem.n2
+        write_vtu(result_dir / "psi.vtu", mesh.geometry, mesh.cells,
+                  {"psi": np.stack([xs[n2: n2 + nv], xs[n2 + nv:]], axis=1)})
     if return_solution:
         x = problem.get_state()
         problem.close()

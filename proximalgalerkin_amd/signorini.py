@@ -241,6 +241,11 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
         output = Path(output)
         output.mkdir(parents=True, exist_ok=True)
         np.savetxt(output / "lvpp_history.csv", np.asarray(iterations, dtype=np.int64), header="newton")
+        from .io import write_vtu  # displacement for ParaView - the reference writes uh.bp with VTXWriter (:293-294)
+
+        xs = problem.get_state()
+        nv = problem.nv
+        write_vtu(output / "uh.vtu", mesh.geometry, mesh.cells, {"displacement": np.stack([xs[:nv], xs[nv:2 * nv], xs[2 * nv:3 * nv]], axis=1)})
     if verbose:
         print(f"num_dofs_u={3 * problem.nv}, num_cells={mesh.cells.shape[0]}")
     if return_solution:
