@@ -176,7 +176,10 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
     its_p = one_step()
     prof = problem.profile(False)
     st = problem.lu_stats()
-    tflops = st["flops_padded"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
+    # ALGORITHMIC flops (the unpadded multifrontal factorisation) decide `achieved`; the level-batched kernels execute
+    # the padded count (fronts of a level share one shape), reported beside it
+    tflops = st["flops"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
+    tflops_exec = st["flops_padded"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
     out = None
     if rank == 0:
         out = {
@@ -190,10 +193,13 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
                                                                    "(one dissection subtree each, RCCL gather/scatter + all-reduce)"},
             "setup_s": t_setup,
             "roofline": {"kernel": "k_nd_gemm<4>/<2> inside pgx_nd_factor (fp64 MFMA GEMM of the multifrontal LU; the figure is the "
-                                   "WHOLE factorisation: padded flops of this rank / its device time, panels and extend-add included)",
+                                   "WHOLE factorisation: algorithmic flops of this rank / its device time, panels and extend-add "
+                                   "included)",
                          "bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "flops_padded_per_factorisation": st["flops_padded"], "arena_GB": st["arena_doubles"] * 8 / 1e9,
+                         "algorithmic_flops_per_factorisation": st["flops"],
+                         "executed_flops_per_factorisation_padded": st["flops_padded"], "executed_TFLOPs": tflops_exec,
+                         "arena_GB": st["arena_doubles"] * 8 / 1e9,
                          "lu_factor_ms_per_newton_step": prof["lu_factor"] / max(sum(its_p), 1),
                          "lu_solve_ms_per_newton_step": prof["lu_solve"] / max(sum(its_p), 1)},
         }
