@@ -69,11 +69,13 @@ int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
 int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
 
 /* Symbolic structure, for tests (the numpy emulation in tests/test_nd_symbolic.py factorises with exactly these maps).
- * Call with NULL arrays to get sizes.  Layout: fronts are numbered level by level, root level first ("slots");
- * level l holds slots [lev_start[l], lev_start[l+1]) and pads every front to pivot order P[l], border B[l], M = P+B,
+ * Call with NULL arrays to get sizes.  Layout: fronts are numbered batch by batch ("slots"); a batch = the fronts of one
+ * tree depth and one size class, batches ordered by depth (root first);
+ * batch l holds slots [lev_start[l], lev_start[l+1]) and pads every front to pivot order P[l], border B[l], M = P+B,
  * stored column-major at arena offset lev_off[l] + (slot - lev_start[l]) * M*M.  Local index of an own dof k: k; of the
  * s-th border dof: P + s.  rel[rel_ptr[f] + s] = local index in the PARENT's front of border dof s of front f. */
-int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B, int64_t* lev_off);
+int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B, int64_t* lev_off,
+                         int32_t* depth /* tree depth of each batch; the children of depth d live at depth d+1 */);
 int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t* fp, int32_t* fb, int32_t* parent, int32_t* slot01,
                          int64_t* dof_ptr, int32_t* own_dofs, int64_t* rel_ptr, int32_t* rel);
 int pgx_nd_export_dest(const pgx_nd* s, int64_t* nnz, int64_t* dest);

@@ -38,8 +38,9 @@
 
 static thread_local std::string g_nd_error;
 
-struct NdLevel {
+struct NdLevel {  // one BATCH: the fronts of one tree depth and one size class, padded to a common (P, B)
   int64_t start = 0, count = 0;
+  int depth = 0;
   int P = 0, B = 0;
   int64_t off = 0;   // arena offset (doubles)
   int64_t voff = 0;  // vector arena offset
@@ -66,7 +67,13 @@ struct pgx_nd {
   // distributed factorisation (pgx_nd_create_dist): the 2^kdist subtrees below tree depth kdist live on one rank each,
   // the levels above on rank 0, which also holds GHOST copies of the other ranks' subtree-root fronts (identity pivot
   // block; their Schur block / border vector arrives through pgx_comm::gather0, leaves through scatter0)
+  std::vector<int> dfirst;  // batches of tree depth d: lev[dfirst[d]] .. lev[dfirst[d+1] - 1]
+  // the batches (size classes) of one tree depth are independent: their launch chains run on side streams, forked from
+  // and joined into the main stream per depth (few large fronts near the root cannot fill 256 CUs one class at a time)
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   pgx_comm* comm = nullptr;
+  int kbatch = 0;  // distributed: the (single) batch holding the subtree roots at depth kdist
   int rank = 0, size = 1, kdist = 0;
   int root_slot = -1;             // this rank's subtree-root front (depth kdist)
   std::vector<int> ghost_slot;    // rank 0: slot of rank j's subtree-root front (index j; [0] unused)
@@ -309,25 +316,91 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
         state[t] = (drank == 0 && T[t].depth == kd) ? 2 : 0;
     }
   }
-  // levels by depth; slots ordered by postorder inside a level; only the fronts living on this rank get a slot
+  // Batches: the fronts of one tree depth, split into up to four SIZE CLASSES so that padding every front of a batch to
+  // the batch's largest (P, B) wastes little (one class per depth executed 1.35x the algorithmic flops on the 3-D and
+  // 1.31x on the 2-D Newton matrices).  Classes are chosen on ALL fronts of the depth (identical on every rank of a
+  // distributed factorisation); slots are postorder inside a batch; only fronts living on this rank get a slot.
   int maxd = 0;
   for (auto& t : T) maxd = std::max(maxd, t.depth);
-  const int L = maxd + 1;
-  s->lev.assign(L, NdLevel());
   std::vector<int> slot_of(nt, -1);
   auto ndofs = [&](int32_t g) { return (int)(S.nd_ptr[g + 1] - S.nd_ptr[g]); };
-  std::vector<int> tp(nt), tb(nt);
+  std::vector<int> tp(nt), tb(nt), tp_true(nt), tbatch(nt, 0);
   int nloc = 0;
   for (int t = 0; t < nt; ++t) {
     int p = 0, b = 0;
     for (int32_t g : T[t].own) p += ndofs(g);
     for (int32_t g : T[t].border) b += ndofs(g);
+    tp_true[t] = p;
     tp[t] = state[t] == 2 ? 0 : p;  // a ghost eliminates nothing here
     tb[t] = b;
-    if (state[t]) s->lev[T[t].depth].count++, ++nloc;
-    s->lev[T[t].depth].P = std::max(s->lev[T[t].depth].P, p);  // padding is the same on every rank
-    s->lev[T[t].depth].B = std::max(s->lev[T[t].depth].B, b);
+    if (state[t]) ++nloc;
   }
+  auto cost = [](double P, double B) { return 2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B + 30.0 * (P + B) * (P + B); };
+  s->lev.clear();
+  s->dfirst.assign(maxd + 2, 0);
+  {
+    std::vector<std::vector<int>> by_depth(maxd + 1);
+    for (int t : post) by_depth[T[t].depth].push_back(t);
+    for (int d = 0; d <= maxd; ++d) {
+      s->dfirst[d] = (int)s->lev.size();
+      std::vector<int> order = by_depth[d];  // postorder
+      std::vector<std::vector<int>> classes(1, order);
+      if (!(dsize > 1 && d == kd) && order.size() > 1) {
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return tp_true[a] + tb[a] > tp_true[c] + tb[c]; });
+        classes.assign(1, order);
+        for (int round = 0; round < 2; ++round) {  // each class may split once per round: at most 4 classes
+          std::vector<std::vector<int>> next;
+          for (auto& cl : classes) {
+            const int m = (int)cl.size();
+            const int mins = m > 32 ? 4 : 1;  // few, large fronts near the root: even one front per batch pays
+            if (m < 2 * mins) {
+              next.push_back(cl);
+              continue;
+            }
+            std::vector<int> pP(m), pB(m), sP(m), sB(m);
+            for (int i = 0; i < m; ++i) {
+              pP[i] = std::max(i ? pP[i - 1] : 0, tp_true[cl[i]]);
+              pB[i] = std::max(i ? pB[i - 1] : 0, tb[cl[i]]);
+            }
+            for (int i = m - 1; i >= 0; --i) {
+              sP[i] = std::max(i + 1 < m ? sP[i + 1] : 0, tp_true[cl[i]]);
+              sB[i] = std::max(i + 1 < m ? sB[i + 1] : 0, tb[cl[i]]);
+            }
+            const double whole = m * cost(pP[m - 1], pB[m - 1]);
+            double best = whole;
+            int cut = -1;
+            for (int i = mins - 1; i + mins < m; ++i) {  // first class cl[0..i], second cl[i+1..]
+              const double c2 = (i + 1) * cost(pP[i], pB[i]) + (m - i - 1) * cost(sP[i + 1], sB[i + 1]);
+              if (c2 < best) best = c2, cut = i;
+            }
+            if (cut >= 0 && best < 0.93 * whole) {
+              next.emplace_back(cl.begin(), cl.begin() + cut + 1);
+              next.emplace_back(cl.begin() + cut + 1, cl.end());
+            } else {
+              next.push_back(cl);
+            }
+          }
+          classes.swap(next);
+        }
+        for (auto& cl : classes)  // back to postorder inside a class (spatial locality of the slots)
+          std::sort(cl.begin(), cl.end(), [&](int a, int c) { return order_of[a] < order_of[c]; });
+      }
+      for (auto& cl : classes) {
+        NdLevel Lv;
+        Lv.depth = d;
+        for (int t : cl) {
+          Lv.P = std::max(Lv.P, tp_true[t]);
+          Lv.B = std::max(Lv.B, tb[t]);
+          tbatch[t] = (int)s->lev.size();
+          if (state[t]) Lv.count++;
+        }
+        if (dsize > 1 && d == kd) s->kbatch = (int)s->lev.size();
+        s->lev.push_back(Lv);
+      }
+    }
+    s->dfirst[maxd + 1] = (int)s->lev.size();
+  }
+  const int L = (int)s->lev.size();
   int64_t off = 0, voff = 0, start = 0;
   s->stats = pgx_nd_stats();
   for (int l = 0; l < L; ++l) {
@@ -354,7 +427,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     std::vector<int64_t> next(L);
     for (int l = 0; l < L; ++l) next[l] = s->lev[l].start;
     for (int t : post)
-      if (state[t]) slot_of[t] = (int)next[T[t].depth]++;
+      if (state[t]) slot_of[t] = (int)next[tbatch[t]]++;
   }
   s->fp.assign(nloc, 0);
   s->fb.assign(nloc, 0);
@@ -371,8 +444,8 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     int f = slot_of[t];
     s->fp[f] = tp[t];
     s->fb[f] = tb[t];
-    s->flevel[f] = T[t].depth;
-    const NdLevel& Lv = s->lev[T[t].depth];
+    s->flevel[f] = tbatch[t];
+    const NdLevel& Lv = s->lev[tbatch[t]];
     int64_t M = Lv.P + Lv.B;
     s->fbase[f] = Lv.off + (f - Lv.start) * M * M;
     if (T[t].parent >= 0 && slot_of[T[t].parent] >= 0) s->parent[f] = slot_of[T[t].parent];
@@ -411,7 +484,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   for (int t : post) {
     if (state[t] != 1) continue;  // ghosts are neither assembled nor eliminated here; their maps into the parent are built below
     const int f = slot_of[t];
-    const NdLevel& Lv = s->lev[T[t].depth];
+    const NdLevel& Lv = s->lev[tbatch[t]];
     const int64_t M = Lv.P + Lv.B;
     int k = 0;
     int64_t w = s->dof_ptr[f];
@@ -508,6 +581,7 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
   const int32_t* R = rel + rel_ptr[f];
   const double* src = arena + fbase[f] + (int64_t)Pc * Mc + Pc;
   const int pf = parent[f];
+  if (pf < 0) return;  // distributed: the parent of a subtree root lives on rank 0
   const int64_t Mp = fM[pf];
   double* dst = arena + fbase[pf];
   const int64_t total = (int64_t)b * b;
@@ -1048,8 +1122,13 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if ((rc = nd_alloc(s, &s->d_info, (size_t)maxbatch))) return fail(rc);
   hipEventCreate(&s->e0);
   hipEventCreate(&s->e1);
+  hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+  for (int i = 0; i < 3; ++i) {
+    if (hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking) != hipSuccess) s->side[i] = nullptr;
+    hipEventCreateWithFlags(&s->ev_join[i], hipEventDisableTiming);
+  }
   if (s->size > 1) {  // exchange buffers: one Schur block / border vector per rank on rank 0, one on the others
-    const NdLevel& Lk = s->lev[s->kdist];
+    const NdLevel& Lk = s->lev[s->kbatch];
     const size_t nb = (size_t)Lk.B * Lk.B, mult = s->rank == 0 ? (size_t)s->size : 1;
     if ((rc = nd_alloc(s, &s->d_xbuf, mult * nb)) || (rc = nd_alloc(s, &s->d_vbuf, mult * (size_t)Lk.B))) return fail(rc);
   }
@@ -1081,6 +1160,11 @@ extern "C" void pgx_nd_destroy(pgx_nd* s) {
     for (void* p : s->allocs) hipFree(p);
     if (s->e0) hipEventDestroy(s->e0);
     if (s->e1) hipEventDestroy(s->e1);
+    if (s->ev_fork) hipEventDestroy(s->ev_fork);
+    for (int i = 0; i < 3; ++i) {
+      if (s->side[i]) hipStreamSynchronize(s->side[i]), hipStreamDestroy(s->side[i]);
+      if (s->ev_join[i]) hipEventDestroy(s->ev_join[i]);
+    }
     if (s->own_stream && s->st) hipStreamDestroy(s->st);
   }
   delete s;
@@ -1101,17 +1185,33 @@ extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* s
   return PGX_OK;
 }
 
+// stream of the idx-th non-empty batch of the current depth (idx 0: the main stream); nd_join waits for all of them
+static hipStream_t nd_fork(pgx_nd* s, int idx) {
+  if (idx == 0) return s->st;
+  hipStream_t q = s->side[(idx - 1) % 3];
+  if (!q) return s->st;
+  if (idx <= 3) hipStreamWaitEvent(q, s->ev_fork, 0);
+  return q;
+}
+static void nd_join(pgx_nd* s, int nused) {
+  for (int i = 0; i < std::min(nused - 1, 3); ++i)
+    if (s->side[i]) {
+      hipEventRecord(s->ev_join[i], s->side[i]);
+      hipStreamWaitEvent(s->st, s->ev_join[i], 0);
+    }
+}
+
 // C -= A B on one rectangle of every front of a level: 128 x 128 tiles where both sides are long, 64 x 64 otherwise
-static void nd_launch_gemm(pgx_nd* s, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1) {
+static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1) {
   if (r1 <= r0 || c1 <= c0 || k1 <= k0) return;
   const int M = Lv.P + Lv.B;
   const bool big = (r1 - r0) >= 256 && (c1 - c0) >= 256;
   const int TS = big ? 128 : 64;
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   if (big)
-    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
+    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, q, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
   else
-    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, s->st, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
+    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, q, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -1136,52 +1236,60 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   }
   NDHIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
   const int L = (int)s->lev.size();
-  for (int l = L - 1; l >= 0; --l) {
-    const NdLevel& Lv = s->lev[l];
-    const int P = Lv.P, B = Lv.B, M = P + B;
-    if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
-    if (l + 1 < L && s->lev[l + 1].count > 0) {
-      const NdLevel& C = s->lev[l + 1];
-      if (C.B > 0) {
-        int64_t per = (int64_t)C.B * C.B;
-        unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 1024));
-        // keep the grid bounded for very wide levels
-        while ((int64_t)gy * C.count > (int64_t)1 << 22 && gy > 1) gy /= 2;
-        for (int pass = 0; pass < 2; ++pass)
-          hipLaunchKernelGGL(k_nd_extend_add, dim3((unsigned)C.count, gy), dim3(256), 0, s->st, C.start, pass, C.P,
-                             C.P + C.B, s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel,
-                             s->arena);
-      }
+  const int maxdepth = (int)s->dfirst.size() - 2;
+  for (int d = maxdepth; d >= 0; --d) {
+    // every batch of depth d+1 is factorised: extend-add their Schur complements into the fronts of depth d (two
+    // conflict-free passes: first children, second children)
+    for (int cb = s->dfirst[d + 1]; cb < (d + 2 < (int)s->dfirst.size() ? s->dfirst[d + 2] : L); ++cb) {
+      const NdLevel& C = s->lev[cb];
+      if (C.count == 0 || C.B == 0) continue;
+      int64_t per = (int64_t)C.B * C.B;
+      unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 1024));
+      while ((int64_t)gy * C.count > (int64_t)1 << 22 && gy > 1) gy /= 2;  // keep the grid bounded for very wide levels
+      for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_nd_extend_add, dim3((unsigned)C.count, gy), dim3(256), 0, s->st, C.start, pass, C.P, C.P + C.B,
+                           s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel, s->arena);
     }
-    // Two-level blocked partial LU of the level.  Outer blocks of <= ND_OUTER pivots; inside one, <= 64-wide panels:
-    // diagonal block, both panel solves, then rank-64 updates of the outer block's row and column STRIPS only.  The rest
-    // of the trailing pivot block and panels gets ONE rank-ND_OUTER update per outer block (arithmetic intensity
-    // ND_OUTER/8 flop/byte: MFMA-bound instead of HBM-bound), the Schur block F22 ONE update with K = P at the end.
-    const int nouter = (P + ND_OUTER - 1) / ND_OUTER;
-    int ob = 0;
-    for (int ou = 0; ou < nouter; ++ou) {
-      const int W = P / nouter + (ou < P % nouter ? 1 : 0), oe = ob + W;
-      const int nsteps = (W + ND_NB - 1) / ND_NB;
-      int kb = ob;
-      for (int st = 0; st < nsteps; ++st) {
-        const int nb = W / nsteps + (st < W % nsteps ? 1 : 0), ke = kb + nb;
-        hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb, s->d_info);
-        if (M - ke > 0) {
-          const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
-          hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, s->st, s->arena, Lv.off, M, kb, nb);
-          nd_launch_gemm(s, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
-          nd_launch_gemm(s, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
+    hipEventRecord(s->ev_fork, s->st);
+    int used = 0;
+    for (int l = s->dfirst[d + 1] - 1; l >= s->dfirst[d]; --l) {
+      const NdLevel& Lv = s->lev[l];
+      const int P = Lv.P, B = Lv.B, M = P + B;
+      if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
+      hipStream_t q = nd_fork(s, used++);
+      // Two-level blocked partial LU of the batch.  Outer blocks of <= ND_OUTER pivots; inside one, <= 64-wide panels:
+      // diagonal block, both panel solves, then rank-64 updates of the outer block's row and column STRIPS only.  The
+      // rest of the trailing pivot block and panels gets ONE rank-ND_OUTER update per outer block (arithmetic intensity
+      // ND_OUTER/8 flop/byte: MFMA-bound instead of HBM-bound), the Schur block F22 ONE update with K = P at the end.
+      const int nouter = (P + ND_OUTER - 1) / ND_OUTER;
+      int ob = 0;
+      for (int ou = 0; ou < nouter; ++ou) {
+        const int W = P / nouter + (ou < P % nouter ? 1 : 0), oe = ob + W;
+        const int nsteps = (W + ND_NB - 1) / ND_NB;
+        int kb = ob;
+        for (int st = 0; st < nsteps; ++st) {
+          const int nb = W / nsteps + (st < W % nsteps ? 1 : 0), ke = kb + nb;
+          hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, M, kb, nb, s->d_info);
+          if (M - ke > 0) {
+            const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
+            hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, q, s->arena, Lv.off, M, kb, nb);
+            nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
+            nd_launch_gemm(s, q, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
+          }
+          kb = ke;
         }
-        kb = ke;
+        // trailing matrix beyond the outer block, without the Schur block
+        nd_launch_gemm(s, q, Lv, oe, P, oe, P, ob, oe);
+        nd_launch_gemm(s, q, Lv, oe, P, P, M, ob, oe);
+        nd_launch_gemm(s, q, Lv, P, M, oe, P, ob, oe);
+        ob = oe;
       }
-      // trailing matrix beyond the outer block, without the Schur block
-      nd_launch_gemm(s, Lv, oe, P, oe, P, ob, oe);
-      nd_launch_gemm(s, Lv, oe, P, P, M, ob, oe);
-      nd_launch_gemm(s, Lv, P, M, oe, P, ob, oe);
-      ob = oe;
+      if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P);
     }
-    if (B > 0) nd_launch_gemm(s, Lv, P, M, P, M, 0, P);
-    if (s->size > 1 && l == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
+    nd_join(s, used);
+    if (s->size > 1 && d == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
+      const NdLevel& Lv = s->lev[s->kbatch];
+      const int P = Lv.P, B = Lv.B, M = P + B;
       const size_t nb = (size_t)B * B;
       const unsigned pb = (unsigned)std::min<size_t>((nb + 255) / 256, 65535);
       if (s->rank != 0)
@@ -1229,24 +1337,32 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     dx = s->d_b;
   }
   if (s->timing) hipEventRecord(s->e0, s->st);
-  const int L = (int)s->lev.size();
-  for (int l = L - 1; l >= 0; --l) {
-    const NdLevel& Lv = s->lev[l];
-    const int P = Lv.P, B = Lv.B, M = P + B;
-    if (Lv.count == 0) continue;
-    hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, M, s->d_fp, s->d_fb,
-                       s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
-                       db, s->vec);
-    // forward substitution in slabs of ND_SLAB pivots: triangle by one workgroup per front, everything below the slab
-    // (rest of the pivot block AND the border rows) by a gemv over many workgroups
-    for (int k0 = 0; k0 < P; k0 += ND_SLAB) {
-      const int k1 = std::min(P, k0 + ND_SLAB);
-      hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 0);
-      if (k1 < M)
-        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + 255) / 256)), dim3(256), 0, s->st, s->arena,
-                           Lv.off, s->vec, Lv.voff, M, k1, M, k0, k1);
+  const int maxdepth = (int)s->dfirst.size() - 2;
+  for (int d = maxdepth; d >= 0; --d) {  // forward: leaves to root; the batches of one depth run on forked streams
+    hipEventRecord(s->ev_fork, s->st);
+    int used = 0;
+    for (int l = s->dfirst[d + 1] - 1; l >= s->dfirst[d]; --l) {
+      const NdLevel& Lv = s->lev[l];
+      const int P = Lv.P, B = Lv.B, M = P + B;
+      if (Lv.count == 0) continue;
+      hipStream_t q = nd_fork(s, used++);
+      hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, M, s->d_fp, s->d_fb,
+                         s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
+                         db, s->vec);
+      // forward substitution in slabs of ND_SLAB pivots: triangle by one workgroup per front, everything below the slab
+      // (rest of the pivot block AND the border rows) by a gemv over many workgroups
+      for (int k0 = 0; k0 < P; k0 += ND_SLAB) {
+        const int k1 = std::min(P, k0 + ND_SLAB);
+        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 0);
+        if (k1 < M)
+          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + 255) / 256)), dim3(256), 0, q, s->arena,
+                             Lv.off, s->vec, Lv.voff, M, k1, M, k0, k1);
+      }
     }
-    if (s->size > 1 && l == s->kdist && B > 0) {  // border contributions of the subtree roots -> rank 0's ghost fronts
+    nd_join(s, used);
+    if (s->size > 1 && d == s->kdist && s->lev[s->kbatch].B > 0) {  // border contributions of the subtree roots -> ghosts
+      const NdLevel& Lv = s->lev[s->kbatch];
+      const int P = Lv.P, B = Lv.B, M = P + B;
       const int64_t vb = Lv.voff + (int64_t)(s->root_slot - Lv.start) * M + P;
       int rcx = s->comm->gather0(s->st, s->vec + vb, (size_t)B, s->d_vbuf);
       if (rcx) {
@@ -1259,36 +1375,49 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
                                sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
     }
   }
-  for (int l = 0; l < L; ++l) {
-    const NdLevel& Lv = s->lev[l];
-    const int P = Lv.P, B = Lv.B, M = P + B;
-    if (Lv.count == 0) continue;
-    if (B > 0) {
-      hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
-                         s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
-      if (s->size > 1 && l == s->kdist) {  // border values of the other ranks' subtree roots leave rank 0
-        if (s->rank == 0)
-          for (int j = 1; j < s->size; ++j)
-            NDHIP(hipMemcpyAsync(s->d_vbuf + (size_t)j * B, s->vec + Lv.voff + (int64_t)(s->ghost_slot[j] - Lv.start) * M + P,
-                                 sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
-        const int64_t vb = Lv.voff + (int64_t)(s->root_slot - Lv.start) * M + P;
-        int rcx = s->comm->scatter0(s->st, s->d_vbuf, (size_t)B, s->vec + vb);
-        if (rcx) {
-          s->err = "distributed solve: " + s->comm->err;
-          return rcx;
-        }
+  for (int d = 0; d <= maxdepth; ++d) {  // backward: root to leaves
+    const bool xchg = s->size > 1 && d == s->kdist && s->lev[s->kbatch].B > 0;
+    if (xchg) {  // the subtree roots' border values: gathered from the parents on rank 0, then sent to their owners
+      const NdLevel& Lv = s->lev[s->kbatch];
+      const int P = Lv.P, B = Lv.B, M = P + B;
+      if (Lv.count)
+        hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, s->st, Lv.start, P, s->d_fb, s->d_parent,
+                           s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
+      if (s->rank == 0)
+        for (int j = 1; j < s->size; ++j)
+          NDHIP(hipMemcpyAsync(s->d_vbuf + (size_t)j * B, s->vec + Lv.voff + (int64_t)(s->ghost_slot[j] - Lv.start) * M + P,
+                               sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
+      const int64_t vb = Lv.voff + (int64_t)(s->root_slot - Lv.start) * M + P;
+      int rcx = s->comm->scatter0(s->st, s->d_vbuf, (size_t)B, s->vec + vb);
+      if (rcx) {
+        s->err = "distributed solve: " + s->comm->err;
+        return rcx;
       }
-      hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, s->st, s->arena,
-                         Lv.off, s->vec, Lv.voff, M, 0, P, P, M);
     }
-    const int nsl = (P + ND_SLAB - 1) / ND_SLAB;
-    for (int sl = nsl - 1; sl >= 0; --sl) {
-      const int k0 = sl * ND_SLAB, k1 = std::min(P, k0 + ND_SLAB);
-      hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, s->st, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 1);
-      if (k0 > 0)
-        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + 255) / 256)), dim3(256), 0, s->st, s->arena,
-                           Lv.off, s->vec, Lv.voff, M, 0, k0, k0, k1);
+    hipEventRecord(s->ev_fork, s->st);
+    int used = 0;
+    for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) {
+      const NdLevel& Lv = s->lev[l];
+      const int P = Lv.P, B = Lv.B, M = P + B;
+      if (Lv.count == 0) continue;
+      hipStream_t q = nd_fork(s, used++);
+      if (B > 0) {
+        if (!(xchg && l == s->kbatch))
+          hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, s->d_fb, s->d_parent,
+                             s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
+        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, q, s->arena, Lv.off,
+                           s->vec, Lv.voff, M, 0, P, P, M);
+      }
+      const int nsl = (P + ND_SLAB - 1) / ND_SLAB;
+      for (int sl = nsl - 1; sl >= 0; --sl) {
+        const int k0 = sl * ND_SLAB, k1 = std::min(P, k0 + ND_SLAB);
+        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 1);
+        if (k0 > 0)
+          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + 255) / 256)), dim3(256), 0, q, s->arena, Lv.off,
+                             s->vec, Lv.voff, M, 0, k0, k0, k1);
+      }
     }
+    nd_join(s, used);
   }
   if (s->size > 1) NDHIP(hipMemsetAsync(dx, 0, sizeof(double) * s->n, s->st));  // every rank writes its own dofs only
   hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
@@ -1319,7 +1448,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
 // symbolic export (tests)
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B,
-                                    int64_t* lev_off) {
+                                    int64_t* lev_off, int32_t* depth) {
   if (!s || !n_levels) return PGX_EINVAL;
   const int64_t L = (int64_t)s->lev.size();
   *n_levels = L;
@@ -1328,6 +1457,7 @@ extern "C" int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t*
     if (P) P[l] = s->lev[l].P;
     if (B) B[l] = s->lev[l].B;
     if (lev_off) lev_off[l] = s->lev[l].off;
+    if (depth) depth[l] = s->lev[l].depth;
   }
   if (lev_start) lev_start[L] = s->nfronts;
   return PGX_OK;

@@ -69,11 +69,12 @@ class DirectSolver:
         i64, i32 = np.int64, np.int32
         p64 = lambda a: a.ctypes.data_as(L.c_int64_p)  # noqa: E731
         nl = C.c_int64()
-        self._check(lib.pgx_nd_export_levels(h, C.byref(nl), None, None, None, None), "export_levels")
+        self._check(lib.pgx_nd_export_levels(h, C.byref(nl), None, None, None, None, None), "export_levels")
         nl = nl.value
         lev_start, P, B, lev_off = np.zeros(nl + 1, i64), np.zeros(nl, i32), np.zeros(nl, i32), np.zeros(nl, i64)
+        depth = np.zeros(nl, i32)
         n1 = C.c_int64()
-        lib.pgx_nd_export_levels(h, C.byref(n1), p64(lev_start), L.iptr(P), L.iptr(B), p64(lev_off))
+        lib.pgx_nd_export_levels(h, C.byref(n1), p64(lev_start), L.iptr(P), L.iptr(B), p64(lev_off), L.iptr(depth))
         nf = C.c_int64()
         lib.pgx_nd_export_fronts(h, C.byref(nf), None, None, None, None, None, None, None, None)
         nf = nf.value
@@ -87,7 +88,7 @@ class DirectSolver:
         lib.pgx_nd_export_dest(h, C.byref(nnz), None)
         dest = np.zeros(nnz.value, i64)
         lib.pgx_nd_export_dest(h, C.byref(nnz), p64(dest))
-        return dict(lev_start=lev_start, P=P, B=B, lev_off=lev_off, fp=fp, fb=fb, parent=par, slot01=s01,
+        return dict(lev_start=lev_start, P=P, B=B, lev_off=lev_off, depth=depth, fp=fp, fb=fb, parent=par, slot01=s01,
                     dof_ptr=dof_ptr, own_dofs=own[: int(dof_ptr[-1])], rel_ptr=rel_ptr, rel=rel[: int(rel_ptr[-1])],
                     dest=dest)
 

@@ -33,17 +33,21 @@ def factor(sym, vals):
         F = front(f)
         for k in range(sym["fp"][f], P[l]):
             F[k, k] = 1.0
+    depth = sym["depth"]
     for l in range(L - 1, -1, -1):
-        if l + 1 < L:
+        if l == L - 1 or depth[l + 1] != depth[l]:  # entering tree depth depth[l]: extend-add every front of depth + 1
             for ps in (0, 1):
-                for c in range(int(start[l + 1]), int(start[l + 2])):
-                    if sym["slot01"][c] != ps:
+                for cb in range(L):
+                    if depth[cb] != depth[l] + 1:
                         continue
-                    b = sym["fb"][c]
-                    R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + b]
-                    Fc = front(c)
-                    Fp = front(sym["parent"][c])
-                    Fp[np.ix_(R, R)] += Fc[P[l + 1]: P[l + 1] + b, P[l + 1]: P[l + 1] + b]
+                    for c in range(int(start[cb]), int(start[cb + 1])):
+                        if sym["slot01"][c] != ps:
+                            continue
+                        b = sym["fb"][c]
+                        R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + b]
+                        Fc = front(c)
+                        Fp = front(sym["parent"][c])
+                        Fp[np.ix_(R, R)] += Fc[P[cb]: P[cb] + b, P[cb]: P[cb] + b]
         for f in range(int(start[l]), int(start[l + 1])):
             F = front(f)
             p = P[l]
@@ -76,7 +80,8 @@ def solve(sym, fac, b):
             for c in sorted(children[f], key=lambda c: sym["slot01"][c]):
                 bc = sym["fb"][c]
                 R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + bc]
-                v[R] += w[c][P[l + 1]: P[l + 1] + bc]
+                Pc = P[level_of[c]]
+                v[R] += w[c][Pc: Pc + bc]
             F = front(f)
             pp = P[l]
             v[:pp] = np.linalg.solve(np.tril(F[:pp, :pp], -1) + np.eye(pp), v[:pp])
