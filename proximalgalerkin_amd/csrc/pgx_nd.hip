@@ -1,26 +1,31 @@
 // pgx_nd.hip - geometric nested-dissection multifrontal LU on the GPU (C ABI: include/pgx_nd.h).
 //
 // Replaces PETSc "pc_type lu / pc_factor_mat_solver_type mumps" of the reference (obstacle_pg.py:129-131,
-// gradient_constraint_dolfinx.py:118-121) for the Newton systems of the LVPP examples.
+// gradient_constraint_dolfinx.py:118-121, signorini_dolfinx.py:271-279, thermoforming_dolfinx.py:105-107) for the Newton
+// systems of the LVPP examples.  DESIGN.md section 9 has the measurements.
 //
 // Host (symbolic, once per pattern): node graph -> recursive coordinate bisection (separator = nodes of the lower half
-// adjacent to the upper half) -> postorder, border ("struct") sets, fronts grouped by tree DEPTH into levels; all fronts
-// of a level are padded to a common pivot order P and border B so that a level is ONE strided batch.
-// Device (numeric, every Newton step): zero the arena, scatter the CSR values to their frontal positions (precomputed,
-// conflict-free), then per level, deepest first: extend-add the children's Schur complements (two conflict-free passes,
-// no atomics -> bitwise reproducible), LU of the pivot blocks without pivoting, two triangular solves, one GEMM update.
-// Solve: the same tree walk on per-front vectors (forward bottom-up, backward top-down).
-//
-// MI355X notes: the arena is sized for 288 GB HBM3E (tens of GB of fronts are kept resident so that the solve phase and
-// the next factorisation re-use the allocation).  All dense work is hand-written and batched over the fronts of a level:
-//   k_nd_diag   LU of one nb x nb diagonal block (nb <= 72) in LDS, no pivoting
-//   k_nd_panel  the two triangular panel solves against that block, 64-wide chunks, right-looking in LDS
-//   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 64x64 tiles, 4 waves x (2x2) MFMA tiles;
-//               operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes
-// organised as a partial left-looking factorisation: the pivot block and both panels are updated step by step, the
-// Schur complement F22 -= L21 U12 is applied ONCE with K = P (its bytes move once; arithmetic intensity P/8 flop/byte).
-// (A first version used rocSOLVER getrf_npvt / rocBLAS trsm+gemm strided-batched: 859 ms at 1024^2, dominated by
-// 4e5 tiny Tensile launches; profiles/r01_nd_rocblas_baseline_kernel_stats.csv.)
+// adjacent to the upper half, leaves of 16 nodes) -> postorder, border ("struct") sets.  Fronts are grouped into BATCHES =
+// one tree depth x one size class (<= 4 classes per depth, chosen to minimise padded flops + storage); every front of a
+// batch is padded to the batch's pivot order P and border B, so a batch is one strided launch set.  Assembly destinations
+// and child -> parent maps are precomputed.
+// Device (numeric, every Newton step): zero the arena, scatter the CSR values to their frontal positions (conflict-free),
+// then depth by depth, deepest first: extend-add the children's Schur complements (two conflict-free passes, no atomics ->
+// bitwise reproducible), then for every batch of the depth - on forked HIP streams, joined per depth - a two-level blocked
+// partial LU without pivoting across nodes:
+//   k_nd_diag   LU of one <= 64-wide diagonal block in LDS (8-column panels by one wave with lane shuffles)
+//   k_nd_panel  both triangular panel solves against that block, 64-wide chunks, blocked by 8 in LDS
+//   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 64^2 / 128^2 tiles, 4 waves x (2x2 | 4x4) MFMA
+//               tiles, operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes;
+//               rank-64 updates touch only the strips of the current 256-pivot outer block, the rest of the trailing
+//               matrix gets one rank-256 update per outer block, the Schur block F22 ONE update with K = P.
+// Solve: the same tree walk on per-front vectors (forward leaves -> root, backward root -> leaves): k_nd_trsv on slabs of
+// 256 pivots (64 x 64 triangles by wave shuffles), everything outside the slab by k_nd_gemv over many workgroups.
+// Distributed (pgx_nd_create_dist): the tree is cut at depth log2(ranks); one subtree per rank, the levels above on rank 0
+// with ghost copies of the other subtree roots; pgx_comm::gather0 / scatter0 / allreduce carry the Schur blocks, border
+// vectors and the solution.
+// (A first version used rocSOLVER getrf_npvt / rocBLAS trsm+gemm strided-batched: 859 ms at 1024^2 against 40 ms now,
+// dominated by 4e5 tiny Tensile launches; profiles/r01_nd_rocblas_baseline_kernel_stats.csv.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
