@@ -79,6 +79,11 @@ int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start,
 int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t* fp, int32_t* fb, int32_t* parent, int32_t* slot01,
                          int64_t* dof_ptr, int32_t* own_dofs, int64_t* rel_ptr, int32_t* rel);
 int pgx_nd_export_dest(const pgx_nd* s, int64_t* nnz, int64_t* dest);
+/* Tests: the symbolic structure rank `rank` of `size` would build in pgx_nd_create_dist (no GPU, no communicator), and its
+ * distribution data: tree depth of the cut, batch holding the subtree roots, this rank's root slot, and on rank 0 the slots
+ * of all subtree roots (own + ghosts; dest[] entries of fronts living on other ranks are -1). */
+int pgx_nd_create_symbolic_dist(const pgx_nd_matrix* A, int rank, int size, pgx_nd** out);
+int pgx_nd_export_dist(const pgx_nd* s, int32_t* kdist, int32_t* kbatch, int32_t* root_slot, int32_t* ghost_slot /* [size] */);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,8 @@ SYMBOLS = [
     # sparse direct solver (include/pgx_nd.h)
     ("pgx_nd_create", C.c_int, [C.POINTER(pgx_nd_matrix), C.c_int, C.c_void_p, C.POINTER(_H)]),
     ("pgx_nd_create_dist", C.c_int, [C.POINTER(pgx_nd_matrix), _COMM, C.c_int, C.c_void_p, C.POINTER(_H)]),
+    ("pgx_nd_create_symbolic_dist", C.c_int, [C.POINTER(pgx_nd_matrix), C.c_int, C.c_int, C.POINTER(_H)]),
+    ("pgx_nd_export_dist", C.c_int, [_H, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ("pgx_nd_destroy", None, [_H]),
     ("pgx_nd_last_error", C.c_char_p, [_H]),
     ("pgx_nd_get_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),

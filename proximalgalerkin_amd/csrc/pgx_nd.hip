@@ -1060,7 +1060,8 @@ static int nd_alloc(pgx_nd* s, T** d, size_t count) {
   return PGX_OK;
 }
 
-static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, void* hip_stream, pgx_nd** out) {
+static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, void* hip_stream, pgx_nd** out,
+                          int sym_rank = 0, int sym_size = 1) {
   if (!A || !out || A->n <= 0 || !A->rowptr || !A->col || !A->node_of_dof || !A->node_coords || A->n_nodes <= 0 ||
       (A->dim != 2 && A->dim != 3)) {
     g_nd_error = "pgx_nd_create: bad arguments";
@@ -1068,7 +1069,10 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   }
   pgx_nd* s = new pgx_nd();
   s->n = A->n;
-  if (comm) s->comm = comm, s->rank = comm->rank, s->size = comm->size;
+  if (comm)
+    s->comm = comm, s->rank = comm->rank, s->size = comm->size;
+  else
+    s->rank = sym_rank, s->size = sym_size;  // symbolic-only view of one rank of a distributed factorisation (tests)
   int rc = nd_symbolic(s, A);
   if (rc) {
     g_nd_error = s->err;
@@ -1143,6 +1147,24 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
 
 extern "C" int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream, pgx_nd** out) {
   return nd_create_impl(A, nullptr, device, hip_stream, out);
+}
+
+extern "C" int pgx_nd_create_symbolic_dist(const pgx_nd_matrix* A, int rank, int size, pgx_nd** out) {
+  if (size < 1 || rank < 0 || rank >= size) {
+    g_nd_error = "pgx_nd_create_symbolic_dist: bad rank / size";
+    return PGX_EINVAL;
+  }
+  return nd_create_impl(A, nullptr, -1, nullptr, out, rank, size);
+}
+
+extern "C" int pgx_nd_export_dist(const pgx_nd* s, int32_t* kdist, int32_t* kbatch, int32_t* root_slot, int32_t* ghost_slot) {
+  if (!s) return PGX_EINVAL;
+  if (kdist) *kdist = s->kdist;
+  if (kbatch) *kbatch = s->kbatch;
+  if (root_slot) *root_slot = s->root_slot;
+  if (ghost_slot)
+    for (size_t j = 0; j < s->ghost_slot.size(); ++j) ghost_slot[j] = s->ghost_slot[j];
+  return PGX_OK;
 }
 
 extern "C" int pgx_nd_create_dist(const pgx_nd_matrix* A, pgx_comm* comm, int device, void* hip_stream, pgx_nd** out) {

@@ -15,7 +15,8 @@ from . import _lib as L
 
 
 class DirectSolver:
-    def __init__(self, indptr, indices, node_of_dof, node_coords, leaf_nodes: int = 0, device: int = 0, comm=None):
+    def __init__(self, indptr, indices, node_of_dof, node_coords, leaf_nodes: int = 0, device: int = 0, comm=None,
+                 symbolic_rank: tuple | None = None):
         """comm: a proximalgalerkin_amd.comm.Communicator -> distributed factorisation (pgx_nd_create_dist): one subtree of
         the dissection tree per rank; every rank passes the same matrix / right-hand sides, all calls are collective."""
         self._lib = L.load()
@@ -28,7 +29,11 @@ class DirectSolver:
         m = L.pgx_nd_matrix(self.n, L.iptr(self.indptr), L.iptr(self.indices), int(self.node_coords.shape[0]),
                             L.iptr(self.node_of_dof), int(self.node_coords.shape[1]), L.dptr(self.node_coords),
                             int(leaf_nodes))
-        if comm is None:
+        self._dist_size = 1
+        if symbolic_rank is not None:  # (rank, size): symbolic view of one rank of a distributed factorisation (tests)
+            self._dist_size = int(symbolic_rank[1])
+            rc = self._lib.pgx_nd_create_symbolic_dist(C.byref(m), int(symbolic_rank[0]), int(symbolic_rank[1]), C.byref(self._h))
+        elif comm is None:
             rc = self._lib.pgx_nd_create(C.byref(m), int(device), None, C.byref(self._h))
         else:
             self._comm = comm  # keep the communicator alive
@@ -88,7 +93,11 @@ class DirectSolver:
         lib.pgx_nd_export_dest(h, C.byref(nnz), None)
         dest = np.zeros(nnz.value, i64)
         lib.pgx_nd_export_dest(h, C.byref(nnz), p64(dest))
-        return dict(lev_start=lev_start, P=P, B=B, lev_off=lev_off, depth=depth, fp=fp, fb=fb, parent=par, slot01=s01,
+        kd, kb, rs = C.c_int32(), C.c_int32(), C.c_int32()
+        gs = np.full(max(self._dist_size, 1), -1, i32)
+        lib.pgx_nd_export_dist(h, C.byref(kd), C.byref(kb), C.byref(rs), L.iptr(gs))
+        dist = dict(kdist=kd.value, kbatch=kb.value, root_slot=rs.value, ghost_slot=gs)
+        return dict(dist=dist, lev_start=lev_start, P=P, B=B, lev_off=lev_off, depth=depth, fp=fp, fb=fb, parent=par, slot01=s01,
                     dof_ptr=dof_ptr, own_dofs=own[: int(dof_ptr[-1])], rel_ptr=rel_ptr, rel=rel[: int(rel_ptr[-1])],
                     dest=dest)
 

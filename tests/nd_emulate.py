@@ -101,3 +101,167 @@ def solve(sym, fac, b):
             p = sym["fp"][f]
             x[sym["own_dofs"][sym["dof_ptr"][f]: sym["dof_ptr"][f] + p]] = v[:p]
     return x
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# distributed factorisation (pgx_nd_create_dist): R per-rank symbolic views, explicit exchanges
+# ------------------------------------------------------------------------------------------------------------------
+def _setup_rank(sym, vals):
+    """arena with the entries this rank owns assembled and identity on padded / ghost pivots"""
+    P, B, off, start = sym["P"], sym["B"], sym["lev_off"], sym["lev_start"]
+    L = len(P)
+    M = P.astype(np.int64) + B
+    total = int(sum((start[l + 1] - start[l]) * M[l] * M[l] for l in range(L)))
+    arena = np.zeros(max(total, 1))
+    d = sym["dest"]
+    own = d >= 0
+    arena[d[own]] = vals[own]
+    level_of = np.zeros(int(start[-1]), dtype=np.int64)
+    for l in range(L):
+        level_of[start[l]: start[l + 1]] = l
+
+    def front(f):
+        l = level_of[f]
+        base = off[l] + (f - start[l]) * M[l] * M[l]
+        return arena[base: base + M[l] * M[l]].reshape(M[l], M[l]).T
+
+    for f in range(int(start[-1])):
+        F = front(f)
+        for k in range(sym["fp"][f], P[level_of[f]]):
+            F[k, k] = 1.0
+    return dict(arena=arena, front=front, level_of=level_of, M=M)
+
+
+def _factor_depth(sym, st, d):
+    """extend-add from depth d+1 into depth d, then factor every local front of depth d"""
+    P, B, start, depth = sym["P"], sym["B"], sym["lev_start"], sym["depth"]
+    L = len(P)
+    front, level_of = st["front"], st["level_of"]
+    for ps in (0, 1):
+        for cb in range(L):
+            if depth[cb] != d + 1:
+                continue
+            for c in range(int(start[cb]), int(start[cb + 1])):
+                if sym["slot01"][c] != ps or sym["parent"][c] < 0:
+                    continue
+                b = sym["fb"][c]
+                R = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + b]
+                front(sym["parent"][c])[np.ix_(R, R)] += front(c)[P[cb]: P[cb] + b, P[cb]: P[cb] + b]
+    for l in range(L):
+        if depth[l] != d:
+            continue
+        for f in range(int(start[l]), int(start[l + 1])):
+            F = front(f)
+            p = P[l]
+            F11 = F[:p, :p]
+            _lu_nopivot(F11)
+            if B[l]:
+                Lm = np.tril(F11, -1) + np.eye(p)
+                U = np.triu(F11)
+                F[:p, p:] = np.linalg.solve(Lm, F[:p, p:])
+                F[p:, :p] = np.linalg.solve(U.T, F[p:, :p].T).T
+                F[p:, p:] -= F[p:, :p] @ F[:p, p:]
+
+
+def factor_dist(syms, vals):
+    """syms[r] = export_symbolic() of rank r's view.  Mirrors pgx_nd_factor on R ranks incl. the gather0 exchange."""
+    R = len(syms)
+    sts = [_setup_rank(s, vals) for s in syms]
+    maxd = int(max(s["depth"].max() for s in syms))
+    kd = syms[0]["dist"]["kdist"]
+    for d in range(maxd, -1, -1):
+        for r in range(R):
+            _factor_depth(syms[r], sts[r], d)
+        if d == kd and R > 1:  # Schur blocks of the subtree roots -> rank 0's ghost fronts
+            kb = syms[0]["dist"]["kbatch"]
+            P0, B0 = syms[0]["P"][kb], syms[0]["B"][kb]
+            for r in range(1, R):
+                Fr = sts[r]["front"](syms[r]["dist"]["root_slot"])
+                Fg = sts[0]["front"](syms[0]["dist"]["ghost_slot"][r])
+                Fg[P0: P0 + B0, P0: P0 + B0] = Fr[P0: P0 + B0, P0: P0 + B0]
+    return sts
+
+
+def solve_dist(syms, sts, b):
+    R = len(syms)
+    maxd = int(max(s["depth"].max() for s in syms))
+    kd = syms[0]["dist"]["kdist"]
+    kb = syms[0]["dist"]["kbatch"]
+    P0, B0 = syms[0]["P"][kb], syms[0]["B"][kb]
+    W = []
+    for r in range(R):
+        sym = syms[r]
+        nf = int(sym["lev_start"][-1])
+        W.append([None] * nf)
+    children = []
+    for r in range(R):
+        sym = syms[r]
+        ch = [[] for _ in range(int(sym["lev_start"][-1]))]
+        for f in range(len(ch)):
+            if sym["parent"][f] >= 0:
+                ch[sym["parent"][f]].append(f)
+        children.append(ch)
+
+    def fwd_depth(r, d):
+        sym, st, w = syms[r], sts[r], W[r]
+        P, B, start, depth = sym["P"], sym["B"], sym["lev_start"], sym["depth"]
+        for l in range(len(P)):
+            if depth[l] != d:
+                continue
+            for f in range(int(start[l]), int(start[l + 1])):
+                v = np.zeros(st["M"][l])
+                p = sym["fp"][f]
+                v[:p] = b[sym["own_dofs"][sym["dof_ptr"][f]: sym["dof_ptr"][f] + p]]
+                for c in sorted(children[r][f], key=lambda c: sym["slot01"][c]):
+                    bc = sym["fb"][c]
+                    Rm = sym["rel"][sym["rel_ptr"][c]: sym["rel_ptr"][c] + bc]
+                    Pc = P[st["level_of"][c]]
+                    v[Rm] += w[c][Pc: Pc + bc]
+                F = st["front"](f)
+                pp = P[l]
+                v[:pp] = np.linalg.solve(np.tril(F[:pp, :pp], -1) + np.eye(pp), v[:pp])
+                v[pp:] -= F[pp:, :pp] @ v[:pp]
+                w[f] = v
+
+    def bwd_depth(r, d, skip_gather_root):
+        sym, st, w = syms[r], sts[r], W[r]
+        P, B, start, depth = sym["P"], sym["B"], sym["lev_start"], sym["depth"]
+        for l in range(len(P)):
+            if depth[l] != d:
+                continue
+            for f in range(int(start[l]), int(start[l + 1])):
+                v, F, pp = w[f], st["front"](f), P[l]
+                if B[l]:
+                    bf = sym["fb"][f]
+                    if sym["parent"][f] >= 0:
+                        Rm = sym["rel"][sym["rel_ptr"][f]: sym["rel_ptr"][f] + bf]
+                        v[pp: pp + bf] = w[sym["parent"][f]][Rm]
+                    v[:pp] -= F[:pp, pp:] @ v[pp:]
+                v[:pp] = np.linalg.solve(np.triu(F[:pp, :pp]), v[:pp])
+
+    for d in range(maxd, -1, -1):
+        for r in range(R):
+            fwd_depth(r, d)
+        if d == kd and R > 1:
+            for r in range(1, R):
+                W[0][syms[0]["dist"]["ghost_slot"][r]][P0: P0 + B0] = W[r][syms[r]["dist"]["root_slot"]][P0: P0 + B0]
+    x = np.zeros_like(b, dtype=float)
+    for d in range(0, maxd + 1):
+        if d == kd and R > 1:
+            # rank 0 gathers the ghosts' border values from their parents and sends them to the owners
+            sym0 = syms[0]
+            for r in range(1, R):
+                g = sym0["dist"]["ghost_slot"][r]
+                bf = sym0["fb"][g]
+                Rm = sym0["rel"][sym0["rel_ptr"][g]: sym0["rel_ptr"][g] + bf]
+                vals = W[0][sym0["parent"][g]][Rm]
+                W[r][syms[r]["dist"]["root_slot"]][P0: P0 + bf] = vals
+        for r in range(R):
+            bwd_depth(r, d, True)
+    for r in range(R):
+        sym = syms[r]
+        for f in range(int(sym["lev_start"][-1])):
+            p = sym["fp"][f]
+            if p:
+                x[sym["own_dofs"][sym["dof_ptr"][f]: sym["dof_ptr"][f] + p]] = W[r][f][:p]
+    return x

@@ -65,3 +65,35 @@ def test_unsymmetric_pattern_is_rejected():
     with pytest.raises(PgxError):
         DirectSolver(A.indptr, A.indices, np.arange(3), np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]]), leaf_nodes=1,
                      device=-1)
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_distributed_symbolic_views_reproduce_lu(R):
+    """The N>1 logic of the sparse LU without a GPU: every rank's symbolic view (pgx_nd_create_symbolic_dist: ownership of
+    the dissection subtrees, ghost subtree roots on rank 0, assembly destinations, child->parent maps) drives a numpy
+    emulation of the distributed numeric phase incl. the gather / scatter exchanges (tests/nd_emulate.py); the result must
+    solve the system like SuperLU does."""
+    N = 14
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    rng = np.random.default_rng(4)
+    x0 = 0.3 * rng.standard_normal(2 * p1.n)
+    x0[p1.n:] -= 40.0 * (np.hypot(*p1.coords.T) < 0.4)
+    J = p1.jacobian(x0, 7.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p1.n)] * 2)
+    syms = []
+    for r in range(R):
+        ds = DirectSolver(J.indptr, J.indices, nod, p1.coords, leaf_nodes=6, device=-1, symbolic_rank=(r, R))
+        syms.append(ds.export_symbolic())
+    # every dof is eliminated on exactly one rank, every matrix entry assembled on exactly one rank
+    owned = np.concatenate([s["own_dofs"] for s in syms])
+    assert np.array_equal(np.sort(owned), np.arange(J.shape[0]))
+    assert np.array_equal(sum((s["dest"] >= 0).astype(int) for s in syms), np.ones(J.nnz, dtype=int))
+    assert all(s["dist"]["kdist"] == int(np.log2(R)) for s in syms)
+    sts = E.factor_dist(syms, J.data)
+    b = rng.standard_normal(J.shape[0])
+    x = E.solve_dist(syms, sts, b)
+    xr = spla.splu(J.tocsc()).solve(b)
+    assert np.linalg.norm(J @ x - b) <= 1e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
