@@ -1123,6 +1123,10 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
 #undef UP
   if ((rc = nd_upload(s, &s->d_fM, fM)) || (rc = nd_upload(s, &s->d_fP, fP)) || (rc = nd_upload(s, &s->d_vbase, vbase)))
     return fail(rc);
+  // the maps live on the device from here on: release the host copies of the large ones (8 bytes per matrix entry)
+  std::vector<int64_t>().swap(s->dest);
+  std::vector<int32_t>().swap(s->own_dofs);
+  std::vector<int32_t>().swap(s->rel);
   if ((rc = nd_alloc(s, &s->arena, (size_t)s->arena_len)) || (rc = nd_alloc(s, &s->vec, (size_t)s->vec_len)) ||
       (rc = nd_alloc(s, &s->d_vals, (size_t)s->nnz)) || (rc = nd_alloc(s, &s->d_b, (size_t)s->n)))
     return fail(rc);
@@ -1493,6 +1497,7 @@ extern "C" int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t*
 extern "C" int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t* fp, int32_t* fb, int32_t* parent,
                                     int32_t* slot01, int64_t* dof_ptr, int32_t* own_dofs, int64_t* rel_ptr, int32_t* rel) {
   if (!s || !n_fronts) return PGX_EINVAL;
+  if (s->device >= 0 && (own_dofs || rel)) return PGX_ESTATE;  // released after upload (see pgx_nd_export_dest)
   *n_fronts = s->nfronts;
   auto cp = [](auto* dst, const auto& v) {
     if (dst) std::copy(v.begin(), v.end(), dst);
@@ -1510,6 +1515,7 @@ extern "C" int pgx_nd_export_fronts(const pgx_nd* s, int64_t* n_fronts, int32_t*
 
 extern "C" int pgx_nd_export_dest(const pgx_nd* s, int64_t* nnz, int64_t* dest) {
   if (!s || !nnz) return PGX_EINVAL;
+  if (s->device >= 0) return PGX_ESTATE;  // a device handle has released its host maps; export from a symbolic-only handle
   *nnz = s->nnz;
   if (dest) std::copy(s->dest.begin(), s->dest.end(), dest);
   return PGX_OK;
