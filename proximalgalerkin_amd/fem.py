@@ -279,12 +279,51 @@ class Function:
         return self.x.array[i * n:(i + 1) * n]
 
 
-class Constant:
+class _FormOperand:
+    """Arithmetic on Constants / quadrature-space coefficients builds form expressions (proximalgalerkin_amd/ufl.py)."""
+
+    def _e(self):
+        from . import ufl
+
+        return ufl.as_expr(self)
+
+    def __mul__(self, o):
+        return self._e() * o
+
+    def __rmul__(self, o):
+        return o * self._e()
+
+    def __add__(self, o):
+        return self._e() + o
+
+    def __radd__(self, o):
+        return o + self._e()
+
+    def __sub__(self, o):
+        return self._e() - o
+
+    def __rsub__(self, o):
+        return o - self._e()
+
+    def __neg__(self):
+        return -self._e()
+
+    def __truediv__(self, o):
+        return self._e() / o
+
+    def __rtruediv__(self, o):
+        return o / self._e()
+
+
+class Constant(_FormOperand):
     def __init__(self, mesh, value):
         self.value = float(value)
 
+    def __float__(self):
+        return self.value
 
-class QuadratureFunction:
+
+class QuadratureFunction(_FormOperand):
     """Function in a quadrature space of the given degree: one value per (cell, point), dof =
     cell*nq + q (basix.ufl.quadrature_element + fem.functionspace, obstacle_pg.py:107-110)."""
 

@@ -11,8 +11,8 @@ from pathlib import Path
 
 import numpy as np
 
-from . import fem
-from .problem import NonlinearProblem, ObstacleResidual, derivative
+from . import fem, ufl
+from .problem import NonlinearProblem
 
 
 def phi_set(x):
@@ -48,8 +48,15 @@ def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict 
     quadrature_degree = 6  # :106
     phi_fn = fem.QuadratureFunction(msh, quadrature_degree, name="phi")
     phi_fn.interpolate(phi)  # :110-111
-    F = ObstacleResidual(sol, sol_k, alpha, f, phi_fn, quadrature_degree)  # :116-124
-    J = derivative(F, sol)  # :125
+    # the residual as the reference states it (:88-89,114-125), through the UFL-subset front end (ufl.py), which selects the
+    # HIP kernel family for it
+    u, psi = ufl.split(sol)
+    u_k, psi_k = ufl.split(sol_k)
+    v, w = ufl.TestFunctions(V)
+    dx = ufl.Measure("dx", domain=msh, metadata={"quadrature_degree": quadrature_degree})
+    F = (alpha * ufl.inner(ufl.grad(u), ufl.grad(v)) * dx + psi * v * dx + u * w * dx - ufl.exp(psi) * w * dx
+         - phi_fn * w * dx - alpha * f * v * dx - psi_k * v * dx)
+    J = ufl.derivative(F, sol)
     if petsc_options is None:
         petsc_options = {  # :128-139
             "ksp_type": "preonly",

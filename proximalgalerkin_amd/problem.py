@@ -63,6 +63,20 @@ def derivative(F, u, du=None):
     return Derivative(F, u)
 
 
+def _compile(F, u, J):
+    """Symbolic forms (proximalgalerkin_amd.ufl) -> the family description the HIP path is built from; J must be the exact
+    derivative of F with respect to u (obstacle_pg.py:125) or None (NonlinearProblem's default)."""
+    from . import ufl
+
+    if isinstance(F, ufl.Form):
+        spec = ufl.compile_form(F, u, J)
+        if not isinstance(spec, ObstacleResidual):
+            raise NotImplementedError(f"this form is a {type(spec).__name__}: construct it with the family's own NonlinearProblem "
+                                      "(proximalgalerkin_amd.thermoforming.NonlinearProblem)")
+        return spec, (Derivative(spec, u) if J is not None else None)
+    return F, J
+
+
 _IGNORED_KEYS = {"pc_factor_mat_solver_type", "mat_mumps_icntl_14", "mat_mumps_icntl_24"}
 
 
@@ -152,8 +166,9 @@ class NonlinearProblem:
     def __init__(self, F, u: Function, bcs=None, J=None, petsc_options=None, petsc_options_prefix="", device=0, lu_comm=None):
         """lu_comm: a comm.Communicator -> this handle is one of several REPLICAS (whole mesh on every rank) whose sparse-LU
         preconditioner is distributed over the ranks (include/pgx.h: pgx_create_lu_dist); every call is collective."""
+        F, J = _compile(F, u, J)
         if not isinstance(F, ObstacleResidual):
-            raise TypeError("F must be an ObstacleResidual form description")
+            raise TypeError("F must be a form (proximalgalerkin_amd.ufl) or an ObstacleResidual form description")
         if J is not None and not (isinstance(J, Derivative) and J.form is F):
             raise NotImplementedError("only J = derivative(F, u) (the exact Jacobian) is supported")
         if u is not F.sol:

@@ -175,3 +175,107 @@ def solve_problem(M: int = 150, alpha_0: float = 2.0**-6, alpha_max: float = 2.0
         return num_iterations, diffs, x
     problem.close()
     return num_iterations, diffs
+
+
+class NonlinearProblem:
+    """`dolfinx.fem.petsc.NonlinearProblem(F, u=s, bcs=[bc], J=J, petsc_options=sp)` (:114-116) for FORMS of the thermoforming
+    family: the UFL-subset front end (ufl.py) recognises the residual (:62-67) and the modified Jacobian form (:69-71), reads
+    beta, f, the knees of g and eps off the forms' Constants and selects the HIP kernels of include/pgx_qvi.h.  `alpha` and the
+    two Functions stay live: every `.solve()` takes their current values (:119,156-158)."""
+
+    def __init__(self, F, u: fem.Function, bcs=None, J=None, petsc_options=None, petsc_options_prefix="", device=0):
+        from . import ufl
+
+        spec = ufl.compile_form(F, u, J)
+        if not isinstance(spec, ufl.ThermoformingSpec):
+            raise NotImplementedError(f"this form is a {type(spec).__name__}, not the thermoforming QVI")
+        V = u.function_space
+        if V.degree != 1 or spec.s_prev.function_space != V:
+            raise NotImplementedError("the thermoforming kernels are written for the mixed [P1, P1, P1] space (:28-33)")
+        if spec.bound0.value != 0.0 or not spec.bound1.value > 0.0:
+            raise NotImplementedError("g is implemented with knees 0 < bound1 (:36-48)")
+        ext = np.sort(V.mesh.exterior_dofs(1))
+        bcs = list(bcs or [])
+        ok = (len(bcs) == 1 and bcs[0].sub == 0 and np.array_equal(np.sort(bcs[0].dofs), ext) and not np.any(bcs[0].values))
+        if not ok:
+            raise NotImplementedError("boundary conditions: u = 0 on the whole boundary (:73-79)")
+        self.spec, self.u = spec, u
+        self._p = ThermoformingProblem(V.mesh, petsc_options, beta=spec.beta.value, f=spec.f.value, knee=spec.bound1.value,
+                                       eps_mod=spec.eps.value if spec.eps is not None else 0.0,
+                                       quadrature_degree=spec.quadrature_degree or 6, device=device)
+        self.solver = self._p.solver
+
+    def solve(self):
+        p, sp = self._p, self.spec
+        p.set_alpha(sp.alpha.value)
+        p.set_prev(sp.s_prev.x.array)
+        p.set_state(self.u.x.array)
+        p.solve()
+        self.u.x.array[:] = p.get_state()
+        return self.u
+
+    def h1_increment(self):
+        """sqrt(assemble_scalar(inner(u-u_prev, u-u_prev)*dx + inner(grad(u-u_prev), grad(u-u_prev))*dx)) (:81-83,139-140)
+        for the Functions' current values."""
+        self._p.set_prev(self.spec.s_prev.x.array)
+        self._p.set_state(self.u.x.array)
+        return self._p.h1_increment()
+
+    def close(self):
+        self._p.close()
+
+
+def solve_problem_forms(M: int = 150, alpha_0: float = 2.0**-6, alpha_max: float = 2.0**14, termination_tol: float = 1e-9,
+                        max_lvpp_iterations: int = 100, verbose: bool = False, device: int = 0):
+    """The reference script with its problem stated as forms (:23-160), through the front end.  Returns
+    (num_iterations, final state)."""
+    from . import ufl
+    from .ufl import conditional, dx, exp, grad, inner, lt, max_value, pi, sin
+
+    mesh = fem.create_unit_square(M, M)  # :24-25
+    V = fem.functionspace(mesh, ("Lagrange", 1), ncomp=3)  # :28-30
+    s = fem.Function(V)
+    u, T, psi = ufl.split(s)  # :31
+    v, q, w = ufl.TestFunctions(V)  # :33
+    bound0, bound1 = fem.Constant(mesh, 0.0), fem.Constant(mesh, 0.01)  # :36-39
+
+    def g(t):  # :42-48
+        return conditional(lt(t, bound0), 1, conditional(lt(t, bound1), 1 - t / bound1, 0))
+
+    x, y = ufl.SpatialCoordinate(mesh)  # :51
+    s_prev = fem.Function(V)
+    u_prev, _, psi_prev = ufl.split(s_prev)
+    beta, alpha, f = fem.Constant(mesh, 1.0), fem.Constant(mesh, alpha_0), fem.Constant(mesh, 25)  # :55-57
+    Phi0 = 1 - 2 * max_value(abs(x - 0.5), abs(y - 0.5))  # :58
+    xi = sin(pi * x) * sin(pi * y)  # :59
+    F = alpha * inner(grad(u), grad(v)) * dx + inner(psi, v) * dx  # :62-67
+    F += -alpha * inner(f, v) * dx - inner(psi_prev, v) * dx
+    F += inner(grad(T), grad(q)) * dx + beta * inner(T, q) * dx
+    F += -inner(g(exp(-psi)), q) * dx
+    F += inner(u, w) * dx + inner(exp(-psi), w) * dx
+    F += -inner(Phi0 + xi * T, w) * dx
+    eps = fem.Constant(mesh, 1.0e-10)  # :70
+    J = ufl.derivative(F - eps / alpha * inner(grad(psi), grad(w)) * dx, s)  # :71
+    bc = fem.dirichletbc(0.0, mesh.exterior_dofs(1), V.sub(0))  # :73-79
+    problem = NonlinearProblem(F, u=s, bcs=[bc], J=J, petsc_options=dict(SP), petsc_options_prefix="snes_", device=device)
+    n = V.block_size
+    s.x.array[n:2 * n] = 1.0  # :119
+    num_iterations = []
+    for i in range(1, max_lvpp_iterations + 1):
+        problem.solve()  # :124
+        num_its = problem.solver.getIterationNumber()
+        converged_reason = problem.solver.getConvergedReason()
+        if converged_reason <= 0:  # :127-128
+            raise ConvergenceError(f"Solver did not converge with {converged_reason}")
+        normed_diff = problem.h1_increment()  # :138-140
+        if verbose:
+            print(f"LVPP iteration {i}, Converged reason {converged_reason}",
+                  f" Newton iterations {num_its} ||u-u_prev||_L2={normed_diff}", flush=True)
+        num_iterations.append(num_its)
+        if normed_diff < termination_tol:
+            break
+        s_prev.x.array[:] = s.x.array  # :156
+        alpha.value = min(alpha_max, alpha.value * 4)  # :157-158
+    x_final = s.x.array.copy()
+    problem.close()
+    return num_iterations, x_final

@@ -1,0 +1,537 @@
+"""UFL-subset front end: symbolic residual forms in, kernel selection out.
+
+The reference states its problems as UFL forms and lets FFCx generate element kernels
+(/root/reference/examples/01_obstacle_problem/obstacle_pg.py:88-125).  Here the element kernels are hand-written
+HIP, one set per problem family, so the front end does not generate code: it
+
+  1. builds an expression tree for the operator subset the in-scope examples use (split, TestFunctions, inner, dot, grad,
+     exp, sqrt, sin, abs, max_value, conditional, lt, SpatialCoordinate, arithmetic, Measure("dx", metadata=
+     {"quadrature_degree": q}), derivative) - SURVEY.md App. B,
+  2. expands a form into a canonical sum of monomials  coef * (scalar factors) * [inner(vector, vector)]  per measure
+     (bilinearity of inner, linearity of grad, constants pulled out of grad, like terms combined), so that forms that
+     are EQUAL as polynomials in their terminals compare equal however they were written, and
+  3. matches the canonical form against the registered family templates - written in this same language - by unifying
+     the user's terminals (unknown, previous iterate, Constants, quadrature-space coefficients) with the template's roles.
+
+A match returns the declarative description the HIP path is built from (problem.ObstacleResidual for example 01,
+ThermoformingSpec for example 05, whose Jacobian form differs from the derivative of the residual); anything else raises
+NotImplementedError naming the terms that do not fit, never a silent approximation.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+
+from . import fem
+
+# ---------------------------------------------------------------------------------------------------------------------
+# expression tree
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+class Expr:
+    rank = 0  # 0 scalar, 1 vector
+
+    def __add__(self, o):
+        return Sum(self, as_expr(o))
+
+    def __radd__(self, o):
+        return Sum(as_expr(o), self)
+
+    def __sub__(self, o):
+        return Sum(self, Scaled(-1.0, as_expr(o)))
+
+    def __rsub__(self, o):
+        return Sum(as_expr(o), Scaled(-1.0, self))
+
+    def __neg__(self):
+        return Scaled(-1.0, self)
+
+    def __mul__(self, o):
+        if isinstance(o, Measure):
+            return Form([Integral(self, o)])
+        if isinstance(o, Form):
+            return o.__rmul__(self)
+        return Product(self, as_expr(o))
+
+    def __rmul__(self, o):
+        return Product(as_expr(o), self)
+
+    def __truediv__(self, o):
+        return Division(self, as_expr(o))
+
+    def __rtruediv__(self, o):
+        return Division(as_expr(o), self)
+
+
+class Number(Expr):
+    def __init__(self, v):
+        self.v = float(v)
+
+
+class Terminal(Expr):
+    """kind: 'component' (obj = fem.Function, index), 'argument' (obj = FunctionSpace, index), 'constant' (fem.Constant),
+    'quadrature' (fem.QuadratureFunction), 'role' (template placeholder, obj = role name)."""
+
+    def __init__(self, kind, obj, index=0, rank=0):
+        self.kind, self.obj, self.index, self.rank = kind, obj, index, rank
+
+    def key(self):
+        return (self.kind, id(self.obj) if self.kind != "role" else self.obj, self.index)
+
+
+class Sum(Expr):
+    def __init__(self, a, b):
+        if a.rank != b.rank:
+            raise ValueError("cannot add a scalar and a vector expression")
+        self.a, self.b, self.rank = a, b, a.rank
+
+
+class Scaled(Expr):
+    def __init__(self, c, a):
+        self.c, self.a, self.rank = float(c), a, a.rank
+
+
+class Product(Expr):
+    def __init__(self, a, b):
+        if a.rank and b.rank:
+            raise ValueError("product of two vectors: use inner() or dot()")
+        self.a, self.b, self.rank = a, b, max(a.rank, b.rank)
+
+
+class Division(Expr):
+    def __init__(self, a, b):
+        if b.rank:
+            raise ValueError("division by a vector")
+        self.a, self.b, self.rank = a, b, a.rank
+
+
+class Grad(Expr):
+    def __init__(self, a):
+        if a.rank:
+            raise NotImplementedError("grad of a vector expression")
+        self.a, self.rank = a, 1
+
+
+class Inner(Expr):
+    def __init__(self, a, b):
+        if a.rank != b.rank:
+            raise ValueError("inner() of operands of different rank")
+        self.a, self.b, self.rank = a, b, 0
+
+
+class Func(Expr):
+    """exp, sqrt, sin, abs, max_value, lt, conditional of scalar expressions: opaque to the polynomial expansion, compared
+    through the canonical text of the arguments."""
+
+    def __init__(self, name, *args):
+        if any(a.rank for a in args):
+            raise ValueError(f"{name} of a vector expression")
+        self.name, self.args, self.rank = name, args, 0
+
+
+def as_expr(o):
+    if isinstance(o, Expr):
+        return o
+    if isinstance(o, (int, float)):
+        return Number(o)
+    if isinstance(o, fem.Constant):
+        return Terminal("constant", o)
+    if isinstance(o, fem.QuadratureFunction):
+        return Terminal("quadrature", o)
+    if isinstance(o, fem.Function):
+        raise TypeError("a mixed Function enters a form through split(function)")
+    raise TypeError(f"cannot use {type(o).__name__} in a form")
+
+
+def split(function: fem.Function):
+    """ufl.split(sol) (obstacle_pg.py:88-89): the components of a mixed Function."""
+    return tuple(Terminal("component", function, i) for i in range(function.function_space.ncomp))
+
+
+def TestFunctions(V: fem.FunctionSpace):
+    """ufl.TestFunctions(V) (obstacle_pg.py:114)."""
+    return tuple(Terminal("argument", V, i) for i in range(V.ncomp))
+
+
+def grad(a):
+    return Grad(as_expr(a))
+
+
+def inner(a, b):
+    return Inner(as_expr(a), as_expr(b))
+
+
+dot = inner  # real-valued: the same contraction for the ranks supported here
+
+
+def exp(a):
+    return Func("exp", as_expr(a))
+
+
+def sqrt(a):
+    return Func("sqrt", as_expr(a))
+
+
+def sin(a):
+    return Func("sin", as_expr(a))
+
+
+def max_value(a, b):
+    return Func("max_value", as_expr(a), as_expr(b))
+
+
+def lt(a, b):
+    return Func("lt", as_expr(a), as_expr(b))
+
+
+def conditional(c, a, b):
+    return Func("conditional", as_expr(c), as_expr(a), as_expr(b))
+
+
+def _abs(a):
+    return Func("abs", as_expr(a))
+
+
+Expr.__abs__ = lambda self: _abs(self)
+pi = 3.141592653589793
+
+
+def SpatialCoordinate(mesh: fem.Mesh):
+    """ufl.SpatialCoordinate(mesh) (thermoforming_dolfinx.py:51)."""
+    return tuple(Terminal("coordinate", mesh, i) for i in range(mesh.geometry.shape[1]))
+
+
+class Measure:
+    """ufl.Measure("dx", domain=msh, metadata={"quadrature_degree": q}) (obstacle_pg.py:115); `ufl.dx` is the default cell
+    measure (thermoforming_dolfinx.py:14), whose quadrature degree the family picks."""
+
+    def __init__(self, name="dx", domain=None, metadata=None):
+        if name != "dx":
+            raise NotImplementedError("only the cell measure dx is supported by the front end")
+        self.name, self.domain = name, domain
+        self.degree = None if not metadata else metadata.get("quadrature_degree")
+
+    def __rmul__(self, o):
+        return Form([Integral(as_expr(o), self)])
+
+
+dx = Measure("dx")
+
+
+@dataclass
+class Integral:
+    integrand: Expr
+    measure: Measure
+    scale: float = 1.0
+
+
+class Form:
+    def __init__(self, integrals):
+        self.integrals = list(integrals)
+
+    def __add__(self, o):
+        if not isinstance(o, Form):
+            return NotImplemented
+        return Form(self.integrals + o.integrals)
+
+    def __neg__(self):
+        return Form([Integral(i.integrand, i.measure, -i.scale) for i in self.integrals])
+
+    def __sub__(self, o):
+        if not isinstance(o, Form):
+            return NotImplemented
+        return self + (-o)
+
+    def __rmul__(self, c):
+        c = as_expr(c)
+        return Form([Integral(Product(c, i.integrand), i.measure, i.scale) for i in self.integrals])
+
+
+@dataclass
+class Derivative:
+    """ufl.derivative(F, sol) (obstacle_pg.py:125): the exact Jacobian of the residual form."""
+    form: object
+    u: fem.Function
+
+
+def derivative(F, u, du=None):
+    return Derivative(F, u)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# canonical form: {(measure degree, scalar factors, vector pair) -> coefficient}
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def _fmt(c):
+    return repr(float(c))
+
+
+class _Canon:
+    def __init__(self, name_of):
+        self.name_of = name_of  # Terminal -> (name, is_spatially_constant)
+
+    # a monomial is (coef, tuple(sorted scalar factor names), vector factor name | None)
+    def expand(self, e):
+        if isinstance(e, Number):
+            return [(e.v, (), None)]
+        if isinstance(e, Terminal):
+            name, _ = self.name_of(e)
+            return [(1.0, (), name)] if e.rank else [(1.0, (name,), None)]
+        if isinstance(e, Sum):
+            return self.expand(e.a) + self.expand(e.b)
+        if isinstance(e, Scaled):
+            return [(e.c * c, s, v) for c, s, v in self.expand(e.a)]
+        if isinstance(e, Product):
+            out = []
+            for ca, sa, va in self.expand(e.a):
+                for cb, sb, vb in self.expand(e.b):
+                    out.append((ca * cb, tuple(sorted(sa + sb)), va if va is not None else vb))
+            return out
+        if isinstance(e, Division):
+            den = self.combine(self.expand(e.b))
+            if len(den) == 1 and den[0][1] == () and den[0][2] is None:
+                return [(c / den[0][0], s, v) for c, s, v in self.expand(e.a)]
+            d = "1/(" + self.text(den) + ")"
+            return [(c, tuple(sorted(s + (d,))), v) for c, s, v in self.expand(e.a)]
+        if isinstance(e, Inner):
+            out = []
+            for ca, sa, va in self.expand(e.a):
+                for cb, sb, vb in self.expand(e.b):
+                    s = sa + sb
+                    if va is not None:
+                        s = s + ("inner(" + ",".join(sorted((va, vb))) + ")",)
+                    out.append((ca * cb, tuple(sorted(s)), None))
+            return out
+        if isinstance(e, Grad):
+            out = []
+            for c, s, _ in self.expand(e.a):
+                varying = [f for f in s if not self._const(f)]
+                if len(varying) != 1:
+                    raise NotImplementedError("grad of a product of fields or of a constant")
+                rest = tuple(f for f in s if self._const(f))
+                out.append((c, rest, "grad(" + varying[0] + ")"))
+            return out
+        if isinstance(e, Func):
+            return [(1.0, (e.name + "(" + ",".join(self.text(self.combine(self.expand(a))) for a in e.args) + ")",), None)]
+        raise TypeError(f"unsupported expression node {type(e).__name__}")
+
+    def _const(self, factor_name):
+        return factor_name in self._const_names
+
+    def combine(self, monos):
+        acc = {}
+        for c, s, v in monos:
+            acc[(s, v)] = acc.get((s, v), 0.0) + c
+        return sorted(((c, s, v) for (s, v), c in acc.items() if c != 0.0), key=lambda m: (m[1], m[2] or ""))
+
+    def text(self, monos):
+        return "+".join(_fmt(c) + "*" + "*".join(s + ((v,) if v else ())) for c, s, v in monos) or "0"
+
+    def form(self, F: Form):
+        acc = {}
+        for it in F.integrals:
+            if it.integrand.rank:
+                raise ValueError("the integrand of a form must be scalar")
+            for c, s, v in self.expand(it.integrand):
+                k = (it.measure.degree, s)
+                acc[k] = acc.get(k, 0.0) + it.scale * c
+        return {k: c for k, c in acc.items() if c != 0.0}
+
+
+def canonical(F: Form, names: dict):
+    """names: Terminal.key() -> (name, spatially constant?).  Returns {(degree, factors): coefficient}."""
+    cn = _Canon(lambda t: names[t.key()])
+    cn._const_names = {n for n, const in names.values() if const}
+    return cn.form(F)
+
+
+def terminals(F: Form):
+    seen, out = set(), []
+
+    def walk(e):
+        if isinstance(e, Terminal):
+            if e.key() not in seen:
+                seen.add(e.key())
+                out.append(e)
+        for a in ("a", "b"):
+            if hasattr(e, a) and isinstance(getattr(e, a), Expr):
+                walk(getattr(e, a))
+        for a in getattr(e, "args", ()):
+            walk(a)
+
+    for it in F.integrals:
+        walk(it.integrand)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# family templates and matching
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def _role(name, rank=0):
+    return Terminal("role", name, 0, rank)
+
+
+def _template_names(F, const_roles):
+    return {t.key(): (t.obj, t.obj in const_roles) for t in terminals(F)}
+
+
+def _obstacle_template(degree, roles_present):
+    """The residual of obstacle_pg.py:116-124 in terms of roles (without the role f: the source term left out)."""
+    u, psi, psi_k, v, w = (_role(n) for n in ("u", "psi", "psi_k", "v", "w"))
+    alpha, f, phi = _role("alpha"), _role("f"), _role("phi")
+    dx = Measure("dx", metadata={"quadrature_degree": degree})
+    F = alpha * inner(grad(u), grad(v)) * dx + psi * v * dx + u * w * dx - exp(psi) * w * dx - phi * w * dx - psi_k * v * dx
+    if "f" in roles_present:
+        F = F - alpha * f * v * dx
+    return F
+
+
+def _thermoforming_template(degree, roles_present):
+    """The residual of thermoforming_dolfinx.py:36-67 in terms of roles; with the role eps the form the reference
+    differentiates for its modified Jacobian (:69-71)."""
+    u, T, psi, psi_prev, v, q, w = (_role(n) for n in ("u", "T", "psi", "psi_prev", "v", "q", "w"))
+    alpha, beta, f, bound0, bound1, eps = (_role(n) for n in ("alpha", "beta", "f", "bound0", "bound1", "eps"))
+    x, y = _role("x"), _role("y")
+    dx = Measure("dx", metadata={"quadrature_degree": degree} if degree is not None else None)
+
+    def g(s):
+        return conditional(lt(s, bound0), 1, conditional(lt(s, bound1), 1 - s / bound1, 0))
+
+    Phi0 = 1 - 2 * max_value(abs(x - 0.5), abs(y - 0.5))
+    xi = sin(pi * x) * sin(pi * y)
+    F = alpha * inner(grad(u), grad(v)) * dx + inner(psi, v) * dx - alpha * inner(f, v) * dx - inner(psi_prev, v) * dx
+    F += inner(grad(T), grad(q)) * dx + beta * inner(T, q) * dx - inner(g(exp(-psi)), q) * dx
+    F += inner(u, w) * dx + inner(exp(-psi), w) * dx - inner(Phi0 + xi * T, w) * dx
+    if "eps" in roles_present:
+        F = F - eps / alpha * inner(grad(psi), grad(w)) * dx
+    return F
+
+
+@dataclass
+class ThermoformingSpec:
+    """Example 05 (thermoforming_dolfinx.py:28-71): s = (u, T, psi) in [P1]^3, g with knees bound0 < bound1, eps of the
+    modified Jacobian (None: exact derivative)."""
+    s: fem.Function
+    s_prev: fem.Function
+    alpha: fem.Constant
+    beta: fem.Constant
+    f: fem.Constant
+    bound0: fem.Constant
+    bound1: fem.Constant
+    eps: fem.Constant | None
+    quadrature_degree: int | None
+
+
+# name, components of the unknown, of the previous iterate, test functions, roles of Constants (required, optional),
+# number of quadrature-space coefficients (role phi), template
+_FAMILIES = [
+    dict(name="obstacle (example 01)", comps=("u", "psi"), prev=("u_k", "psi_k"), args=("v", "w"), required=("alpha",),
+         optional=("f",), quads=1, needs_degree=True, template=_obstacle_template,
+         text="alpha*inner(grad(u),grad(v)) + psi*v + u*w - exp(psi)*w - phi*w - alpha*f*v - psi_k*v"),
+    dict(name="thermoforming QVI (example 05)", comps=("u", "T", "psi"), prev=("u_prev", "T_prev", "psi_prev"),
+         args=("v", "q", "w"), required=("alpha", "beta", "f", "bound0", "bound1"), optional=("eps",), quads=0,
+         needs_degree=False, template=_thermoforming_template, text="the residual of thermoforming_dolfinx.py:62-67"),
+]
+
+
+def _describe(diff):
+    return "; ".join(f"{_fmt(c)} * {' * '.join(s)} [quadrature degree {d}]" for (d, s), c in sorted(diff.items(), key=str))
+
+
+def _match(F: Form, u: fem.Function):
+    """-> (family, {role: object}, degree) or raises NotImplementedError."""
+    if not isinstance(F, Form):
+        raise TypeError("F must be a Form")
+    terms = terminals(F)
+    V = u.function_space
+    comps = [t for t in terms if t.kind == "component"]
+    others = []
+    for t in comps:
+        if t.obj is not u and t.obj not in others:
+            others.append(t.obj)
+    args = [t for t in terms if t.kind == "argument"]
+    if any(t.obj is not V for t in args):
+        raise ValueError("test functions must come from the unknown's function space")
+    consts = [t for t in terms if t.kind == "constant"]
+    quads = [t for t in terms if t.kind == "quadrature"]
+    coords = [t for t in terms if t.kind == "coordinate"]
+    degrees = {it.measure.degree for it in F.integrals}
+    if len(degrees) != 1:
+        raise NotImplementedError("all integrals must use one measure")
+    degree = degrees.pop()
+    problems = []
+    for fam in _FAMILIES:
+        nreq, nall = len(fam["required"]), len(fam["required"]) + len(fam["optional"])
+        if (V.ncomp != len(fam["comps"]) or len(others) != 1 or len(quads) != fam["quads"] or not nreq <= len(consts) <= nall
+                or (fam["needs_degree"] and degree is None)):
+            continue
+        fixed = {}
+        for t in comps:
+            fixed[t.key()] = ((fam["comps"] if t.obj is u else fam["prev"])[t.index], False)
+        for t in args:
+            fixed[t.key()] = (fam["args"][t.index], False)
+        for t in quads:
+            fixed[t.key()] = ("phi", False)
+        for t in coords:
+            fixed[t.key()] = ("xyz"[t.index], False)
+        best = None
+        templates = {}
+        for perm in itertools.permutations(fam["required"] + fam["optional"], len(consts)):
+            if not set(fam["required"]) <= set(perm):
+                continue
+            present = frozenset(perm)
+            if present not in templates:
+                T = fam["template"](degree, present)
+                templates[present] = canonical(T, _template_names(T, set(fam["required"] + fam["optional"])))
+            template = templates[present]
+            names = dict(fixed)
+            for t, r in zip(consts, perm):
+                names[t.key()] = (r, True)
+            got = canonical(F, names)
+            diff = {k: got.get(k, 0.0) - template.get(k, 0.0) for k in set(got) | set(template)}
+            diff = {k: c for k, c in diff.items() if abs(c) > 1e-14}
+            if not diff:
+                roles = {r: t.obj for t, r in zip(consts, perm)}
+                roles.update(unknown=u, previous=others[0], quads=[t.obj for t in quads])
+                return fam, roles, degree
+            if best is None or len(diff) < len(best):
+                best = diff
+        problems.append(f"{fam['name']}: terms that differ from {fam['text']}: " + _describe(best or {}))
+    raise NotImplementedError("the form matches no problem family implemented in HIP" +
+                              ("".join("\n  " + p for p in problems) if problems else
+                               " (expected the mixed unknown and its previous iterate of example 01 or 05 with their Constants)"))
+
+
+def compile_form(F: Form, u: fem.Function, J=None):
+    """Match a residual form (and, if given, the Jacobian J = derivative(G, u)) against the problem families the HIP path
+    implements.  Returns the family's declarative description: problem.ObstacleResidual (example 01, J must be the exact
+    derivative) or ThermoformingSpec (example 05, G may carry the -eps/alpha (grad psi, grad w) modification)."""
+    from .problem import ObstacleResidual
+
+    fam, r, degree = _match(F, u)
+    G = None
+    if J is not None:
+        if not (hasattr(J, "form") and hasattr(J, "u")) or J.u is not u:
+            raise NotImplementedError("J must be derivative(G, u) of a form G with respect to the unknown")
+        G = J.form
+    V = u.function_space
+    if fam["name"].startswith("obstacle"):
+        if G is not None and G is not F:
+            famG, rG, _ = _match(G, u)
+            if famG is not fam or any(rG.get(k) is not r.get(k) for k in ("alpha", "f", "previous")) or rG["quads"] != r["quads"]:
+                raise NotImplementedError("only J = derivative(F, u) (the exact Jacobian) is supported for the obstacle family")
+        return ObstacleResidual(u, r["previous"], r["alpha"], r.get("f") or fem.Constant(V.mesh, 0.0), r["quads"][0], degree)
+    eps = None
+    if "eps" in r:
+        raise NotImplementedError("the eps modification belongs in the Jacobian form, not in the residual")
+    if G is not None and G is not F:
+        famG, rG, _ = _match(G, u)
+        same = all(rG.get(k) is r.get(k) for k in ("alpha", "beta", "f", "bound0", "bound1", "previous"))
+        if famG is not fam or not same:
+            raise NotImplementedError("J must be the derivative of F or of F - eps/alpha*inner(grad(psi),grad(w))*dx")
+        eps = rG.get("eps")
+    return ThermoformingSpec(u, r["previous"], r["alpha"], r["beta"], r["f"], r["bound0"], r["bound1"], eps, degree)
