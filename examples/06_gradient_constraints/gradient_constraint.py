@@ -2,7 +2,7 @@
 
 Counterpart of /root/reference/examples/06_gradient_constraints/gradient_constraint_dolfinx.py with the same CLI flags
 (:208-320) where they apply: -N -M --alpha_scheme --alpha_0 --alpha_c --max_iterations -s --result_dir;
---primal_degree is fixed at 2 and --cell_type at triangle (the reference's defaults), --warm_start is not implemented.
+--primal_degree is fixed at 2 and --cell_type at triangle (the reference's defaults).
 """
 import argparse
 import sys
@@ -23,11 +23,13 @@ if __name__ == "__main__":
     parser.add_argument("--max_iterations", type=int, default=25, help="Maximum number of iterations")
     parser.add_argument("-s", "--stopping_tol", type=float, default=1e-8,
                         help="Stopping tolerance between two successive PG iterations (L2-difference)")
+    parser.add_argument("--warm_start", action="store_true", help="Use warm start (solve Poisson problem to get initial guess)")
     parser.add_argument("--result_dir", type=Path, default=Path("results"), help="Directory to store results")
     a = parser.parse_args()
     iteration_counts, L2_diffs = solve_problem(N=a.N, M=a.M, alpha_scheme=a.alpha_scheme, alpha_0=a.alpha_0,
                                                alpha_c=a.alpha_c, max_iterations=a.max_iterations,
-                                               stopping_tol=a.stopping_tol, result_dir=a.result_dir)
+                                               stopping_tol=a.stopping_tol, result_dir=a.result_dir,
+                                               warm_start=a.warm_start)
     print(f"Number of LVPP iterations {len(iteration_counts)}")
     print(f"Minimum number of solves {np.min(iteration_counts)}")
     print(f"Maximum number of solves {np.max(iteration_counts)}")

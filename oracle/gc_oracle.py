@@ -144,11 +144,19 @@ def alpha_value(scheme, alpha_0, alpha_c, i):
 
 
 def solve_problem(prob: GradientConstraintP2, alpha_scheme="doubling", alpha_0=1.0, alpha_c=1.0, max_iterations=25,
-                  stopping_tol=1e-8, snes: O.SnesOptions | None = None, linear_solve=None, verbose=False, iterates=None):
-    """Mirror of gradient_constraint_dolfinx.solve_problem's loop (:168-205). Returns (x, newton_iterations, L2_diffs)."""
+                  stopping_tol=1e-8, snes: O.SnesOptions | None = None, linear_solve=None, verbose=False, iterates=None,
+                  warm_start=False):
+    """Mirror of gradient_constraint_dolfinx.solve_problem's loop (:168-205). Returns (x, newton_iterations, L2_diffs).
+    warm_start: the Poisson pre-solve of :72-96 (u <- K^-1 (f, q) with u = 0 on the boundary, psi <- 0; w0 stays 0)."""
     snes = snes or O.SnesOptions(rtol=1e-9, atol=1e-9, stol=1e-9, max_it=20)
     x = np.zeros(prob.ntot)
     xk = x.copy()
+    if warm_start:
+        import scipy.sparse.linalg as spla
+
+        n2 = prob.n2
+        K = prob.jacobian(x, 1.0)[:n2, :n2].tocsc()  # Dirichlet rows/cols = identity
+        x[:n2] = spla.spsolve(K, -prob.residual(x, xk, 1.0)[:n2])
     its_all, diffs = [], []
     for i in range(max_iterations):
         alpha = alpha_value(alpha_scheme, alpha_0, alpha_c, i)

@@ -133,6 +133,32 @@ class GradientConstraintProblem:
         self._check(self._lib.pgx_gc_l2_increment(self._h, C.byref(out)), "pgx_gc_l2_increment")
         return out.value
 
+    def warm_start(self, device: int = 0):
+        """The reference's --warm_start (:72-96): u <- solution of the Poisson problem (grad p, grad q) = (f, q), u = 0 on the
+        boundary; psi <- 0.  At alpha = 1, psi = psi0 = 0 the u-block of the assembled Newton matrix IS that stiffness matrix
+        (Dirichlet rows = identity) and the u-residual at u = 0 is -(f, q), so the pre-solve is one sparse-LU solve
+        (include/pgx_nd.h) of that block with one refinement step - the reference's LinearProblem with pc_type lu."""
+        from .direct import DirectSolver
+
+        n2 = self.n2
+        x0 = np.zeros(self.ndofs)
+        alpha = self.alpha
+        self.set_alpha(1.0)
+        self.set_prev(x0)
+        F, _ = self.residual(x0)
+        K = self.jacobian(x0)[:n2, :n2].tocsr()
+        K.sort_indices()
+        self.set_alpha(alpha)
+        lu = DirectSolver(K.indptr, K.indices, np.arange(n2, dtype=np.int32), self.U.dof_coordinates(), device=device)
+        lu.factor(K.data)
+        b = -F[:n2]
+        u = lu.solve(b)
+        u += lu.solve(b - K @ u)
+        lu.close()
+        x0[:n2] = u
+        self.set_state(x0)
+        return x0
+
     # -- fine-grained probes (tests) -----------------------------------------------------------------------------------
     def residual(self, x=None):
         out = np.empty(self.ndofs)
@@ -189,10 +215,12 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
     """gradient_constraint_dolfinx.solve_problem (:18-205): returns (newton_iterations, L2_diff) [, final state]."""
     if primal_space not in ("Lagrange", "P", "CG") or primal_degree != 2 or cell_type != "triangle":
         raise NotImplementedError("HIP backend: primal Lagrange degree 2 on triangles (the reference's defaults)")
-    if warm_start:
-        raise NotImplementedError("warm_start (a Poisson pre-solve, :71-98) is not implemented")
     mesh = fem.create_unit_square(N, M)  # :36
     problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device, comm=comm)
+    if warm_start:  # :72-96
+        if comm is not None:
+            raise NotImplementedError("warm_start with a distributed LU")
+        problem.warm_start(device=device)
     if verbose:
         print(f"Number of dofs: {problem.n2}")  # :112
     newton_iterations = np.zeros(max_iterations, dtype=np.int32)
