@@ -40,7 +40,7 @@ typedef struct {
 /* Host-only symbolic statistics (no GPU needed). */
 typedef struct {
   int64_t n_fronts, n_levels, max_front;   /* max padded front order */
-  int64_t arena_doubles;                   /* padded storage of all frontal matrices */
+  int64_t arena_doubles;                   /* device storage: compact padded factors + the two working buffers */
   int64_t factor_nnz;                      /* unpadded entries kept (L and U) */
   double flops;                            /* unpadded factorisation flops */
   double flops_padded;                     /* flops the level-batched kernels execute */
@@ -72,7 +72,9 @@ int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
  * Call with NULL arrays to get sizes.  Layout: fronts are numbered batch by batch ("slots"); a batch = the fronts of one
  * tree depth and one size class, batches ordered by depth (root first);
  * batch l holds slots [lev_start[l], lev_start[l+1]) and pads every front to pivot order P[l], border B[l], M = P+B,
- * stored column-major at arena offset lev_off[l] + (slot - lev_start[l]) * M*M.  Local index of an own dof k: k; of the
+ * stored column-major at offset lev_off[l] + (slot - lev_start[l]) * M*M of a VIRTUAL arena in which every front is a
+ * full M x M matrix (the device keeps the factors compactly and the M x M matrices only while a tree depth is being
+ * factorised - same local positions, other base addresses).  Local index of an own dof k: k; of the
  * s-th border dof: P + s.  rel[rel_ptr[f] + s] = local index in the PARENT's front of border dof s of front f. */
 int pgx_nd_export_levels(const pgx_nd* s, int64_t* n_levels, int64_t* lev_start, int32_t* P, int32_t* B, int64_t* lev_off,
                          int32_t* depth /* tree depth of each batch; the children of depth d live at depth d+1 */);

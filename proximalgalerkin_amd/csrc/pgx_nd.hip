@@ -9,10 +9,15 @@
 // one tree depth x one size class (<= 4 classes per depth, chosen to minimise padded flops + storage); every front of a
 // batch is padded to the batch's pivot order P and border B, so a batch is one strided launch set.  Assembly destinations
 // and child -> parent maps are precomputed.
-// Device (numeric, every Newton step): zero the arena, scatter the CSR values to their frontal positions (conflict-free),
-// then depth by depth, deepest first: extend-add the children's Schur complements (two conflict-free passes, no atomics ->
-// bitwise reproducible), then for every batch of the depth - on forked HIP streams, joined per depth - a two-level blocked
-// partial LU without pivoting across nodes:
+// Device memory: the FACTORS of a front live compactly ([M x P: L11\\U11 over L21][P x B: U12]); the M x M matrix a front is
+// assembled and eliminated in lives in one of two WORKING buffers chosen by the parity of its tree depth and reused two
+// depths further up, once the parents have absorbed the Schur blocks - 2-D problems need ~1/2 of the storage of keeping
+// every front whole (ex 06 1024^2: 77 -> 42 GB, ex 02 70^3: 139 -> 76 GB).
+// Device (numeric, every Newton step), depth by depth, deepest first: zero the depth's working buffer, scatter its CSR
+// values to their frontal positions (conflict-free; the assembly list is sorted by depth), extend-add the children's Schur
+// complements (two conflict-free passes, no atomics -> bitwise reproducible), then for every batch of the depth - on
+// forked HIP streams, joined per depth - a two-level blocked partial LU without pivoting across nodes; solved panels are
+// written to the compact store only, which is also where the trailing updates read their operands:
 //   k_nd_diag   LU of one <= 64-wide diagonal block in LDS (8-column panels by one wave with lane shuffles)
 //   k_nd_panel  both triangular panel solves against that block, 64-wide chunks, blocked by 8 in LDS
 //   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 64^2 / 128^2 tiles, 4 waves x (2x2 | 4x4) MFMA
@@ -29,8 +34,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -47,8 +54,12 @@ struct NdLevel {  // one BATCH: the fronts of one tree depth and one size class,
   int64_t start = 0, count = 0;
   int depth = 0;
   int P = 0, B = 0;
-  int64_t off = 0;   // arena offset (doubles)
+  int64_t off = 0;   // offset in the VIRTUAL arena (every front a full M x M matrix; symbolic maps, exports, tests)
   int64_t voff = 0;  // vector arena offset
+  // device layout: the factors of a front are kept COMPACT ([M x P: L11\\U11 over L21][P x B: U12]) at poff + i * (MP + PB);
+  // the M x M matrix it is assembled and factorised in lives in one of two WORKING buffers (tree depth parity) at
+  // woff + i * M*M, which the fronts two depths further up reuse once the parents have absorbed the Schur blocks
+  int64_t poff = 0, woff = 0;
 };
 
 struct pgx_nd {
@@ -62,10 +73,15 @@ struct pgx_nd {
   std::vector<int64_t> dof_ptr, rel_ptr, dest, fbase;
   std::vector<int32_t> own_dofs, rel;
   pgx_nd_stats stats{};
-  int64_t arena_len = 0, vec_len = 0;
+  int64_t arena_len = 0, vec_len = 0;  // arena_len: device layout = compact factors + both working buffers
+  int64_t virt_len = 0;                 // virtual arena (full fronts)
+  std::vector<int64_t> wd_off, wd_len;  // per tree depth: its range of the working buffer
+  std::vector<int64_t> dnz;             // per tree depth: range of the depth-sorted assembly list
+  int64_t* d_sdest = nullptr;           // assembly list sorted by tree depth: destination in the working buffer ...
+  int32_t* d_ssrc = nullptr;            // ... and index of the matrix entry
   // device
   double *arena = nullptr, *vec = nullptr, *d_vals = nullptr, *d_b = nullptr;
-  int64_t *d_dest = nullptr, *d_dof_ptr = nullptr, *d_rel_ptr = nullptr, *d_fbase = nullptr, *d_vbase = nullptr;
+  int64_t *d_dof_ptr = nullptr, *d_rel_ptr = nullptr, *d_fbase = nullptr, *d_vbase = nullptr;
   int32_t *d_fp = nullptr, *d_fb = nullptr, *d_parent = nullptr, *d_slot01 = nullptr, *d_child0 = nullptr,
           *d_child1 = nullptr, *d_own_dofs = nullptr, *d_rel = nullptr, *d_fM = nullptr, *d_fP = nullptr;
   int* d_info = nullptr;  // [0] = number of (near-)zero pivots met by the last factorisation
@@ -422,12 +438,36 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     s->stats.flops_padded += Lv.count * (2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B);
     if (Lv.count) s->stats.max_front = std::max<int64_t>(s->stats.max_front, M);
   }
-  s->arena_len = off;
+  s->virt_len = off;
   s->vec_len = voff;
   s->nfronts = nloc;
   s->stats.n_fronts = nloc;
   s->stats.n_levels = L;
-  s->stats.arena_doubles = off;
+  {  // device layout: compact factors first, then the two working buffers
+    const int nd = (int)s->dfirst.size() - 1;
+    s->wd_off.assign(nd, 0);
+    s->wd_len.assign(nd, 0);
+    int64_t poff = 0, wmax[2] = {0, 0};
+    for (int d = 0; d < nd; ++d) {
+      int64_t w = 0;
+      for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) {
+        NdLevel& Lv = s->lev[l];
+        const int64_t M = Lv.P + Lv.B;
+        Lv.poff = poff;
+        Lv.woff = w;  // relative to the depth's buffer for now
+        poff += Lv.count * (M * Lv.P + (int64_t)Lv.P * Lv.B);
+        w += Lv.count * M * M;
+      }
+      s->wd_len[d] = w;
+      wmax[d & 1] = std::max(wmax[d & 1], w);
+    }
+    for (int d = 0; d < nd; ++d) {
+      s->wd_off[d] = poff + ((d & 1) ? wmax[0] : 0);
+      for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) s->lev[l].woff += s->wd_off[d];
+    }
+    s->arena_len = poff + wmax[0] + wmax[1];
+  }
+  s->stats.arena_doubles = s->arena_len;
   {
     std::vector<int64_t> next(L);
     for (int l = 0; l < L; ++l) next[l] = s->lev[l].start;
@@ -554,21 +594,17 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
 // ------------------------------------------------------------------------------------------------------------------
 // device kernels
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_nd_scatter(int64_t nnz, const int64_t* __restrict__ dest, const double* __restrict__ vals,
-                             double* __restrict__ arena) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_nd_scatter(int64_t t0, int64_t t1, const int64_t* __restrict__ sdest, const int32_t* __restrict__ ssrc,
+                             const double* __restrict__ vals, double* __restrict__ arena) {
+  int64_t t = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; k < nnz; k += stride) {
-    const int64_t d = dest[k];
-    if (d >= 0) arena[d] = __builtin_nontemporal_load(vals + k);  // < 0: the entry lives in another rank's front
-  }
+  for (; t < t1; t += stride) arena[sdest[t]] = vals[ssrc[t]];
 }
 
-// identity on the padded part of every pivot block
-__global__ void k_nd_pad(int64_t nfronts, const int32_t* __restrict__ fp, const int32_t* __restrict__ fP,
+// identity on the padded part of every pivot block of the fronts [f0, f0 + gridDim.x)
+__global__ void k_nd_pad(int64_t f0, const int32_t* __restrict__ fp, const int32_t* __restrict__ fP,
                          const int32_t* __restrict__ fM, const int64_t* __restrict__ fbase, double* __restrict__ arena) {
-  const int64_t f = blockIdx.x;
-  if (f >= nfronts) return;
+  const int64_t f = f0 + blockIdx.x;
   const int64_t M = fM[f];
   double* F = arena + fbase[f];
   for (int k = fp[f] + threadIdx.x; k < fP[f]; k += blockDim.x) F[k * M + k] = 1.0;
@@ -671,7 +707,7 @@ typedef double nd_v4d __attribute__((ext_vector_type(4)));
 // by all 256 threads: 3 barriers per 8 columns instead of 2 per column (84 -> ~20 us per launch near the root, where the
 // launches of a level form one dependent chain).
 __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
-                                                 int* __restrict__ info) {
+                                                 int* __restrict__ info, int64_t store_off, int P) {
   __shared__ double D[ND_NB][ND_NB + 1];
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M + (int64_t)kb * M + kb;
   const int tid = threadIdx.x;
@@ -746,9 +782,11 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
       __syncthreads();
     }
   }
+  // L11\\U11 is final: it goes to the compact factor store, where the panel solves (and the solve phase) read it
+  double* S = arena + store_off + (int64_t)blockIdx.x * ((int64_t)M * P + (int64_t)P * (M - P)) + (int64_t)kb * M + kb;
   for (int idx = tid; idx < nb * nb; idx += 256) {
     const int r = idx % nb, c = idx / nb;
-    F[(int64_t)c * M + r] = D[r][c];
+    S[(int64_t)c * M + r] = D[r][c];
   }
 }
 
@@ -756,16 +794,21 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
 // chunk >= nch: rows [o0, o0+64) of the column panel, X <- X U^{-1}.  Blocked by 8 pivots in LDS: the 8x8 triangle by
 // one thread per column/row (registers), the rank-8 update of the rest by all 256 threads; the entries of the diagonal
 // block are packed so that the 8 coefficients a thread needs are contiguous.  2 barriers per 8 pivots.
-__global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb) {
+__global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
+                                                  int64_t store_off, int P) {
   __shared__ double T[ND_NB * (ND_NB + 1) / 2];
   __shared__ double X[ND_NB][ND_TS + 1];
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  // the solved panels are final factor entries: they go to the compact store [M x P, ld M][P x B, ld P] of the front, which
+  // is also where the trailing updates (k_nd_gemm) read their operands; the working matrix keeps the unsolved values
+  const int64_t MP = (int64_t)M * P;
+  double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));
   const int tid = threadIdx.x;
   const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
   const bool isL = (int)blockIdx.y >= nch;
   const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
   const int wd = min(ND_TS, M - o0);
-  const double* Dg = F + (int64_t)kb * M + kb;
+  const double* Dg = S + (int64_t)kb * M + kb;
   const int j = tid & 63, g = tid >> 6;
   if (!isL) {
     // T: strict lower triangle, row-major packed: L[r][c] at r(r-1)/2 + c
@@ -812,7 +855,10 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
       const int k = idx % nb, jj = idx / nb;
-      if (jj < wd) F[(int64_t)(o0 + jj) * M + kb + k] = X[k][jj];
+      if (jj < wd) {
+        const int c = o0 + jj;
+        S[c < P ? (int64_t)c * M + kb + k : MP + (int64_t)(c - P) * P + kb + k] = X[k][jj];
+      }
     }
   } else {
     // T: upper triangle incl. diagonal, column-major packed: U[k][c] at c(c+1)/2 + k
@@ -861,7 +907,9 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
     }
     for (int idx = tid; idx < nb * ND_TS; idx += 256) {
       const int ii = idx % ND_TS, k = idx / ND_TS;
-      if (ii < wd) F[(int64_t)(kb + k) * M + o0 + ii] = X[k][ii];
+      if (ii < wd) {
+        S[(int64_t)(kb + k) * M + o0 + ii] = X[k][ii];
+      }
     }
   }
 }
@@ -872,7 +920,7 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
 // into registers while the current one feeds the matrix cores.
 template <int WT>
 __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1) {
+                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
@@ -880,7 +928,9 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
   const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
   const int rmax = r1g, cmax = c1g;
   if (r0 >= rmax || c0 >= cmax) return;
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
+  const int64_t MP = (int64_t)M * P;
+  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels (compact store)
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const int wi = (wv >> 1) * 16 * WT, wj = (wv & 1) * 16 * WT;
   nd_v4d acc[WT][WT];  // [tj][ti]
@@ -895,9 +945,9 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
     for (int q = 0; q < NLD; ++q) {
       const int idx = tid + 256 * q;
       const int i = idx % TS, k = idx / TS;
-      ra[q] = (k < kn && r0 + i < rmax) ? F[(int64_t)(kc + k) * M + r0 + i] : 0.0;
-      const int k2 = idx % ND_KC, j2 = idx / ND_KC;
-      rb[q] = (k2 < kn && c0 + j2 < cmax) ? F[(int64_t)(c0 + j2) * M + kc + k2] : 0.0;
+      ra[q] = (k < kn && r0 + i < rmax) ? S[(int64_t)(kc + k) * M + r0 + i] : 0.0;
+      const int k2 = idx % ND_KC, j2 = idx / ND_KC, cj = c0 + j2;
+      rb[q] = (k2 < kn && cj < cmax) ? S[cj < P ? (int64_t)cj * M + kc + k2 : MP + (int64_t)(cj - P) * P + kc + k2] : 0.0;
     }
   };
   fetch(k0);
@@ -944,12 +994,12 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
 // upper != 0: U11.  One workgroup per front, 64-wide blocks: the 64x64 triangle is solved by wave 0 with lane shuffles,
 // the remaining rows OF THE RANGE are updated by all threads; rows outside the range are left to k_nd_gemv (many
 // workgroups), so that the big fronts near the root do not stream their factors through a single CU.
-__global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
-                                                 int64_t voff, int M, int k0, int k1, int upper) {
+__global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ arena, int64_t lev_off, int64_t fs,
+                                                 double* __restrict__ vec, int64_t voff, int M, int k0, int k1, int upper) {
   __shared__ double Ds[64][65];
   __shared__ double ys[64];
   __shared__ double red[4][64];
-  const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * fs;  // compact store: the first P columns keep leading dimension M
   double* w = vec + voff + (int64_t)blockIdx.x * M;
   const int tid = threadIdx.x;
   const int nblk = (k1 - k0 + 63) / 64;
@@ -1000,11 +1050,14 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
   }
 }
 
-// w[r0:r1) -= F[r0:r1, c0:c1) w[c0:c1): one thread per row, 256 rows per block (blockIdx.y), columns staged through LDS
-__global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, double* __restrict__ vec,
-                                                 int64_t voff, int M, int r0, int r1, int c0, int c1) {
+// w[r0:r1) -= F[r0:r1, c0:c1) w[c0:c1): one thread per row, 256 rows per block (blockIdx.y), columns staged through LDS.
+// Column c of the operand starts at F + cbase + (c - c0) * ld (compact store: ld = M inside the first P columns, the U12
+// block has its own base and ld = P).
+__global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, int64_t fs,
+                                                 double* __restrict__ vec, int64_t voff, int M, int r0, int r1, int c0, int c1,
+                                                 int64_t cbase, int ld) {
   __shared__ double xs[256];
-  const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * fs + cbase;
   double* w = vec + voff + (int64_t)blockIdx.x * M;
   const int r = r0 + blockIdx.y * 256 + threadIdx.x;
   double a = 0.0;
@@ -1014,9 +1067,9 @@ __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ aren
     if ((int)threadIdx.x < kn) xs[threadIdx.x] = w[k0 + threadIdx.x];
     __syncthreads();
     if (r < r1) {
-      const double* col = F + (int64_t)k0 * M + r;
+      const double* col = F + (int64_t)(k0 - c0) * ld + r;
 #pragma unroll 4
-      for (int k = 0; k < kn; ++k) a += col[(int64_t)k * M] * xs[k];
+      for (int k = 0; k < kn; ++k) a += col[(int64_t)k * ld] * xs[k];
     }
   }
   if (r < r1) w[r] -= a;
@@ -1115,9 +1168,46 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     fP[f] = Lv.P;
     vbase[f] = Lv.voff + (f - Lv.start) * (int64_t)(Lv.P + Lv.B);
   }
+  {  // assembly list: virtual destination -> working-buffer destination, sorted (stably) by the tree depth of the front
+    if (s->nnz > (int64_t)INT32_MAX) {
+      s->err = "pgx_nd_create: more than 2^31 matrix entries";
+      return fail(PGX_EINVAL);
+    }
+    const int L = (int)s->lev.size(), nd = (int)s->dfirst.size() - 1;
+    std::vector<int64_t> voffs(L);
+    for (int l = 0; l < L; ++l) voffs[l] = s->lev[l].off;
+    auto batch_of = [&](int64_t v) {  // last batch with off <= v and count > 0 containing v
+      int l = (int)(std::upper_bound(voffs.begin(), voffs.end(), v) - voffs.begin()) - 1;
+      while (l > 0 && s->lev[l].count == 0) --l;
+      return l;
+    };
+    s->dnz.assign(nd + 1, 0);
+    std::vector<int32_t> bl(s->nnz, -1);
+    for (int64_t k = 0; k < s->nnz; ++k)
+      if (s->dest[k] >= 0) {
+        bl[k] = batch_of(s->dest[k]);
+        s->dnz[s->lev[bl[k]].depth + 1]++;
+      }
+    for (int d = 0; d < nd; ++d) s->dnz[d + 1] += s->dnz[d];
+    std::vector<int64_t> cur(s->dnz.begin(), s->dnz.end() - 1), sdest(s->dnz[nd]);
+    std::vector<int32_t> ssrc(s->dnz[nd]);
+    for (int64_t k = 0; k < s->nnz; ++k)
+      if (bl[k] >= 0) {
+        const NdLevel& Lv = s->lev[bl[k]];
+        const int64_t t = cur[Lv.depth]++;
+        sdest[t] = Lv.woff + (s->dest[k] - Lv.off);  // same front-local position: both layouts use M x M fronts here
+        ssrc[t] = (int32_t)k;
+      }
+    std::vector<int32_t>().swap(bl);
+    if ((rc = nd_upload(s, &s->d_sdest, sdest)) || (rc = nd_upload(s, &s->d_ssrc, ssrc))) return fail(rc);
+    for (int64_t f = 0; f < s->nfronts; ++f) {
+      const NdLevel& Lv = s->lev[s->flevel[f]];
+      s->fbase[f] = Lv.woff + (f - Lv.start) * (int64_t)(Lv.P + Lv.B) * (Lv.P + Lv.B);
+    }
+  }
 #define UP(d, h)                        \
   if ((rc = nd_upload(s, &s->d, h))) return fail(rc);
-  UP(d_dest, s->dest) UP(d_dof_ptr, s->dof_ptr) UP(d_rel_ptr, s->rel_ptr) UP(d_fbase, s->fbase) UP(d_fp, s->fp) UP(d_fb, s->fb)
+  UP(d_dof_ptr, s->dof_ptr) UP(d_rel_ptr, s->rel_ptr) UP(d_fbase, s->fbase) UP(d_fp, s->fp) UP(d_fb, s->fb)
   UP(d_parent, s->parent) UP(d_slot01, s->slot01) UP(d_child0, s->child0) UP(d_child1, s->child1) UP(d_own_dofs, s->own_dofs)
   UP(d_rel, s->rel)
 #undef UP
@@ -1240,9 +1330,9 @@ static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, 
   const int TS = big ? 128 : 64;
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   if (big)
-    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, q, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
+    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
   else
-    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, q, s->arena, Lv.off, M, r0, r1, c0, c1, k0, k1);
+    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -1258,17 +1348,25 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     dv = s->d_vals;
   }
   if (s->timing) hipEventRecord(s->e0, s->st);
-  NDHIP(hipMemsetAsync(s->arena, 0, (size_t)s->arena_len * sizeof(double), s->st));
-  {
-    int blocks = (int)std::min<int64_t>((s->nnz + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, s->nnz, s->d_dest, dv, s->arena);
-    hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)s->nfronts), dim3(64), 0, s->st, s->nfronts, s->d_fp, s->d_fP, s->d_fM,
-                       s->d_fbase, s->arena);
-  }
   NDHIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
   const int L = (int)s->lev.size();
   const int maxdepth = (int)s->dfirst.size() - 2;
   for (int d = maxdepth; d >= 0; --d) {
+    // the working buffer of this depth: zero, matrix entries, identity on the padded pivots.  (Its previous tenants, the
+    // fronts of depth d+2, are stored compactly and their Schur blocks were absorbed at depth d+1.)
+    if (s->wd_len[d] > 0) {
+      NDHIP(hipMemsetAsync(s->arena + s->wd_off[d], 0, (size_t)s->wd_len[d] * sizeof(double), s->st));
+      const int64_t t0 = s->dnz[d], t1 = s->dnz[d + 1];
+      if (t1 > t0) {
+        int blocks = (int)std::min<int64_t>((t1 - t0 + 255) / 256, 256 * 64);
+        hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, t0, t1, s->d_sdest, s->d_ssrc, dv, s->arena);
+      }
+      const int64_t f0 = s->lev[s->dfirst[d]].start;
+      const int64_t f1 = s->lev[s->dfirst[d + 1] - 1].start + s->lev[s->dfirst[d + 1] - 1].count;
+      if (f1 > f0)
+        hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, s->st, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase,
+                           s->arena);
+    }
     // every batch of depth d+1 is factorised: extend-add their Schur complements into the fronts of depth d (two
     // conflict-free passes: first children, second children)
     for (int cb = s->dfirst[d + 1]; cb < (d + 2 < (int)s->dfirst.size() ? s->dfirst[d + 2] : L); ++cb) {
@@ -1300,10 +1398,10 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
         int kb = ob;
         for (int st = 0; st < nsteps; ++st) {
           const int nb = W / nsteps + (st < W % nsteps ? 1 : 0), ke = kb + nb;
-          hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, M, kb, nb, s->d_info);
+          hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.woff, M, kb, nb, s->d_info, Lv.poff, P);
           if (M - ke > 0) {
             const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
-            hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, q, s->arena, Lv.off, M, kb, nb);
+            hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, q, s->arena, Lv.woff, M, kb, nb, Lv.poff, P);
             nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
             nd_launch_gemm(s, q, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
           }
@@ -1375,6 +1473,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     for (int l = s->dfirst[d + 1] - 1; l >= s->dfirst[d]; --l) {
       const NdLevel& Lv = s->lev[l];
       const int P = Lv.P, B = Lv.B, M = P + B;
+      const int64_t fs = (int64_t)M * P + (int64_t)P * B;
       if (Lv.count == 0) continue;
       hipStream_t q = nd_fork(s, used++);
       hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, M, s->d_fp, s->d_fb,
@@ -1384,10 +1483,10 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       // (rest of the pivot block AND the border rows) by a gemv over many workgroups
       for (int k0 = 0; k0 < P; k0 += ND_SLAB) {
         const int k1 = std::min(P, k0 + ND_SLAB);
-        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 0);
+        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 0);
         if (k1 < M)
           hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + 255) / 256)), dim3(256), 0, q, s->arena,
-                             Lv.off, s->vec, Lv.voff, M, k1, M, k0, k1);
+                             Lv.poff, fs, s->vec, Lv.voff, M, k1, M, k0, k1, (int64_t)k0 * M, M);
       }
     }
     nd_join(s, used);
@@ -1430,22 +1529,23 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) {
       const NdLevel& Lv = s->lev[l];
       const int P = Lv.P, B = Lv.B, M = P + B;
+      const int64_t fs = (int64_t)M * P + (int64_t)P * B;
       if (Lv.count == 0) continue;
       hipStream_t q = nd_fork(s, used++);
       if (B > 0) {
         if (!(xchg && l == s->kbatch))
           hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, s->d_fb, s->d_parent,
                              s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
-        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, q, s->arena, Lv.off,
-                           s->vec, Lv.voff, M, 0, P, P, M);
+        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + 255) / 256)), dim3(256), 0, q, s->arena, Lv.poff,
+                           fs, s->vec, Lv.voff, M, 0, P, P, M, (int64_t)M * P, P);
       }
       const int nsl = (P + ND_SLAB - 1) / ND_SLAB;
       for (int sl = nsl - 1; sl >= 0; --sl) {
         const int k0 = sl * ND_SLAB, k1 = std::min(P, k0 + ND_SLAB);
-        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.off, s->vec, Lv.voff, M, k0, k1, 1);
+        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 1);
         if (k0 > 0)
-          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + 255) / 256)), dim3(256), 0, q, s->arena, Lv.off,
-                             s->vec, Lv.voff, M, 0, k0, k0, k1);
+          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + 255) / 256)), dim3(256), 0, q, s->arena, Lv.poff,
+                             fs, s->vec, Lv.voff, M, 0, k0, k0, k1, (int64_t)k0 * M, M);
       }
     }
     nd_join(s, used);

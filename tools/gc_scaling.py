@@ -29,4 +29,5 @@ for i in range(maxit):
     problem.advance_prev()
 dt = time.perf_counter() - t
 print(f"  total {dt:.2f}s, Newton {its} sum {sum(its)} -> {sum(its) / dt:.2f} Newton it/s", flush=True)
+print(f"  sparse LU storage {problem.lu_stats()['arena_doubles'] * 8 / 1e9:.1f} GB", flush=True)
 print("  phases ms:", {k: round(v, 1) for k, v in problem.profile(False).items()}, flush=True)

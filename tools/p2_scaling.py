@@ -1,5 +1,6 @@
 """One full LVPP solve (settings B) of the ex 01 obstacle problem at degree `p` on an N x N mesh with a chosen
-preconditioner: python tools/p2_scaling.py N [p] [pgx_lu|pgx_mg|auto]"""
+preconditioner: python tools/p2_scaling.py N [p] [pgx_lu|pgx_mg|auto] [double_exponential|constant] [reps]
+(constant = settings A: alpha = 1, tol 1e-6)"""
 import sys
 import time
 
@@ -10,6 +11,8 @@ from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem  # noqa:
 N = int(sys.argv[1])
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 pc = sys.argv[3] if len(sys.argv) > 3 else "auto"
+scheme = sys.argv[4] if len(sys.argv) > 4 else "double_exponential"
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 opts = {"ksp_type": "preonly", "pc_type": pc, "snes_error_if_not_converged": False, "snes_linesearch_type": "none",
         "snes_rtol": 1e-6, "snes_max_it": 100}
 msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
@@ -17,9 +20,10 @@ t = time.perf_counter()
 problem, sol, sol_k, alpha = setup_problem(msh, p, petsc_options=opts)
 print(f"N={N} p={p} pc={pc} dofs={problem.ndofs} setup {time.perf_counter() - t:.2f}s", flush=True)
 problem.profile(True)
-for rep in range(2):
+for rep in range(reps):
     t = time.perf_counter()
-    hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4)
+    hist = (run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4) if scheme == "double_exponential"
+            else run_outer_loop(problem, sol, sol_k, alpha, 100, "constant", 1e5, 1e-6))
     dt = time.perf_counter() - t
     print(f"  run {rep}: {dt * 1e3:.0f} ms  Newton {hist['Newton steps']} (sum {sum(hist['Newton steps'])}) "
           f"reason {problem.solver.getConvergedReason()}  lin its last {problem.solver.ksp._its}", flush=True)
