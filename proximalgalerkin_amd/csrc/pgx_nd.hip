@@ -75,8 +75,19 @@ struct pgx_nd {
   pgx_nd_stats stats{};
   int64_t arena_len = 0, vec_len = 0;  // arena_len: device layout = compact factors + both working buffers
   int64_t virt_len = 0;                 // virtual arena (full fronts)
-  std::vector<int64_t> wd_off, wd_len;  // per tree depth: its range of the working buffer
-  std::vector<int64_t> dnz;             // per tree depth: range of the depth-sorted assembly list
+  // GROUPS = units of the factorisation schedule: all batches of one tree depth, or - below the cut depth kcut of a
+  // large factorisation - the batches of one depth inside ONE of the subtrees hanging at depth kcut.  The subtrees are
+  // factorised one after the other (each level by level), so the working buffers of the deep levels only ever hold one
+  // subtree's fronts; the levels from kcut upwards follow as before.
+  struct Group {
+    int depth = 0, sub = -1;   // sub < 0: every front of the depth
+    int l0 = 0, l1 = 0;        // batches lev[l0 .. l1)
+    int64_t w_off = 0, w_len = 0;  // its range of a working buffer
+    int64_t nz0 = 0, nz1 = 0;      // its range of the group-sorted assembly list
+  };
+  std::vector<Group> groups;
+  std::vector<int> gfirst;  // groups of depth d: groups[gfirst[d]] .. groups[gfirst[d+1] - 1]
+  int kcut = -1, nsub = 0;
   int64_t* d_sdest = nullptr;           // assembly list sorted by tree depth: destination in the working buffer ...
   int32_t* d_ssrc = nullptr;            // ... and index of the matrix entry
   // device
@@ -357,15 +368,37 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     if (state[t]) ++nloc;
   }
   auto cost = [](double P, double B) { return 2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B + 30.0 * (P + B) * (P + B); };
+  // subtree of every node below the cut depth (see pgx_nd::Group); the cut is tried only when the uncut layout is large
+  int kcut = -1;
+  std::vector<int> sub_of(nt, -1);
+  int nsub = 0;
+  int64_t off = 0, voff = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
   s->lev.clear();
+  s->groups.clear();
+  s->gfirst.assign(maxd + 2, 0);
   s->dfirst.assign(maxd + 2, 0);
+  std::fill(tbatch.begin(), tbatch.end(), 0);
   {
     std::vector<std::vector<int>> by_depth(maxd + 1);
     for (int t : post) by_depth[T[t].depth].push_back(t);
     for (int d = 0; d <= maxd; ++d) {
       s->dfirst[d] = (int)s->lev.size();
-      std::vector<int> order = by_depth[d];  // postorder
+      s->gfirst[d] = (int)s->groups.size();
+      const int nparts = (kcut >= 0 && d > kcut) ? nsub : 1;
+      for (int part = 0; part < nparts; ++part) {
+      pgx_nd::Group G;
+      G.depth = d;
+      G.sub = nparts > 1 ? part : -1;
+      G.l0 = (int)s->lev.size();
+      std::vector<int> order;  // postorder
+      if (nparts == 1)
+        order = by_depth[d];
+      else
+        for (int t : by_depth[d])
+          if (sub_of[t] == part) order.push_back(t);
       std::vector<std::vector<int>> classes(1, order);
+      if (order.empty()) classes.clear();
       if (!(dsize > 1 && d == kd) && order.size() > 1) {
         std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return tp_true[a] + tb[a] > tp_true[c] + tb[c]; });
         classes.assign(1, order);
@@ -418,11 +451,16 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
         if (dsize > 1 && d == kd) s->kbatch = (int)s->lev.size();
         s->lev.push_back(Lv);
       }
+      G.l1 = (int)s->lev.size();
+      s->groups.push_back(G);
+      }  // part
     }
     s->dfirst[maxd + 1] = (int)s->lev.size();
+    s->gfirst[maxd + 1] = (int)s->groups.size();
   }
   const int L = (int)s->lev.size();
-  int64_t off = 0, voff = 0, start = 0;
+  int64_t start = 0;
+  off = 0, voff = 0;
   s->stats = pgx_nd_stats();
   for (int l = 0; l < L; ++l) {
     NdLevel& Lv = s->lev[l];
@@ -443,30 +481,57 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   s->nfronts = nloc;
   s->stats.n_fronts = nloc;
   s->stats.n_levels = L;
-  {  // device layout: compact factors first, then the two working buffers
-    const int nd = (int)s->dfirst.size() - 1;
-    s->wd_off.assign(nd, 0);
-    s->wd_len.assign(nd, 0);
-    int64_t poff = 0, wmax[2] = {0, 0};
-    for (int d = 0; d < nd; ++d) {
+  {  // device layout: compact factors first, then the working buffers: two (depth parity) for the groups that span a whole
+     // depth, two smaller ones for the groups of the subtrees below the cut
+    int64_t poff = 0, wmax[2][2] = {{0, 0}, {0, 0}};  // [deep?][parity]
+    for (auto& G : s->groups) {
       int64_t w = 0;
-      for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) {
+      for (int l = G.l0; l < G.l1; ++l) {
         NdLevel& Lv = s->lev[l];
         const int64_t M = Lv.P + Lv.B;
         Lv.poff = poff;
-        Lv.woff = w;  // relative to the depth's buffer for now
+        Lv.woff = w;  // relative to the group's buffer for now
         poff += Lv.count * (M * Lv.P + (int64_t)Lv.P * Lv.B);
         w += Lv.count * M * M;
       }
-      s->wd_len[d] = w;
-      wmax[d & 1] = std::max(wmax[d & 1], w);
+      G.w_len = w;
+      int64_t& m = wmax[G.sub >= 0][G.depth & 1];
+      m = std::max(m, w);
     }
-    for (int d = 0; d < nd; ++d) {
-      s->wd_off[d] = poff + ((d & 1) ? wmax[0] : 0);
-      for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) s->lev[l].woff += s->wd_off[d];
+    const int64_t base[2][2] = {{poff, poff + wmax[0][0]},
+                                {poff + wmax[0][0] + wmax[0][1], poff + wmax[0][0] + wmax[0][1] + wmax[1][0]}};
+    for (auto& G : s->groups) {
+      G.w_off = base[G.sub >= 0][G.depth & 1];
+      for (int l = G.l0; l < G.l1; ++l) s->lev[l].woff += G.w_off;
     }
-    s->arena_len = poff + wmax[0] + wmax[1];
+    s->arena_len = poff + wmax[0][0] + wmax[0][1] + wmax[1][0] + wmax[1][1];
   }
+  s->kcut = kcut;
+  s->nsub = nsub;
+  // large factorisation on one GPU: cut the tree at depth 3 and factorise the (up to) 8 subtrees below one after the other
+  {
+    const char* e = getenv("PGX_ND_CUT_GB");  // threshold in GB of device storage (default 96); 0 = always, < 0 = never
+    const double thr = e ? atof(e) : 96.0;
+    const int kc = 3;
+    if (attempt == 0 && dsize == 1 && thr >= 0 && maxd >= kc + 3 && (double)s->arena_len * 8 > thr * 1e9) {
+      nsub = 0;
+      for (int t : post)
+        if (T[t].depth == kc) sub_of[t] = nsub++;
+      for (int t = 0; t < nt; ++t)  // tree ids are assigned parent-before-child
+        if (T[t].depth > kc) sub_of[t] = sub_of[T[t].parent];
+      bool ok = nsub >= 2;
+      for (int t = 0; t < nt; ++t)
+        if (T[t].depth > kc && sub_of[t] < 0) ok = false;  // a branch that ends above the cut
+      if (ok) {
+        kcut = kc;
+        continue;
+      }
+      nsub = 0;
+    }
+  }
+  break;
+  }  // attempt
+  const int L = (int)s->lev.size();
   s->stats.arena_doubles = s->arena_len;
   {
     std::vector<int64_t> next(L);
@@ -1173,7 +1238,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
       s->err = "pgx_nd_create: more than 2^31 matrix entries";
       return fail(PGX_EINVAL);
     }
-    const int L = (int)s->lev.size(), nd = (int)s->dfirst.size() - 1;
+    const int L = (int)s->lev.size();
     std::vector<int64_t> voffs(L);
     for (int l = 0; l < L; ++l) voffs[l] = s->lev[l].off;
     auto batch_of = [&](int64_t v) {  // last batch with off <= v and count > 0 containing v
@@ -1181,20 +1246,25 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
       while (l > 0 && s->lev[l].count == 0) --l;
       return l;
     };
-    s->dnz.assign(nd + 1, 0);
+    const int ng = (int)s->groups.size();
+    std::vector<int> group_of(L, 0);
+    for (int g = 0; g < ng; ++g)
+      for (int l = s->groups[g].l0; l < s->groups[g].l1; ++l) group_of[l] = g;
+    std::vector<int64_t> gnz(ng + 1, 0);
     std::vector<int32_t> bl(s->nnz, -1);
     for (int64_t k = 0; k < s->nnz; ++k)
       if (s->dest[k] >= 0) {
         bl[k] = batch_of(s->dest[k]);
-        s->dnz[s->lev[bl[k]].depth + 1]++;
+        gnz[group_of[bl[k]] + 1]++;
       }
-    for (int d = 0; d < nd; ++d) s->dnz[d + 1] += s->dnz[d];
-    std::vector<int64_t> cur(s->dnz.begin(), s->dnz.end() - 1), sdest(s->dnz[nd]);
-    std::vector<int32_t> ssrc(s->dnz[nd]);
+    for (int g = 0; g < ng; ++g) gnz[g + 1] += gnz[g];
+    for (int g = 0; g < ng; ++g) s->groups[g].nz0 = gnz[g], s->groups[g].nz1 = gnz[g + 1];
+    std::vector<int64_t> cur(gnz.begin(), gnz.end() - 1), sdest(gnz[ng]);
+    std::vector<int32_t> ssrc(gnz[ng]);
     for (int64_t k = 0; k < s->nnz; ++k)
       if (bl[k] >= 0) {
         const NdLevel& Lv = s->lev[bl[k]];
-        const int64_t t = cur[Lv.depth]++;
+        const int64_t t = cur[group_of[bl[k]]]++;
         sdest[t] = Lv.woff + (s->dest[k] - Lv.off);  // same front-local position: both layouts use M x M fronts here
         ssrc[t] = (int32_t)k;
       }
@@ -1349,27 +1419,26 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   }
   if (s->timing) hipEventRecord(s->e0, s->st);
   NDHIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
-  const int L = (int)s->lev.size();
   const int maxdepth = (int)s->dfirst.size() - 2;
-  for (int d = maxdepth; d >= 0; --d) {
-    // the working buffer of this depth: zero, matrix entries, identity on the padded pivots.  (Its previous tenants, the
-    // fronts of depth d+2, are stored compactly and their Schur blocks were absorbed at depth d+1.)
-    if (s->wd_len[d] > 0) {
-      NDHIP(hipMemsetAsync(s->arena + s->wd_off[d], 0, (size_t)s->wd_len[d] * sizeof(double), s->st));
-      const int64_t t0 = s->dnz[d], t1 = s->dnz[d + 1];
-      if (t1 > t0) {
-        int blocks = (int)std::min<int64_t>((t1 - t0 + 255) / 256, 256 * 64);
-        hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, t0, t1, s->d_sdest, s->d_ssrc, dv, s->arena);
-      }
-      const int64_t f0 = s->lev[s->dfirst[d]].start;
-      const int64_t f1 = s->lev[s->dfirst[d + 1] - 1].start + s->lev[s->dfirst[d + 1] - 1].count;
-      if (f1 > f0)
-        hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, s->st, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase,
-                           s->arena);
+  // the working buffer of a group: zero, matrix entries, identity on the padded pivots.  (Its previous tenants are
+  // stored compactly and their Schur blocks have been absorbed by their parents.)
+  auto prep = [&](const pgx_nd::Group& G) -> int {
+    if (G.w_len <= 0) return PGX_OK;
+    NDHIP(hipMemsetAsync(s->arena + G.w_off, 0, (size_t)G.w_len * sizeof(double), s->st));
+    if (G.nz1 > G.nz0) {
+      int blocks = (int)std::min<int64_t>((G.nz1 - G.nz0 + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, G.nz0, G.nz1, s->d_sdest, s->d_ssrc, dv, s->arena);
     }
-    // every batch of depth d+1 is factorised: extend-add their Schur complements into the fronts of depth d (two
-    // conflict-free passes: first children, second children)
-    for (int cb = s->dfirst[d + 1]; cb < (d + 2 < (int)s->dfirst.size() ? s->dfirst[d + 2] : L); ++cb) {
+    const int64_t f0 = s->lev[G.l0].start, f1 = s->lev[G.l1 - 1].start + s->lev[G.l1 - 1].count;
+    if (f1 > f0)
+      hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, s->st, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase,
+                         s->arena);
+    return PGX_OK;
+  };
+  // extend-add of the Schur complements of a (factorised) group into its parents' fronts (two conflict-free passes: first
+  // children, second children)
+  auto extend = [&](const pgx_nd::Group& G) {
+    for (int cb = G.l0; cb < G.l1; ++cb) {
       const NdLevel& C = s->lev[cb];
       if (C.count == 0 || C.B == 0) continue;
       int64_t per = (int64_t)C.B * C.B;
@@ -1379,9 +1448,11 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
         hipLaunchKernelGGL(k_nd_extend_add, dim3((unsigned)C.count, gy), dim3(256), 0, s->st, C.start, pass, C.P, C.P + C.B,
                            s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel, s->arena);
     }
+  };
+  auto eliminate = [&](const pgx_nd::Group& G) {  // the batches of a group on forked streams
     hipEventRecord(s->ev_fork, s->st);
     int used = 0;
-    for (int l = s->dfirst[d + 1] - 1; l >= s->dfirst[d]; --l) {
+    for (int l = G.l1 - 1; l >= G.l0; --l) {
       const NdLevel& Lv = s->lev[l];
       const int P = Lv.P, B = Lv.B, M = P + B;
       if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
@@ -1416,6 +1487,27 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P);
     }
     nd_join(s, used);
+  };
+  auto grp = [&](int d, int sub) -> const pgx_nd::Group& { return s->groups[s->gfirst[d] + (sub < 0 ? 0 : sub)]; };
+  int rcp = PGX_OK;
+  const int kc = s->kcut;
+  if (kc >= 0) {
+    // subtrees below the cut, one after the other; their roots' fronts (depth kc) wait in the other working buffer
+    if ((rcp = prep(grp(kc, -1)))) return rcp;
+    for (int g = 0; g < s->nsub; ++g) {
+      for (int d = maxdepth; d > kc; --d) {
+        if ((rcp = prep(grp(d, g)))) return rcp;
+        if (d < maxdepth) extend(grp(d + 1, g));
+        eliminate(grp(d, g));
+      }
+      extend(grp(kc + 1, g));
+    }
+    eliminate(grp(kc, -1));
+  }
+  for (int d = (kc >= 0 ? kc - 1 : maxdepth); d >= 0; --d) {
+    if ((rcp = prep(grp(d, -1)))) return rcp;
+    if (d < maxdepth) extend(grp(d + 1, -1));
+    eliminate(grp(d, -1));
     if (s->size > 1 && d == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
       const NdLevel& Lv = s->lev[s->kbatch];
       const int P = Lv.P, B = Lv.B, M = P + B;

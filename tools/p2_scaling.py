@@ -22,8 +22,8 @@ print(f"N={N} p={p} pc={pc} dofs={problem.ndofs} setup {time.perf_counter() - t:
 problem.profile(True)
 for rep in range(reps):
     t = time.perf_counter()
-    hist = (run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4) if scheme == "double_exponential"
-            else run_outer_loop(problem, sol, sol_k, alpha, 100, "constant", 1e5, 1e-6))
+    hist = (run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4, verbose=N >= 1024) if scheme == "double_exponential"
+            else run_outer_loop(problem, sol, sol_k, alpha, 100, "constant", 1e5, 1e-6, verbose=N >= 1024))
     dt = time.perf_counter() - t
     print(f"  run {rep}: {dt * 1e3:.0f} ms  Newton {hist['Newton steps']} (sum {sum(hist['Newton steps'])}) "
           f"reason {problem.solver.getConvergedReason()}  lin its last {problem.solver.ksp._its}", flush=True)
