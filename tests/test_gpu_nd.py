@@ -70,3 +70,25 @@ def test_ex06_newton_matrix(require_gpu):
     nod = np.concatenate([np.arange(g.n2), np.arange(g.nv), np.arange(g.nv)])
     _check(g.jacobian(its[1], 4.0), nod, g.dof_coords, 16)
     _check(g.jacobian(its[-1], 256.0), nod, g.dof_coords, 16, rtol_x=1e-4)
+
+
+def test_subtree_sequencing_gives_the_same_factorisation(require_gpu, monkeypatch):
+    """Large factorisations cut the tree at depth 3 and factorise the subtrees one after the other (PGX_ND_CUT_GB, default
+    96 GB of device storage); forced here on a small matrix: same solutions as SuperLU, less storage than without the cut."""
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    N = 48
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    its = []
+    O.solve_problem(p1, 500, "double_exponential", 1e2, 1e-4, iterates=its)
+    J = p1.jacobian(its[-2], 100.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p1.n)] * 2)
+    monkeypatch.setenv("PGX_ND_CUT_GB", "-1")
+    plain = DirectSolver(J.indptr, J.indices, nod, p1.coords, device=-1).stats()
+    monkeypatch.setenv("PGX_ND_CUT_GB", "0")
+    cut = DirectSolver(J.indptr, J.indices, nod, p1.coords, device=-1).stats()
+    assert cut["n_levels"] > plain["n_levels"] and cut["arena_doubles"] < plain["arena_doubles"]
+    assert cut["flops"] == plain["flops"] and cut["factor_nnz"] == plain["factor_nnz"]
+    _check(J, nod, p1.coords, 0)

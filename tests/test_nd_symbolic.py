@@ -47,6 +47,31 @@ def test_symbolic_maps_reproduce_lu(case):
     assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
 
 
+def test_subtree_sequencing_keeps_the_maps_valid(monkeypatch):
+    """PGX_ND_CUT_GB=0 forces the large-problem schedule (tree cut at depth 3, batches per subtree): the exported maps still
+    reproduce LU, with more, smaller batches and less device storage; flop count and factor size do not change."""
+    N = 40
+    coords, cells = O.create_rectangle(N, N)
+    p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    x = 0.3 * np.random.default_rng(5).standard_normal(2 * p1.n)
+    J = p1.jacobian(x, 5.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p1.n)] * 2)
+    monkeypatch.setenv("PGX_ND_CUT_GB", "-1")
+    plain = DirectSolver(J.indptr, J.indices, nod, p1.coords, leaf_nodes=8, device=-1)
+    monkeypatch.setenv("PGX_ND_CUT_GB", "0")
+    cut = DirectSolver(J.indptr, J.indices, nod, p1.coords, leaf_nodes=8, device=-1)
+    sp_, sc_ = plain.stats(), cut.stats()
+    assert sc_["n_levels"] > sp_["n_levels"] and sc_["arena_doubles"] < sp_["arena_doubles"]
+    assert sc_["flops"] == sp_["flops"] and sc_["factor_nnz"] == sp_["factor_nnz"] and sc_["n_fronts"] == sp_["n_fronts"]
+    sym = cut.export_symbolic()
+    assert np.all(np.diff(sym["depth"]) >= 0)  # batches stay ordered by tree depth
+    fac = E.factor(sym, J.data)
+    b = np.random.default_rng(0).standard_normal(J.shape[0])
+    xs = E.solve(sym, fac, b)
+    assert np.linalg.norm(J @ xs - b) <= 1e-10 * np.linalg.norm(b)
+
+
 def test_symbolic_handle_refuses_numeric_phase_without_gpu():
     coords, cells = O.create_rectangle(4, 4)
     p1 = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(4, 4))
