@@ -33,6 +33,8 @@ struct MixedBase {
   double* h_out = nullptr;  // pinned
   std::vector<int32_t> h_rowptr, h_col;
   pgx_nd* lu = nullptr;
+  double* gm_V = nullptr;  // Krylov basis of the GMRES safeguard (allocated on first use)
+  int gm_m = 0;
   // distributed handles (one per GPU, replicated iterate, distributed LU): every scalar that steers control flow - norms,
   // dot products of the line search - is taken from rank 0, so that all ranks make the same collective calls even though
   // their redundantly assembled residuals differ in the last bits (atomics)
@@ -223,6 +225,12 @@ static int mx_out(MixedBase* h, double* dst, const double* src, int64_t len = 0)
 }
 
 // dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
+static int mx_dot(MixedBase* h, const double* a, const double* b, double* out);
+static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres);
+
+// J dx = b by the sparse LU + iterative refinement on the exact operator (the reference: ksp_type preonly + MUMPS).  The LU
+// does not pivot across nodes; where refinement alone cannot bring the true relative residual below 1e-7 (late, extremely
+// ill-conditioned steps on very fine meshes), the same LU preconditions a short GMRES on the exact operator.
 static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_snes_opts* o, int* nsolves, double* relres) {
   double bnorm = 0, rnorm = 0, prev = 1e300;
   int rc = mx_norm(h, b, &bnorm);
@@ -255,6 +263,10 @@ static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_
     ++*nsolves;
     mx_axpby(h, 1.0, h->z, 1.0, dx);
   }
+  const char* ea = getenv("PGX_MX_GMRES_ALWAYS");  // test hook: polish with GMRES whenever refinement stops above tol
+  const bool always = ea && atoi(ea);
+  if (std::isfinite(*relres) && (*relres > 1e-7 || (always && *relres > tol)))
+    return mx_gmres_lu(h, b, dx, bnorm, tol, nsolves, relres);
   return PGX_OK;
 }
 
@@ -383,6 +395,88 @@ static int mx_dot(MixedBase* h, const double* a, const double* b, double* out) {
   MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
   MXHIP(hipStreamSynchronize(h->st));
   *out = h->h_out[0];
+  return PGX_OK;
+}
+
+// Right-preconditioned GMRES(m) on the exact operator with the (inaccurate) LU as preconditioner, from the current dx;
+// h->r holds b - J dx on entry.  Modified Gram-Schmidt, Givens rotations, the true residual decides.  At most 3 cycles of 12.
+static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres) {
+  const int m = 12;
+  if (!h->gm_V) {
+    const int rca = mx_alloc(h, &h->gm_V, (size_t)(m + 1) * h->ntot);
+    if (rca) return rca;
+    h->gm_m = m;
+  }
+  auto V = [&](int j) { return h->gm_V + (size_t)j * h->ntot; };
+  int rc = PGX_OK;
+  for (int cycle = 0; cycle < 3; ++cycle) {
+    double beta = 0;
+    if ((rc = mx_norm(h, h->r, &beta))) return rc;
+    if (!(beta > 0.0) || !std::isfinite(beta)) break;
+    mx_axpby(h, 1.0 / beta, h->r, 0.0, V(0));
+    std::vector<double> H((m + 1) * m, 0.0), cs(m, 0.0), sn(m, 0.0), g(m + 1, 0.0);
+    g[0] = beta;
+    int k = 0;
+    for (int j = 0; j < m; ++j) {
+      {
+        MxTimer t(h, 3);
+        if ((rc = pgx_nd_solve(h->lu, V(j), h->z, 1))) {
+          h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+          return rc;
+        }
+      }
+      ++*nsolves;
+      mx_spmv_dev(h, h->z, V(j + 1));
+      for (int i = 0; i <= j; ++i) {
+        double hij = 0;
+        if ((rc = mx_dot(h, V(j + 1), V(i), &hij))) return rc;
+        H[i * m + j] = hij;
+        mx_axpby(h, -hij, V(i), 1.0, V(j + 1));
+      }
+      double hn = 0;
+      if ((rc = mx_norm(h, V(j + 1), &hn))) return rc;
+      H[(j + 1) * m + j] = hn;
+      if (hn > 0.0) mx_axpby(h, 0.0, V(0), 1.0 / hn, V(j + 1));  // scale in place (the x operand is not read: a = 0)
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * H[i * m + j] + sn[i] * H[(i + 1) * m + j];
+        H[(i + 1) * m + j] = -sn[i] * H[i * m + j] + cs[i] * H[(i + 1) * m + j];
+        H[i * m + j] = t;
+      }
+      const double a = H[j * m + j], c = H[(j + 1) * m + j], d = std::hypot(a, c);
+      cs[j] = d > 0 ? a / d : 1.0;
+      sn[j] = d > 0 ? c / d : 0.0;
+      H[j * m + j] = d;
+      H[(j + 1) * m + j] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      k = j + 1;
+      if (std::fabs(g[j + 1]) <= tol * bnorm || !(hn > 0.0)) break;
+    }
+    std::vector<double> y(k, 0.0);
+    for (int i = k - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int l = i + 1; l < k; ++l) t -= H[i * m + l] * y[l];
+      y[i] = t / H[i * m + i];
+    }
+    // dx += M^-1 (V y)
+    mx_axpby(h, y[0], V(0), 0.0, h->r);
+    for (int i = 1; i < k; ++i) mx_axpby(h, y[i], V(i), 1.0, h->r);
+    {
+      MxTimer t(h, 3);
+      if ((rc = pgx_nd_solve(h->lu, h->r, h->z, 1))) {
+        h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+        return rc;
+      }
+    }
+    ++*nsolves;
+    mx_axpby(h, 1.0, h->z, 1.0, dx);
+    mx_spmv_dev(h, dx, h->r);
+    mx_axpby(h, 1.0, b, -1.0, h->r);  // r = b - J dx
+    double rnorm = 0;
+    if ((rc = mx_norm(h, h->r, &rnorm))) return rc;
+    *relres = rnorm / bnorm;
+    if (!std::isfinite(*relres) || *relres <= tol) break;
+  }
   return PGX_OK;
 }
 

@@ -130,3 +130,36 @@ def test_hip_reproduces_golden_fixture(require_gpu):
     its, diffs, x = solve_problem(N, N, verbose=False, return_solution=True)
     assert list(its) == list(z["newton"])
     assert _rel(x[: prob.n2], z["x_final"][: prob.n2]) < 1e-10
+
+
+def test_gmres_safeguard_of_the_linear_solve(require_gpu, monkeypatch):
+    """Where LU + refinement cannot reach a true relative residual of 1e-7 (seen at 2048^2, alpha = 1024) the same LU
+    preconditions a GMRES on the exact operator (pgx_mixed.h::mx_gmres_lu).  Forced here: no refinement steps, GMRES polishes
+    every solve to 1e-12 - the LVPP run must not change."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default
+
+    N = 16
+    coords, cells = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(coords, cells)
+    x_ref, its_ref, _ = G.solve_problem(prob)
+    monkeypatch.setenv("PGX_MX_GMRES_ALWAYS", "1")
+    problem = GradientConstraintProblem(fem.create_unit_square(N, N), phi_default, f_default)
+    problem._opts.ksp_max_it = 1  # plain LU solve, no refinement
+    problem.profile(True)
+    its, lin = [], 0
+    for i in range(25):
+        problem.set_alpha(2.0**i)
+        reason, n = problem.solve()
+        assert reason > 0
+        its.append(n)
+        lin += problem.solver.ksp._its  # LU solves of this Newton solve
+        d = problem.l2_increment()
+        if d < 1e-8:
+            break
+        problem.advance_prev()
+    x = problem.get_state()
+    problem.close()
+    assert its == list(its_ref)
+    assert _rel(x[: prob.n2], x_ref[: prob.n2]) < 1e-10
+    assert lin > sum(its)  # more LU solves than Newton steps although refinement is off: GMRES ran
