@@ -776,9 +776,18 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
   __shared__ double D[ND_NB][ND_NB + 1];
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M + (int64_t)kb * M + kb;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int r = idx % nb, c = idx / nb;
-    D[r][c] = F[(int64_t)c * M + r];
+  {  // all loads in flight before the first LDS write
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q;
+      v[q] = idx < nb * nb ? F[(int64_t)(idx / nb) * M + idx % nb] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < nb * nb) D[idx % nb][idx / nb] = v[q];
+    }
   }
   __syncthreads();
   for (int jb = 0; jb < nb; jb += 8) {
@@ -877,13 +886,20 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
   const int j = tid & 63, g = tid >> 6;
   if (!isL) {
     // T: strict lower triangle, row-major packed: L[r][c] at r(r-1)/2 + c
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-      const int r = idx % nb, c = idx / nb;
-      if (r > c) T[r * (r - 1) / 2 + c] = Dg[(int64_t)c * M + r];
-    }
-    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
-      const int k = idx % nb, jj = idx / nb;
-      X[k][jj] = jj < wd ? F[(int64_t)(o0 + jj) * M + kb + k] : 0.0;
+    {  // all loads in flight before the first LDS write
+      double v[16], u[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, r = idx % nb, c = idx / nb;
+        v[q] = (idx < nb * nb && r > c) ? Dg[(int64_t)c * M + r] : 0.0;
+        u[q] = (idx < nb * ND_TS && c < wd) ? F[(int64_t)(o0 + c) * M + kb + r] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, r = idx % nb, c = idx / nb;
+        if (idx < nb * nb && r > c) T[r * (r - 1) / 2 + c] = v[q];
+        if (idx < nb * ND_TS) X[r][c] = u[q];
+      }
     }
     __syncthreads();
     for (int jb = 0; jb < nb; jb += 8) {
@@ -927,13 +943,20 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
     }
   } else {
     // T: upper triangle incl. diagonal, column-major packed: U[k][c] at c(c+1)/2 + k
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-      const int k = idx % nb, c = idx / nb;
-      if (k <= c) T[c * (c + 1) / 2 + k] = Dg[(int64_t)c * M + k];
-    }
-    for (int idx = tid; idx < nb * ND_TS; idx += 256) {
-      const int i = idx % ND_TS, k = idx / ND_TS;
-      X[k][i] = i < wd ? F[(int64_t)(kb + k) * M + o0 + i] : 0.0;
+    {  // all loads in flight before the first LDS write
+      double v[16], u[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, k = idx % nb, c = idx / nb, i = idx % ND_TS, k2 = idx / ND_TS;
+        v[q] = (idx < nb * nb && k <= c) ? Dg[(int64_t)c * M + k] : 0.0;
+        u[q] = (idx < nb * ND_TS && i < wd) ? F[(int64_t)(kb + k2) * M + o0 + i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, k = idx % nb, c = idx / nb, i = idx % ND_TS, k2 = idx / ND_TS;
+        if (idx < nb * nb && k <= c) T[c * (c + 1) / 2 + k] = v[q];
+        if (idx < nb * ND_TS) X[k2][i] = u[q];
+      }
     }
     __syncthreads();
     for (int jb = 0; jb < nb; jb += 8) {
@@ -1071,9 +1094,18 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
   for (int bb = 0; bb < nblk; ++bb) {
     const int kb = k0 + (upper ? (nblk - 1 - bb) * 64 : bb * 64);
     const int nb = min(64, k1 - kb);
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-      const int r = idx % nb, c = idx / nb;
-      Ds[r][c] = F[(int64_t)(kb + c) * M + kb + r];
+    {  // all loads in flight before the first LDS write (a load -> wait -> write loop costs 16 memory latencies)
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q;
+        v[q] = idx < nb * nb ? F[(int64_t)(kb + idx / nb) * M + kb + idx % nb] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q;
+        if (idx < nb * nb) Ds[idx % nb][idx / nb] = v[q];
+      }
     }
     __syncthreads();
     if (tid < 64) {
