@@ -1,6 +1,7 @@
-"""BASELINE.json configs on ONE MI355X, one line each (what can run on a single GPU; configs 3 and 5 name multi-GPU
-launches - the single-GPU numbers are the N = 1 point of those series):
-python tools/run_all_configs.py > profiles/rNN_all_configs.txt"""
+"""BASELINE.json configs on ONE MI355X, one line each (configs 3 and 5 name multi-GPU launches - the single-GPU numbers are
+the N = 1 point of those series):
+python tools/run_all_configs.py [--full] > profiles/rNN_all_configs.txt
+--full adds config 3 at its full size (2048^2 P2, 33.6 M unknowns, ~4 minutes incl. the symbolic phase)."""
 import sys
 import time
 
@@ -43,7 +44,8 @@ print(f"config 1  ex01 64^2 P1: oracle (CPU, SuperLU) {sum(hr['Newton steps'])} 
 h, dt, _, _ = obstacle(2048, 1, B)
 print(f"config 2  ex01 2048^2 P1 (settings B): {sum(h['Newton steps'])} Newton its, {h['outer_iterations']} proximal its in {dt * 1e3:.0f} ms "
       f"= {sum(h['Newton steps']) / dt:.1f} Newton it/s", flush=True)
-for N, S, tag in ((512, B, "B"), (1024, A, "A: constant alpha")):
+sizes = [(512, B, "B"), (1024, A, "A: constant alpha")] + ([(2048, A, "A: constant alpha")] if "--full" in sys.argv else [])
+for N, S, tag in sizes:
     h, dt, reason, _ = obstacle(N, 2, S)
     print(f"config 3' ex01 {N}^2 P2 (settings {tag}; single GPU, sparse-LU preconditioner; the 2048^2 8-GPU case is pgx_create_lu_dist): "
           f"{sum(h['Newton steps'])} Newton its in {dt:.2f} s, last SNES reason {reason}", flush=True)
