@@ -20,8 +20,8 @@
 // written to the compact store only, which is also where the trailing updates read their operands:
 //   k_nd_diag   LU of one <= 64-wide diagonal block in LDS (8-column panels by one wave with lane shuffles)
 //   k_nd_panel  both triangular panel solves against that block, 64-wide chunks, blocked by 8 in LDS
-//   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 64^2 / 128^2 tiles, 4 waves x (2x2 | 4x4) MFMA
-//               tiles, operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes;
+//   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 64^2 tiles by 4 waves x (2x2) MFMA tiles
+//               (k_nd_gemm<2>) and 128^2 tiles by 8 waves x (4x2) MFMA tiles at 4 waves per SIMD (k_nd_gemm8), operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes;
 //               rank-64 updates touch only the strips of the current 256-pivot outer block, the rest of the trailing
 //               matrix gets one rank-256 update per outer block, the Schur block F22 ONE update with K = P.
 // Solve: the same tree walk on per-front vectors (forward leaves -> root, backward root -> leaves): k_nd_trsv on slabs of
@@ -1078,6 +1078,78 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
     }
 }
 
+// 128 x 128 tiles with EIGHT waves (wave tile 64 x 32 = 4 x 2 MFMA tiles): 64 accumulator VGPRs instead of 128, so that
+// two workgroups = 4 waves per SIMD are resident (launch bounds: 4 waves per SIMD -> <= 128 VGPRs) and one wave's LDS staging and
+// barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
+__global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
+                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P) {
+  constexpr int TS = 128, NT = 512;
+  constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
+  __shared__ double As[ND_KC][TS + 8];
+  __shared__ double Bs[TS][ND_KC + 1];
+  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
+  const int rmax = r1g, cmax = c1g;
+  if (r0 >= rmax || c0 >= cmax) return;
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
+  const int64_t MP = (int64_t)M * P;
+  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  const int wi = (wv >> 2) * 64, wj = (wv & 3) * 32;
+  nd_v4d acc[2][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
+  double ra[NLD], rb[NLD];
+  auto fetch = [&](int kc) {
+    const int kn = min(ND_KC, k1 - kc);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + NT * q;
+      const int i = idx % TS, k = idx / TS;
+      ra[q] = (k < kn && r0 + i < rmax) ? S[(int64_t)(kc + k) * M + r0 + i] : 0.0;
+      const int k2 = idx % ND_KC, j2 = idx / ND_KC, cj = c0 + j2;
+      rb[q] = (k2 < kn && cj < cmax) ? S[cj < P ? (int64_t)cj * M + kc + k2 : MP + (int64_t)(cj - P) * P + kc + k2] : 0.0;
+    }
+  };
+  fetch(k0);
+  for (int kc = k0; kc < k1; kc += ND_KC) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + NT * q;
+      As[idx / TS][idx % TS] = ra[q];
+      Bs[idx / ND_KC][idx % ND_KC] = rb[q];
+    }
+    __syncthreads();
+    if (kc + ND_KC < k1) fetch(kc + ND_KC);
+#pragma unroll
+    for (int kk = 0; kk < ND_KC; kk += 4) {
+      const int kq = kk + (l >> 4);
+      double uf[2], lf[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) uf[t] = Bs[wj + 16 * t + (l & 15)][kq];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lf[t] = As[kq][wi + 16 * t + (l & 15)];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[tj], lf[ti], acc[tj][ti], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int i = r0 + wi + 16 * ti + (l & 15);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
+        if (i < rmax && j < cmax) F[(int64_t)j * M + i] -= acc[tj][ti][reg];
+      }
+    }
+}
+
 // in-place triangular solve of the diagonal range [k0,k1) of every front's pivot block on w: upper == 0: unit lower L11;
 // upper != 0: U11.  One workgroup per front, 64-wide blocks: the 64x64 triangle is solved by wave 0 with lane shuffles,
 // the remaining rows OF THE RANGE are updated by all threads; rows outside the range are left to k_nd_gemv (many
@@ -1439,7 +1511,7 @@ static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, 
   const int TS = big ? 128 : 64;
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   if (big)
-    hipLaunchKernelGGL(k_nd_gemm<4>, grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
+    hipLaunchKernelGGL(k_nd_gemm8, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
   else
     hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
 }
