@@ -766,6 +766,15 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 #define ND_OUTER 256 // pivots per outer block of the factorisation (rank of the big trailing updates)
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
+// broadcast of one lane's double to the wave when the lane index is wave-uniform: two v_readlane_b32 (scalar result) instead
+// of the two ds_bpermute_b32 round trips through the LDS crossbar that __shfl compiles to - these broadcasts sit on the
+// serial chains of the diagonal-block LU and of the triangular solves
+__device__ __forceinline__ double nd_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level.  Blocked by 8 columns:
 // (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
 // (b) the 8 x rest block row of U by forward substitution, one thread per column, (c) rank-8 update of the trailing block
@@ -809,7 +818,7 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
           }
           double pv[8];
 #pragma unroll
-          for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? __shfl(a[c2], pr) : 0.0;
+          for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? nd_bcast(a[c2], pr) : 0.0;
           if (act && r > pr) {
             const double l = a[c] / pv[c];
             a[c] = l;
@@ -1185,13 +1194,13 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
       double y = r < nb ? w[kb + r] : 0.0;
       if (!upper) {
         for (int k = 0; k < nb; ++k) {
-          const double yk = __shfl(y, k);
+          const double yk = nd_bcast(y, k);
           if (r > k && r < nb) y -= Ds[r][k] * yk;
         }
       } else {
         const double dinv = r < nb ? 1.0 / Ds[r][r] : 0.0;
         for (int k = nb - 1; k >= 0; --k) {
-          const double xk = __shfl(y * dinv, k);
+          const double xk = nd_bcast(y * dinv, k);
           if (r < k) y -= Ds[r][k] * xk;
           if (r == k) y = xk;
         }
