@@ -932,13 +932,25 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
       if (jb + w < nb) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) xs[m] = m < w ? X[jb + m][j] : 0.0;
-        for (int r = jb + w + g; r < nb; r += 4) {
-          const double* Lr = T + r * (r - 1) / 2 + jb;
-          double v = X[r][j];
+        // four rows per trip, every LDS read issued before the first use (a row-at-a-time loop with a run-time trip
+        // count serialises read -> 8 fma -> write, one LDS latency per row)
+        for (int r = jb + w + g; r < nb; r += 16) {
+          double v[4], lc[4][8];
 #pragma unroll
-          for (int m = 0; m < 8; ++m)
-            if (m < w) v -= Lr[m] * xs[m];
-          X[r][j] = v;
+          for (int q = 0; q < 4; ++q) {
+            const int rr = min(r + 4 * q, nb - 1);
+            const double* Lr = T + rr * (rr - 1) / 2 + jb;
+            v[q] = X[rr][j];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) lc[q][m] = Lr[m];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < w) v[q] -= lc[q][m] * xs[m];
+            if (r + 4 * q < nb) X[r + 4 * q][j] = v[q];
+          }
         }
         __syncthreads();
       }
@@ -991,13 +1003,23 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
       if (jb + w < nb) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) xs[m] = m < w ? X[jb + m][j] : 0.0;
-        for (int c = jb + w + g; c < nb; c += 4) {
-          const double* Uc = T + c * (c + 1) / 2 + jb;
-          double v = X[c][j];
+        for (int c = jb + w + g; c < nb; c += 16) {  // four columns per trip, reads first (see the row panel)
+          double v[4], uc[4][8];
 #pragma unroll
-          for (int m = 0; m < 8; ++m)
-            if (m < w) v -= xs[m] * Uc[m];
-          X[c][j] = v;
+          for (int q = 0; q < 4; ++q) {
+            const int cc = min(c + 4 * q, nb - 1);
+            const double* Uc = T + cc * (cc + 1) / 2 + jb;
+            v[q] = X[cc][j];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) uc[q][m] = Uc[m];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < w) v[q] -= xs[m] * uc[q][m];
+            if (c + 4 * q < nb) X[c + 4 * q][j] = v[q];
+          }
         }
         __syncthreads();
       }
