@@ -854,13 +854,24 @@ __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int
           if (i < w) D[jb + i][c] = u[i];
       }
       __syncthreads();
-      for (int idx = tid; idx < rest * rest; idx += 256) {
-        const int r = jb + w + idx % rest, c = jb + w + idx / rest;
-        double v = D[r][c];
+      for (int idx = tid; idx < rest * rest; idx += 512) {  // two entries per trip, all LDS reads issued first
+        double v[2], lr[2][8], uc[2][8];
+        int rr[2], cc[2];
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-          if (m < w) v -= D[r][jb + m] * D[jb + m][c];
-        D[r][c] = v;
+        for (int q = 0; q < 2; ++q) {
+          const int id = min(idx + 256 * q, rest * rest - 1);
+          rr[q] = jb + w + id % rest, cc[q] = jb + w + id / rest;
+          v[q] = D[rr[q]][cc[q]];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) lr[q][m] = D[rr[q]][jb + m], uc[q][m] = D[jb + m][cc[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+            if (m < w) v[q] -= lr[q][m] * uc[q][m];
+          if (idx + 256 * q < rest * rest) D[rr[q]][cc[q]] = v[q];
+        }
       }
       __syncthreads();
     }
