@@ -1225,17 +1225,37 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
     if (tid < 64) {
       const int r = tid;
       double y = r < nb ? w[kb + r] : 0.0;
+      // the lane's row of the triangle comes 16 coefficients at a time, read before the 16 dependent steps that use
+      // them (one LDS latency per 16 steps instead of one per step: this loop is the serial core of the solve phase)
       if (!upper) {
-        for (int k = 0; k < nb; ++k) {
-          const double yk = nd_bcast(y, k);
-          if (r > k && r < nb) y -= Ds[r][k] * yk;
+        for (int kc = 0; kc < nb; kc += 16) {
+          double d[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) d[q] = Ds[r][min(kc + q, 63)];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int k = kc + q;
+            if (k < nb) {  // uniform
+              const double yk = nd_bcast(y, k);
+              if (r > k && r < nb) y -= d[q] * yk;
+            }
+          }
         }
       } else {
         const double dinv = r < nb ? 1.0 / Ds[r][r] : 0.0;
-        for (int k = nb - 1; k >= 0; --k) {
-          const double xk = nd_bcast(y * dinv, k);
-          if (r < k) y -= Ds[r][k] * xk;
-          if (r == k) y = xk;
+        for (int kc = ((nb - 1) / 16) * 16; kc >= 0; kc -= 16) {
+          double d[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) d[q] = Ds[r][min(kc + q, 63)];
+#pragma unroll
+          for (int q = 15; q >= 0; --q) {
+            const int k = kc + q;
+            if (k < nb) {  // uniform
+              const double xk = nd_bcast(y * dinv, k);
+              if (r < k) y -= d[q] * xk;
+              if (r == k) y = xk;
+            }
+          }
         }
       }
       ys[r] = y;
