@@ -59,6 +59,19 @@ def test_p2_auto_lu_matches_oracle_where_multigrid_failed(require_gpu):
     assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
 
 
+def test_p2_through_the_subtree_sequenced_lu(require_gpu, monkeypatch):
+    """The schedule BASELINE config 3 (2048^2 P2) runs with on one GPU - tree cut at depth 3, subtrees factorised one after
+    the other, PGX_ND_CUT_GB - forced on a small P2 problem: same LVPP run as the oracle."""
+    monkeypatch.setenv("PGX_ND_CUT_GB", "0")
+    N = 32
+    x, hist, _ = _run(N, 2, None)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
+
+
 def test_p2_n256_reproduces_the_oracles_newton_divergence(require_gpu):
     """P2, N = 256, settings B: the exact-Newton CPU oracle (SuperLU) itself ends with SNES_DIVERGED_DTOL (-9) at the
     alpha 16 -> 85 step (tests/golden/obstacle_p2_n256_settingsB_divergence.json, tools/p2_divergence_oracle.py) - the
