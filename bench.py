@@ -39,6 +39,30 @@ SETTINGS = {
 }
 
 
+def _ladder(name):
+    """Committed CPU ladder (profiles/<name>, written in the build container by tools/make_golden_large.py /
+    tools/cpu_ladder.py): seconds per Newton step of the oracle at a series of mesh sizes + the fitted exponent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh)
+    except OSError:
+        return None
+
+
+def extrapolate(v_measured, n_measured, n_workload, ladder, size_key="N"):
+    """Newton it/s of the CPU oracle at the benchmarked mesh, from the live measurement at n_measured and the exponent p of
+    the committed ladder (time per Newton step = c N^p).  Labelled as an extrapolation wherever it is printed."""
+    if not ladder or "fit" not in ladder:
+        return None
+    p = ladder["fit"]["p"]
+    pts = ladder["points"]
+    return {"value": v_measured * (n_measured / n_workload) ** p, "unit": "Newton iterations/s", "mesh": n_workload,
+            "method": f"EXTRAPOLATED, not measured: seconds per Newton step fitted as c*N^p with p = {p:.2f} on the committed "
+                      f"ladder ({size_key} = {', '.join(str(q[size_key]) for q in pts)}; largest measured point "
+                      f"{pts[-1]['s_per_newton_step']:.1f} s per step at {size_key} = {pts[-1][size_key]}), applied to the live "
+                      f"measurement at {size_key} = {n_measured}"}
+
+
 def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
     """Oracle (numpy assembly + SuperLU exact Newton, 1 thread) timed on this host: the SAME LVPP run at a
     reduced mesh size n_sample, cut off after ~budget_s of CPU work.  Timed region = the loop of
@@ -72,6 +96,23 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
     return steps / dt, steps, dt
 
 
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"host_cores": os.cpu_count(), "host_cores_usable": usable, "host_cpu": model}
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (dense)
 
 
@@ -82,9 +123,7 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
 
     comm = None
     if world > 1:
-        from proximalgalerkin_amd.comm import rccl_from_torch_distributed
-
-        comm = rccl_from_torch_distributed(local_rank)
+        comm = make_comm(local_rank)
     t_setup = time.perf_counter()
     if args.workload == "ex06":
         from proximalgalerkin_amd import fem
@@ -218,6 +257,16 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
         print(json.dumps(out))
 
 
+def make_comm(local_rank):
+    """The communicator of the N>1 launch: RCCL over xGMI.  BENCH_COMM=shm (test hook) swaps in the host-staged shared-memory
+    transport so that the SAME launch runs with all ranks on one GPU, where RCCL refuses to start (tests/test_gpu_multiprocess.py)."""
+    from proximalgalerkin_amd import comm as pcomm
+
+    if os.environ.get("BENCH_COMM", "rccl") == "shm":
+        return pcomm.shm_from_torch_distributed()
+    return pcomm.rccl_from_torch_distributed(local_rank)
+
+
 def reduce_over_ranks(dist, dt, newton_total, outer_total, device):
     """Launch-contract aggregation: wall time = MAX over ranks, work counts = SUM over ranks (whole-job value)."""
     import torch
@@ -238,7 +287,7 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=2048, help="cells per side (BASELINE config: 2048)")
     ap.add_argument("--settings", choices=["A", "B"], default="B")
     ap.add_argument("--degree", type=int, choices=[1, 2], default=1, help="Lagrange degree (obstacle_pg.py -p)")
-    ap.add_argument("--cpu-n", type=int, default=384, help="mesh size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=256, help="mesh size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
     ap.add_argument("--opts", default="", help="extra solver options key=val,key=val (e.g. ksp_gmres_restart=20)")
@@ -272,6 +321,19 @@ def main():
             dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if dist is not None:
+        # every call on a sharded / distributed-LU handle is collective: if one rank dies the others would wait in RCCL for
+        # ever.  Bound the damage for EVERY workload: the whole run has args.watchdog seconds.
+        import threading
+
+        def _abort():
+            sys.stderr.write(f"bench.py rank {rank}: no result after {args.watchdog} s - aborting (stuck collective?)\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd = threading.Timer(args.watchdog, _abort)
+        wd.daemon = True
+        wd.start()
 
     if args.workload != "ex01":
         return bench_lu_workload(args, rank, world, local_rank, dist, backend)
@@ -284,26 +346,11 @@ def main():
     # ---- setup (untimed): mesh, obstacle at quadrature points, plan, constant blocks, MG hierarchy ----
     t_setup = time.perf_counter()
     sharded = (world > 1 and not args.replicas) or force_sharded
-    if dist is not None:
-        # every call on a sharded handle is collective: if one rank dies the others would wait in RCCL for ever.
-        # Bound the damage: the whole run has args.watchdog seconds.
-        import threading
-
-        def _abort():
-            sys.stderr.write(f"bench.py rank {rank}: no result after {args.watchdog} s - aborting (stuck collective?)\n")
-            sys.stderr.flush()
-            os._exit(3)
-
-        wd = threading.Timer(args.watchdog, _abort)
-        wd.daemon = True
-        wd.start()
     comm = None
     if sharded:
         if args.degree != 1:
             raise SystemExit("bench.py: the sharded path covers P1; use --replicas for --degree 2")
-        from proximalgalerkin_amd.comm import rccl_from_torch_distributed
-
-        comm = rccl_from_torch_distributed(local_rank)  # id broadcast through the torch.distributed group
+        comm = make_comm(local_rank)  # id / segment-name broadcast through the torch.distributed group
     msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N), comm=comm, dist_levels=args.dist_levels)
     petsc_options = None
     if args.opts:
@@ -314,6 +361,8 @@ def main():
             petsc_options[k] = float(v) if any(c in v for c in ".e") else int(v)
     problem, sol, sol_k, alpha = setup_problem(msh, args.degree, petsc_options=petsc_options, device=local_rank)
     t_setup = time.perf_counter() - t_setup
+    if os.environ.get("BENCH_TEST_DIE_RANK") == str(rank):  # test hook: a rank that vanishes before the first collective solve
+        os._exit(17)
     if args.profile:
         problem.profile(enable=True, reset=True)
 
@@ -357,13 +406,19 @@ def main():
     prof = problem.profile() if args.profile else None
     if sharded:
         parallelism = (f"sharded: ONE {N}x{N} solve on {world} strips of {N // world} vertex rows (+ ghost rows, "
-                       f"{msh.partition.dist_levels} distributed multigrid levels, coarser levels replicated), RCCL halo "
-                       f"exchange + packed all-reduces over xGMI")
+                       f"{msh.partition.dist_levels} distributed multigrid levels, coarser levels replicated), "
+                       + ("RCCL halo exchange + packed all-reduces over xGMI" if comm.kind == "rccl" else
+                          f"transport '{comm.kind}' (host-staged rehearsal of the RCCL launch, not a performance number)"))
     elif world > 1:
         parallelism = "replicas: N INDEPENDENT solves, one per GPU (--replicas) - NOT a speed-up measurement"
     else:
         parallelism = "single"
 
+    traffic, traffic_source = None, None
+    tj = _ladder("r02_spmv_pmc_traffic.json")
+    if tj and tj.get("cells") == N and args.degree == 1 and not sharded:
+        traffic = tj["hbm_traffic_bytes_per_launch"]
+        traffic_source = {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date", "traffic_over_algorithmic")}
     out = None
     if rank == 0:
         out = {
@@ -401,9 +456,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction) for this kernel
-                # at this size: profiles/r01_spmv_pmc_traffic.json.  Only meaningful for the default 2048^2 workload.
-                "traffic": 993765512.8 if (N == 2048 and args.degree == 1 and not sharded) else None,
+                # HBM bytes per launch of THIS kernel build from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
+                # x2 read correction; tools/pmc_summary.py).  A profile of another run, not of this one: `traffic_source`
+                # says which; null when the profile does not match the workload.
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)
@@ -414,15 +471,26 @@ def main():
             out["phase_ms"] = prof
         if not args.no_cpu_baseline and world == 1:
             v, steps, secs = cpu_baseline(args.cpu_n, S)
+            ladder = _ladder("r02_cpu_ladder.json") if args.degree == 1 else None
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "Newton iterations/s",
                 "cores": 1,
                 "kind": "port",
-                "sample": f"{steps} Newton steps ({secs:.1f} s) of the same LVPP run on a {args.cpu_n}x{args.cpu_n} mesh "
-                          f"(numpy assembly + SuperLU(COLAMD) exact Newton, 1 thread); the 2048^2 factorisation "
-                          f"does not fit a bounded sample - see DESIGN.md for the measured scaling",
+                # `value` is MEASURED, here, now - but on the mesh named in `mesh`, not on the benchmarked one: SuperLU on the
+                # 2048^2 saddle point needs hours per Newton step and > 100 GB.  `at_workload` carries it to the benchmarked
+                # mesh with the exponent of the committed ladder and says so.
+                "mesh": f"{args.cpu_n}x{args.cpu_n}",
+                "workload_mesh": f"{N}x{N}",
+                "sample": f"{steps} Newton steps ({secs:.1f} s) of the same LVPP run (settings {args.settings}) on a "
+                          f"{args.cpu_n}x{args.cpu_n} mesh: numpy assembly + SuperLU(COLAMD) exact Newton, 1 thread (the "
+                          f"oracle; a stand-in for, not a measurement of, FEniCSx+MUMPS)",
+                **host_info(),
             }
+            ex = extrapolate(v, args.cpu_n, N, ladder)
+            if ex:
+                ex["gpu_over_cpu"] = out["value"] / ex["value"]
+                out["cpu_baseline"]["at_workload"] = ex
     problem.close()
     if comm is not None:
         comm.free()

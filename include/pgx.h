@@ -195,6 +195,23 @@ int pgx_comm_rccl_init(const char id[128], int rank, int size, int device, pgx_c
  * (any mix of devices, also all on one GPU).  Same call sequence as RCCL through host-synchronised device
  * copies; used by the test-suite to run the sharded algorithm on a single-GPU box. */
 int pgx_comm_local_group(int size, pgx_comm** out /* [size] */);
+/* Inter-PROCESS transport through a POSIX shared-memory segment `name` ("/..."; rank 0 creates it, the others attach, the name
+ * is unlinked once all ranks are in), host-staged: one communicator per process, any mix of devices - also several processes on
+ * ONE GPU, which RCCL refuses.  A torch.distributed.run launch with this transport executes everything the multi-GPU launch
+ * does except RCCL's byte movement (mpirun-style process model of the reference: obstacle_pg.py:64, problem.py:56-73).
+ * slot_bytes: mailbox per rank (0 = 64 MiB; larger payloads move in chunks).  host_mode != 0: the buffers handed to the
+ * operations are HOST memory (protocol tests on machines without a GPU).  A peer that does not arrive within
+ * PGX_COMM_TIMEOUT seconds (default 120) fails every rank with PGX_ECOMM instead of hanging. */
+int pgx_comm_shm_init(const char* name, int rank, int size, uint64_t slot_bytes, int host_mode, pgx_comm** out);
+/* the four operations of a communicator, callable directly (tests): in-place sum over the ranks; exchange of the entries
+ * [send_lo, +n_send_lo) / [send_hi, +n_send_hi) of f0 (and f1 if non-null) with rank-1 / rank+1 into [recv_lo, ...) /
+ * [recv_hi, ...); rank r > 0 -> rank 0 at recv0 + r*n; rank 0's send0 + r*n -> rank r.  Buffers: device memory, or host
+ * memory for a host_mode communicator. */
+int pgx_comm_allreduce(pgx_comm* c, double* buf, uint64_t n);
+int pgx_comm_halo(pgx_comm* c, double* f0, double* f1, uint64_t send_lo, uint64_t n_send_lo, uint64_t recv_lo, uint64_t n_recv_lo,
+                  uint64_t send_hi, uint64_t n_send_hi, uint64_t recv_hi, uint64_t n_recv_hi);
+int pgx_comm_gather0(pgx_comm* c, const double* send, uint64_t n, double* recv0);
+int pgx_comm_scatter0(pgx_comm* c, const double* send0, uint64_t n, double* recv);
 void pgx_comm_free(pgx_comm* c);
 const char* pgx_comm_last_error(void);
 

@@ -188,6 +188,11 @@ SYMBOLS = [
     ("pgx_comm_rccl_unique_id", C.c_int, [C.c_char_p]),
     ("pgx_comm_rccl_init", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_COMM)]),
     ("pgx_comm_local_group", C.c_int, [C.c_int, C.POINTER(_COMM)]),
+    ("pgx_comm_shm_init", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(_COMM)]),
+    ("pgx_comm_allreduce", C.c_int, [_COMM, c_double_p, C.c_uint64]),
+    ("pgx_comm_halo", C.c_int, [_COMM, c_double_p, c_double_p] + [C.c_uint64] * 8),
+    ("pgx_comm_gather0", C.c_int, [_COMM, c_double_p, C.c_uint64, c_double_p]),
+    ("pgx_comm_scatter0", C.c_int, [_COMM, c_double_p, C.c_uint64, c_double_p]),
     ("pgx_comm_free", None, [_COMM]),
     ("pgx_comm_last_error", C.c_char_p, []),
     ("pgx_create_sharded", C.c_int,

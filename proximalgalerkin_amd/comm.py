@@ -6,6 +6,8 @@ The reference runs under `mpirun` and inherits its parallelism from DOLFINx/PETS
 (obstacle_pg.py:50).  Here a `Communicator` plays the role of that MPI communicator for ONE handle per GPU:
 
     rccl_from_torch_distributed(device)   one process per GPU (torch.distributed launch), RCCL over xGMI
+    shm_from_torch_distributed()          one process per rank, host-staged through POSIX shared memory: the same launch on a
+                                          box whose ranks share ONE GPU (RCCL refuses that) - rehearsal of the multi-GPU run
     local_group(n)                        n communicators for n host threads of one process (tests / one-GPU boxes)
 
 `mesh.create_rectangle(points, n, comm=c)` then builds only this rank's strip of vertex rows.
@@ -80,3 +82,27 @@ def rccl_single(device: int = 0):
     if rc:
         _comm_error(lib, "pgx_comm_rccl_init", rc)
     return Communicator(ptr, 0, 1, "rccl")
+
+
+def shm_init(name: str, rank: int, size: int, slot_bytes: int = 0, host_mode: bool = False):
+    """Join the shared-memory group `name` ("/...") as `rank` of `size` (include/pgx.h: pgx_comm_shm_init)."""
+    lib = _lib.load()
+    ptr = C.c_void_p()
+    rc = lib.pgx_comm_shm_init(name.encode(), int(rank), int(size), int(slot_bytes), int(host_mode), C.byref(ptr))
+    if rc:
+        _comm_error(lib, "pgx_comm_shm_init", rc)
+    return Communicator(ptr, rank, size, "shm")
+
+
+def shm_from_torch_distributed(slot_bytes: int = 0, host_mode: bool = False):
+    """Shared-memory communicator over the ranks of the initialised torch.distributed process group (all on this host): rank 0
+    picks the segment name, torch.distributed broadcasts it - the same bootstrap as rccl_from_torch_distributed."""
+    import os
+    import time
+
+    import torch.distributed as dist
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    box = [f"/pgx_{os.getpid()}_{time.monotonic_ns() & 0xffffffff:x}" if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return shm_init(box[0], rank, size, slot_bytes, host_mode)

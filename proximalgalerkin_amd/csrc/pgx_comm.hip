@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -373,6 +375,338 @@ extern "C" int pgx_comm_local_group(int size, pgx_comm** out) {
     out[r] = c;
   }
   return PGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter-process transport through POSIX shared memory (host-staged)
+// ------------------------------------------------------------------------------------------------
+// One communicator per PROCESS, any mix of devices - in particular several processes on ONE GPU, which RCCL refuses.  A
+// torch.distributed.run launch of bench.py with BENCH_COMM=shm therefore executes, on a one-GPU box, everything the real
+// multi-GPU launch executes except RCCL's byte movement: process spawn, rendezvous, name broadcast, the collective call order
+// of every rank, the watchdog (tests/test_gpu_multiprocess.py).  Layout of the segment: header (sense-reversing barrier on
+// process-shared atomics, per-rank publication records) followed by one mailbox of `slot_bytes` per rank.  Every operation is
+// "stage my part into my mailbox - barrier - read the peers' mailboxes - barrier"; payloads larger than a mailbox move in
+// chunks.  host_mode (tests without a GPU): the buffers are host memory and the staging copies are memcpy.
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+
+namespace {
+constexpr int kShmMaxRanks = 64;
+struct ShmHeader {
+  std::atomic<uint32_t> magic, attached, arrived, gen, broken;
+  uint32_t size;
+  uint64_t slot_bytes;
+  struct Pub {
+    uint64_t n_lo, n_hi, nf, n;
+  } pub[kShmMaxRanks];
+};
+constexpr uint32_t kShmMagic = 0x70677863u;  // "pgxc"
+constexpr size_t kShmHeaderBytes = (sizeof(ShmHeader) + 4095) / 4096 * 4096;
+
+double now_s() {
+  timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+struct ShmComm : pgx_comm {
+  ShmHeader* hd = nullptr;
+  char* base = nullptr;
+  size_t map_bytes = 0;
+  bool host_mode = false;
+  double timeout_s = 120.0;
+  std::string name;
+  bool owner = false;
+  ~ShmComm() override {
+    if (base) munmap(base, map_bytes);
+    if (owner) shm_unlink(name.c_str());
+  }
+  double* slot(int r) const { return (double*)(base + kShmHeaderBytes + (size_t)r * hd->slot_bytes); }
+  size_t cap() const { return hd->slot_bytes / sizeof(double); }
+  int dead() {
+    err = "shm group: a peer rank did not arrive within the timeout (it failed, or the ranks made different calls)";
+    return PGX_ECOMM;
+  }
+  int bad(const char* what) {
+    hd->broken.store(1);
+    err = std::string("shm group: ") + what;
+    return PGX_ECOMM;
+  }
+  // all ranks arrive, or the group is declared broken: no silent hang
+  bool barrier() {
+    if (hd->broken.load()) return false;
+    const uint32_t my = hd->gen.load();
+    if (hd->arrived.fetch_add(1) + 1 == (uint32_t)size) {
+      hd->arrived.store(0);
+      hd->gen.fetch_add(1);
+      return true;
+    }
+    const double t0 = now_s();
+    for (unsigned spin = 0;; ++spin) {
+      if (hd->gen.load() != my) return true;
+      if (hd->broken.load()) return false;
+      if (spin < 2000) {
+        sched_yield();
+      } else {
+        timespec ts{0, 50000};
+        nanosleep(&ts, nullptr);
+        if ((spin & 1023) == 0 && now_s() - t0 > timeout_s) {
+          hd->broken.store(1);
+          return false;
+        }
+      }
+    }
+  }
+  int d2h(hipStream_t st, double* host, const double* dev, size_t n) {
+    if (!n) return PGX_OK;
+    if (host_mode) {
+      memcpy(host, dev, n * sizeof(double));
+      return PGX_OK;
+    }
+    const hipError_t e = hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, st);
+    return e == hipSuccess ? PGX_OK : hipfail(e);
+  }
+  int h2d(hipStream_t st, double* dev, const double* host, size_t n) {
+    if (!n) return PGX_OK;
+    if (host_mode) {
+      memcpy(dev, host, n * sizeof(double));
+      return PGX_OK;
+    }
+    const hipError_t e = hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, st);
+    return e == hipSuccess ? PGX_OK : hipfail(e);
+  }
+  int sync(hipStream_t st) {
+    if (host_mode) return PGX_OK;
+    const hipError_t e = hipStreamSynchronize(st);
+    return e == hipSuccess ? PGX_OK : hipfail(e);
+  }
+  int hipfail(hipError_t e) {
+    hd->broken.store(1);
+    err = std::string("shm group: ") + hipGetErrorString(e);
+    return PGX_EHIP;
+  }
+  int halo(hipStream_t st, double* const* f, int nf, size_t send_lo, size_t n_send_lo, size_t recv_lo, size_t n_recv_lo,
+           size_t send_hi, size_t n_send_hi, size_t recv_hi, size_t n_recv_hi) override {
+    if (size == 1) return PGX_OK;
+    const bool lo = rank > 0, hi = rank + 1 < size;
+    const size_t nlo = lo ? n_send_lo : 0, nhi = hi ? n_send_hi : 0, per = nlo + nhi;
+    if ((size_t)nf * per > cap()) return bad("halo message exceeds the mailbox (raise the slot size)");
+    int rc = PGX_OK;
+    double* mine = slot(rank);
+    for (int k = 0; k < nf && !rc; ++k) {
+      rc = d2h(st, mine + (size_t)k * per, f[k] + send_lo, nlo);
+      if (!rc) rc = d2h(st, mine + (size_t)k * per + nlo, f[k] + send_hi, nhi);
+    }
+    if (!rc) rc = sync(st);
+    if (rc) return rc;
+    hd->pub[rank] = {nlo, nhi, (uint64_t)nf, 0};
+    if (!barrier()) return dead();
+    if (lo) {
+      const ShmHeader::Pub q = hd->pub[rank - 1];
+      if (q.nf != (uint64_t)nf || q.n_hi != n_recv_lo) return bad("halo layouts of neighbouring ranks disagree");
+      const double* src = slot(rank - 1);
+      for (int k = 0; k < nf && !rc; ++k) rc = h2d(st, f[k] + recv_lo, src + (size_t)k * (q.n_lo + q.n_hi) + q.n_lo, n_recv_lo);
+    }
+    if (hi && !rc) {
+      const ShmHeader::Pub q = hd->pub[rank + 1];
+      if (q.nf != (uint64_t)nf || q.n_lo != n_recv_hi) return bad("halo layouts of neighbouring ranks disagree");
+      const double* src = slot(rank + 1);
+      for (int k = 0; k < nf && !rc; ++k) rc = h2d(st, f[k] + recv_hi, src + (size_t)k * (q.n_lo + q.n_hi), n_recv_hi);
+    }
+    if (!rc) rc = sync(st);
+    if (rc) return rc;
+    if (!barrier()) return dead();  // the neighbours have read my mailbox: it may be overwritten
+    return PGX_OK;
+  }
+  int allreduce(hipStream_t st, double* dev, size_t n) override {
+    if (size == 1) return PGX_OK;
+    std::vector<double> sum;
+    for (size_t off = 0; off < n; off += cap()) {
+      const size_t m = std::min(cap(), n - off);
+      int rc = d2h(st, slot(rank), dev + off, m);
+      if (!rc) rc = sync(st);
+      if (rc) return rc;
+      hd->pub[rank].n = n;
+      if (!barrier()) return dead();
+      sum.assign(m, 0.0);
+      for (int r = 0; r < size; ++r) {  // fixed rank order: bitwise identical on every rank
+        if (hd->pub[r].n != n) return bad("all-reduce lengths of the ranks disagree");
+        const double* o = slot(r);
+        for (size_t i = 0; i < m; ++i) sum[i] += o[i];
+      }
+      rc = h2d(st, dev + off, sum.data(), m);
+      if (!rc) rc = sync(st);
+      if (rc) return rc;
+      if (!barrier()) return dead();
+    }
+    return PGX_OK;
+  }
+  int gather0(hipStream_t st, const double* send, size_t n, double* recv0) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    for (size_t off = 0; off < n; off += cap()) {
+      const size_t m = std::min(cap(), n - off);
+      int rc = PGX_OK;
+      if (rank != 0) {
+        rc = d2h(st, slot(rank), send + off, m);
+        if (!rc) rc = sync(st);
+        if (rc) return rc;
+      }
+      hd->pub[rank].n = n;
+      if (!barrier()) return dead();
+      if (rank == 0) {
+        for (int q = 1; q < size && !rc; ++q) {
+          if (hd->pub[q].n != n) return bad("gather0 lengths of the ranks disagree");
+          rc = h2d(st, recv0 + (size_t)q * n + off, slot(q), m);
+        }
+        if (!rc) rc = sync(st);
+        if (rc) return rc;
+      }
+      if (!barrier()) return dead();
+    }
+    return PGX_OK;
+  }
+  int scatter0(hipStream_t st, const double* send0, size_t n, double* recv) override {
+    if (size == 1 || n == 0) return PGX_OK;
+    const size_t chunk = cap() / (size_t)size;  // rank 0's mailbox holds one chunk per receiver
+    if (!chunk) return bad("mailbox too small for scatter0");
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t m = std::min(chunk, n - off);
+      int rc = PGX_OK;
+      if (rank == 0) {
+        for (int q = 1; q < size && !rc; ++q) rc = d2h(st, slot(0) + (size_t)q * chunk, send0 + (size_t)q * n + off, m);
+        if (!rc) rc = sync(st);
+        if (rc) return rc;
+      }
+      hd->pub[rank].n = n;
+      if (!barrier()) return dead();
+      if (rank != 0) {
+        if (hd->pub[0].n != n) return bad("scatter0 lengths of the ranks disagree");
+        rc = h2d(st, recv + off, slot(0) + (size_t)rank * chunk, m);
+        if (!rc) rc = sync(st);
+        if (rc) return rc;
+      }
+      if (!barrier()) return dead();
+    }
+    return PGX_OK;
+  }
+};
+}  // namespace
+
+extern "C" int pgx_comm_shm_init(const char* name, int rank, int size, uint64_t slot_bytes, int host_mode, pgx_comm** out) {
+  if (!name || !out || size < 1 || size > kShmMaxRanks || rank < 0 || rank >= size || name[0] != '/') {
+    g_comm_error = "pgx_comm_shm_init: bad argument (name must start with '/', size <= 64)";
+    return PGX_EINVAL;
+  }
+  *out = nullptr;
+  if (slot_bytes == 0) slot_bytes = (uint64_t)64 << 20;
+  slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
+  const size_t bytes = kShmHeaderBytes + (size_t)size * slot_bytes;
+  std::unique_ptr<ShmComm> c(new ShmComm());
+  c->rank = rank;
+  c->size = size;
+  c->host_mode = host_mode != 0;
+  c->name = name;
+  if (const char* t = getenv("PGX_COMM_TIMEOUT")) c->timeout_s = std::max(1.0, atof(t));
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+      g_comm_error = std::string("shm_open/ftruncate(") + name + "): " + strerror(errno);
+      if (fd >= 0) close(fd);
+      return PGX_ECOMM;
+    }
+    c->owner = true;
+  } else {  // wait for rank 0 to create and size the segment
+    const double t0 = now_s();
+    while (true) {
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+        close(fd);
+        fd = -1;
+      }
+      if (now_s() - t0 > c->timeout_s) {
+        g_comm_error = std::string("shm segment ") + name + " did not appear (rank 0 missing?)";
+        return PGX_ECOMM;
+      }
+      timespec ts{0, 2000000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) {
+    g_comm_error = std::string("mmap: ") + strerror(errno);
+    return PGX_ECOMM;
+  }
+  c->base = (char*)m;
+  c->map_bytes = bytes;
+  c->hd = (ShmHeader*)m;
+  if (rank == 0) {  // a fresh segment is zero-filled: counters start at 0
+    c->hd->size = (uint32_t)size;
+    c->hd->slot_bytes = slot_bytes;
+    c->hd->magic.store(kShmMagic);
+  } else {
+    const double t0 = now_s();
+    while (c->hd->magic.load() != kShmMagic) {
+      if (now_s() - t0 > c->timeout_s) {
+        g_comm_error = "shm segment was never initialised by rank 0";
+        return PGX_ECOMM;
+      }
+      sched_yield();
+    }
+    if (c->hd->size != (uint32_t)size || c->hd->slot_bytes != slot_bytes) {
+      g_comm_error = "shm segment was created with another size / slot size";
+      return PGX_ECOMM;
+    }
+  }
+  c->hd->attached.fetch_add(1);
+  if (!c->barrier()) {
+    g_comm_error = "shm group: not every rank attached";
+    return PGX_ECOMM;
+  }
+  if (rank == 0) {  // everybody has mapped it: the name can go (the memory lives until the last unmap)
+    shm_unlink(name);
+    c->owner = false;
+  }
+  *out = c.release();
+  return PGX_OK;
+}
+
+// Direct calls of a communicator's four operations (tests; `host` buffers need a communicator created with host_mode).
+extern "C" int pgx_comm_allreduce(pgx_comm* c, double* buf, uint64_t n) {
+  if (!c || !buf) return PGX_EINVAL;
+  const int rc = c->allreduce(nullptr, buf, n);
+  if (rc) g_comm_error = c->err;
+  return rc;
+}
+extern "C" int pgx_comm_halo(pgx_comm* c, double* f0, double* f1, uint64_t send_lo, uint64_t n_send_lo, uint64_t recv_lo,
+                             uint64_t n_recv_lo, uint64_t send_hi, uint64_t n_send_hi, uint64_t recv_hi, uint64_t n_recv_hi) {
+  if (!c || !f0) return PGX_EINVAL;
+  double* f[2] = {f0, f1};
+  const int rc = c->halo(nullptr, f, f1 ? 2 : 1, send_lo, n_send_lo, recv_lo, n_recv_lo, send_hi, n_send_hi, recv_hi, n_recv_hi);
+  if (rc) g_comm_error = c->err;
+  return rc;
+}
+extern "C" int pgx_comm_gather0(pgx_comm* c, const double* send, uint64_t n, double* recv0) {
+  if (!c) return PGX_EINVAL;
+  const int rc = c->gather0(nullptr, send, n, recv0);
+  if (rc) g_comm_error = c->err;
+  return rc;
+}
+extern "C" int pgx_comm_scatter0(pgx_comm* c, const double* send0, uint64_t n, double* recv) {
+  if (!c) return PGX_EINVAL;
+  const int rc = c->scatter0(nullptr, send0, n, recv);
+  if (rc) g_comm_error = c->err;
+  return rc;
 }
 
 extern "C" void pgx_comm_free(pgx_comm* c) { delete c; }

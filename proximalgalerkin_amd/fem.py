@@ -257,6 +257,17 @@ class _Vector:
         self._dev_valid = False
         return self._a
 
+    @property
+    def array_r(self):
+        """Read-only host view: pulls if the device copy is newer but, unlike `.array`, leaves the device copy valid
+        (nothing can be written through it), so a diagnostic read between solves costs no re-upload."""
+        if not self._host_valid:
+            self._binding[0]._pull(self._binding[1], self._a)
+            self._host_valid = True
+        v = self._a.view()
+        v.flags.writeable = False
+        return v
+
     def assign_from(self, other: "_Vector"):
         """self <- other without a host round trip when both live on the same handle
         (the device-resident form of `sol_k.x.array[:] = sol.x.array[:]`, obstacle_pg.py:226)."""

@@ -240,12 +240,13 @@ class NonlinearProblem:
             v._dev_valid, v._host_valid = True, False
 
     def _sync_inputs(self):
-        stale = not (self.F_form.sol.x._dev_valid and self.F_form.sol_k.x._dev_valid)
         self._push("state", self.F_form.sol.x)
         self._push("prev", self.F_form.sol_k.x)
-        if stale and self.partition is not None:
-            # host arrays were written: their ghost entries are whatever the caller left there, the owners' values
-            # win (Vec.ghostUpdate(INSERT, FORWARD), lvpp/problem.py:56)
+        if self.partition is not None:
+            # the owners' values win over whatever sits in the ghost entries (Vec.ghostUpdate(INSERT, FORWARD),
+            # lvpp/problem.py:56).  UNCONDITIONAL, like the reference's: the exchange is collective, and whether a host
+            # array was touched is a per-rank fact (`if rank == 0: print(sol.x.array...)`) - a rank-local test would
+            # leave the other ranks out of the exchange and hang the run.  One 16-33 KB exchange per call.
             _lib.check(self._lib, self._h, self._lib.pgx_sync_ghosts(self._h), "pgx_sync_ghosts")
         _lib.check(self._lib, self._h, self._lib.pgx_set_alpha(self._h, float(self.F_form.alpha.value)),
                    "pgx_set_alpha")

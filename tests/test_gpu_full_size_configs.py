@@ -1,0 +1,137 @@
+"""BASELINE.json configs 3, 4 and 5 at (or, for config 3 on one GPU, near) their full sizes, where no CPU oracle can run:
+size-independent properties of the converged LVPP runs + the Newton counts of the committed run logs
+(profiles/r01_all_configs.txt).  The oracle-compared runs of the same code paths are in test_gpu_p2.py,
+test_gpu_gradient_constraint.py and test_gpu_signorini.py (oracle-sized meshes).
+
+What is asserted at full size:
+* every Newton solve converged (reason > 0) and the final nonlinear residual, recomputed through the fine-grained C ABI call
+  (independent of the Newton driver's bookkeeping), is below the SNES tolerance - i.e. the last linear solves were accurate
+  enough to drive the TRUE residual down;
+* the constraint the latent variable enforces holds at the solution (u >= phi; |grad u| <= phi; u.n <= g on the contact face);
+* Dirichlet data is reproduced exactly;
+* Newton counts per proximal step equal the committed run's (mesh-independent and equal to the oracle's on small meshes).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_p2_obstacle_512_and_1024(require_gpu):
+    """Config 3 is 2048^2 P2 on 8 GPUs; its one-GPU points: 512^2 settings B (the CI settings; 1024^2 and 2048^2 end with
+    SNES_DIVERGED_DTOL under B exactly like the CPU oracle at 256^2) and 1024^2 settings A."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import phi_set, run_outer_loop, setup_problem
+
+    for N, (scheme, amax, tol), counts in ((512, ("double_exponential", 1e2, 1e-4), [5, 4, 3, 2, 1, 1, 4, 1]),
+                                           (1024, ("constant", 1e5, 1e-6), None)):
+        msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+        problem, sol, sol_k, alpha = setup_problem(msh, 2)
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 500, scheme, amax, tol)
+        assert problem.solver.getConvergedReason() > 0
+        if counts is not None:
+            assert hist["Newton steps"] == counts, hist["Newton steps"]
+        else:
+            assert sum(hist["Newton steps"]) == 27 and hist["outer_iterations"] <= 20, hist["Newton steps"]
+        V = sol.function_space
+        nd = V.block_size
+        x = sol.x.array.copy()
+        u = x[:nd]
+        bc = msh.exterior_dofs(2)
+        assert np.all(u[bc] == 0.0)
+        xy = V.dof_coordinates()
+        assert (u - phi_set(xy.T.copy())).min() > -1e-5  # feasible up to O(h^2) at the dofs
+        assert abs(u.max() - 0.5) < 1e-5
+        assert hist["Primal increments"][-1] < tol
+        # the converged state is a root of the discrete problem: true residual through pgx_residual
+        F, fn = problem.residual()
+        alpha0 = alpha.value
+        sol.x.array[:] = 0.0
+        _, f0 = problem.residual()
+        print(f"config 3 N={N}: |F(x*)| = {fn:.2e} vs |F| at u = psi = 0: {f0:.2e}; min(u - phi) = {(u - phi_set(xy.T.copy())).min():.2e}")
+        assert fn <= 1e-6 * f0, (fn, f0)
+        alpha.value = alpha0
+        problem.close()
+        if N == 512:  # independent discretisation of the same problem: P1 on the same vertices agrees to O(h^2)
+            p1, s1, sk1, a1 = setup_problem(msh, 1)
+            run_outer_loop(p1, s1, sk1, a1, 500, scheme, amax, tol)
+            nv = msh.num_vertices
+            assert np.abs(s1.x.array[:nv] - u[:nv]).max() < 2e-4
+            p1.close()
+
+
+def test_config4_gradient_constraint_1024(require_gpu):
+    """examples/06 at 1024 x 1024 (primal P2 / latent vector-P1, 6.3 M unknowns), the reference's default settings."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default
+
+    N = 1024
+    mesh = fem.create_unit_square(N, N)
+    problem = GradientConstraintProblem(mesh, phi_default, f_default)
+    its, reasons = [], []
+    for i in range(25):
+        problem.set_alpha(2.0**i)
+        r, n = problem.solve()
+        its.append(n)
+        reasons.append(r)
+        d = problem.l2_increment()
+        if d < 1e-8:
+            break
+        problem.advance_prev()
+    assert all(r > 0 for r in reasons), reasons
+    assert len(its) == 16 and sum(its) == 42, its  # profiles/r01_all_configs.txt
+    assert its[0] >= its[-1] and its[-1] == 1
+    F, fn = problem.residual()
+    assert fn < 1e-8, fn  # SNES atol 1e-9 at the last step; the residual is recomputed here
+    x = problem.get_state()
+    n2, nv = problem.n2, problem.nv
+    u = x[:n2]
+    bc = mesh.exterior_dofs(2)
+    assert np.all(u[bc] == 0.0)
+    # |grad u| <= phi: gradient of the P2 field at the cell centroids (P2 gradient at the centroid = combination of the six dofs)
+    cd = problem.U.cell_dofs()
+    X = mesh.geometry[mesh.cells]
+    J = np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]], axis=2)
+    det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+    iJ = np.empty_like(J)
+    iJ[:, 0, 0], iJ[:, 0, 1], iJ[:, 1, 0], iJ[:, 1, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det, -J[:, 1, 0] / det, J[:, 0, 0] / det
+    # reference gradients of the P2 basis at the centroid (1/3, 1/3): vertices (4 l_i - 1) grad l_i, edges 4 (l_j grad l_k + l_k grad l_j)
+    gl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    L = 1.0 / 3.0
+    gref = np.concatenate([(4 * L - 1) * gl, [4 * L * (gl[1] + gl[2]), 4 * L * (gl[0] + gl[2]), 4 * L * (gl[0] + gl[1])]])
+    g = np.einsum("ca,ak,ckd->cd", u[cd], gref, iJ)
+    xc = X.mean(axis=1)
+    phi_c = 0.1 + 0.2 * xc[:, 0] + 0.4 * xc[:, 1]
+    viol = np.sqrt((g * g).sum(axis=1)) - phi_c
+    print(f"config 4: max(|grad u| - phi) = {viol.max():.3e}, active fraction {(viol > -1e-3).mean():.3f}, |F| = {fn:.2e}")
+    assert viol.max() < 5e-3, viol.max()  # the bound holds up to the discretisation error of the latent projection
+    assert (viol > -1e-3).mean() > 0.05  # and it is ACTIVE on a sizeable part of the domain (elastoplastic torsion)
+    st = problem.lu_stats()
+    assert st["flops"] > 1e12
+    problem.close()
+
+
+def test_config5_signorini_70_cubed(require_gpu):
+    """examples/02 on 70^3 x 6 = 2 058 000 P1 tetrahedra (1.08 M unknowns), the reference's default parameters."""
+    from proximalgalerkin_amd import signorini as G
+
+    n = 70
+    mesh = G.create_unit_cube(n, n, n)
+    mt, bcs = G.native_tags(mesh)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, verbose=False, return_solution=True)
+    assert it == 3 and sum(iterations) == 6, (it, iterations)  # profiles/r01_all_configs.txt
+    nv = mesh.geometry.shape[0]
+    ux, uy, uz = x[:nv], x[nv:2 * nv], x[2 * nv:3 * nv]
+    top = np.flatnonzero(np.isclose(mesh.geometry[:, 2], 1.0))
+    assert np.all(ux[top] == 0.0) and np.all(uy[top] == 0.0) and np.all(uz[top] == -0.25)
+    bottom = np.flatnonzero(np.isclose(mesh.geometry[:, 2], 0.0))
+    assert np.array_equal(np.sort(cv), bottom)
+    # non-penetration: u.n_g <= g with n_g = -e_z, g = x_z - gap = 0 on the contact face, i.e. u_z >= 0 there; the latent
+    # variable enforces it as u_z = e^psi > 0 in the weak sense, so nodal values may undershoot by the discretisation error
+    assert uz[bottom].min() > -1e-4, uz[bottom].min()
+    # the block is pressed down by 0.25 and bulges sideways (nu = 0.3): lateral displacement is outward and symmetric
+    c = mesh.geometry
+    mid = np.flatnonzero(np.isclose(c[:, 2], 0.5) & np.isclose(c[:, 1], 0.5))
+    right, left = mid[np.argmax(c[mid, 0])], mid[np.argmin(c[mid, 0])]
+    print(f"config 5: min u_z on the contact face {uz[bottom].min():.3e}, lateral bulge {ux[right]:.4e} / {ux[left]:.4e}")
+    assert ux[right] > 1e-3 and abs(ux[right] + ux[left]) < 0.05 * abs(ux[right])  # the 6-tet split is not mirror-symmetric

@@ -180,6 +180,15 @@ def main():
         "points": [[float(x), float(y)] for (x, y) in pts4],
         "weights": [float(w) for w in wts4],
     }
+    # vertex (trapezoidal) rule, exact to degree 1: with it the P1 system on a uniform right-triangle grid IS the 5-point
+    # finite-difference LVPP system of obstacle_finite_difference.jl (lumped mass, lumped D) - oracle/fd_oracle.py
+    table["tri_vertex_3"] = {
+        "cell": "triangle",
+        "degree": 1,
+        "source": "vertex rule: the three vertices, weights 1/6 (exact to degree 1; mass lumping); tools/make_quadrature_tables.py",
+        "points": [[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]],
+        "weights": [1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0],
+    }
     out = pathlib.Path(__file__).resolve().parents[1] / "proximalgalerkin_amd" / "tables" / "quadrature.json"
     out.write_text(json.dumps(table, indent=1) + "\n")
     print("wrote", out, "max moment error", mp.nstr(worst, 3))
