@@ -67,6 +67,7 @@ struct pgx_handle {
   int32_t *cdofs = nullptr, *p2_v2c_ptr = nullptr, *p2_v2c_ent = nullptr, *p2_v2c_pos = nullptr;
   int32_t *v2e_ptr = nullptr, *v2e = nullptr, *edge_ends = nullptr;
   double *p2_xu = nullptr, *p2_xp = nullptr, *p2_ru = nullptr, *p2_rp = nullptr;
+  double* p2_stash = nullptr;  // [16 * nc] element residual vectors of the P2 assembly (deterministic scatter, pgx_p2.hip)
   double *c1_bu = nullptr, *c1_bp = nullptr, *c1_xu = nullptr, *c1_xp = nullptr;
   // state
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
@@ -96,6 +97,7 @@ struct pgx_handle {
   pgx_comm* lu_comm = nullptr;
   double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
+  bool check_replicas = false;  // PGX_CHECK_REPLICAS=1: assert that the replicas' residuals are bitwise identical
   // observables
   double *obs_partials = nullptr, *d_out6 = nullptr;
   int obs_blocks = 0;
@@ -896,6 +898,10 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       int r2 = build_plan_p2(h, m, hmask);
       if (r2) return r2;
     }
+    {  // the P1 plan first: its vertex -> (cell, local vertex) lists also drive the b_phi scatter
+      const int r = build_plan(h, m, hmask);
+      if (r) return r;
+    }
     // b_phi from phi at quadrature points, then phi_q is dropped (it never changes: obstacle_pg.py:107-111)
     double* phi_q = nullptr;
     const size_t nphi = (size_t)nc * p->nq;
@@ -904,20 +910,21 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       return PGX_ENOMEM;
     }
     hipError_t e = hipMemcpy(phi_q, p->phi_q, nphi * sizeof(double), hipMemcpyHostToDevice);
+    double* stash = nullptr;  // element vectors, summed per dof in list order (no atomics: b_phi is bitwise reproducible)
+    if (e == hipSuccess) e = hipMalloc((void**)&stash, sizeof(double) * 8 * (size_t)nc);
     if (e == hipSuccess) {
       if (p->degree == 2)
-        pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->bphi);
+        pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->p2_v2c_ptr, h->p2_v2c_ent, stash, h->bphi);
       else
-        pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->bphi);
+        pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->v2c_ptr, h->v2c_ent, stash, h->bphi);
       e = hipStreamSynchronize(h->st);
     }
     hipFree(phi_q);
+    if (stash) hipFree(stash);
     if (e != hipSuccess) {
       h->err = std::string("b_phi assembly: ") + hipGetErrorString(e);
       return PGX_EHIP;
     }
-    int r = build_plan(h, m, hmask);
-    if (r) return r;
     DALLOC(h->Kv, h->nnz);
     DALLOC(h->Mv, h->nnz);
     DALLOC(h->Dv, h->nnz);
@@ -933,6 +940,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
                         h->coords, nullptr, h->q2, h->s_K);
       pgxk_fill_rows_p2(h->st, 1, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
                         h->coords, nullptr, h->q2, h->s_M);
+      DALLOC(h->p2_stash, (size_t)16 * nc);
       DALLOC(h->p2_xu, nd);
       DALLOC(h->p2_xp, nd);
       DALLOC(h->p2_ru, nd);
@@ -989,7 +997,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       DALLOC(h->dist.sb, n2);
       DALLOC(h->dist.wc, 2 * h->dist.own_cnt + 2);
     }
-    r = h->dist.on ? build_multigrid_dist(h) : build_multigrid(h);
+    const int r = h->dist.on ? build_multigrid_dist(h) : build_multigrid(h);
     if (r) return r;
     HIPCHK(hipStreamSynchronize(h->st));
     return PGX_OK;
@@ -1011,6 +1019,7 @@ extern "C" int pgx_create_lu_dist(const pgx_mesh* m, const pgx_problem* p, pgx_c
   int rc = create_impl(m, p, device, nullptr, nullptr, out);
   if (rc) return rc;
   (*out)->lu_comm = comm;
+  if (const char* e = getenv("PGX_CHECK_REPLICAS")) (*out)->check_replicas = atoi(e) != 0;
   return PGX_OK;
 }
 extern "C" int pgx_create_sharded(const pgx_mesh* m, const pgx_problem* p, const pgx_partition* part, pgx_comm* comm,
@@ -1131,8 +1140,8 @@ static int dev_norm(pgx_handle* h, const double* v, double* out, size_t len = 0)
 static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d = 0) {
   PhaseTimer t(h, 0);
   if (h->degree == 2) {
-    hipMemsetAsync(F, 0, sizeof(double) * 2 * (size_t)h->nd, h->st);
-    pgxk_residual_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->mask, h->gbc, x, h->xk, h->alpha, h->f, h->q2, F);
+    pgxk_residual_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->mask, h->gbc, x, h->xk, h->alpha, h->f, h->q2,
+                           h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_stash, F);
     pgxk_residual_final(h->st, h->nd, h->mask, h->gbc, h->bphi, x, F);
     return;
   }
@@ -1497,6 +1506,28 @@ static int replica_bcast(pgx_handle* h, double* dev, size_t n) {
   if (rc) h->err = "replica broadcast: " + h->lu_comm->err;
   return rc;
 }
+// The replicas assemble redundantly and every assembly kernel is atomic-free (fixed summation order), so their residuals are
+// bitwise identical and nothing needs to be broadcast.  PGX_CHECK_REPLICAS=1 turns that claim into a run-time assertion
+// (tests): rank 0's copy travels to every rank and must equal the local one exactly.  Collective; h->w is the scratch.
+static int replica_check(pgx_handle* h, const double* dev, size_t n, const char* what) {
+  if (!h->lu_comm || h->lu_comm->size == 1 || !h->check_replicas) return PGX_OK;
+  HIPCHK(hipMemcpyAsync(h->w, dev, n * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  int rc = replica_bcast(h, h->w, n);
+  if (rc) return rc;
+  pgxk_axpy(h->st, n, -1.0, dev, h->w);
+  pgxk_multidot(h->st, n, 1, h->w, 0, h->w, h->partials, h->d_small);
+  if ((rc = h->lu_comm->allreduce(h->st, h->d_small, 1))) {  // sum of the ranks' squared differences: one verdict for all
+    h->err = "replica check: " + h->lu_comm->err;
+    return rc;
+  }
+  HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  if (h->h_small[0] != 0.0) {
+    h->err = std::string("replicas of a distributed-LU handle disagree on ") + what;
+    return PGX_ECOMM;
+  }
+  return PGX_OK;
+}
 
 static int lu_factor(pgx_handle* h) {
   PhaseTimer t(h, 2);
@@ -1813,7 +1844,7 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
     }
   }
   {
-    const int rcb = replica_bcast(h, h->d_out6, 6);  // the loop's stopping test must agree on every replica
+    const int rcb = replica_check(h, h->d_out6, 6, "the observables");  // fixed-shape reductions: identical on every replica
     if (rcb) return rcb;
   }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_out6, sizeof(double) * 6, hipMemcpyDeviceToHost, h->st));
@@ -1883,7 +1914,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   };
   HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   residual_dev(h, h->xw, h->F, 1);
-  if ((rc = replica_bcast(h, h->F, n2))) return rc;
+  if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
   if (dist) {
     gather_owned(h, h->F, h->rhs);
     rc = dev_norm(h, h->rhs, &fnorm, nk);
@@ -1924,7 +1955,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
     if (dist && (rc = halo_level(h, 0, h->xw, h->xw + h->n))) return rc;
     residual_dev(h, h->xw, h->F, 1);
-    if ((rc = replica_bcast(h, h->F, n2))) return rc;
+    if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
     if (dist) {
       gather_owned(h, h->F, h->rhs);
       rc = dev_norm(h, h->rhs, &fnorm, nk);

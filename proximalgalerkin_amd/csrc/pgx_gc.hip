@@ -10,6 +10,7 @@
 
 #include "../../include/pgx_gc.h"
 #include "pgx_mixed.h"
+#include "pgx_scatter.h"
 
 #define GC_MAXQ 40
 struct GcQuad {
@@ -26,9 +27,11 @@ struct pgx_gc_handle : MixedBase {
   double *coords = nullptr, *phi = nullptr, *f = nullptr, *gbc = nullptr;
   int32_t* cdofs = nullptr;
   uint8_t* mask = nullptr;
-  int32_t* dest36 = nullptr;
   uint8_t* kind = nullptr;
   double* Jc = nullptr;  // constant part of the Jacobian values (K and G slots), assembled once
+  // deterministic assembly (pgx_scatter.h): element kernels park [slot * nc + cell] in `stash`, one thread per destination sums
+  PgxScatter sc_res, sc_N;  // residual: 12 slots per cell -> dofs; N(psi): 36 slots per cell -> CSR positions
+  double* stash = nullptr;  // [36 * nc]
   void residual_dev(const double* xin, double* Fout) override;
   void jacobian_dev(const double* xin) override;
 };
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(128) void k_gc_residual(int nc, int n2, int nv, con
                                                      const double* __restrict__ gbc, const double* __restrict__ phi,
                                                      const double* __restrict__ f, const double* __restrict__ x,
                                                      const double* __restrict__ xk, double alpha, GcQuad Q,
-                                                     double* __restrict__ F) {
+                                                     double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cd = cdofs + 6 * (size_t)c;
@@ -142,12 +145,13 @@ __global__ __launch_bounds__(128) void k_gc_residual(int nc, int n2, int nv, con
       Ry[b] += wd * l[b] * ry;
     }
   }
+  // parked slot-major (coalesced across the cells of a wave); pgx_scatter sums them per dof in a fixed order
 #pragma unroll
-  for (int a = 0; a < 6; ++a) atomicAdd(&F[cd[a]], Ru[a]);
+  for (int a = 0; a < 6; ++a) stash[(size_t)a * nc + c] = Ru[a];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    atomicAdd(&F[n2 + cd[b]], Rx[b]);
-    atomicAdd(&F[n2 + nv + cd[b]], Ry[b]);
+    stash[(size_t)(6 + b) * nc + c] = Rx[b];
+    stash[(size_t)(9 + b) * nc + c] = Ry[b];
   }
 }
 
@@ -157,9 +161,9 @@ __global__ void k_gc_resid_bc(int n2, const uint8_t* __restrict__ mask, const do
   if (i < n2 && mask[i]) F[i] = x[i] - gbc[i];
 }
 
-// constant part, once: K (36 entries) and G, G^T (36 + 36) per cell through dest108
+// constant part, once: K (36 entries) and G, G^T (36 + 36) per cell, parked in a [108 * nc] stash
 __global__ __launch_bounds__(128) void k_gc_const(int nc, const int32_t* __restrict__ cdofs, const double* __restrict__ coords,
-                                                  const int32_t* __restrict__ dest108, GcQuad Q, double* __restrict__ Jc) {
+                                                  GcQuad Q, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cd = cdofs + 6 * (size_t)c;
@@ -185,15 +189,14 @@ __global__ __launch_bounds__(128) void k_gc_const(int nc, const int32_t* __restr
       }
     }
   }
-  const int32_t* D = dest108 + 108 * (size_t)c;
   for (int a = 0; a < 6; ++a)
-    for (int b = 0; b < 6; ++b) atomicAdd(&Jc[D[a * 6 + b]], Ke[a][b]);
+    for (int b = 0; b < 6; ++b) stash[(size_t)(a * 6 + b) * nc + c] = Ke[a][b];
   for (int b = 0; b < 3; ++b)
     for (int d = 0; d < 2; ++d)
       for (int a = 0; a < 6; ++a) {
         const int e = 36 + ((b * 2 + d) * 6 + a) * 2;
-        atomicAdd(&Jc[D[e]], Ge[b][d][a]);
-        atomicAdd(&Jc[D[e + 1]], Ge[b][d][a]);
+        stash[(size_t)e * nc + c] = Ge[b][d][a];
+        stash[(size_t)(e + 1) * nc + c] = Ge[b][d][a];
       }
 }
 
@@ -208,8 +211,7 @@ __global__ void k_gc_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, con
 
 __global__ __launch_bounds__(128) void k_gc_jac_N(int nc, int n2, int nv, const int32_t* __restrict__ cdofs,
                                                   const double* __restrict__ coords, const double* __restrict__ phi,
-                                                  const double* __restrict__ x, const int32_t* __restrict__ dest36, GcQuad Q,
-                                                  double* __restrict__ Jv) {
+                                                  const double* __restrict__ x, GcQuad Q, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cd = cdofs + 6 * (size_t)c;
@@ -247,14 +249,13 @@ __global__ __launch_bounds__(128) void k_gc_jac_N(int nc, int n2, int nv, const 
         Nyy[a][b] += cyy * ll;
       }
   }
-  const int32_t* D = dest36 + 36 * (size_t)c;
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) {
       const int e = (a * 3 + b) * 4;  // (c,d) = xx, xy, yx, yy
-      atomicAdd(&Jv[D[e]], -Nxx[a][b]);
-      atomicAdd(&Jv[D[e + 1]], -Nxy[a][b]);
-      atomicAdd(&Jv[D[e + 2]], -Nxy[a][b]);
-      atomicAdd(&Jv[D[e + 3]], -Nyy[a][b]);
+      stash[(size_t)e * nc + c] = Nxx[a][b];
+      stash[(size_t)(e + 1) * nc + c] = Nxy[a][b];
+      stash[(size_t)(e + 2) * nc + c] = Nxy[a][b];
+      stash[(size_t)(e + 3) * nc + c] = Nyy[a][b];
     }
 }
 
@@ -413,27 +414,29 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
       }
   });
   // destination tables
-  std::vector<int32_t> d108((size_t)nc * 108), d36((size_t)nc * 36);
+  std::vector<int32_t> d108((size_t)nc * 108), d36((size_t)nc * 36), d12((size_t)nc * 12);
   mx_par_for(nc, [&](int64_t a0, int64_t b0) {
     for (int64_t c = a0; c < b0; ++c) {
       int32_t md[12];
       mixed((int)c, md);
-      int32_t* D = d108.data() + 108 * (size_t)c;
+      // slot-major like the stashes the element kernels write: table[slot * nc + cell]
+      auto D = [&](int e) -> int32_t& { return d108[(size_t)e * nc + (size_t)c]; };
       for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 6; ++b) D[a * 6 + b] = find(md[a], md[b]);
+        for (int b = 0; b < 6; ++b) D(a * 6 + b) = find(md[a], md[b]);
       for (int b = 0; b < 3; ++b)
         for (int d = 0; d < 2; ++d)
           for (int a = 0; a < 6; ++a) {
             const int e = 36 + ((b * 2 + d) * 6 + a) * 2;
             const int32_t pr = md[6 + 3 * d + b];
-            D[e] = find(pr, md[a]);
-            D[e + 1] = find(md[a], pr);
+            D(e) = find(pr, md[a]);
+            D(e + 1) = find(md[a], pr);
           }
-      int32_t* E = d36.data() + 36 * (size_t)c;
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b)
           for (int cc = 0; cc < 2; ++cc)
-            for (int d = 0; d < 2; ++d) E[(a * 3 + b) * 4 + cc * 2 + d] = find(md[6 + 3 * cc + a], md[6 + 3 * d + b]);
+            for (int d = 0; d < 2; ++d)
+              d36[(size_t)((a * 3 + b) * 4 + cc * 2 + d) * nc + (size_t)c] = find(md[6 + 3 * cc + a], md[6 + 3 * d + b]);
+      for (int a = 0; a < 12; ++a) d12[(size_t)a * nc + (size_t)c] = md[a];
     }
   });
   // node coordinates for the nested-dissection ordering: vertices, then edge midpoints
@@ -477,7 +480,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   GCALLOC(h->rowptr, ntot + 1);
   GCALLOC(h->col, tot);
   GCALLOC(h->kind, tot);
-  GCALLOC(h->dest36, d36.size());
+  GCALLOC(h->stash, (size_t)36 * nc);
   GCALLOC(h->Jc, tot);
   GCALLOC(h->Jv, tot);
   {
@@ -493,22 +496,33 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   GCHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
   GCHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
-  GCHIP(hipMemcpy(h->dest36, d36.data(), sizeof(int32_t) * d36.size(), hipMemcpyHostToDevice));
+  {
+    std::string e1 = pgx_scatter_build(d12.data(), (int64_t)12 * nc, ntot, h->allocs, &h->sc_res);
+    if (e1.empty()) e1 = pgx_scatter_build(d36.data(), (int64_t)36 * nc, tot, h->allocs, &h->sc_N);
+    if (!e1.empty()) {
+      h->err = e1;
+      return PGX_ENOMEM;
+    }
+  }
+  // constant blocks, once: park 108 entries per cell, sum per CSR position; the table and the stash are temporary
   GCHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
-  int32_t* d_d108 = nullptr;
-  if (hipMalloc((void**)&d_d108, sizeof(int32_t) * d108.size()) != hipSuccess) {
-    h->err = "hipMalloc(dest108)";
-    return PGX_ENOMEM;
-  }
-  hipError_t e = hipMemcpy(d_d108, d108.data(), sizeof(int32_t) * d108.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_gc_const, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, h->cdofs, h->coords, d_d108, h->Q, h->Jc);
-    e = hipStreamSynchronize(h->st);
-  }
-  hipFree(d_d108);
-  if (e != hipSuccess) {
-    h->err = std::string("constant Jacobian blocks: ") + hipGetErrorString(e);
-    return PGX_EHIP;
+  {
+    std::vector<void*> tmp;
+    PgxScatter sc_c;
+    std::string e1 = pgx_scatter_build(d108.data(), (int64_t)108 * nc, tot, tmp, &sc_c);
+    double* st108 = nullptr;
+    hipError_t e = e1.empty() ? hipMalloc((void**)&st108, sizeof(double) * 108 * (size_t)nc) : hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_gc_const, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, h->cdofs, h->coords, h->Q, st108);
+      pgx_scatter_run(h->st, sc_c, st108, 1.0, 0, h->Jc);
+      e = hipStreamSynchronize(h->st);
+    }
+    if (st108) hipFree(st108);
+    for (void* q : tmp) hipFree(q);
+    if (e != hipSuccess) {
+      h->err = std::string("constant Jacobian blocks: ") + (e1.empty() ? hipGetErrorString(e) : e1.c_str());
+      return PGX_EHIP;
+    }
   }
   return PGX_OK;
 }
@@ -601,7 +615,8 @@ void pgx_gc_handle::residual_dev(const double* xin, double* Fout) {
   GcTimer t(h, 0);
   hipMemsetAsync(Fout, 0, sizeof(double) * h->ntot, h->st);
   hipLaunchKernelGGL(k_gc_residual, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
-                     h->mask, h->gbc, h->phi, h->f, xin, h->xk, h->alpha, h->Q, Fout);
+                     h->mask, h->gbc, h->phi, h->f, xin, h->xk, h->alpha, h->Q, h->stash);
+  pgx_scatter_run(h->st, h->sc_res, h->stash, 1.0, 0, Fout);
   hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, xin, Fout);
 }
 void pgx_gc_handle::jacobian_dev(const double* xin) {
@@ -610,7 +625,8 @@ void pgx_gc_handle::jacobian_dev(const double* xin) {
   hipLaunchKernelGGL(k_gc_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
   hipLaunchKernelGGL(k_gc_jac_N, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
-                     h->phi, xin, h->dest36, h->Q, h->Jv);
+                     h->phi, xin, h->Q, h->stash);
+  pgx_scatter_run(h->st, h->sc_N, h->stash, -1.0, 1, h->Jv);  // the latent block is -N(psi)
   h->jac_valid = true;
 }
 static void gc_residual_dev(pgx_gc_handle* h, const double* x, double* F) { h->residual_dev(x, F); }

@@ -72,8 +72,10 @@ struct TailArgs {
 void pgxk_mg_tail(hipStream_t st, const TailArgs& A);
 
 // ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
+// stash: [4 * nc] scratch (element contributions parked at cell * 4 + a, summed per vertex through the v2c lists: no atomics)
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
-               QuadTab q, double* bphi);
+               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi);
+void pgxk_gather_ent(hipStream_t st, int n, const int32_t* ptr, const int32_t* ent, const double* stash, double* out);
 // mode 0: K, 1: M, 2: D(psi)
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                     const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
@@ -137,11 +139,13 @@ struct QuadTab2 {
   double w[PGX_MAX_NQ];
   int nq;
 };
+// stash: [8 * nc] (bphi) / [16 * nc] (residual: u part then psi part) scratch, entries parked at cell * 8 + a and summed per
+// dof through the dof -> (cell, local dof) lists of the P2 plan: no atomics, bitwise reproducible
 void pgxk_bphi_p2(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords, const double* phi_q,
-                  QuadTab2 q, double* bphi);
+                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi);
 void pgxk_residual_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                             const uint8_t* mask, const double* gbc, const double* x, const double* xk, double alpha,
-                            double f, QuadTab2 q, double* F);
+                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F);
 void pgxk_residual_final(hipStream_t st, int n, const uint8_t* mask, const double* gbc, const double* bphi,
                          const double* x, double* F);
 void pgxk_fill_rows_p2(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr,

@@ -96,7 +96,7 @@ __device__ __forceinline__ P1Geom p1_geom(double x0, double y0, double x1, doubl
 __global__ void __launch_bounds__(PGX_BLOCK) k_bphi(int nc, const int32_t* __restrict__ cells,
                                                     const double* __restrict__ coords,
                                                     const double* __restrict__ phi_q, QuadTab q,
-                                                    double* __restrict__ bphi) {
+                                                    double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int v0 = cells[3 * c], v1 = cells[3 * c + 1], v2 = cells[3 * c + 2];
@@ -109,16 +109,31 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bphi(int nc, const int32_t* __res
     b1 += wp * q.N[k][1];
     b2 += wp * q.N[k][2];
   }
-  atomicAdd(&bphi[v0], g.adet * b0);
-  atomicAdd(&bphi[v1], g.adet * b1);
-  atomicAdd(&bphi[v2], g.adet * b2);
+  // parked at the index the vertex -> (cell, local vertex) lists use (cell * 4 + a); k_gather_ent sums per vertex in list order
+  stash[4 * (size_t)c] = g.adet * b0;
+  stash[4 * (size_t)c + 1] = g.adet * b1;
+  stash[4 * (size_t)c + 2] = g.adet * b2;
+}
+
+// out[i] = sum of stash[ent[k]] over the dof's (cell, local index) list, in list order (ascending cells): the scatter-add of an
+// assembly loop as a segmented reduction - no atomics, bitwise reproducible (pgx_scatter.h states the general case)
+__global__ void __launch_bounds__(PGX_BLOCK) k_gather_ent(int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent,
+                                                          const double* __restrict__ stash, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = ptr[i]; k < ptr[i + 1]; ++k) s += stash[ent[k]];
+  out[i] = s;
+}
+void pgxk_gather_ent(hipStream_t st, int n, const int32_t* ptr, const int32_t* ent, const double* stash, double* out) {
+  hipLaunchKernelGGL(k_gather_ent, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, ptr, ent, stash, out);
 }
 
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
-               QuadTab q, double* bphi) {
-  hipMemsetAsync(bphi, 0, sizeof(double) * n, st);
+               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi) {
   hipLaunchKernelGGL(k_bphi, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cells, coords, phi_q,
-                     q, bphi);
+                     q, stash);
+  pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, bphi);
 }
 
 // ------------------------------------------------------------------------------------------------

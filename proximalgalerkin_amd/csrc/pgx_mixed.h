@@ -164,6 +164,37 @@ static int mx_sync_scalar(MixedBase* h) {
   return rc;
 }
 
+// The replicas of a distributed-LU handle assemble redundantly with atomic-free kernels (pgx_scatter.h), so their vectors are
+// bitwise identical.  PGX_CHECK_REPLICAS=1 asserts it (tests): rank 0's copy of v must equal the local one exactly.  Collective.
+static int mx_replica_check(MixedBase* h, const double* v, const char* what) {
+  if (!h->comm || h->comm->size == 1) return PGX_OK;
+  static const bool on = [] {
+    const char* e = getenv("PGX_CHECK_REPLICAS");
+    return e && atoi(e) != 0;
+  }();
+  if (!on) return PGX_OK;
+  MXHIP(hipMemcpyAsync(h->z, v, sizeof(double) * h->ntot, hipMemcpyDeviceToDevice, h->st));
+  if (h->comm->rank != 0) MXHIP(hipMemsetAsync(h->z, 0, sizeof(double) * h->ntot, h->st));
+  int rc = h->comm->allreduce(h->st, h->z, (size_t)h->ntot);  // z = rank 0's copy, on every rank
+  if (!rc) {
+    hipLaunchKernelGGL(k_mx_axpby, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, -1.0, v, 1.0, h->z);
+    hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, h->ntot, h->z, h->z, h->partials);
+    hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
+    rc = h->comm->allreduce(h->st, h->d_out, 1);  // sum of the ranks' squared differences: every rank sees the verdict
+  }
+  if (rc) {
+    h->err = "replica check: " + h->comm->err;
+    return rc;
+  }
+  MXHIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  if (h->h_out[0] != 0.0) {
+    h->err = std::string("replicas of a distributed-LU handle disagree on ") + what;
+    return PGX_ECOMM;
+  }
+  return PGX_OK;
+}
+
 static int mx_norm(MixedBase* h, const double* v, double* out, int64_t len = 0) {
   hipLaunchKernelGGL(k_mx_dot, dim3(MX_RED), dim3(256), 0, h->st, len ? len : h->ntot, v, v, h->partials);
   hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, MX_RED, h->partials, h->d_out);
@@ -308,6 +339,7 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
   double fnorm = 0, fnorm0 = 0;
   MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
   h->residual_dev(h->xw, h->F);
+  if ((rc = mx_replica_check(h, h->F, "the residual"))) return rc;
   if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
   fnorm0 = fnorm;
   if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
@@ -345,6 +377,7 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
     }
     mx_axpby(h, 1.0, h->dx, 1.0, h->xw);
     h->residual_dev(h->xw, h->F);
+    if ((rc = mx_replica_check(h, h->F, "the residual"))) return rc;
     if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
     if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
     if (!std::isfinite(fnorm)) {
@@ -524,6 +557,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
   double fnorm = 0, fnorm0 = 0;
   MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
   h->residual_dev(h->xw, h->F);
+  if ((rc = mx_replica_check(h, h->F, "the residual"))) return rc;
   if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
   fnorm0 = fnorm;
   if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);

@@ -32,7 +32,7 @@ __device__ __forceinline__ Geom2 geom2(const double* __restrict__ coords, int v0
 __global__ void __launch_bounds__(PGX_BLOCK) k_bphi_p2(int nc, const int32_t* __restrict__ cdofs,
                                                        const double* __restrict__ coords,
                                                        const double* __restrict__ phi_q, QuadTab2 q,
-                                                       double* __restrict__ bphi) {
+                                                       double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   int d[6];
@@ -46,13 +46,13 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bphi_p2(int nc, const int32_t* __
     for (int a = 0; a < 6; ++a) b[a] += wp * q.N[k][a];
   }
 #pragma unroll
-  for (int a = 0; a < 6; ++a) atomicAdd(&bphi[d[a]], g.adet * b[a]);
+  for (int a = 0; a < 6; ++a) stash[8 * (size_t)c + a] = g.adet * b[a];  // index = the dof lists' (cell * 8 + a)
 }
 void pgxk_bphi_p2(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords, const double* phi_q,
-                  QuadTab2 q, double* bphi) {
-  hipMemsetAsync(bphi, 0, sizeof(double) * n, st);
+                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi) {
   hipLaunchKernelGGL(k_bphi_p2, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cdofs, coords,
-                     phi_q, q, bphi);
+                     phi_q, q, stash);
+  pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, bphi);
 }
 
 // residual (obstacle_pg.py:116-124) for P2; BC contract identical to k_residual_p1
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_p2(int nc, int n, const 
                                                            const double* __restrict__ gbc,
                                                            const double* __restrict__ x,
                                                            const double* __restrict__ xk, double alpha, double f,
-                                                           QuadTab2 q, double* __restrict__ F) {
+                                                           QuadTab2 q, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   int d[6];
@@ -98,17 +98,22 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_p2(int nc, int n, const 
       Fp[a] += wd * (uq - e) * q.N[k][a];
     }
   }
+  // element vectors parked at the index the dof -> (cell, local dof) lists use; summed per dof by k_gather_ent (no atomics)
+  double* su = stash + 8 * (size_t)c;
+  double* sp = stash + 8 * ((size_t)nc + c);
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
-    atomicAdd(&F[d[a]], Fu[a]);
-    atomicAdd(&F[n + d[a]], Fp[a]);
+    su[a] = Fu[a];
+    sp[a] = Fp[a];
   }
 }
 void pgxk_residual_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                             const uint8_t* mask, const double* gbc, const double* x, const double* xk, double alpha,
-                            double f, QuadTab2 q, double* F) {
+                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F) {
   hipLaunchKernelGGL(k_residual_p2, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, n, cdofs,
-                     coords, mask, gbc, x, xk, alpha, f, q, F);
+                     coords, mask, gbc, x, xk, alpha, f, q, stash);
+  pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, F);
+  pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash + 8 * (size_t)nc, F + n);
 }
 
 // row-parallel fill of a P2 scalar CSR block (same LDS-image scheme as k_fill_rows of pgx_kernels.hip)

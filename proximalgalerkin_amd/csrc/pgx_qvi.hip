@@ -7,6 +7,7 @@
 
 #include "../../include/pgx_qvi.h"
 #include "pgx_mixed.h"
+#include "pgx_scatter.h"
 
 #define QV_MAXQ 16
 struct QvQuad {
@@ -21,7 +22,10 @@ struct pgx_qvi_handle : MixedBase {
   QvQuad Q{};
   double alpha = 1.0, beta = 1.0, f = 25.0, knee = 0.01, eps_mod = 1e-10;
   double* coords = nullptr;
-  int32_t *cells = nullptr, *dest18 = nullptr;
+  int32_t* cells = nullptr;
+  // deterministic assembly (pgx_scatter.h): element kernels park [slot * nc + cell]; one thread per destination sums
+  PgxScatter sc_res, sc_psi;  // residual: 9 slots per cell -> dofs; psi-dependent blocks: 18 slots per cell -> CSR positions
+  double* stash = nullptr;    // [18 * nc]
   uint8_t *mask = nullptr, *kind = nullptr;
   double* Jc = nullptr;
   void residual_dev(const double* xin, double* Fout) override;
@@ -59,7 +63,7 @@ __device__ inline void qv_space(const QvGeom& g, const double N[3], double* phi0
 __global__ __launch_bounds__(128) void k_qv_residual(int nc, int nv, const int32_t* __restrict__ cells,
                                                      const double* __restrict__ coords, const uint8_t* __restrict__ mask,
                                                      const double* __restrict__ x, const double* __restrict__ xk, double alpha,
-                                                     double beta, double f, double knee, QvQuad Q, double* __restrict__ F) {
+                                                     double beta, double f, double knee, QvQuad Q, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cv = cells + 3 * (size_t)c;
@@ -93,10 +97,10 @@ __global__ __launch_bounds__(128) void k_qv_residual(int nc, int nv, const int32
     const double cu = wd * (pq - pkq - alpha * f), cT = wd * (beta * Tq - gv), cp = wd * (uq + s - phi0 - xi * Tq);
     for (int a = 0; a < 3; ++a) Ru[a] += cu * N[a], RT[a] += cT * N[a], Rp[a] += cp * N[a];
   }
-  for (int a = 0; a < 3; ++a) {
-    atomicAdd(&F[cv[a]], Ru[a]);
-    atomicAdd(&F[nv + cv[a]], RT[a]);
-    atomicAdd(&F[2 * nv + cv[a]], Rp[a]);
+  for (int a = 0; a < 3; ++a) {  // parked slot-major; pgx_scatter sums per dof in a fixed order
+    stash[(size_t)a * nc + c] = Ru[a];
+    stash[(size_t)(3 + a) * nc + c] = RT[a];
+    stash[(size_t)(6 + a) * nc + c] = Rp[a];
   }
 }
 __global__ void k_qv_resid_bc(int nv, const uint8_t* __restrict__ mask, const double* __restrict__ x, double* __restrict__ F) {
@@ -104,10 +108,10 @@ __global__ void k_qv_resid_bc(int nv, const uint8_t* __restrict__ mask, const do
   if (i < nv && mask[i]) F[i] = x[i];
 }
 
-// constant blocks, once.  dest81[(fr*3+a)*9 + fc*3+b]: row (field fr, vertex a), column (field fc, vertex b)
+// constant blocks, once: five 3x3 blocks per cell parked at stash[(blk * 9 + a * 3 + b) * nc + cell], blk = (u,u), (u,psi),
+// (T,T), (psi,u), (psi,T)
 __global__ __launch_bounds__(128) void k_qv_const(int nc, const int32_t* __restrict__ cells, const double* __restrict__ coords,
-                                                  const int32_t* __restrict__ dest81, double beta, QvQuad Q,
-                                                  double* __restrict__ Jc) {
+                                                  double beta, QvQuad Q, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cv = cells + 3 * (size_t)c;
@@ -126,15 +130,14 @@ __global__ __launch_bounds__(128) void k_qv_const(int nc, const int32_t* __restr
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) Me[a][b] += wd * N[a] * N[b], Mx[a][b] += wd * xi * N[a] * N[b];
   }
-  const int32_t* D = dest81 + 81 * (size_t)c;
-  auto slot = [&](int fr, int a, int fc, int b) { return D[(fr * 3 + a) * 9 + fc * 3 + b]; };
+  auto park = [&](int blk, int a, int b, double v) { stash[(size_t)(blk * 9 + a * 3 + b) * nc + c] = v; };
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) {
-      atomicAdd(&Jc[slot(0, a, 0, b)], Ke[a][b]);                    // (u,u): K, scaled by alpha per step
-      atomicAdd(&Jc[slot(0, a, 2, b)], Me[a][b]);                    // (u,psi): M
-      atomicAdd(&Jc[slot(1, a, 1, b)], Ke[a][b] + beta * Me[a][b]);  // (T,T)
-      atomicAdd(&Jc[slot(2, a, 0, b)], Me[a][b]);                    // (psi,u): M
-      atomicAdd(&Jc[slot(2, a, 1, b)], -Mx[a][b]);                   // (psi,T): -M_xi
+      park(0, a, b, Ke[a][b]);                    // (u,u): K, scaled by alpha per step
+      park(1, a, b, Me[a][b]);                    // (u,psi): M
+      park(2, a, b, Ke[a][b] + beta * Me[a][b]);  // (T,T)
+      park(3, a, b, Me[a][b]);                    // (psi,u): M
+      park(4, a, b, -Mx[a][b]);                   // (psi,T): -M_xi
     }
 }
 
@@ -150,8 +153,8 @@ __global__ void k_qv_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, con
 // (T,psi): C_e = int g'(s) s N_a N_b, g' = -1/knee on (0, knee);  (psi,psi): -int s N_a N_b - (eps/alpha) K_e   (:69-71)
 __global__ __launch_bounds__(128) void k_qv_jac_psi(int nc, int nv, const int32_t* __restrict__ cells,
                                                     const double* __restrict__ coords, const double* __restrict__ x,
-                                                    const int32_t* __restrict__ dest18, double knee, double eps_over_alpha,
-                                                    QvQuad Q, double* __restrict__ Jv) {
+                                                    double knee, double eps_over_alpha, QvQuad Q,
+                                                    double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cv = cells + 3 * (size_t)c;
@@ -174,11 +177,10 @@ __global__ __launch_bounds__(128) void k_qv_jac_psi(int nc, int nv, const int32_
         De[a][b] -= ws * N[a] * N[b];
       }
   }
-  const int32_t* D = dest18 + 18 * (size_t)c;
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) {
-      atomicAdd(&Jv[D[a * 3 + b]], Ce[a][b]);
-      atomicAdd(&Jv[D[9 + a * 3 + b]], De[a][b]);
+      stash[(size_t)(a * 3 + b) * nc + c] = Ce[a][b];
+      stash[(size_t)(9 + a * 3 + b) * nc + c] = De[a][b];
     }
 }
 
@@ -224,7 +226,8 @@ void pgx_qvi_handle::residual_dev(const double* xin, double* Fout) {
   MxTimer t(h, 0);
   hipMemsetAsync(Fout, 0, sizeof(double) * h->ntot, h->st);
   hipLaunchKernelGGL(k_qv_residual, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->nv, h->cells, h->coords, h->mask,
-                     xin, h->xk, h->alpha, h->beta, h->f, h->knee, h->Q, Fout);
+                     xin, h->xk, h->alpha, h->beta, h->f, h->knee, h->Q, h->stash);
+  pgx_scatter_run(h->st, h->sc_res, h->stash, 1.0, 0, Fout);
   hipLaunchKernelGGL(k_qv_resid_bc, dim3((h->nv + 255) / 256), dim3(256), 0, h->st, h->nv, h->mask, xin, Fout);
 }
 void pgx_qvi_handle::jacobian_dev(const double* xin) {
@@ -233,7 +236,8 @@ void pgx_qvi_handle::jacobian_dev(const double* xin) {
   hipLaunchKernelGGL(k_qv_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
   hipLaunchKernelGGL(k_qv_jac_psi, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->nv, h->cells, h->coords, xin,
-                     h->dest18, h->knee, h->eps_mod / h->alpha, h->Q, h->Jv);
+                     h->knee, h->eps_mod / h->alpha, h->Q, h->stash);
+  pgx_scatter_run(h->st, h->sc_psi, h->stash, 1.0, 1, h->Jv);
   h->jac_valid = true;
 }
 
@@ -332,19 +336,22 @@ static int qvi_create_impl(pgx_qvi_handle* h, const pgx_mesh* m, const pgx_qvi_p
     const int k = (int)(std::lower_bound(b, b + len, j) - b);
     return (int32_t)(rowptr[(int64_t)fr * nv + v] + (int64_t)fc * len + k);
   };
-  std::vector<int32_t> d81((size_t)nc * 81), d18((size_t)nc * 18);
+  // destination tables, slot-major like the stashes: table[slot * nc + cell]
+  std::vector<int32_t> d45((size_t)nc * 45), d18((size_t)nc * 18), d9((size_t)nc * 9);
   mx_par_for(nc, [&](int64_t a0, int64_t b0) {
+    const int blk_r[5] = {0, 0, 1, 2, 2}, blk_c[5] = {0, 2, 1, 0, 1};
     for (int64_t c = a0; c < b0; ++c) {
       const int32_t* cv = m->cells + 3 * (size_t)c;
-      for (int fr = 0; fr < 3; ++fr)
+      for (int k = 0; k < 5; ++k)
         for (int a = 0; a < 3; ++a)
-          for (int fc = 0; fc < 3; ++fc)
-            for (int b = 0; b < 3; ++b) d81[81 * (size_t)c + (fr * 3 + a) * 9 + fc * 3 + b] = find(fr, cv[a], fc, cv[b]);
-      for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) d45[(size_t)(k * 9 + a * 3 + b) * nc + (size_t)c] = find(blk_r[k], cv[a], blk_c[k], cv[b]);
+      for (int a = 0; a < 3; ++a) {
+        for (int fld = 0; fld < 3; ++fld) d9[(size_t)(fld * 3 + a) * nc + (size_t)c] = fld * nv + cv[a];
         for (int b = 0; b < 3; ++b) {
-          d18[18 * (size_t)c + a * 3 + b] = find(1, cv[a], 2, cv[b]);
-          d18[18 * (size_t)c + 9 + a * 3 + b] = find(2, cv[a], 2, cv[b]);
+          d18[(size_t)(a * 3 + b) * nc + (size_t)c] = find(1, cv[a], 2, cv[b]);
+          d18[(size_t)(9 + a * 3 + b) * nc + (size_t)c] = find(2, cv[a], 2, cv[b]);
         }
+      }
     }
   });
   std::vector<int32_t> nod(ntot);
@@ -369,7 +376,7 @@ static int qvi_create_impl(pgx_qvi_handle* h, const pgx_mesh* m, const pgx_qvi_p
   MXALLOC(h->coords, 2 * (size_t)nv);
   MXALLOC(h->cells, 3 * (size_t)nc);
   MXALLOC(h->mask, nv);
-  MXALLOC(h->dest18, d18.size());
+  MXALLOC(h->stash, 18 * (size_t)nc);
   MXALLOC(h->rowptr, ntot + 1);
   MXALLOC(h->col, tot);
   MXALLOC(h->kind, tot);
@@ -379,23 +386,35 @@ static int qvi_create_impl(pgx_qvi_handle* h, const pgx_mesh* m, const pgx_qvi_p
   MXHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * nv, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->cells, m->cells, sizeof(int32_t) * 3 * (size_t)nc, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->mask, hmask.data(), nv, hipMemcpyHostToDevice));
-  MXHIP(hipMemcpy(h->dest18, d18.data(), sizeof(int32_t) * d18.size(), hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
   MXHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
-  int32_t* d_d81 = nullptr;
-  hipError_t e = hipMalloc((void**)&d_d81, sizeof(int32_t) * d81.size());
-  if (e == hipSuccess) e = hipMemcpy(d_d81, d81.data(), sizeof(int32_t) * d81.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_qv_const, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, h->cells, h->coords, d_d81, h->beta, h->Q,
-                       h->Jc);
-    e = hipStreamSynchronize(h->st);
+  {
+    std::string e1 = pgx_scatter_build(d9.data(), (int64_t)9 * nc, ntot, h->allocs, &h->sc_res);
+    if (e1.empty()) e1 = pgx_scatter_build(d18.data(), (int64_t)18 * nc, tot, h->allocs, &h->sc_psi);
+    if (!e1.empty()) {
+      h->err = e1;
+      return PGX_ENOMEM;
+    }
   }
-  hipFree(d_d81);
-  if (e != hipSuccess) {
-    h->err = std::string("constant Jacobian blocks: ") + hipGetErrorString(e);
-    return PGX_EHIP;
+  {  // constant blocks, once, deterministic: table and stash are temporary
+    std::vector<void*> tmp;
+    PgxScatter sc_c;
+    std::string e1 = pgx_scatter_build(d45.data(), (int64_t)45 * nc, tot, tmp, &sc_c);
+    double* st45 = nullptr;
+    hipError_t e = e1.empty() ? hipMalloc((void**)&st45, sizeof(double) * 45 * (size_t)nc) : hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_qv_const, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, h->cells, h->coords, h->beta, h->Q, st45);
+      pgx_scatter_run(h->st, sc_c, st45, 1.0, 0, h->Jc);
+      e = hipStreamSynchronize(h->st);
+    }
+    if (st45) hipFree(st45);
+    for (void* q : tmp) hipFree(q);
+    if (e != hipSuccess) {
+      h->err = std::string("constant Jacobian blocks: ") + (e1.empty() ? hipGetErrorString(e) : e1.c_str());
+      return PGX_EHIP;
+    }
   }
   return PGX_OK;
 }

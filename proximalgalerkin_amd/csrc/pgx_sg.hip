@@ -10,6 +10,7 @@
 
 #include "../../include/pgx_sg.h"
 #include "pgx_mixed.h"
+#include "pgx_scatter.h"
 
 #define SG_MAXQ 16
 struct SgQuad {
@@ -24,7 +25,10 @@ struct pgx_sg_handle : MixedBase {
   SgQuad Q{};
   double alpha = 1.0, gap = 0.0, mu = 0.0, lmbda = 0.0;
   double *coords = nullptr, *gbc = nullptr, *bg = nullptr;
-  int32_t *facets = nullptr, *fpsi = nullptr, *destD = nullptr;
+  int32_t *facets = nullptr, *fpsi = nullptr;
+  // deterministic facet assembly (pgx_scatter.h): k_sg_exp parks [slot * nf + facet]; one thread per destination sums
+  PgxScatter sc_D, sc_b;  // D(psi): 9 slots per facet -> CSR positions; <exp(psi), w>: 3 slots per facet -> residual rows
+  double* stash = nullptr;  // [9 * nf]
   uint8_t *mask = nullptr, *kind = nullptr;
   double* Jc = nullptr;
   std::vector<int32_t> cverts;
@@ -39,8 +43,7 @@ extern "C" const char* pgx_sg_last_error(const pgx_sg_handle* h) { return h ? h-
 // ------------------------------------------------------------------------------------------------------------------
 // elasticity block, once: A_e[(a,i),(b,j)] = vol (lambda G_ai G_bj + mu G_aj G_bi + mu delta_ij G_a.G_b)
 __global__ __launch_bounds__(128) void k_sg_const_cells(int nc, const int32_t* __restrict__ cells, const double* __restrict__ coords,
-                                                        double mu, double lmbda, const int32_t* __restrict__ dest144,
-                                                        double* __restrict__ Jc) {
+                                                        double mu, double lmbda, double* __restrict__ stash) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const int32_t* cv = cells + 4 * (size_t)c;
@@ -71,23 +74,21 @@ __global__ __launch_bounds__(128) void k_sg_const_cells(int nc, const int32_t* _
     G[0][d] = -(inv[0][d] + inv[1][d] + inv[2][d]);
   }
   const double vol = fabs(det) / 6.0;
-  const int32_t* D = dest144 + 144 * (size_t)c;
   for (int a = 0; a < 4; ++a)
     for (int b = 0; b < 4; ++b) {
       const double gg = G[a][0] * G[b][0] + G[a][1] * G[b][1] + G[a][2] * G[b][2];
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
           const double v = vol * (lmbda * G[a][i] * G[b][j] + mu * G[a][j] * G[b][i] + (i == j ? mu * gg : 0.0));
-          atomicAdd(&Jc[D[(a * 3 + i) * 12 + (b * 3 + j)]], v);
+          stash[(size_t)((a * 3 + i) * 12 + (b * 3 + j)) * nc + c] = v;  // parked slot-major; summed per CSR position by pgx_scatter
         }
     }
 }
 
 // facet mass coupling (+M on (u_z, psi), -M on (psi, u_z)) and b_g = <g, w>, once
 __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* __restrict__ facets, const int32_t* __restrict__ fpsi,
-                                                         const double* __restrict__ coords, double gap,
-                                                         const int32_t* __restrict__ dest18, SgQuad Q, double* __restrict__ Jc,
-                                                         double* __restrict__ bg) {
+                                                         const double* __restrict__ coords, double gap, SgQuad Q,
+                                                         double* __restrict__ stash /* [21 * nf]: 18 matrix slots, 3 of b_g */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int32_t* fv = facets + 3 * (size_t)f;
@@ -107,12 +108,11 @@ __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* 
       for (int b = 0; b < 3; ++b) Me[a][b] += wd * Q.L[q][a] * Q.L[q][b];
     }
   }
-  const int32_t* D = dest18 + 18 * (size_t)f;
   for (int a = 0; a < 3; ++a) {
-    atomicAdd(&bg[fpsi[3 * (size_t)f + a]], g[a]);
+    stash[(size_t)(18 + a) * nf + f] = g[a];
     for (int b = 0; b < 3; ++b) {
-      atomicAdd(&Jc[D[a * 3 + b]], Me[a][b]);       // row u_z(a), col psi(b)
-      atomicAdd(&Jc[D[9 + a * 3 + b]], -Me[a][b]);  // row psi(a), col u_z(b)
+      stash[(size_t)(a * 3 + b) * nf + f] = Me[a][b];       // row u_z(a), col psi(b)
+      stash[(size_t)(9 + a * 3 + b) * nf + f] = -Me[a][b];  // row psi(a), col u_z(b)
     }
   }
 }
@@ -126,11 +126,10 @@ __global__ void k_sg_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, con
   Jv[k] = t == 0 ? alpha * Jc[k] : t == 1 ? Jc[k] : t == 3 ? 1.0 : 0.0;
 }
 
-// out (mode 0): D_e[a][b] = <exp(psi) N_a, N_b> into the Jacobian; (mode 1): b_exp[a] = <exp(psi), N_a> into the residual
+// parks (mode 0) D_e[a][b] = <exp(psi) N_a, N_b> for the Jacobian, (mode 1) b_exp[a] = <exp(psi), N_a> for the residual
 __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const int32_t* __restrict__ facets,
                                                 const int32_t* __restrict__ fpsi, const double* __restrict__ coords,
-                                                const double* __restrict__ x, const int32_t* __restrict__ destD, SgQuad Q,
-                                                double* __restrict__ out) {
+                                                const double* __restrict__ x, SgQuad Q, double* __restrict__ stash) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int32_t* fv = facets + 3 * (size_t)f;
@@ -152,11 +151,10 @@ __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const 
     }
   }
   if (mode == 0) {
-    const int32_t* D = destD + 9 * (size_t)f;
     for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) atomicAdd(&out[D[a * 3 + b]], De[a][b]);
+      for (int b = 0; b < 3; ++b) stash[(size_t)(a * 3 + b) * nf + f] = De[a][b];
   } else {
-    for (int a = 0; a < 3; ++a) atomicAdd(&out[nu + fp[a]], be[a]);
+    for (int a = 0; a < 3; ++a) stash[(size_t)a * nf + f] = be[a];
   }
 }
 
@@ -206,16 +204,22 @@ void pgx_sg_handle::residual_dev(const double* xin, double* Fout) {
   const int nu = 3 * h->nv;
   hipLaunchKernelGGL(k_sg_resid_rows, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, nu, h->rowptr,
                      h->col, h->Jc, h->mask, h->gbc, h->bg, xin, h->xk, h->alpha, Fout);
-  hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                     h->destD, h->Q, Fout);
+  if (h->nf > 0) {
+    hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                       h->Q, h->stash);
+    pgx_scatter_run(h->st, h->sc_b, h->stash, 1.0, 1, Fout);
+  }
 }
 void pgx_sg_handle::jacobian_dev(const double* xin) {
   pgx_sg_handle* h = this;
   MxTimer t(h, 1);
   hipLaunchKernelGGL(k_sg_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
-  hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi, h->coords,
-                     xin, h->destD, h->Q, h->Jv);
+  if (h->nf > 0) {
+    hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi, h->coords,
+                       xin, h->Q, h->stash);
+    pgx_scatter_run(h->st, h->sc_D, h->stash, 1.0, 1, h->Jv);
+  }
   h->jac_valid = true;
 }
 
@@ -367,25 +371,28 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
         kind[k] = t;
       }
   });
-  std::vector<int32_t> d144((size_t)nc * 144), d18((size_t)nf * 18), dD((size_t)nf * 9);
+  // destination tables, slot-major like the stashes the kernels write: table[slot * n_entities + entity]
+  std::vector<int32_t> d144((size_t)nc * 144), d18((size_t)nf * 18), dD((size_t)nf * 9), dbg((size_t)nf * 3), dbe((size_t)nf * 3);
   mx_par_for(nc, [&](int64_t a0, int64_t b0) {
     for (int64_t c = a0; c < b0; ++c) {
       int32_t md[12];
       cell_dofs((int)c, md);
-      int32_t* D = d144.data() + 144 * (size_t)c;
       for (int a = 0; a < 12; ++a)
-        for (int b = 0; b < 12; ++b) D[a * 12 + b] = find(md[a], md[b]);
+        for (int b = 0; b < 12; ++b) d144[(size_t)(a * 12 + b) * nc + (size_t)c] = find(md[a], md[b]);
     }
   });
   for (int f = 0; f < nf; ++f) {
     int32_t md[6];
     facet_dofs(f, md);
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a) {
+      dbg[(size_t)a * nf + f] = fpsi[3 * (size_t)f + a];
+      dbe[(size_t)a * nf + f] = nu + fpsi[3 * (size_t)f + a];
       for (int b = 0; b < 3; ++b) {
-        d18[18 * (size_t)f + a * 3 + b] = find(md[a], md[3 + b]);
-        d18[18 * (size_t)f + 9 + a * 3 + b] = find(md[3 + a], md[b]);
-        dD[9 * (size_t)f + a * 3 + b] = find(md[3 + a], md[3 + b]);
+        d18[(size_t)(a * 3 + b) * nf + f] = find(md[a], md[3 + b]);
+        d18[(size_t)(9 + a * 3 + b) * nf + f] = find(md[3 + a], md[b]);
+        dD[(size_t)(a * 3 + b) * nf + f] = find(md[3 + a], md[3 + b]);
       }
+    }
   }
   std::vector<int32_t> nod(ntot);
   for (int v = 0; v < nv; ++v) nod[v] = nod[(size_t)nv + v] = nod[2 * (size_t)nv + v] = v;
@@ -412,7 +419,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXALLOC(h->coords, 3 * (size_t)nv);
   MXALLOC(h->facets, 3 * (size_t)nf);
   MXALLOC(h->fpsi, 3 * (size_t)nf);
-  MXALLOC(h->destD, dD.size());
+  MXALLOC(h->stash, 9 * (size_t)std::max(nf, 1));
   MXALLOC(h->mask, nu);
   MXALLOC(h->gbc, nu);
   MXALLOC(h->bg, npsi);
@@ -425,7 +432,6 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 3 * nv, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->facets, m->facets, sizeof(int32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->fpsi, fpsi.data(), sizeof(int32_t) * fpsi.size(), hipMemcpyHostToDevice));
-  MXHIP(hipMemcpy(h->destD, dD.data(), sizeof(int32_t) * dD.size(), hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->mask, hmask.data(), nu, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nu, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
@@ -433,26 +439,42 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
   MXHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
   MXHIP(hipMemsetAsync(h->bg, 0, sizeof(double) * npsi, h->st));
-  int32_t *d_d144 = nullptr, *d_d18 = nullptr;
-  hipError_t e = hipMalloc((void**)&d_cells, sizeof(int32_t) * 4 * (size_t)nc);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_d144, sizeof(int32_t) * d144.size());
-  if (e == hipSuccess) e = hipMalloc((void**)&d_d18, sizeof(int32_t) * std::max<size_t>(d18.size(), 1));
+  {
+    std::string e1 = pgx_scatter_build(dD.data(), (int64_t)9 * nf, tot, h->allocs, &h->sc_D);
+    if (e1.empty()) e1 = pgx_scatter_build(dbe.data(), (int64_t)3 * nf, ntot, h->allocs, &h->sc_b);
+    if (!e1.empty()) {
+      h->err = e1;
+      return PGX_ENOMEM;
+    }
+  }
+  // constant blocks, once, deterministic: park per entity, sum per destination; tables and stashes are temporary
+  std::vector<void*> tmp;
+  PgxScatter sc_c, sc_f, sc_g;
+  std::string e1 = pgx_scatter_build(d144.data(), (int64_t)144 * nc, tot, tmp, &sc_c);
+  if (e1.empty()) e1 = pgx_scatter_build(d18.data(), (int64_t)18 * nf, tot, tmp, &sc_f);
+  if (e1.empty()) e1 = pgx_scatter_build(dbg.data(), (int64_t)3 * nf, npsi, tmp, &sc_g);
+  double *st_c = nullptr, *st_f = nullptr;
+  hipError_t e = e1.empty() ? hipMalloc((void**)&d_cells, sizeof(int32_t) * 4 * (size_t)nc) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipMalloc((void**)&st_c, sizeof(double) * 144 * (size_t)nc);
+  if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * 21 * (size_t)std::max(nf, 1));
   if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * 4 * (size_t)nc, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_d144, d144.data(), sizeof(int32_t) * d144.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess && !d18.empty()) e = hipMemcpy(d_d18, d18.data(), sizeof(int32_t) * d18.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda,
-                       d_d144, h->Jc);
-    if (nf > 0)
+    hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+    pgx_scatter_run(h->st, sc_c, st_c, 1.0, 0, h->Jc);
+    if (nf > 0) {
       hipLaunchKernelGGL(k_sg_const_facets, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
-                         d_d18, h->Q, h->Jc, h->bg);
+                         h->Q, st_f);
+      pgx_scatter_run(h->st, sc_f, st_f, 1.0, 1, h->Jc);  // the +-M_G slots are disjoint from the elasticity slots
+      pgx_scatter_run(h->st, sc_g, st_f + 18 * (size_t)nf, 1.0, 0, h->bg);
+    }
     e = hipStreamSynchronize(h->st);
   }
   hipFree(d_cells);
-  hipFree(d_d144);
-  hipFree(d_d18);
+  hipFree(st_c);
+  hipFree(st_f);
+  for (void* q : tmp) hipFree(q);
   if (e != hipSuccess) {
-    h->err = std::string("constant Jacobian blocks: ") + hipGetErrorString(e);
+    h->err = std::string("constant Jacobian blocks: ") + (e1.empty() ? hipGetErrorString(e) : e1.c_str());
     return PGX_EHIP;
   }
   return PGX_OK;

@@ -22,7 +22,8 @@ def _launch(nproc, args, timeout=600):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_COMM="shm", PGX_COMM_TIMEOUT="120")
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_COMM="shm", PGX_COMM_TIMEOUT="120",
+               PGX_CHECK_REPLICAS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",

@@ -3,6 +3,7 @@ GPU through the in-process transport (pgx_comm_local_group: one host thread per 
 RCCL refuses two ranks on one device).  The same code path runs over RCCL with one process per GPU.
 Checks: every rank returns the solution of the single-handle factorisation to rounding; example 02 on 2 and 4 ranks
 reproduces the single-GPU LVPP run (Newton counts, displacement <= 1e-10)."""
+import os
 import threading
 
 import numpy as np
@@ -13,6 +14,9 @@ from oracle import pg_oracle as O
 from oracle import sg_oracle as S
 
 pytestmark = pytest.mark.gpu
+# replicated handles must stay bitwise identical WITHOUT broadcasting residuals (atomic-free assembly, pgx_scatter.h): the
+# library asserts it on every residual evaluation of the distributed runs below
+os.environ["PGX_CHECK_REPLICAS"] = "1"
 
 
 def _run_ranks(comms, fn):
