@@ -398,6 +398,7 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
 // coefficients from kernel arguments.  Setup-time host check on a downloaded copy.
 static int detect_uniform(pgx_handle* h, GridLevel& L) {
   L.uniform = 0;
+  L.interior_free = 0;
   if (L.nx < 2 || L.ny < 2) return PGX_OK;
   std::vector<double> K((size_t)7 * L.n), M((size_t)7 * L.n);
   HIPCHK(hipMemcpyAsync(K.data(), L.K, K.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -424,6 +425,16 @@ static int detect_uniform(pgx_handle* h, GridLevel& L) {
         }
     }
   L.uniform = same ? 1 : 0;
+  std::vector<uint8_t> mk(L.n);
+  HIPCHK(hipMemcpyAsync(mk.data(), L.mask, L.n, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  L.interior_free = 1;
+  for (int j = 1; j < L.ny && L.interior_free; ++j)
+    for (int i = 1; i < L.nx; ++i)
+      if (mk[(size_t)j * sx + i]) {
+        L.interior_free = 0;
+        break;
+      }
   return PGX_OK;
 }
 

@@ -18,6 +18,12 @@ typedef double dsten_t;
                        // the kernels are latency-bound, so LDS footprint (occupancy) beats halo redundancy
 #define PGX_TILE_Y 16
 #endif
+#ifndef PGX_ROWMAP_TY
+#define PGX_ROWMAP_TY 16  // tile rows of the row-mapped smoother k_st_smoothR (image 64 x (TY + 6) vertices)
+#endif
+#ifndef PGX_ROWMAP_BLOCK
+#define PGX_ROWMAP_BLOCK 512  // threads per tile of k_st_smoothR: 8 waves, each owning every 8th image row
+#endif
 
 // Quadrature + P1 reference-element tables, passed BY VALUE as a kernel argument: they land in the
 // kernarg segment and are read with scalar loads (wave-uniform), no constant-memory symbol to manage.
@@ -41,6 +47,8 @@ struct GridLevel {
   // On a uniform grid every interior vertex has the same K and M stencil: passed in the kernarg segment
   // instead of streaming 14 coefficient arrays. Verified on the host at create; 0 -> explicit arrays.
   int uniform;
+  int interior_free;         // no Dirichlet dof strictly inside the grid (0 < i < nx, 0 < j < ny): interior tiles of the
+                             // row-mapped smoother then need no mask tests.  Verified on the host at create.
   double Kc[7], Mc[7];
   uint8_t* mask;             // [n] 1 = Dirichlet dof of the u block
   double *xu, *xp, *xu2, *xp2;  // solution ping-pong

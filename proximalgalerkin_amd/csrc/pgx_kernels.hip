@@ -1449,6 +1449,297 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-mapped K-sweep smoother (the production kernel on uniform levels; k_st_smoothK above stays as the general-mesh /
+// A-B reference, PGX_SMOOTH_ROWMAP=0).
+// rocprofv3 counters on k_st_smoothK at 2048^2 (profiles/r02_smoother_pmc_before.json): the SIMDs issue instructions 71 % of
+// the time and only 44 % of that is fp64 arithmetic - ~180 VALU instructions per point-sweep for ~40 flops: index
+// arithmetic of the p -> (li, lj) loops, per-lane "is this link inside the grid" tests (each ld7h condition became a branch),
+// coefficient selects, 64-bit address computations for 9 global loads.  LDS conflicts and LDS issue stalls are negligible.
+// The kernel was instruction-bound, not bandwidth- or latency-bound, so this version removes instructions:
+//  * a wave owns one 64-vertex ROW of the image at a time: the row index, every row base address and all bounds tests are
+//    wave-uniform (scalar unit); per-lane work is arithmetic plus loads at "scalar base + lane";
+//  * tiles whose whole image (tile + K halo) is interior take a FAST path with no bounds / Dirichlet tests at all: K and M
+//    stencils are scalar constants (uniform grid), symmetric link pairs are summed before they are multiplied;
+//  * (u, psi) are interleaved in LDS: one ds_read_b128 per neighbour instead of two ds_read_b64;
+//  * boundary tiles (7 % at 2048^2) run the same general per-point code as k_st_smoothK.
+// Image: 64 x (TY + 2K) vertices, tile = the inner (64 - 2K) x TY.  Same algebra as k_st_smoothK (different summation order).
+// ------------------------------------------------------------------------------------------------
+// Tiles whose image is interior: tx in [1, nfx], ty in [1, nfy]; all others are "boundary tiles" (k_st_smoothRb).
+struct RowmapGrid {
+  int ntx, nty, nfx, nfy;
+};
+template <int TY, int K>
+static inline RowmapGrid rowmap_grid(int nx, int ny, int fast_ok) {
+  constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K;
+  RowmapGrid g;
+  g.ntx = (nx + TX) / TX;
+  g.nty = (ny + TY) / TY;
+  // fast <=> tx*TX - K >= 1, tx*TX - K + W - 1 <= nx - 1, ty*TY - K >= 1, ty*TY - K + H0 - 1 <= ny - 1
+  g.nfx = (nx - 1 - (W - 1 - K)) >= TX ? (nx - 1 - (W - 1 - K)) / TX : 0;
+  g.nfy = (ny - 1 - (H0 - 1 - K)) >= TY ? (ny - 1 - (H0 - 1 - K)) / TY : 0;
+  g.nfx = std::min(g.nfx, g.ntx - 1);
+  g.nfy = std::min(g.nfy, g.nty - 1);
+  if (!fast_ok || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
+  return g;
+}
+
+// interior tiles: no bounds / Dirichlet tests, scalar K and M stencils with symmetric link pairs pre-summed; the global loads
+// of the NEXT row are in flight while the current row is computed (register double buffer)
+template <int TY, int K, bool POST>
+__device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, const dsten_t* __restrict__ Dh,
+                                                          const StConst& sc, double alpha, const double* __restrict__ xu,
+                                                          const double* __restrict__ xp, const double* __restrict__ cu,
+                                                          const double* __restrict__ cp, int nxc,
+                                                          const double* __restrict__ bu, const double* __restrict__ bp,
+                                                          double omega, double* __restrict__ yu, double* __restrict__ yp,
+                                                          double2* img_a, double2* img_b) {
+  // A wave owns the SAME image rows in every sweep: lj = wave + NW k.  Their iterate-independent data (7 D links, b_u, b_psi)
+  // is loaded ONCE, all loads in flight together, and stays in registers for the K sweeps: a wave's chain of dependent
+  // HBM round trips - which, not bandwidth or arithmetic, bounded the 4-wave version (6 + 14 sequential row iterations of
+  // ~1-2 us per workgroup) - shrinks to one.
+  constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K, NW = PGX_ROWMAP_BLOCK / 64, R = (H0 + NW - 1) / NW;
+  const int sx = nx + 1;
+  const int i0 = (1 + b % nfx) * TX - K, j0 = (1 + b / nfx) * TY - K;  // origin of the image
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  double2* const img0 = img_a;
+  double2* const img1 = img_b;
+  const double k0 = alpha * sc.K[0], k1 = alpha * 0.5 * (sc.K[1] + sc.K[2]), k3 = alpha * 0.5 * (sc.K[3] + sc.K[4]),
+               k5 = alpha * 0.5 * (sc.K[5] + sc.K[6]);
+  const double m0 = sc.M[0], m1 = 0.5 * (sc.M[1] + sc.M[2]), m3 = 0.5 * (sc.M[3] + sc.M[4]), m5 = 0.5 * (sc.M[5] + sc.M[6]);
+  const double nb2 = -m0 * m0;
+  const dsten_t* const D1 = Dh + n;
+  const dsten_t* const D2 = Dh + 2 * (size_t)n;
+  const dsten_t* const D3 = Dh + 3 * (size_t)n;
+  double rd[R][7], rbu[R], rbp[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj >= 1 && lj < H0 - 1) {  // rows 0 and H0-1 are halo only
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      rd[k][0] = Dh[v];
+      rd[k][1] = D1[v];
+      rd[k][2] = D1[v - 1];
+      rd[k][3] = D2[v];
+      rd[k][4] = D2[v - sx];
+      rd[k][5] = D3[v];
+      rd[k][6] = D3[v - sx - 1];
+      rbu[k] = bu[v];
+      rbp[k] = bp[v];
+    }
+  }
+  if (POST) {
+    double xa[R], xc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < H0) {
+        const int gj = j0 + lj;
+        const unsigned v = (unsigned)(gj * sx + gi);
+        xa[k] = xu[v];
+        xc[k] = xp[v];
+        if (cu) {
+          const int sxc = nxc + 1;
+          const int jc = gj >> 1, ic = gi >> 1;
+          const unsigned c0 = (unsigned)(jc * sxc + ic), c1 = (unsigned)((jc + (gj & 1)) * sxc + ic + (gi & 1));
+          xa[k] += 0.5 * (cu[c0] + cu[c1]);
+          xc[k] += 0.5 * (cp[c0] + cp[c1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < H0) img0[lj * W + lane] = make_double2(xa[k], xc[k]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 1; s <= K; ++s) {
+    const double2* const src = ((s - 1) & 1) ? img1 : img0;
+    double2* const dst = (s & 1) ? img1 : img0;
+    const bool act = lane >= s && lane < W - s;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < s || lj >= H0 - s) continue;  // wave-uniform
+      double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+      if (POST || s > 1) {
+        const int q = lj * W + lane;
+        const double2 x0 = src[q], x1 = src[q + 1], x2 = src[q - 1], x3 = src[q + W], x4 = src[q - W], x5 = src[q + W + 1],
+                      x6 = src[q - W - 1];
+        const double u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+        const double p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+        au = k0 * x0.x + k1 * u12 + k3 * u34 + k5 * u56 + m0 * x0.y + m1 * p12 + m3 * p34 + m5 * p56;
+        ap = m0 * x0.x + m1 * u12 + m3 * u34 + m5 * u56 -
+             (rd[k][0] * x0.y + rd[k][1] * x1.y + rd[k][2] * x2.y + rd[k][3] * x3.y + rd[k][4] * x4.y + rd[k][5] * x5.y +
+              rd[k][6] * x6.y);
+        xur = x0.x;
+        xpr = x0.y;
+      }
+      const double su = rbu[k] - au, sp = rbp[k] - ap;
+      const double det = fma(-k0, rd[k][0], nb2);  // < 0: k0 > 0, d0 >= 0, m0 > 0
+      double rc = __builtin_amdgcn_rcp(det);
+      rc = rc * (2.0 - det * rc);
+      const double ou = xur + omega * ((-rd[k][0] * su - m0 * sp) * rc);
+      const double op = xpr + omega * ((-m0 * su + k0 * sp) * rc);
+      if (act) {
+        if (s == K) {
+          const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+          yu[v] = ou;
+          yp[v] = op;
+        } else {
+          dst[lj * W + lane] = make_double2(ou, op);
+        }
+      }
+    }
+    if (s < K) __syncthreads();
+  }
+}
+
+// boundary tiles (and every tile of a level without uniform stencils): the general per-point code of k_st_smoothK on the
+// row mapping.  Tile index: row ty = 0 | rows 1..nfy: columns 0 and nfx+1.. | rows nfy+1..
+// TB: boundary tiles are cut into TY/TB sub-tiles of TB rows, one workgroup each: a boundary workgroup is a chain of dependent
+// loads (coefficient arrays, per-lane tests) of ~1 us per row iteration, and with TY + 6 rows per image that chain - 20-30 us -
+// was the floor of EVERY level's launch time; TB = 4 gives 10-row images, 8 iterations instead of 21 (2.5x redundant work on
+// 7 % of the tiles).
+template <int TY, int TB, int K, bool POST>
+__device__ __forceinline__ void st_smoothR_bnd(int b, int nx, int ny, int n, const RowmapGrid& g,
+                                                         const double* __restrict__ Kc, const double* __restrict__ M,
+                                                         const dsten_t* __restrict__ Dh, const StConst& sc,
+                                                         const uint8_t* __restrict__ mask, double alpha,
+                                                         const double* __restrict__ xu, const double* __restrict__ xp,
+                                                         const double* __restrict__ cu, const double* __restrict__ cp,
+                                                         int nxc, const double* __restrict__ bu,
+                                                         const double* __restrict__ bp, double omega,
+                                                         double* __restrict__ yu, double* __restrict__ yp, double2* img_a,
+                                                         double2* img_b) {
+  constexpr int W = 64, TX = W - 2 * K, H0 = TB + 2 * K, NSUB = TY / TB, NW = PGX_ROWMAP_BLOCK / 64;
+  static_assert(TY % TB == 0, "sub-tiles must cover a tile");
+  const int sx = nx + 1;
+  int tx, ty;
+  const int sub = b % NSUB;
+  b /= NSUB;
+  const int side = g.ntx - g.nfx;  // boundary tiles in a row that also holds fast tiles
+  if (b < g.ntx) {
+    tx = b;
+    ty = 0;
+  } else if ((b -= g.ntx) < g.nfy * side) {
+    ty = 1 + b / side;
+    const int r = b % side;
+    tx = r == 0 ? 0 : g.nfx + r;
+  } else {
+    b -= g.nfy * side;
+    ty = g.nfy + 1 + b / g.ntx;
+    tx = b % g.ntx;
+  }
+  const int i0 = tx * TX - K, j0 = ty * TY + sub * TB - K;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  double2* const img0 = img_a;
+  double2* const img1 = img_b;
+  if (POST) {
+    for (int lj = wave; lj < H0; lj += NW) {
+      const int gj = j0 + lj;
+      const bool in = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+      double a = 0.0, c2 = 0.0;
+      if (in) {
+        const int v = gj * sx + gi;
+        a = xu[v];
+        c2 = xp[v];
+        if (cu) {
+          const int sxc = nxc + 1;
+          const int ic = gi >> 1, jc = gj >> 1;
+          const int c0 = jc * sxc + ic, c1 = (jc + (gj & 1)) * sxc + (ic + (gi & 1));
+          a += 0.5 * (cu[c0] + cu[c1]);
+          c2 += 0.5 * (cp[c0] + cp[c1]);
+        }
+        if (mask[v]) a = 0.0;  // pre-masked image: Dirichlet entries of u read as 0 by neighbours
+      }
+      img0[lj * W + lane] = make_double2(a, c2);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 1; s <= K; ++s) {
+    const double2* const src = ((s - 1) & 1) ? img1 : img0;
+    double2* const dst = (s & 1) ? img1 : img0;
+    const bool act = lane >= s && lane < W - s;
+    for (int lj = s + wave; lj < H0 - s; lj += NW) {
+      const int gj = j0 + lj;
+      const int q = lj * W + lane;
+      double ou = 0.0, op = 0.0;
+      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        StCoef c;
+        st_load_coef(v, gi, gj, nx, ny, n, Kc, M, Dh, sc, mask, c);
+        double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+        if (POST || s > 1) {
+          const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+#pragma unroll
+          for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0, links leaving the grid have zero coefficients
+            const double2 xn = src[q + off[t]];
+            au += alpha * c.kv[t] * xn.x + c.mv[t] * xn.y;
+            ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
+          }
+          const double2 x0 = src[q];
+          xur = x0.x;
+          xpr = x0.y;
+        }
+        st_jacobi(c, alpha, omega, au, ap, xur, xpr, bu[v], bp[v], ou, op);
+        if (s == K) {
+          yu[v] = ou;
+          yp[v] = op;
+        }
+        if (c.rowbc) ou = 0.0;  // pre-masked image
+      }
+      if (s < K && act) dst[q] = make_double2(ou, op);
+    }
+    if (s < K) __syncthreads();
+  }
+}
+
+// ONE launch per smoother call: blocks [0, nbnd) are the boundary tiles - they start first, so their long dependent-load
+// chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
+template <int TY, int K, bool POST>
+__global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_smoothR(int nx, int ny, int n, RowmapGrid g, int nbnd,
+                                                          const double* __restrict__ Kc, const double* __restrict__ M,
+                                                          const dsten_t* __restrict__ Dh, StConst sc,
+                                                          const uint8_t* __restrict__ mask, double alpha,
+                                                          const double* __restrict__ xu, const double* __restrict__ xp,
+                                                          const double* __restrict__ cu, const double* __restrict__ cp,
+                                                          int nxc, const double* __restrict__ bu,
+                                                          const double* __restrict__ bp, double omega, int remap,
+                                                          double* __restrict__ yu, double* __restrict__ yp) {
+  constexpr int W = 64, H0 = TY + 2 * K, PAD = W + 1;
+  __shared__ double2 img_[2][H0 * W + 2 * PAD];  // guard band: inactive edge lanes read (and discard) one entry outside a row
+  const int blk = blockIdx.x;
+  if (blk < nbnd)
+    st_smoothR_bnd<TY, 4, K, POST>(blk, nx, ny, n, g, Kc, M, Dh, sc, mask, alpha, xu, xp, cu, cp, nxc, bu, bp, omega, yu, yp,
+                                img_[0] + PAD, img_[1] + PAD);
+  else
+    st_smoothR_fast<TY, K, POST>(xcd_block(blk - nbnd, gridDim.x - nbnd, remap), nx, n, g.nfx, Dh, sc, alpha, xu, xp, cu, cp, nxc,
+                                 bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD);
+}
+
+template <int TYR>
+static void launch_rowmap(hipStream_t st, int post, const GridLevel& L, const StConst& sc, double alpha, const double* xu,
+                          const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
+                          const double* bp, double omega, int remap, double* yu, double* yp) {
+  const RowmapGrid g = rowmap_grid<TYR, 3>(L.nx, L.ny, L.interior_free);
+  const int nfast = g.nfx * g.nfy, nbnd = (g.ntx * g.nty - nfast) * (TYR / 4);  // boundary tiles: sub-tiles of 4 rows
+  dim3 grid(nbnd + nfast), block(PGX_ROWMAP_BLOCK);
+  if (post)
+    hipLaunchKernelGGL((k_st_smoothR<TYR, 3, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask, alpha,
+                       xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
+  else
+    hipLaunchKernelGGL((k_st_smoothR<TYR, 3, false>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask,
+                       alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
+}
+
 // post=0: S^K(0);  post=1: S^K((xu,xp) + P (cu,cp)) (cu may be null)   -- out of place; K in {2,3}
 void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
                      const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
@@ -1457,10 +1748,29 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
     pgxk_st_smooth2(st, post, L, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
     return;
   }
+  const StConst sc = make_stconst(L);
+  static const int rowmap = [] {
+    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+    return e ? atoi(e) : 1;
+  }();
+  if (rowmap && L.uniform) {  // row-mapped kernels: image 64 x (TY + 6), tile 58 x TY; interior tiles + boundary tiles
+    // tile height by level size (measured, us per launch at 2049^2 / 1025^2 / 513^2 / 257^2 vertices; PGX_ROWMAP_TY forces one)
+    static const int ty_env = [] {
+      const char* e = getenv("PGX_ROWMAP_TY");
+      return e ? atoi(e) : 0;
+    }();
+    const int ty = ty_env ? ty_env : (L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4);
+    if (ty == 4)
+      launch_rowmap<4>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    else if (ty == 8)
+      launch_rowmap<8>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    else
+      launch_rowmap<16>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    return;
+  }
   constexpr int TX = PGX_TILE_X, TY = PGX_TILE_Y;
   const int ntx = (L.nx + TX) / TX, nty = (L.ny + TY) / TY;
   dim3 grid(ntx * nty), block(PGX_BLOCK);
-  const StConst sc = make_stconst(L);
   if (post)
     hipLaunchKernelGGL((k_st_smoothK<TX, TY, 3, true>), grid, block, 0, st, L.nx, L.ny, L.n, L.K, L.M, L.Dh, sc, L.mask,
                        alpha, xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
