@@ -87,7 +87,14 @@ struct pgx_handle {
   int nu_coarse = 0;    // PGX_NU_COARSE: cap on the sweeps of unfused (small) levels; 0 = same as the fine levels
   int fused_k3 = 1;     // PGX_FUSED_K3=0: two sweeps per launch even when nu is a multiple of 3
   int fused_legs = 1;   // PGX_FUSED_LEGS=0: one launch per sweep / residual / restriction / prolongation
-  int fused_min = 60000;  // fused legs only pay on levels large enough to hide their 3-phase latency
+  int fused_min = 4000;  // fused legs from 65^2 vertices up (measured with the row-mapped kernels: 2048^2 460 -> 451 ms, 1024^2
+                         // 113.5 -> 106.4, 512^2 68.5 -> 61.5 against 60000; the first, tile-mapped kernels needed >= 60000)
+  int cgs_selective = 1;  // second Gram-Schmidt projection only when the first one cancelled (PGX_CGS_SELECTIVE=0: always)
+  long cgs_skipped = 0, cgs_total = 0;
+  // second projection iff |w'|^2 < eta^2 |w|^2.  The textbook eta = 1/sqrt(2) re-orthogonalises 249 of 266 iterations at 2048^2 (a
+  // good preconditioner makes w = J M^-1 v_j ~ v_j: the first projection always cancels most of w); eta = 0.01 bounds the loss of
+  // orthogonality per step by 100 eps, re-orthogonalises 11 of 266 and leaves every Krylov count unchanged: 448 -> 416 ms per solve
+  double cgs_eta2 = 1e-4;
   TailArgs tail{};
   // sparse direct preconditioner (pc_type lu): nested-dissection multifrontal LU of the mixed Newton matrix (pgx_nd.hip)
   pgx_nd* lu = nullptr;
@@ -708,6 +715,7 @@ static int build_multigrid_dist(pgx_handle* h) {
   }
   rc = detect_uniform(h, G);
   if (rc) return rc;
+  D.view.interior_free = G.interior_free;  // the view's mask is a row slice of G's
   h->lev.push_back(G);
   int nx = G.nx, ny = G.ny;
   while (nx % 2 == 0 && ny % 2 == 0 && nx > 2 && ny > 2) {
@@ -757,6 +765,8 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
+  if (const char* e = getenv("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
+  if (const char* e = getenv("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
   if (const char* e = getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
@@ -1046,6 +1056,8 @@ extern "C" void pgx_destroy(pgx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
+  if (h->cgs_selective && getenv("PGX_CGS_REPORT"))
+    fprintf(stderr, "pgx: selective CGS2 skipped the second projection in %ld of %ld Krylov iterations\n", h->cgs_skipped, h->cgs_total);
   if (h->lu) pgx_nd_destroy(h->lu);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_small) hipHostFree(h->h_small);
@@ -1671,15 +1683,28 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         if (dist && (rc = allreduce_dev(h, d_h2, j + 2))) return rc;
         HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
-        double hh = 0.0;
+        double hh = 0.0, h1h1 = 0.0;
         for (int i = 0; i <= j; ++i) {
           const double h2 = h->h_small[(m + 2) + i];
-          H[(size_t)i * m + j] = h->h_small[i] + h2;
           hh += h2 * h2;
+          h1h1 += h->h_small[i] * h->h_small[i];
         }
-        hn = std::sqrt(std::max(h->h_small[(m + 2) + j + 1] - hh, 0.0));
-        // pass 4 fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
-        if (hn > 0.0) pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
+        const double wp2 = h->h_small[(m + 2) + j + 1];  // |w'|^2 after the first projection
+        // "twice is enough" (Kahan / Parlett; Daniel-Gragg-Kaufman-Stewart): the second projection is only needed when the
+        // first one cancelled most of w, |w'| < eta |w| with |w|^2 = |w'|^2 + |h1|^2.  Otherwise w' is orthogonal to V to
+        // working accuracy and the third pass over the basis is replaced by a scaling of w' (h2 is O(eps |w|) and dropped).
+        const bool second = !h->cgs_selective || wp2 < h->cgs_eta2 * (wp2 + h1h1);
+        for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h->h_small[i] + (second ? h->h_small[(m + 2) + i] : 0.0);
+        if (second) {
+          hn = std::sqrt(std::max(wp2 - hh, 0.0));
+          // pass 4 fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
+          if (hn > 0.0) pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
+        } else {
+          hn = std::sqrt(std::max(wp2, 0.0));
+          if (hn > 0.0) pgxk_scale_copy(h->st, nk, 1.0 / hn, wj, wj);
+          ++h->cgs_skipped;
+        }
+        ++h->cgs_total;
       }
       H[(size_t)(j + 1) * m + j] = hn;
       for (int i = 0; i < j; ++i) {

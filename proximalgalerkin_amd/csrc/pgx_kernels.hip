@@ -1847,9 +1847,177 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_resid_restrict_t(int nx, int n
   cbp[C] = sp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-mapped b_c = P^T (b - J x): the same treatment as k_st_smoothR (the tile kernel above was instruction-bound in the same
+// way).  A workgroup of 8 waves owns CX x CY = 30 x 8 coarse vertices: (1) the iterate on the 63 x 19 fine footprint + 1 halo
+// goes into an LDS image, (u, psi) interleaved, a wave per row; (2) a wave per fine row evaluates the residual on 61 x 17
+// vertices into a second image - interior tiles with scalar K / M stencils and no tests; (3) wave w restricts coarse row w.
+// Boundary tiles (blocks [0, nbnd), scheduled first) run the general per-point code on the same mapping.
+// ------------------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ void st_rr_tile(int tx, int ty, int nx, int ny, int n, const double* __restrict__ K,
+                                           const double* __restrict__ M, const dsten_t* __restrict__ Dh, const StConst& sc,
+                                           const uint8_t* __restrict__ mask, double alpha, const double* __restrict__ xu,
+                                           const double* __restrict__ xp, const double* __restrict__ bu,
+                                           const double* __restrict__ bp, int nxc, int nyc, const uint8_t* __restrict__ mask_c,
+                                           double* __restrict__ cbu, double* __restrict__ cbp, double2* ximg, double2* rimg) {
+  constexpr int W = 64, CX = 30, CY = 8, HX = 2 * CY + 3, HR = 2 * CY + 1, NW = PGX_ROWMAP_BLOCK / 64;
+  const int sx = nx + 1, sxc = nxc + 1;
+  const int I0 = tx * CX, J0 = ty * CY;
+  const int i0 = 2 * I0 - 2, j0 = 2 * J0 - 2;  // origin of the x image; the residual image starts one row / column further in
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  // (1) iterate image
+  for (int lj = wave; lj < HX; lj += NW) {
+    const int gj = j0 + lj;
+    double a = 0.0, c2 = 0.0;
+    if (FAST) {
+      const unsigned v = (unsigned)(gj * sx + gi);
+      a = xu[v];
+      c2 = xp[v];
+    } else if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+      const int v = gj * sx + gi;
+      a = mask[v] ? 0.0 : xu[v];  // pre-masked image
+      c2 = xp[v];
+    }
+    ximg[lj * W + lane] = make_double2(a, c2);
+  }
+  __syncthreads();
+  // (2) fine residual on image rows 1 .. HX-2, columns 1 .. 62
+  const bool act = lane >= 1 && lane < W - 1;
+  if (FAST) {
+    const double k0 = alpha * sc.K[0], k1 = alpha * 0.5 * (sc.K[1] + sc.K[2]), k3 = alpha * 0.5 * (sc.K[3] + sc.K[4]),
+                 k5 = alpha * 0.5 * (sc.K[5] + sc.K[6]);
+    const double m0 = sc.M[0], m1 = 0.5 * (sc.M[1] + sc.M[2]), m3 = 0.5 * (sc.M[3] + sc.M[4]), m5 = 0.5 * (sc.M[5] + sc.M[6]);
+    const dsten_t* const D1 = Dh + n;
+    const dsten_t* const D2 = Dh + 2 * (size_t)n;
+    const dsten_t* const D3 = Dh + 3 * (size_t)n;
+#pragma unroll
+    for (int k = 0; k < (HR + NW - 1) / NW; ++k) {
+      const int lj = 1 + wave + NW * k;
+      if (lj > HR) continue;  // wave-uniform
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      const double d0 = Dh[v], d1 = D1[v], d2 = D1[v - 1], d3 = D2[v], d4 = D2[v - sx], d5 = D3[v], d6 = D3[v - sx - 1];
+      const double buv = bu[v], bpv = bp[v];
+      const int q = lj * W + lane;
+      const double2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                    x6 = ximg[q - W - 1];
+      const double u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+      const double p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+      const double au = k0 * x0.x + k1 * u12 + k3 * u34 + k5 * u56 + m0 * x0.y + m1 * p12 + m3 * p34 + m5 * p56;
+      const double ap = m0 * x0.x + m1 * u12 + m3 * u34 + m5 * u56 -
+                        (d0 * x0.y + d1 * x1.y + d2 * x2.y + d3 * x3.y + d4 * x4.y + d5 * x5.y + d6 * x6.y);
+      if (act) rimg[(lj - 1) * W + lane] = make_double2(buv - au, bpv - ap);
+    }
+  } else {
+    for (int lj = 1 + wave; lj <= HR; lj += NW) {
+      const int gj = j0 + lj;
+      double ru = 0.0, rp = 0.0;
+      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        StCoef c;
+        st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+        const int q = lj * W + lane;
+        const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+        double au = 0.0, ap = 0.0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0; links leaving the grid have zero coefficients
+          const double2 xn = ximg[q + off[t]];
+          au += alpha * c.kv[t] * xn.x + c.mv[t] * xn.y;
+          ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
+        }
+        if (c.rowbc) au = xu[v];
+        ru = bu[v] - au;
+        rp = bp[v] - ap;
+      }
+      if (act) rimg[(lj - 1) * W + lane] = make_double2(ru, rp);  // out-of-grid fine vertices hold 0
+    }
+  }
+  __syncthreads();
+  // (3) restriction: wave w -> coarse row J0 + w, lane -> coarse column I0 + lane.  Fine vertex (2I, 2J) sits at residual-image
+  // row 2w + 1 (image rows start at fine row 2 J0 - 1) and column 2 lane + 2 (lane index of fine column 2 I0 + 2 lane)
+  if (wave < CY && lane < CX) {
+    const int I = I0 + lane, J = J0 + wave;
+    if (FAST || (I <= nxc && J <= nyc)) {
+      const int q = (2 * wave + 1) * W + 2 * lane + 2;
+      const double2 r0 = rimg[q], r1 = rimg[q + 1], r2 = rimg[q - 1], r3 = rimg[q + W], r4 = rimg[q - W], r5 = rimg[q + W + 1],
+                    r6 = rimg[q - W - 1];
+      const double su = r0.x + 0.5 * (r1.x + r2.x + r3.x + r4.x + r5.x + r6.x);
+      const double sp = r0.y + 0.5 * (r1.y + r2.y + r3.y + r4.y + r5.y + r6.y);
+      const int C = J * sxc + I;
+      cbu[C] = (!FAST && mask_c[C]) ? 0.0 : su;
+      cbp[C] = sp;
+    }
+  }
+}
+
+struct RrGrid {
+  int ntx, nty, nfx, nfy;  // coarse tiles; interior ("fast") tiles are tx in [1, nfx], ty in [1, nfy]
+};
+
+__global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_resid_restrict_r(int nx, int ny, int n, RrGrid g, int nbnd,
+                                                                          const double* __restrict__ K,
+                                                                          const double* __restrict__ M,
+                                                                          const dsten_t* __restrict__ Dh, StConst sc,
+                                                                          const uint8_t* __restrict__ mask, double alpha,
+                                                                          const double* __restrict__ xu,
+                                                                          const double* __restrict__ xp,
+                                                                          const double* __restrict__ bu,
+                                                                          const double* __restrict__ bp, int nxc, int nyc,
+                                                                          const uint8_t* __restrict__ mask_c, int remap,
+                                                                          double* __restrict__ cbu, double* __restrict__ cbp) {
+  constexpr int W = 64, CY = 8, HX = 2 * CY + 3, HR = 2 * CY + 1, PAD = W + 1;
+  __shared__ double2 ximg_[HX * W + 2 * PAD], rimg_[HR * W + 2 * PAD];
+  int b = blockIdx.x;
+  if (b < nbnd) {
+    int tx, ty;
+    const int side = g.ntx - g.nfx;
+    if (b < g.ntx) {
+      tx = b;
+      ty = 0;
+    } else if ((b -= g.ntx) < g.nfy * side) {
+      ty = 1 + b / side;
+      const int r = b % side;
+      tx = r == 0 ? 0 : g.nfx + r;
+    } else {
+      b -= g.nfy * side;
+      ty = g.nfy + 1 + b / g.ntx;
+      tx = b % g.ntx;
+    }
+    st_rr_tile<false>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, bu, bp, nxc, nyc, mask_c, cbu, cbp, ximg_ + PAD,
+                      rimg_ + PAD);
+  } else {
+    b = xcd_block(b - nbnd, gridDim.x - nbnd, remap);
+    st_rr_tile<true>(1 + b % g.nfx, 1 + b / g.nfx, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, bu, bp, nxc, nyc, mask_c, cbu, cbp,
+                     ximg_ + PAD, rimg_ + PAD);
+  }
+}
+
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp) {
+  static const int rowmap = [] {
+    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+    return e ? atoi(e) : 1;
+  }();
+  if (rowmap && L.uniform) {
+    constexpr int CX = 30, CY = 8;
+    RrGrid g;
+    g.ntx = (C.nx + CX) / CX;
+    g.nty = (C.ny + CY) / CY;
+    // interior <=> every vertex of the x image is strictly inside the fine grid: 2 tx CX - 2 >= 1, 2 tx CX - 2 + 63 <= nx - 1,
+    // 2 ty CY - 2 >= 1, 2 ty CY - 2 + (2 CY + 2) <= ny - 1
+    g.nfx = (L.nx - 62) >= 2 * CX ? (L.nx - 62) / (2 * CX) : 0;
+    g.nfy = (L.ny - 1 - 2 * CY) >= 2 * CY ? (L.ny - 1 - 2 * CY) / (2 * CY) : 0;
+    g.nfx = std::min(g.nfx, g.ntx - 1);
+    g.nfy = std::min(g.nfy, g.nty - 1);
+    if (!L.interior_free || !C.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
+    const int nfast = g.nfx * g.nfy, nbnd = g.ntx * g.nty - nfast;
+    hipLaunchKernelGGL(k_st_resid_restrict_r, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K,
+                       L.M, L.Dh, make_stconst(L), L.mask, alpha, xu, xp, bu, bp, C.nx, C.ny, C.mask, remap, cbu, cbp);
+    return;
+  }
   constexpr int CX = 32, CY = 8;
   const int ntx = (C.nx + CX) / CX, nty = (C.ny + CY) / CY;
   hipLaunchKernelGGL((k_st_resid_restrict_t<CX, CY>), dim3(ntx * nty), dim3(PGX_BLOCK), 0, st, L.nx, L.ny, L.n, L.K,
