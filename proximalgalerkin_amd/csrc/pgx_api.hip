@@ -1196,10 +1196,15 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
       if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks
         const Dist& D = h->dist;
         const GridLevel& G = h->lev[l];
+#ifdef PGX_DSTEN_FLOAT  // measurement build only (fp32 multigrid D stencils): the merge of the replicated level is fp64
+        h->err = "PGX_DSTEN_FLOAT builds do not support sharded handles";
+        return PGX_EINVAL;
+#else
         pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, D.view, D.view_S);
         pgxk_view_to_global(h->st, 4, D.view.n, G.n, G.nx + 1, D.view_row0, D.view_own0, D.view_H, D.view_S, G.Dh);
         const int rc = allreduce_dev(h, G.Dh, (size_t)4 * G.n);
         if (rc) return rc;
+#endif
       } else {
         pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, h->lev[l], h->lev[l].Dh);
       }
@@ -1674,30 +1679,46 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         // Sharded: each batch of partial dot products is completed by ONE packed all-reduce, enqueued on the stream.
         pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h1);
         if (dist && (rc = allreduce_dev(h, d_h1, j + 1))) return rc;
-        if (j + 1 <= 60) {
-          pgxk_axpy_dot(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials2, d_h2);
-        } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
-          pgxk_multiaxpy(h->st, nk, j + 1, h->V, nk, d_h1, wj);
-          pgxk_multidot(h->st, nk, j + 2, h->V, nk, wj, h->partials, d_h2);
+        double wp2, h1h1 = 0.0, hh = 0.0;
+        bool second;
+        if (h->cgs_selective) {
+          // lean second pass: w' = w - V h1 and |w'|^2; V^T w' (for the second projection) only if the test below asks for it
+          pgxk_multiaxpy_norm(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials, d_h2 + j + 1);
+          if (dist && (rc = allreduce_dev(h, d_h2 + j + 1, 1))) return rc;
+          HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
+          HIPCHK(hipStreamSynchronize(h->st));
+          for (int i = 0; i <= j; ++i) h1h1 += h->h_small[i] * h->h_small[i];
+          wp2 = h->h_small[(m + 2) + j + 1];
+          // "twice is enough" (Kahan / Parlett; Daniel-Gragg-Kaufman-Stewart): the second projection is only needed when the
+          // first one cancelled most of w, |w'| < eta |w| with |w|^2 = |w'|^2 + |h1|^2
+          second = wp2 < h->cgs_eta2 * (wp2 + h1h1);
+          if (second) {
+            pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h2);
+            if (dist && (rc = allreduce_dev(h, d_h2, j + 1))) return rc;
+            HIPCHK(hipMemcpyAsync(h->h_small + (m + 2), d_h2, sizeof(double) * (j + 1), hipMemcpyDeviceToHost, h->st));
+            HIPCHK(hipStreamSynchronize(h->st));
+          }
+        } else {
+          if (j + 1 <= 60) {
+            pgxk_axpy_dot(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials2, d_h2);
+          } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
+            pgxk_multiaxpy(h->st, nk, j + 1, h->V, nk, d_h1, wj);
+            pgxk_multidot(h->st, nk, j + 2, h->V, nk, wj, h->partials, d_h2);
+          }
+          if (dist && (rc = allreduce_dev(h, d_h2, j + 2))) return rc;
+          HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
+          HIPCHK(hipStreamSynchronize(h->st));
+          wp2 = h->h_small[(m + 2) + j + 1];
+          second = true;
         }
-        if (dist && (rc = allreduce_dev(h, d_h2, j + 2))) return rc;
-        HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
-        HIPCHK(hipStreamSynchronize(h->st));
-        double hh = 0.0, h1h1 = 0.0;
         for (int i = 0; i <= j; ++i) {
-          const double h2 = h->h_small[(m + 2) + i];
+          const double h2 = second ? h->h_small[(m + 2) + i] : 0.0;
+          H[(size_t)i * m + j] = h->h_small[i] + h2;
           hh += h2 * h2;
-          h1h1 += h->h_small[i] * h->h_small[i];
         }
-        const double wp2 = h->h_small[(m + 2) + j + 1];  // |w'|^2 after the first projection
-        // "twice is enough" (Kahan / Parlett; Daniel-Gragg-Kaufman-Stewart): the second projection is only needed when the
-        // first one cancelled most of w, |w'| < eta |w| with |w|^2 = |w'|^2 + |h1|^2.  Otherwise w' is orthogonal to V to
-        // working accuracy and the third pass over the basis is replaced by a scaling of w' (h2 is O(eps |w|) and dropped).
-        const bool second = !h->cgs_selective || wp2 < h->cgs_eta2 * (wp2 + h1h1);
-        for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h->h_small[i] + (second ? h->h_small[(m + 2) + i] : 0.0);
         if (second) {
           hn = std::sqrt(std::max(wp2 - hh, 0.0));
-          // pass 4 fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
+          // last pass fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
           if (hn > 0.0) pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
         } else {
           hn = std::sqrt(std::max(wp2, 0.0));

@@ -8,7 +8,11 @@
 // storage type of the multigrid D(psi) stencils.  They only feed the PRECONDITIONER (the exact operator's CSR D stays
 // fp64), so fp32 would be admissible; measured on MI355X it made the smoother kernels 27 % SLOWER (same Krylov counts),
 // so the stencils stay fp64.
+#ifdef PGX_DSTEN_FLOAT
+typedef float dsten_t;
+#else
 typedef double dsten_t;
+#endif
 
 #define PGX_MAX_NQ 16
 #define PGX_BLOCK 256
@@ -180,6 +184,9 @@ void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t l
                    double* partials, double* out);
 void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h,
                           double scale, double* w);
+// w -= V h and out[0] = |w'|^2 in one pass over the basis (selective CGS2: the lean second pass)
+void pgxk_multiaxpy_norm(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w,
+                         double* partials, double* out);
 // K (2 or 3) collective-Jacobi sweeps per launch; see k_st_smoothK
 void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
                      const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,

@@ -838,6 +838,68 @@ void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, s
   }
 }
 
+// w -= sum_v h[v] V_v in chunks of <= 8 vectors; the LAST chunk also leaves the block's share of |w'|^2 in partials[block]
+// (fixed-shape two-stage reduction: reproducible).  The lean second pass of selective CGS2: one read of the basis, one
+// read-modify-write of w, no LDS parking of basis slices (k_axpy_dot does that to get V^T w' in the same pass, which is only
+// needed when the second projection is - 11 of 266 iterations at 2048^2).
+template <int NV, bool NORM>
+__global__ void __launch_bounds__(PGX_BLOCK) k_multiaxpy_norm(size_t len2, const double2* __restrict__ V, size_t ldv2,
+                                                              const double* __restrict__ h, double2* __restrict__ w,
+                                                              double* __restrict__ partials) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  double hv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) hv[v] = h[v];
+  double acc = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len2; i += (size_t)gridDim.x * blockDim.x) {
+    double2 wv = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double2 a = ldnt2(V + v * ldv2 + i);
+      wv.x -= hv[v] * a.x;
+      wv.y -= hv[v] * a.y;
+    }
+    w[i] = wv;
+    if (NORM) acc += wv.x * wv.x + wv.y * wv.y;
+  }
+  if (NORM) {
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  }
+}
+template <int NV>
+static void launch_multiaxpy_norm(hipStream_t st, dim3 grid, size_t len2, const double2* Vp, size_t ldv2, const double* h, bool norm,
+                                  double2* w, double* partials) {
+  if (norm)
+    hipLaunchKernelGGL((k_multiaxpy_norm<NV, true>), grid, dim3(PGX_BLOCK), 0, st, len2, Vp, ldv2, h, w, partials);
+  else
+    hipLaunchKernelGGL((k_multiaxpy_norm<NV, false>), grid, dim3(PGX_BLOCK), 0, st, len2, Vp, ldv2, h, w, partials);
+}
+// out[0] = |w - V h|^2, w updated in place.  partials: >= PGX_RED_BLOCKS doubles.
+void pgxk_multiaxpy_norm(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w,
+                         double* partials, double* out) {
+  const size_t len2 = len / 2, ldv2 = ldv / 2;
+  dim3 grid = stream_grid(len2);
+  int done = 0;
+  while (done < nv) {
+    const int step = std::min(8, nv - done);
+    const bool last = done + step == nv;
+    const double2* Vp = (const double2*)(V + (size_t)done * ldv);
+    switch (step) {
+      case 8: launch_multiaxpy_norm<8>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 7: launch_multiaxpy_norm<7>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 6: launch_multiaxpy_norm<6>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 5: launch_multiaxpy_norm<5>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 4: launch_multiaxpy_norm<4>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 3: launch_multiaxpy_norm<3>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      case 2: launch_multiaxpy_norm<2>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+      default: launch_multiaxpy_norm<1>(st, grid, len2, Vp, ldv2, h + done, last, (double2*)w, partials); break;
+    }
+    done += step;
+  }
+  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(PGX_BLOCK), 0, st, (int)grid.x, partials, out);
+}
+
 void pgxk_multiaxpy(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w) {
   const size_t len2 = len / 2, ldv2 = ldv / 2;
   dim3 grid = stream_grid(len2), block(PGX_BLOCK);
