@@ -25,13 +25,13 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("-N", type=int, default=64)
     ap.add_argument("--disk", type=float, default=0.0, help="mesh size of a unit-disk Delaunay mesh (the reference's domain)")
-    ap.add_argument("-f", "--infile", type=pathlib.Path, default=None, help="gmsh .msh file")
+    ap.add_argument("-f", "--infile", type=pathlib.Path, default=None, help="gmsh .msh or inline-data .xdmf file")
     ap.add_argument("--max_iter", type=int, default=500)  # compare_all.py:32
     ap.add_argument("--tol", type=float, default=1e-4)  # compare_all.py:31
     ap.add_argument("--first-order-max-iter", type=int, default=20000)
     a = ap.parse_args()
     if a.infile:
-        mesh = io.read_msh(a.infile)
+        mesh = io.read_mesh(a.infile)
     elif a.disk > 0:
         mesh = fem.create_disk(a.disk)
     else:

@@ -35,9 +35,9 @@ if __name__ == "__main__":
                         help="Tolerance for exiting Newton iteration")
     args = parser.parse_args()
     if args.filename is not None:
-        from proximalgalerkin_amd.io import mesh_from_msh
+        from proximalgalerkin_amd.io import read_mesh
 
-        msh = mesh_from_msh(args.filename)
+        msh = read_mesh(args.filename)  # .xdmf (inline data) or gmsh .msh; order-2 geometry reduced to vertices
     else:
         msh = (fem.create_disk(args.disk_h) if args.disk_h > 0.0 else
                fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N)))

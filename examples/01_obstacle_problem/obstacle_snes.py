@@ -31,7 +31,7 @@ if __name__ == "__main__":
     ap.add_argument("--disk", type=float, default=0.0)
     ap.add_argument("-f", "--infile", type=pathlib.Path, default=None)
     a = ap.parse_args()
-    mesh = io.read_msh(a.infile) if a.infile else fem.create_disk(a.disk) if a.disk > 0 else fem.create_rectangle(
+    mesh = io.read_mesh(a.infile) if a.infile else fem.create_disk(a.disk) if a.disk > 0 else fem.create_rectangle(
         ((-1.0, -1.0), (1.0, 1.0)), (a.N, a.N))
     u, its = snes_solve(mesh, snes_options={"snes_type": "vinewtonssls", "snes_monitor": None, "ksp_type": "preonly", "pc_type": "lu",
                                             "snes_max_it": 1000, "snes_atol": 1e-8, "snes_rtol": 1e-8, "snes_stol": 1e-8})  # :103-115

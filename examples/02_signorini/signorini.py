@@ -1,8 +1,10 @@
 """Signorini contact problem with the latent variable proximal point algorithm on the HIP backend.
 
-Counterpart of /root/reference/examples/02_signorini/signorini_dolfinx.py (`native` mesh branch, :361-386) with the
-reference's flags where they apply: --E --nu --disp --gap --n-tol --max-iterations --tol --alpha_scheme --alpha_0
---alpha_c --nx --ny --nz.  Degree 1 on a tetrahedral unit cube (BASELINE.json config 5).
+Counterpart of /root/reference/examples/02_signorini/signorini_dolfinx.py with the reference's flags where they apply: --E --nu
+--disp --gap --n-tol --max-iterations --tol --alpha_scheme --alpha_0 --alpha_c and the two mesh branches: `--nx --ny --nz` (native,
+:361-386: a tetrahedral unit cube, BASELINE.json config 5) or `--filename mesh.msh|mesh.xdmf --contact-tag --displacement-tag`
+(file, :406-409: tetrahedra + tagged boundary triangles, e.g. the half sphere of generate_mesh.py; order-2 geometry is reduced to
+its vertices, XDMF must carry inline data).  Degree 1.
 """
 import argparse
 import sys
@@ -27,9 +29,18 @@ if __name__ == "__main__":
     parser.add_argument("--nx", type=int, default=16)
     parser.add_argument("--ny", type=int, default=7)
     parser.add_argument("--nz", type=int, default=5)
+    parser.add_argument("--filename", type=Path, default=None, help="mesh file (the reference's `file` sub-command)")
+    parser.add_argument("--contact-tag", dest="ct", type=int, default=2, help="Tag of contact surface")
+    parser.add_argument("--displacement-tag", dest="dt", type=int, default=1, help="Tag of displacement surface")
     a = parser.parse_args()
-    mesh = create_unit_cube(a.nx, a.ny, a.nz)
-    mt, bcs = native_tags(mesh)
+    if a.filename is not None:
+        from proximalgalerkin_amd.io import read_tet_mesh
+
+        mesh, mt = read_tet_mesh(a.filename)
+        bcs = {"contact": (a.ct,), "displacement": (a.dt,)}
+    else:
+        mesh = create_unit_cube(a.nx, a.ny, a.nz)
+        mt, bcs = native_tags(mesh)
     it, iterations = solve_contact_problem(mesh=mesh, facet_tag=mt, boundary_conditions=bcs, degree=1, E=a.E, nu=a.nu,
                                            gap=a.gap, disp=a.disp, newton_max_its=250, newton_tol=a.newton_tol,
                                            max_iterations=a.max_iterations, alpha_scheme=a.alpha_scheme, alpha_0=a.alpha_0,

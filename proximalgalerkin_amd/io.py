@@ -6,6 +6,12 @@ gradient_constraint_dolfinx.py:145-158, signorini_dolfinx.py:293-299).  HDF5 and
 formats offered here are the ones every gmsh / ParaView installation handles directly:
 
     read_msh(path)                      gmsh MSH 2.2 / 4.1 ASCII  -> (points, cells_by_type, cell_tags_by_type)
+    read_xdmf(path, name)               XDMF with INLINE (XML / ASCII-encoded) heavy data - what
+                                        dolfinx.io.XDMFFile(..., encoding=XDMFFile.Encoding.ASCII) writes; HDF5-backed files are
+                                        refused with a message that says how to re-export
+    read_mesh(path) / read_tet_mesh     -> fem.Mesh / (TetMesh, MeshTags) from either format; ORDER-2 geometry (6-node triangles,
+                                        10-node tetrahedra: generate_mesh_gmsh.py:31, mesh_generation.py:88,158) is reduced to
+                                        its vertices - the solvers use affine cells
     write_vtu(path, points, cells, ...) VTK unstructured grid (XML, ASCII) with point / cell data; linear and quadratic
                                         triangles, linear tetrahedra
 """
@@ -16,7 +22,8 @@ from pathlib import Path
 import numpy as np
 
 # gmsh element type -> (name, nodes)
-_GMSH = {1: ("line", 2), 2: ("triangle", 3), 4: ("tetra", 4), 8: ("line3", 3), 9: ("triangle6", 6), 15: ("vertex", 1)}
+_GMSH = {1: ("line", 2), 2: ("triangle", 3), 4: ("tetra", 4), 8: ("line3", 3), 9: ("triangle6", 6), 11: ("tetra10", 10),
+         15: ("vertex", 1)}
 _VTK = {"triangle": 5, "triangle6": 22, "tetra": 10, "line": 3, "vertex": 1}
 
 
@@ -105,21 +112,114 @@ def read_msh(path):
     return pts, out_c, out_t
 
 
-def mesh_from_msh(path):
-    """A 2-D `fem.Mesh` from the triangles of a gmsh file (z dropped, counter-clockwise orientation enforced): what
-    obstacle_pg.py:64-65 obtains from `xdmf.read_mesh`."""
+# XDMF TopologyType (case-insensitive; DOLFINx writes "Triangle", "Triangle_6", "Tetrahedron", "Tetrahedron_10") -> (name, nodes)
+_XDMF = {"triangle": ("triangle", 3), "triangle_6": ("triangle6", 6), "tri_6": ("triangle6", 6), "tetrahedron": ("tetra", 4),
+         "tetrahedron_10": ("tetra10", 10), "tet_10": ("tetra10", 10), "polyline": ("line", 2), "edge_3": ("line3", 3)}
+
+
+def read_xdmf(path, name: str = "mesh"):
+    """Grid `name` of an XDMF file whose DataItems carry their numbers inline (Format="XML").  Returns (points (n, 2|3),
+    {cell type: (m, k) int32 connectivity}, {grid name: (cell type, connectivity, values)} for every further grid with an
+    Attribute - DOLFINx's meshtags grids, e.g. "facet_tags" of examples/02_signorini/signorini_dolfinx.py:407)."""
+    import xml.etree.ElementTree as ET
+
+    root = ET.parse(str(path)).getroot()
+
+    def numbers(item, dtype):
+        fmt = (item.get("Format") or "XML").upper()
+        if fmt != "XML":
+            raise NotImplementedError(
+                f"{path}: DataItem Format=\"{item.get('Format')}\" ({(item.text or '').strip()}): HDF5 is not available here. Re-export "
+                "with inline data - dolfinx.io.XDMFFile(comm, file, 'w', encoding=dolfinx.io.XDMFFile.Encoding.ASCII) - or pass the "
+                "gmsh .msh file")
+        dims = [int(v) for v in item.get("Dimensions").split()]
+        return np.array((item.text or "").split(), dtype=dtype).reshape(dims)
+
+    grids = {g.get("Name"): g for g in root.iter("Grid") if g.find("Topology") is not None}
+    if name not in grids:
+        raise KeyError(f"{path}: no grid named {name!r} (found {sorted(grids)})")
+
+    def topo(g):
+        t = g.find("Topology")
+        key = (t.get("TopologyType") or t.get("Type") or "").lower()
+        if key not in _XDMF:
+            raise NotImplementedError(f"{path}: TopologyType {key!r}")
+        cname, k = _XDMF[key]
+        return cname, np.ascontiguousarray(numbers(t.find("DataItem"), np.int64).reshape(-1, k), dtype=np.int32)
+
+    g = grids[name]
+    pts = numbers(g.find("Geometry").find("DataItem"), np.float64)
+    cname, conn = topo(g)
+    tags = {}
+    for gname, gg in grids.items():
+        att = gg.find("Attribute")
+        if gname == name or att is None:
+            continue
+        tname, tconn = topo(gg)
+        tags[gname] = (tname, tconn, np.asarray(numbers(att.find("DataItem"), np.float64)).ravel().astype(np.int32))
+    return pts, {cname: conn}, tags
+
+
+def _triangles(pts, cells):
+    """vertex triangles of a 2-D mesh given as linear or quadratic (order-2 geometry) triangles, counter-clockwise, compact"""
     from . import fem
 
-    pts, cells, _ = read_msh(path)
-    tri = cells["triangle"].copy()
-    p = pts[:, :2]
+    tri = (cells["triangle"] if "triangle" in cells else cells["triangle6"][:, :3]).copy()
+    p = np.asarray(pts)[:, :2]
     a, b, c = p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]]
     neg = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) < 0
     tri[neg] = tri[neg][:, [0, 2, 1]]
-    used = np.unique(tri)
+    used = np.unique(tri)  # drops the edge-midpoint nodes of an order-2 geometry
     remap = np.full(len(p), -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
     return fem.Mesh(np.ascontiguousarray(p[used]), np.ascontiguousarray(remap[tri], dtype=np.int32))
+
+
+def mesh_from_msh(path):
+    """A 2-D `fem.Mesh` from the triangles of a gmsh file (z dropped, counter-clockwise orientation enforced, order-2 geometry
+    reduced to its vertices): what obstacle_pg.py:64-65 obtains from `xdmf.read_mesh`."""
+    pts, cells, _ = read_msh(path)
+    return _triangles(pts, cells)
+
+
+def read_mesh(path, name: str = "mesh"):
+    """`xdmf.read_mesh(name="mesh")` of obstacle_pg.py:64-65 for a 2-D triangle mesh: .xdmf (inline data) or gmsh .msh."""
+    path = Path(path)
+    if path.suffix.lower() == ".xdmf":
+        pts, cells, _ = read_xdmf(path, name)
+        return _triangles(pts, cells)
+    return mesh_from_msh(path)
+
+
+def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
+    """(TetMesh, MeshTags) of example 02's `file` branch (signorini_dolfinx.py:406-409: read_mesh + read_meshtags "facet_tags";
+    the half-sphere of lvpp/mesh_generation.py:86-168 has order-2 geometry): tetrahedra and tagged boundary triangles from a
+    gmsh .msh file (physical groups) or an inline-data XDMF file, both reduced to their vertices."""
+    from .signorini import MeshTags, TetMesh
+
+    path = Path(path)
+    if path.suffix.lower() == ".xdmf":
+        pts, cells, tagged = read_xdmf(path, name)
+        if tags_name not in tagged:
+            raise KeyError(f"{path}: no meshtags grid {tags_name!r} (found {sorted(tagged)})")
+        tname, fconn, fval = tagged[tags_name]
+    else:
+        pts, cells, tags = read_msh(path)
+        tname = "triangle" if "triangle" in cells else "triangle6"
+        fconn, fval = cells[tname], tags[tname]
+    tet = (cells["tetra"] if "tetra" in cells else cells["tetra10"][:, :4]).copy()
+    fconn = fconn[:, :3]
+    p = np.asarray(pts, dtype=np.float64)[:, :3]
+    # positive orientation
+    a, b, c, d = (p[tet[:, k]] for k in range(4))
+    vol = np.einsum("ij,ij->i", np.cross(b - a, c - a), d - a)
+    tet[vol < 0] = tet[vol < 0][:, [0, 2, 1, 3]]
+    used = np.unique(tet)
+    remap = np.full(len(p), -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    mesh = TetMesh(np.ascontiguousarray(p[used]), np.ascontiguousarray(remap[tet], dtype=np.int32))
+    tagged_facets = {int(t): np.ascontiguousarray(remap[fconn[fval == t]], dtype=np.int32) for t in np.unique(fval) if t != 0}
+    return mesh, MeshTags(tagged_facets)
 
 
 def write_vtu(path, points, cells, point_data: dict | None = None, cell_data: dict | None = None, cell_type: str | None = None):

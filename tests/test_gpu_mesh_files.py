@@ -1,0 +1,40 @@
+"""The reference's CLI reads its meshes from files (obstacle_pg.py:64-65 `-f mesh.xdmf`, signorini_dolfinx.py:406-409).  The HIP
+path run on the COMMITTED mesh files (tests/golden/*.msh, *.xdmf: order-2 gmsh geometry, inline-data XDMF) must match the CPU
+oracle on the same vertices and cells: identical Newton counts, primal field <= 1e-10."""
+import pathlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = pathlib.Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("fname", ["disk_h0.2_order2.msh", "disk_h0.2.xdmf"])
+def test_obstacle_on_a_disk_mesh_file_matches_the_oracle(require_gpu, fname):
+    from oracle import pg_oracle as O
+    from proximalgalerkin_amd import io
+    from proximalgalerkin_amd.obstacle import solve_problem
+
+    mesh = io.read_mesh(GOLD / fname)
+    sol, newton, hist = solve_problem(mesh, 1, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+    prob = O.ObstacleP1(mesh.geometry, mesh.cells, mesh.exterior_vertices())
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    n = prob.n
+    assert np.linalg.norm(sol.x.array[:n] - x_ref[:n]) <= 1e-10 * np.linalg.norm(x_ref[:n])
+
+
+@pytest.mark.parametrize("fname", ["cube_3x2x2_order2.msh", "cube_3x2x2.xdmf"])
+def test_signorini_on_a_tagged_tet_mesh_file_matches_the_oracle(require_gpu, fname):
+    from oracle import sg_oracle as S
+    from proximalgalerkin_amd import io
+    from proximalgalerkin_amd import signorini as sg
+
+    mesh, mt = io.read_tet_mesh(GOLD / fname)
+    it, iters, x, cv = sg.solve_contact_problem(mesh, mt, {"contact": (2,), "displacement": (1,)}, verbose=False, return_solution=True)
+    prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), np.unique(mt.find(1).ravel()))
+    x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
+    assert it == it_ref and list(iters) == list(its_ref)
+    nu3 = 3 * prob.nv
+    assert np.linalg.norm(x[:nu3] - x_ref[:nu3]) <= 1e-10 * np.linalg.norm(x_ref[:nu3])

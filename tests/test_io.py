@@ -91,3 +91,56 @@ def test_write_vtu_is_wellformed(tmp_path):
     X = V.dof_coordinates()
     assert np.allclose(X[conn[:, 3]], 0.5 * (X[conn[:, 0]] + X[conn[:, 1]]))
     assert np.allclose(X[conn[:, 4]], 0.5 * (X[conn[:, 1]] + X[conn[:, 2]]))
+
+
+GOLD = __import__("pathlib").Path(__file__).resolve().parent / "golden"
+
+
+def test_order2_msh_and_inline_xdmf_give_the_same_vertex_mesh():
+    """generate_mesh_gmsh.py:31 writes order-2 geometry; obstacle_pg.py:64-65 reads XDMF: both reduce to the same affine
+    triangles here (mid-side nodes dropped, vertices renumbered compactly, counter-clockwise)."""
+    from proximalgalerkin_amd import fem
+
+    a = io.read_mesh(GOLD / "disk_h0.2_order2.msh")
+    b = io.read_mesh(GOLD / "disk_h0.2.xdmf")
+    ref = fem.create_disk(0.2)
+    for m in (a, b):
+        assert m.geometry.shape == ref.geometry.shape and m.cells.shape == ref.cells.shape
+        assert np.allclose(m.geometry, ref.geometry, atol=1e-15) and np.array_equal(m.cells, ref.cells)
+        x = m.geometry[m.cells]
+        det = (x[:, 1, 0] - x[:, 0, 0]) * (x[:, 2, 1] - x[:, 0, 1]) - (x[:, 1, 1] - x[:, 0, 1]) * (x[:, 2, 0] - x[:, 0, 0])
+        assert (det > 0).all()
+    pts, cells, _ = io.read_msh(GOLD / "disk_h0.2_order2.msh")
+    assert cells["triangle6"].shape[1] == 6 and len(pts) > len(a.geometry)  # the file really carries the mid-side nodes
+
+
+def test_tet_mesh_with_facet_tags_from_order2_msh_and_xdmf():
+    """signorini_dolfinx.py:406-409 (read_mesh + read_meshtags "facet_tags") on the layout mesh_generation.create_half_sphere
+    writes: order-2 tetrahedra, tagged boundary triangles."""
+    from proximalgalerkin_amd import signorini as sg
+
+    ref = sg.create_unit_cube(3, 2, 2)
+    rt, _ = sg.native_tags(ref)
+    for f in ("cube_3x2x2_order2.msh", "cube_3x2x2.xdmf"):
+        mesh, mt = io.read_tet_mesh(GOLD / f)
+        assert np.allclose(mesh.geometry, ref.geometry, atol=1e-15)
+        key = lambda c: np.unique(np.sort(c, axis=1), axis=0)  # noqa: E731
+        assert np.array_equal(key(mesh.cells), key(ref.cells))
+        for tag in (1, 2):
+            assert np.array_equal(key(mt.find(tag)), key(rt.find(tag)))
+        x = mesh.geometry[mesh.cells]
+        vol = np.einsum("ij,ij->i", np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]), x[:, 3] - x[:, 0])
+        assert (vol > 0).all() and np.isclose(vol.sum() / 6.0, 1.0)
+
+
+def test_hdf5_backed_xdmf_is_refused_with_instructions(tmp_path):
+    f = tmp_path / "m.xdmf"
+    f.write_text('<Xdmf><Domain><Grid Name="mesh"><Topology TopologyType="Triangle"><DataItem Dimensions="1 3" Format="HDF">m.h5:/Mesh/mesh/'
+                 'topology</DataItem></Topology><Geometry><DataItem Dimensions="3 2" Format="HDF">m.h5:/Mesh/mesh/geometry</DataItem>'
+                 '</Geometry></Grid></Domain></Xdmf>')
+    try:
+        io.read_mesh(f)
+    except NotImplementedError as e:
+        assert "Encoding.ASCII" in str(e)
+    else:
+        raise AssertionError("an HDF5-backed file must not be read silently")
