@@ -227,15 +227,116 @@ class FunctionSpace:
 
 @dataclass(frozen=True)
 class SubSpace:
-    parent: FunctionSpace
+    parent: object  # FunctionSpace | MixedSpace
     index: int
+
+    def collapse(self):
+        """V.sub(i).collapse() -> (scalar space of the component, dofs of the component within the parent), as
+        gradient_constraint_dolfinx.py:54 uses it."""
+        P = self.parent
+        if isinstance(P, MixedSpace):
+            sizes = P.block_sizes()
+            off = int(sum(sizes[: self.index]))
+            return P.scalar_space(self.index), np.arange(off, off + sizes[self.index])
+        n = P.block_size
+        return FunctionSpace(P.mesh, P.degree, 1), np.arange(self.index * n, (self.index + 1) * n)
+
+
+@dataclass(frozen=True)
+class Element:
+    """basix.ufl.element(family, cell, degree, shape=...) (gradient_constraint_dolfinx.py:38-42): Lagrange, scalar (shape ()) or
+    vector-valued (shape (dim,))."""
+    family: str
+    degree: int
+    shape: tuple = ()
+
+
+def element(family, cell, degree, shape=()):
+    if family not in ("Lagrange", "P", "CG"):
+        raise NotImplementedError(family)
+    return Element("Lagrange", int(degree), tuple(shape))
+
+
+def mixed_element(elements):
+    """basix.ufl.mixed_element([el_0, el_1]) (gradient_constraint_dolfinx.py:44)."""
+    return tuple(elements)
+
+
+@dataclass(frozen=True)
+class MixedSpace:
+    """Mixed Lagrange space with per-component degree and shape, e.g. [P2, (P1)^2] of example 06.  Dofs are blocked in component
+    order, vector components by Cartesian direction: [u | psi_x | psi_y] - the layout of include/pgx_gc.h."""
+    mesh: Mesh
+    elements: tuple
+
+    @property
+    def ncomp(self):
+        return len(self.elements)
+
+    def component_rank(self, i):
+        return len(self.elements[i].shape)
+
+    def scalar_space(self, i):
+        return FunctionSpace(self.mesh, self.elements[i].degree, 1)
+
+    def block_sizes(self):
+        return [self.scalar_space(i).block_size * (int(np.prod(e.shape)) if e.shape else 1) for i, e in enumerate(self.elements)]
+
+    @property
+    def num_dofs(self):
+        return int(sum(self.block_sizes()))
+
+    def sub(self, i):
+        return SubSpace(self, i)
 
 
 def functionspace(mesh, element=("Lagrange", 1), ncomp=2):
+    if isinstance(element, tuple) and element and isinstance(element[0], Element):  # a mixed_element([...])
+        return MixedSpace(mesh, tuple(element))
+    if isinstance(element, Element):
+        if element.shape:
+            raise NotImplementedError("a vector-valued space on its own: put it in a mixed_element")
+        return FunctionSpace(mesh, element.degree, 1)
     family, degree = element
     if family != "Lagrange":
         raise NotImplementedError(family)
     return FunctionSpace(mesh, int(degree), ncomp)
+
+
+class _FormOperand:
+    """Arithmetic on Constants / quadrature-space coefficients builds form expressions (proximalgalerkin_amd/ufl.py)."""
+
+    def _e(self):
+        from . import ufl
+
+        return ufl.as_expr(self)
+
+    def __mul__(self, o):
+        return self._e() * o
+
+    def __rmul__(self, o):
+        return o * self._e()
+
+    def __add__(self, o):
+        return self._e() + o
+
+    def __radd__(self, o):
+        return o + self._e()
+
+    def __sub__(self, o):
+        return self._e() - o
+
+    def __rsub__(self, o):
+        return o - self._e()
+
+    def __neg__(self):
+        return -self._e()
+
+    def __truediv__(self, o):
+        return self._e() / o
+
+    def __rtruediv__(self, o):
+        return o / self._e()
 
 
 class _Vector:
@@ -279,8 +380,8 @@ class _Vector:
             self.array[:] = other.array
 
 
-class Function:
-    def __init__(self, V: FunctionSpace, name="f"):
+class Function(_FormOperand):
+    def __init__(self, V, name="f"):
         self.function_space = V
         self.name = name
         self.x = _Vector(V.num_dofs)
@@ -289,41 +390,13 @@ class Function:
         n = self.function_space.block_size
         return self.x.array[i * n:(i + 1) * n]
 
-
-class _FormOperand:
-    """Arithmetic on Constants / quadrature-space coefficients builds form expressions (proximalgalerkin_amd/ufl.py)."""
-
-    def _e(self):
-        from . import ufl
-
-        return ufl.as_expr(self)
-
-    def __mul__(self, o):
-        return self._e() * o
-
-    def __rmul__(self, o):
-        return o * self._e()
-
-    def __add__(self, o):
-        return self._e() + o
-
-    def __radd__(self, o):
-        return o + self._e()
-
-    def __sub__(self, o):
-        return self._e() - o
-
-    def __rsub__(self, o):
-        return o - self._e()
-
-    def __neg__(self):
-        return -self._e()
-
-    def __truediv__(self, o):
-        return self._e() / o
-
-    def __rtruediv__(self, o):
-        return o / self._e()
+    def interpolate(self, fn):
+        """Function.interpolate(callable) for a scalar Lagrange space: nodal values at the dof coordinates
+        (gradient_constraint_dolfinx.py:55-61); fn takes x of shape (2, npts)."""
+        V = self.function_space
+        if not isinstance(V, FunctionSpace) or V.ncomp != 1:
+            raise NotImplementedError("interpolate: scalar Lagrange spaces")
+        self.x.array[:] = np.asarray(fn(np.ascontiguousarray(V.dof_coordinates().T)), dtype=np.float64)
 
 
 class Constant(_FormOperand):

@@ -48,8 +48,11 @@ class GradientConstraintProblem:
         self.ndofs = self.n2 + 2 * self.nv
         xd = U.dof_coordinates()
         pts, wts = fem.quadrature_rule("triangle", quadrature_degree)  # :53
-        phi = np.ascontiguousarray(phi_func(xd.T.copy()), dtype=np.float64)  # phi.interpolate, :55-56
-        f = np.ascontiguousarray(f_func(xd.T.copy()), dtype=np.float64)  # :60-61
+        # phi.interpolate(phi_func), f.interpolate(f_func) (:55-61); arrays of nodal values are taken as they are (forms front end)
+        phi = np.ascontiguousarray(phi_func(xd.T.copy()) if callable(phi_func) else phi_func, dtype=np.float64)
+        f = np.ascontiguousarray(f_func(xd.T.copy()) if callable(f_func) else f_func, dtype=np.float64)
+        if phi.shape != (U.block_size,) or f.shape != (U.block_size,):
+            raise ValueError("phi and f must be given in the collapsed primal space (one value per P2 dof)")
         bc = np.ascontiguousarray(mesh.exterior_dofs(2), dtype=np.int32)  # :63-69
         cd = U.cell_dofs()
         self._keep = (mesh.geometry, mesh.cells, cd, pts, wts, phi, f, bc)
@@ -266,3 +269,99 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
         return out + (x,)
     problem.close()
     return out
+
+
+class NonlinearProblem:
+    """dolfinx.fem.petsc.NonlinearProblem(F, u=sol, bcs=bcs, petsc_options=..., petsc_options_prefix="pg_") as
+    gradient_constraint_dolfinx.py:113-132 builds it, for the residual FORM of :100-107 stated in proximalgalerkin_amd.ufl: the
+    front end recognises the gradient-constraint family (vector latent variable) and reads alpha, phi, f and the previous
+    iterate off the form; `.solve()` and `.solver` behave like the reference's.  sol / w0 are host Functions, synchronised with
+    the device state around every solve (this is the reference's own usage: `w0.x.array[:] = sol.x.array`, :205)."""
+
+    def __init__(self, F, u: fem.Function, bcs=None, J=None, petsc_options=None, petsc_options_prefix="", device=0):
+        from . import ufl
+
+        spec = ufl.compile_form(F, u, J)
+        if not isinstance(spec, ufl.GradientConstraintSpec):
+            raise NotImplementedError(f"this form is a {type(spec).__name__}, not the gradient-constraint family")
+        V = u.function_space
+        els = V.elements
+        if not (els[0].degree == 2 and els[1].degree == 1 and els[1].shape == (2,)):
+            raise NotImplementedError("HIP backend: primal Lagrange degree 2 with a vector P1 latent variable (the reference's defaults)")
+        bc_dofs = np.zeros(0, dtype=np.int64)
+        for bc in bcs or []:
+            if bc.sub != 0 or np.any(bc.values != 0.0):
+                raise NotImplementedError("homogeneous Dirichlet data on sub(0) (gradient_constraint_dolfinx.py:109-110)")
+            bc_dofs = np.union1d(bc_dofs, bc.dofs)
+        if not np.array_equal(bc_dofs, np.sort(V.mesh.exterior_dofs(2))):
+            raise NotImplementedError("the Dirichlet dofs must be the exterior dofs of the primal space (:63-69)")
+        self.spec, self.u = spec, u
+        self._p = GradientConstraintProblem(V.mesh, spec.phi.x.array.copy(), spec.f.x.array.copy(), petsc_options=petsc_options,
+                                            quadrature_degree=spec.quadrature_degree, device=device)
+        self.solver = self._p.solver
+
+    def solve(self):
+        p, sp = self._p, self.spec
+        p.set_alpha(sp.alpha.value)
+        p.set_state(sp.sol.x.array)
+        p.set_prev(sp.w0.x.array)
+        reason, its = p.solve()
+        if reason > 0:  # NonlinearProblem.solve copies back; SNESSolver keeps the old iterate otherwise (lvpp/problem.py:121-123)
+            sp.sol.x.array[:] = p.get_state()
+        return self.u
+
+    def l2_increment(self):
+        self._p.set_state(self.spec.sol.x.array)
+        self._p.set_prev(self.spec.w0.x.array)
+        return self._p.l2_increment()
+
+    def close(self):
+        self._p.close()
+
+
+def solve_problem_forms(N: int, M: int, alpha_scheme: AlphaScheme = "doubling", alpha_0: float = 1.0, alpha_c: float = 1.0,
+                        max_iterations: int = 25, stopping_tol: float = 1e-8, phi_func: Callable = phi_default,
+                        f_func: Callable = f_default, device: int = 0):
+    """gradient_constraint_dolfinx.solve_problem (:18-205) with the problem stated as the reference states it - elements, spaces,
+    coefficient Functions and the residual FORM - through the UFL-subset front end.  Returns (newton_iterations, L2_diff, sol)."""
+    from . import ufl
+
+    mesh = fem.create_unit_square(N, M)  # :36
+    el_0 = fem.element("Lagrange", mesh.cell_name(), 2)  # :38
+    el_1 = fem.element("Lagrange", mesh.cell_name(), 1, shape=(2,))  # :40-42
+    V_trial = fem.functionspace(mesh, fem.mixed_element([el_0, el_1]))  # :44-45
+    sol = fem.Function(V_trial)
+    u, psi = ufl.split(sol)  # :48-49
+    v, w = ufl.TestFunctions(V_trial)  # :51
+    dx = ufl.Measure("dx", domain=mesh, metadata={"quadrature_degree": 10})  # :53
+    alpha = fem.Constant(mesh, alpha_0)
+    U, U_to_W = V_trial.sub(0).collapse()  # :54
+    phi = fem.Function(U)
+    phi.interpolate(phi_func)
+    w0 = fem.Function(V_trial)
+    f = fem.Function(U)
+    f.interpolate(f_func)
+    boundary_dofs = mesh.exterior_dofs(2)  # :63-69
+    _, psi0 = ufl.split(w0)  # :98
+    F = alpha * ufl.inner(ufl.grad(u), ufl.grad(v)) * dx  # :100-107
+    F += ufl.inner(psi, ufl.grad(v)) * dx
+    F -= alpha * ufl.inner(f, v) * dx
+    F -= ufl.inner(psi0, ufl.grad(v)) * dx
+    F += ufl.inner(ufl.grad(u), w) * dx
+    non_lin_term = 1 / (ufl.sqrt(1 + ufl.dot(psi, psi)))
+    F -= phi * non_lin_term * ufl.dot(psi, w) * dx
+    bcs = [fem.dirichletbc(0.0, boundary_dofs, V_trial.sub(0))]  # :109-110
+    problem = NonlinearProblem(F, u=sol, bcs=bcs, petsc_options_prefix="pg_", petsc_options=dict(PETSC_OPTIONS), device=device)
+    newton_iterations = np.zeros(max_iterations, dtype=np.int32)
+    L2_diff = np.zeros(max_iterations)
+    i = -1
+    for i in range(max_iterations):  # :171-205
+        alpha.value = alpha_0 if alpha_scheme == "constant" else alpha_0 + alpha_c * i if alpha_scheme == "linear" else alpha_0 * 2**i
+        problem.solve()
+        newton_iterations[i] = problem.solver.getIterationNumber()
+        L2_diff[i] = problem.l2_increment()
+        if L2_diff[i] < stopping_tol:
+            break
+        w0.x.array[:] = sol.x.array  # :205
+    problem.close()
+    return newton_iterations[: i + 1], L2_diff[: i + 1], sol

@@ -140,18 +140,26 @@ def as_expr(o):
     if isinstance(o, fem.QuadratureFunction):
         return Terminal("quadrature", o)
     if isinstance(o, fem.Function):
+        V = o.function_space
+        if isinstance(V, fem.FunctionSpace) and V.ncomp == 1:  # a coefficient in a scalar space (phi, f of example 06)
+            return Terminal("coefficient", o)
         raise TypeError("a mixed Function enters a form through split(function)")
     raise TypeError(f"cannot use {type(o).__name__} in a form")
 
 
+def _comp_rank(V, i):
+    return V.component_rank(i) if hasattr(V, "component_rank") else 0
+
+
 def split(function: fem.Function):
     """ufl.split(sol) (obstacle_pg.py:88-89): the components of a mixed Function."""
-    return tuple(Terminal("component", function, i) for i in range(function.function_space.ncomp))
+    V = function.function_space
+    return tuple(Terminal("component", function, i, _comp_rank(V, i)) for i in range(V.ncomp))
 
 
 def TestFunctions(V: fem.FunctionSpace):
     """ufl.TestFunctions(V) (obstacle_pg.py:114)."""
-    return tuple(Terminal("argument", V, i) for i in range(V.ncomp))
+    return tuple(Terminal("argument", V, i, _comp_rank(V, i)) for i in range(V.ncomp))
 
 
 def grad(a):
@@ -185,6 +193,18 @@ def lt(a, b):
     return Func("lt", as_expr(a), as_expr(b))
 
 
+def le(a, b):
+    return Func("le", as_expr(a), as_expr(b))
+
+
+def gt(a, b):
+    return Func("gt", as_expr(a), as_expr(b))
+
+
+def ge(a, b):
+    return Func("ge", as_expr(a), as_expr(b))
+
+
 def conditional(c, a, b):
     return Func("conditional", as_expr(c), as_expr(a), as_expr(b))
 
@@ -214,6 +234,10 @@ class Measure:
 
     def __rmul__(self, o):
         return Form([Integral(as_expr(o), self)])
+
+    def __call__(self, domain=None, metadata=None):
+        """ufl.dx(domain=mesh) (intersecting_constraints_dolfinx.py:32)"""
+        return Measure(self.name, domain=domain, metadata=metadata)
 
 
 dx = Measure("dx")
@@ -255,7 +279,74 @@ class Derivative:
     u: fem.Function
 
 
+def TestFunction(V):
+    """ufl.TestFunction(Z) of a mixed space: use ufl.split(z_test) for its components (intersecting_constraints_dolfinx.py:21-22)."""
+    return _ArgumentTuple(V)
+
+
+class _ArgumentTuple:
+    def __init__(self, V):
+        self.V = V
+        self.parts = TestFunctions(V)
+
+
+_split_function = split
+
+
+def split(obj):  # noqa: F811 - ufl.split of a Function or of a TestFunction
+    """ufl.split(sol) (obstacle_pg.py:88-89) / ufl.split(TestFunction(Z))."""
+    if isinstance(obj, _ArgumentTuple):
+        return obj.parts
+    return _split_function(obj)
+
+
+def _gateaux(e, u, test):
+    """d/d eps e(u + eps test)|_0 for the expression subset: linear in the components of `u` replaced by the test functions,
+    product / inner rules, grad linear, exp' = exp, sqrt' = 1/(2 sqrt)."""
+    if isinstance(e, Number):
+        return None
+    if isinstance(e, Terminal):
+        return test[e.index] if (e.kind == "component" and e.obj is u) else None
+    if isinstance(e, Sum):
+        a, b = _gateaux(e.a, u, test), _gateaux(e.b, u, test)
+        return a if b is None else b if a is None else Sum(a, b)
+    if isinstance(e, Scaled):
+        a = _gateaux(e.a, u, test)
+        return None if a is None else Scaled(e.c, a)
+    if isinstance(e, (Product, Inner)):
+        mk = Product if isinstance(e, Product) else Inner
+        da, db = _gateaux(e.a, u, test), _gateaux(e.b, u, test)
+        parts = ([mk(da, e.b)] if da is not None else []) + ([mk(e.a, db)] if db is not None else [])
+        return None if not parts else parts[0] if len(parts) == 1 else Sum(parts[0], parts[1])
+    if isinstance(e, Division):
+        if _gateaux(e.b, u, test) is not None:
+            raise NotImplementedError("derivative of a quotient whose denominator depends on the unknown")
+        a = _gateaux(e.a, u, test)
+        return None if a is None else Division(a, e.b)
+    if isinstance(e, Grad):
+        a = _gateaux(e.a, u, test)
+        return None if a is None else Grad(a)
+    if isinstance(e, Func):
+        if e.name == "exp":
+            a = _gateaux(e.args[0], u, test)
+            return None if a is None else Product(e, a)
+        if all(_gateaux(a, u, test) is None for a in e.args):
+            return None
+        raise NotImplementedError(f"derivative of {e.name}(...) with respect to the unknown")
+    raise TypeError(type(e).__name__)
+
+
 def derivative(F, u, du=None):
+    """ufl.derivative.  Of a residual form with respect to the unknown (obstacle_pg.py:125): a marker - the HIP families assemble
+    their exact Jacobians themselves.  Of an ENERGY functional with a TestFunction direction (intersecting_constraints_dolfinx.py:48,
+    `derivative(E, z, z_test)`): the Gateaux derivative, symbolically, as a Form."""
+    if isinstance(du, _ArgumentTuple):
+        out = []
+        for it in F.integrals:
+            d = _gateaux(it.integrand, u, du.parts)
+            if d is not None:
+                out.append(Integral(d, it.measure, it.scale))
+        return Form(out)
     return Derivative(F, u)
 
 
@@ -411,6 +502,29 @@ def _thermoforming_template(degree, roles_present):
     return F
 
 
+def _gradient_constraint_template(degree, roles_present):
+    """The residual of gradient_constraint_dolfinx.py:100-107 in terms of roles: u scalar, psi / psi0 / w vector-valued."""
+    u, v = _role("u"), _role("v")
+    psi, psi0, w = _role("psi", 1), _role("psi0", 1), _role("w", 1)
+    alpha, f, phi = _role("alpha"), _role("f"), _role("phi")
+    dx = Measure("dx", metadata={"quadrature_degree": degree})
+    F = alpha * inner(grad(u), grad(v)) * dx + inner(psi, grad(v)) * dx - alpha * inner(f, v) * dx - inner(psi0, grad(v)) * dx
+    F += inner(grad(u), w) * dx - phi * (1 / sqrt(1 + dot(psi, psi))) * dot(psi, w) * dx
+    return F
+
+
+@dataclass
+class GradientConstraintSpec:
+    """Example 06 (gradient_constraint_dolfinx.py:38-107): sol = (u, psi) in [P_k, (P_{k-1})^2], previous iterate w0, bound phi and
+    source f as Functions of the collapsed primal space."""
+    sol: fem.Function
+    w0: fem.Function
+    alpha: fem.Constant
+    phi: fem.Function
+    f: fem.Function
+    quadrature_degree: int
+
+
 @dataclass
 class ThermoformingSpec:
     """Example 05 (thermoforming_dolfinx.py:28-71): s = (u, T, psi) in [P1]^3, g with knees bound0 < bound1, eps of the
@@ -426,6 +540,59 @@ class ThermoformingSpec:
     quadrature_degree: int | None
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# latent-variable rows: the building blocks the family templates share, and their COMPOSITION
+# ---------------------------------------------------------------------------------------------------------------------
+def exp_latent_rows(u, psi, psi_prev, v, w, phi, dx):
+    """Rows an obstacle-type constraint u >= phi adds (obstacle_pg.py:118-123): (psi - psi_prev, v) in the primal equation and
+    the latent equation (u, w) - (exp(psi), w) - (phi, w)."""
+    return inner(psi, v) * dx - inner(psi_prev, v) * dx + inner(u, w) * dx - inner(exp(psi), w) * dx - inner(phi, w) * dx
+
+
+def hellinger_latent_rows(u, psi, psi_prev, v, w, phi, dx):
+    """Rows a gradient bound |grad u| <= phi adds (gradient_constraint_dolfinx.py:101-107): (psi - psi_prev, grad v) in the primal
+    equation and the latent equation (grad u, w) - (phi psi / sqrt(1 + psi.psi), w)."""
+    return (inner(psi, grad(v)) * dx - inner(psi_prev, grad(v)) * dx + inner(grad(u), w) * dx
+            - inner(phi * psi / sqrt(1 + dot(psi, psi)), w) * dx)
+
+
+def compose(primal_rows: Form, constraints):
+    """Residual of a problem with SEVERAL latent variables on one primal field - example 08's structure
+    (intersecting_constraints_dolfinx.py:47-58: an obstacle AND a gradient bound): the primal rows plus, per constraint,
+    ("exp" | "hellinger", u, psi, psi_prev, v, w, phi, dx).  The forms of examples 01 and 06 are compose() with one constraint."""
+    F = primal_rows
+    for kind, *args in constraints:
+        F = F + {"exp": exp_latent_rows, "hellinger": hellinger_latent_rows}[kind](*args)
+    return F
+
+
+def canonical_by_position(F: Form):
+    """Canonical monomials of a form with every terminal named by what it IS (component i of function k, test function i,
+    constant k, ...) in order of first appearance of the underlying objects: two forms over the same objects compare equal iff
+    they are equal as polynomials in their terminals."""
+    objs, names = [], {}
+
+    def oid(o):
+        for k, q in enumerate(objs):
+            if q is o:
+                return k
+        objs.append(o)
+        return len(objs) - 1
+
+    for t in terminals(F):
+        tag = {"component": "fn", "argument": "test", "constant": "c", "quadrature": "q", "coefficient": "coef", "coordinate": "x",
+               "role": "role"}[t.kind]
+        names[t.key()] = (f"{tag}{oid(t.obj)}[{t.index}]", t.kind == "constant")
+    return canonical(F, names), objs
+
+
+def forms_equal(F: Form, G: Form, tol=1e-14):
+    """Equality of two forms over the same Python objects (Functions, Constants, ...) as polynomials in their terminals."""
+    both = Form(F.integrals + (-G).integrals)
+    c, _ = canonical_by_position(both)
+    return all(abs(v) <= tol for v in c.values())
+
+
 # name, components of the unknown, of the previous iterate, test functions, roles of Constants (required, optional),
 # number of quadrature-space coefficients (role phi), template
 _FAMILIES = [
@@ -435,6 +602,11 @@ _FAMILIES = [
     dict(name="thermoforming QVI (example 05)", comps=("u", "T", "psi"), prev=("u_prev", "T_prev", "psi_prev"),
          args=("v", "q", "w"), required=("alpha", "beta", "f", "bound0", "bound1"), optional=("eps",), quads=0,
          needs_degree=False, template=_thermoforming_template, text="the residual of thermoforming_dolfinx.py:62-67"),
+    # vector latent variable: component ranks (0, 1); phi and f are coefficient Functions of the collapsed primal space
+    dict(name="gradient constraint (example 06)", comps=("u", "psi"), prev=("u0", "psi0"), args=("v", "w"), ranks=(0, 1),
+         required=("alpha",), optional=(), coefs=("phi", "f"), quads=0, needs_degree=True, template=_gradient_constraint_template,
+         text="alpha*inner(grad(u),grad(v)) + inner(psi,grad(v)) - alpha*f*v - inner(psi0,grad(v)) + inner(grad(u),w) "
+              "- phi*dot(psi,w)/sqrt(1+dot(psi,psi))"),
 ]
 
 
@@ -459,6 +631,8 @@ def _match(F: Form, u: fem.Function):
     consts = [t for t in terms if t.kind == "constant"]
     quads = [t for t in terms if t.kind == "quadrature"]
     coords = [t for t in terms if t.kind == "coordinate"]
+    coefs = [t for t in terms if t.kind == "coefficient"]
+    ranks = tuple(_comp_rank(V, i) for i in range(V.ncomp))
     degrees = {it.measure.degree for it in F.integrals}
     if len(degrees) != 1:
         raise NotImplementedError("all integrals must use one measure")
@@ -467,7 +641,8 @@ def _match(F: Form, u: fem.Function):
     for fam in _FAMILIES:
         nreq, nall = len(fam["required"]), len(fam["required"]) + len(fam["optional"])
         if (V.ncomp != len(fam["comps"]) or len(others) != 1 or len(quads) != fam["quads"] or not nreq <= len(consts) <= nall
-                or (fam["needs_degree"] and degree is None)):
+                or (fam["needs_degree"] and degree is None) or ranks != fam.get("ranks", (0,) * V.ncomp)
+                or len(coefs) != len(fam.get("coefs", ()))):
             continue
         fixed = {}
         for t in comps:
@@ -480,7 +655,8 @@ def _match(F: Form, u: fem.Function):
             fixed[t.key()] = ("xyz"[t.index], False)
         best = None
         templates = {}
-        for perm in itertools.permutations(fam["required"] + fam["optional"], len(consts)):
+        for cperm in itertools.permutations(fam.get("coefs", ())):  # which coefficient Function plays which role
+          for perm in itertools.permutations(fam["required"] + fam["optional"], len(consts)):
             if not set(fam["required"]) <= set(perm):
                 continue
             present = frozenset(perm)
@@ -491,11 +667,14 @@ def _match(F: Form, u: fem.Function):
             names = dict(fixed)
             for t, r in zip(consts, perm):
                 names[t.key()] = (r, True)
+            for t, r in zip(coefs, cperm):
+                names[t.key()] = (r, False)
             got = canonical(F, names)
             diff = {k: got.get(k, 0.0) - template.get(k, 0.0) for k in set(got) | set(template)}
             diff = {k: c for k, c in diff.items() if abs(c) > 1e-14}
             if not diff:
                 roles = {r: t.obj for t, r in zip(consts, perm)}
+                roles.update({r: t.obj for t, r in zip(coefs, cperm)})
                 roles.update(unknown=u, previous=others[0], quads=[t.obj for t in quads])
                 return fam, roles, degree
             if best is None or len(diff) < len(best):
@@ -503,7 +682,7 @@ def _match(F: Form, u: fem.Function):
         problems.append(f"{fam['name']}: terms that differ from {fam['text']}: " + _describe(best or {}))
     raise NotImplementedError("the form matches no problem family implemented in HIP" +
                               ("".join("\n  " + p for p in problems) if problems else
-                               " (expected the mixed unknown and its previous iterate of example 01 or 05 with their Constants)"))
+                               " (expected the mixed unknown and its previous iterate of example 01, 05 or 06 with their Constants)"))
 
 
 def compile_form(F: Form, u: fem.Function, J=None):
@@ -519,6 +698,10 @@ def compile_form(F: Form, u: fem.Function, J=None):
             raise NotImplementedError("J must be derivative(G, u) of a form G with respect to the unknown")
         G = J.form
     V = u.function_space
+    if fam["name"].startswith("gradient constraint"):
+        if G is not None and G is not F:
+            raise NotImplementedError("example 06 passes no Jacobian form: NonlinearProblem differentiates F (gradient_constraint_dolfinx.py:113)")
+        return GradientConstraintSpec(u, r["previous"], r["alpha"], r["phi"], r["f"], degree)
     if fam["name"].startswith("obstacle"):
         if G is not None and G is not F:
             famG, rG, _ = _match(G, u)

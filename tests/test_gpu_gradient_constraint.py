@@ -163,3 +163,15 @@ def test_gmres_safeguard_of_the_linear_solve(require_gpu, monkeypatch):
     assert its == list(its_ref)
     assert _rel(x[: prob.n2], x_ref[: prob.n2]) < 1e-10
     assert lin > sum(its)  # more LU solves than Newton steps although refinement is off: GMRES ran
+
+
+def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
+    """gradient_constraint_dolfinx.py:36-132 stated through the UFL-subset front end (elements, mixed space, collapsed coefficient
+    space, residual form, NonlinearProblem) reproduces the declarative driver: Newton counts and iterate."""
+    from proximalgalerkin_amd.gradient_constraint import solve_problem, solve_problem_forms
+
+    its, diffs, x = solve_problem(10, 10, verbose=False, return_solution=True)
+    its_f, diffs_f, sol = solve_problem_forms(10, 10)
+    assert list(its_f) == list(its)
+    assert np.allclose(diffs_f, diffs, rtol=1e-9, atol=1e-14)
+    assert np.linalg.norm(sol.x.array - x) <= 1e-12 * np.linalg.norm(x)

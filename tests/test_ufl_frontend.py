@@ -168,3 +168,103 @@ def test_thermoforming_variants_are_refused():
     other = fem.Function(s.function_space)
     with pytest.raises(NotImplementedError):
         ufl.compile_form(F, s, ufl.derivative(G, other))
+
+
+# ---- vector-valued latent variables (example 06) and composition (example 08) --------------------------------------------------
+def _gc_setting(N=4):
+    m = fem.create_unit_square(N, N)
+    V = fem.functionspace(m, fem.mixed_element([fem.element("Lagrange", "triangle", 2), fem.element("Lagrange", "triangle", 1, shape=(2,))]))
+    sol, w0 = fem.Function(V), fem.Function(V)
+    U, U_to_W = V.sub(0).collapse()
+    phi, f = fem.Function(U), fem.Function(U)
+    return m, V, sol, w0, U, phi, f
+
+
+def test_example06_form_is_recognised_however_it_is_written():
+    """gradient_constraint_dolfinx.py:100-107 verbatim, and with the nonlinear term written as example 08 writes it."""
+    m, V, sol, w0, U, phi, f = _gc_setting()
+    assert V.num_dofs == 81 + 2 * 25 and V.component_rank(1) == 1 and U.num_dofs == 81
+    u, psi = ufl.split(sol)
+    v, w = ufl.TestFunctions(V)
+    _, psi0 = ufl.split(w0)
+    dx = ufl.Measure("dx", domain=m, metadata={"quadrature_degree": 10})
+    alpha = fem.Constant(m, 1.0)
+    F = alpha * ufl.inner(ufl.grad(u), ufl.grad(v)) * dx
+    F += ufl.inner(psi, ufl.grad(v)) * dx
+    F -= alpha * ufl.inner(f, v) * dx
+    F -= ufl.inner(psi0, ufl.grad(v)) * dx
+    F += ufl.inner(ufl.grad(u), w) * dx
+    non_lin_term = 1 / (ufl.sqrt(1 + ufl.dot(psi, psi)))
+    F -= phi * non_lin_term * ufl.dot(psi, w) * dx
+    spec = ufl.compile_form(F, sol)
+    assert isinstance(spec, ufl.GradientConstraintSpec)
+    assert spec.phi is phi and spec.f is f and spec.w0 is w0 and spec.alpha is alpha and spec.quadrature_degree == 10
+    G = (alpha * ufl.inner(ufl.grad(u), ufl.grad(v)) * dx - alpha * ufl.inner(f, v) * dx
+         + ufl.compose(ufl.Form([]), [("hellinger", u, psi, psi0, v, w, phi, dx)]))
+    assert isinstance(ufl.compile_form(G, sol), ufl.GradientConstraintSpec) and ufl.forms_equal(F, G)
+    # phi and f swapped, a sign flipped, exp in place of the Hellinger map: none of these is example 06
+    bad1 = F + alpha * ufl.inner(f, v) * dx - alpha * ufl.inner(phi, v) * dx + phi * non_lin_term * ufl.dot(psi, w) * dx - f * non_lin_term * ufl.dot(psi, w) * dx
+    assert ufl.compile_form(bad1, sol).phi is f  # consistently swapped roles are simply the other assignment
+    for bad in (F + 2.0 * ufl.inner(psi0, ufl.grad(v)) * dx, F + ufl.inner(psi, w) * dx):
+        with pytest.raises(NotImplementedError):
+            ufl.compile_form(bad, sol)
+
+
+def test_example08_residual_is_the_composition_of_the_obstacle_and_the_gradient_rows():
+    """SURVEY's acceptance test for the front end: intersecting_constraints_dolfinx.py:17-58 - three components (u, psi0, psi),
+    energy derivative, BOTH latent maps - stated verbatim (on a 2-D mesh: the Mesh type here is 2-D; the form is dimension-blind)
+    equals, as a polynomial in its terminals, the primal rows + example 01's latent rows for psi0 + example 06's for psi."""
+    mesh = fem.create_unit_square(3, 3)
+    el_s = fem.element("Lagrange", "triangle", 1)
+    el_v = fem.element("Lagrange", "triangle", 1, shape=(2,))
+    Z = fem.functionspace(mesh, fem.mixed_element([el_s, el_s, el_v]))
+    z = fem.Function(Z, name="Solution")
+    (u, psi0, psi) = ufl.split(z)
+    z_test = ufl.TestFunction(Z)
+    (v, w0, w) = ufl.split(z_test)
+    z_iter = fem.Function(Z, name="PreviousLVPPSolution")
+    (u_iter, psi0_iter, psi_iter) = ufl.split(z_iter)
+    c = fem.Constant(mesh, 0.0)
+    dx = ufl.dx(domain=mesh)
+    E = 0.5 * ufl.inner(ufl.grad(u), ufl.grad(u)) * dx + c * u * dx
+    x = ufl.SpatialCoordinate(mesh)[0]
+    (l, r) = (0.2, 0.8)
+    bump = ufl.exp(-1 / (10 * (x - l) * (r - x))) / ufl.exp(-1 / (10 * (0.5 - l) * (r - 0.5)))
+    phi0 = ufl.conditional(ufl.le(x, l), 0, ufl.conditional(ufl.ge(x, r), 0, bump))
+    phic = fem.Constant(mesh, 100.0)
+    phi = ufl.conditional(ufl.le(x, 0.2), phic, ufl.conditional(ufl.gt(x, 0.8), phic, 100))
+    alpha = fem.Constant(mesh, 1.0)
+    F = (
+        alpha * ufl.derivative(E, z, z_test)
+        + ufl.inner(psi0, v) * dx
+        + ufl.inner(psi, ufl.grad(v)) * dx
+        - ufl.inner(psi0_iter, v) * dx
+        - ufl.inner(psi_iter, ufl.grad(v)) * dx
+        + ufl.inner(u, w0) * dx
+        - ufl.inner(ufl.exp(psi0), w0) * dx
+        - ufl.inner(phi0, w0) * dx
+        + ufl.inner(ufl.grad(u), w) * dx
+        - ufl.inner(phi * psi / ufl.sqrt(1 + ufl.dot(psi, psi)), w) * dx
+    )
+    primal = alpha * ufl.inner(ufl.grad(u), ufl.grad(v)) * dx + alpha * c * v * dx  # = alpha dE/du[v]
+    G = ufl.compose(primal, [("exp", u, psi0, psi0_iter, v, w0, phi0, dx), ("hellinger", u, psi, psi_iter, v, w, phi, dx)])
+    assert ufl.forms_equal(F, G)
+    # and it is NOT the composition with the maps exchanged or with one constraint dropped
+    assert not ufl.forms_equal(F, ufl.compose(primal, [("exp", u, psi0, psi0_iter, v, w0, phi0, dx)]))
+    H = ufl.compose(primal, [("exp", u, psi0, psi0_iter, v, w0, phi, dx), ("hellinger", u, psi, psi_iter, v, w, phi0, dx)])
+    assert not ufl.forms_equal(F, H)
+    # no fused kernel family exists for the composition: selection refuses, naming what it is
+    with pytest.raises(NotImplementedError):
+        ufl.compile_form(F, z)
+
+
+def test_gateaux_derivative_of_an_energy():
+    m, V, sol, w0, U, phi, f = _gc_setting()
+    u, psi = ufl.split(sol)
+    zt = ufl.TestFunction(V)
+    v, w = ufl.split(zt)
+    dx = ufl.dx(domain=m)
+    E = 0.5 * ufl.inner(ufl.grad(u), ufl.grad(u)) * dx + 0.5 * ufl.inner(psi, psi) * dx + ufl.exp(u) * dx - f * u * dx
+    dE = ufl.derivative(E, sol, zt)
+    expect = ufl.inner(ufl.grad(u), ufl.grad(v)) * dx + ufl.inner(psi, w) * dx + ufl.exp(u) * v * dx - f * v * dx
+    assert ufl.forms_equal(dE, expect)
