@@ -35,6 +35,15 @@ struct MixedBase {
   pgx_nd* lu = nullptr;
   double* gm_V = nullptr;  // Krylov basis of the GMRES safeguard (allocated on first use)
   int gm_m = 0;
+  // Lazy refactorisation (EXPERIMENT, off: PGX_LAZY_LU=1 enables): from the second Newton step of a solve on, the factorisation
+  // of the EARLIER iterate first serves as preconditioner of GMRES on the current exact Jacobian; only if that does not reach
+  // the linear tolerance within `lazy_budget` iterations is the matrix factorised again.  Measured (tools/lazy_lu_ab.py): it
+  // NEVER pays on these problems - 0 of 36 stale attempts converged within 10 iterations on example 06 at 1024^2 (13.8 -> 16.8 s),
+  // 0 of 3 on example 02 at 70^3: between two Newton iterates the latent block N(psi) / D(psi) moves by orders of magnitude
+  // where the constraint switches, and the 1e-12 true-residual bar leaves a stale factorisation no room.
+  int lazy_lu = 0, lazy_budget = 10;
+  bool lu_factored = false, stale_failed = false;
+  long lazy_hits = 0, lazy_misses = 0, lazy_its = 0;
   // distributed handles (one per GPU, replicated iterate, distributed LU): every scalar that steers control flow - norms,
   // dot products of the line search - is taken from rank 0, so that all ranks make the same collective calls even though
   // their redundantly assembled residuals differ in the last bits (atomics)
@@ -229,12 +238,17 @@ static int mx_alloc_state(MixedBase* h) {
   MXHIP(hipMemsetAsync(h->xk, 0, sizeof(double) * h->ntot, h->st));
   hipEventCreate(&h->e0);
   hipEventCreate(&h->e1);
+  if (const char* e = getenv("PGX_LAZY_LU")) h->lazy_lu = atoi(e);
+  if (const char* e = getenv("PGX_LAZY_BUDGET")) h->lazy_budget = std::max(1, atoi(e));
   return PGX_OK;
 }
 
 static void mx_release(MixedBase* h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
+  if (getenv("PGX_LAZY_REPORT"))
+    fprintf(stderr, "pgx: lazy refactorisation: %ld Newton systems solved with a stale LU (%ld LU solves), %ld attempts fell back\n",
+            h->lazy_hits, h->lazy_its, h->lazy_misses);
   if (h->lu) pgx_nd_destroy(h->lu);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_out) hipHostFree(h->h_out);
@@ -258,7 +272,8 @@ static int mx_out(MixedBase* h, double* dst, const double* src, int64_t len = 0)
 
 // dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
 static int mx_dot(MixedBase* h, const double* a, const double* b, double* out);
-static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres);
+static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres,
+                       int max_cycles = 3, int max_m = 12);
 static int mx_linear_solve_ok(MixedBase* h, const double* b, const double* dx, double relres, bool* ok);
 
 // J dx = b by the sparse LU + iterative refinement on the exact operator (the reference: ksp_type preonly + MUMPS).  The LU
@@ -308,6 +323,48 @@ static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_
   return PGX_OK;
 }
 
+
+// One Newton linear system J dx = rhs (Jv holds J at the current iterate).  newton_it = 0: factorise and solve (LU + refinement,
+// GMRES safeguard).  Later steps: first the stale factorisation as GMRES preconditioner (see MixedBase::lazy_lu).
+static int mx_newton_linear(MixedBase* h, const pgx_snes_opts* opts, int newton_it, int* ns, double* relres) {
+  int rc;
+  *ns = 0;
+  if (h->lazy_lu && newton_it > 0 && h->lu_factored && !h->stale_failed) {
+    const double tol = opts->ksp_rtol > 0.0 ? opts->ksp_rtol : 1e-12;
+    double bnorm = 0;
+    if ((rc = mx_norm(h, h->rhs, &bnorm))) return rc;
+    if (bnorm > 0.0 && std::isfinite(bnorm)) {
+      MXHIP(hipMemsetAsync(h->dx, 0, sizeof(double) * h->ntot, h->st));
+      MXHIP(hipMemcpyAsync(h->r, h->rhs, sizeof(double) * h->ntot, hipMemcpyDeviceToDevice, h->st));  // r = b - J 0
+      *relres = 1.0;
+      if ((rc = mx_gmres_lu(h, h->rhs, h->dx, bnorm, tol, ns, relres, 1, h->lazy_budget))) return rc;
+      h->lazy_its += *ns;
+      if (std::isfinite(*relres) && *relres <= tol) {
+        ++h->lazy_hits;
+        if (opts->monitor > 1) printf("      stale LU + GMRES: %d solves, true rel residual %.3e\n", *ns, *relres);
+        return PGX_OK;
+      }
+      ++h->lazy_misses;
+      h->stale_failed = true;  // the matrix is moving too fast in this solve: factorise from here on
+      if (opts->monitor > 1) printf("      stale LU + GMRES gave %.3e after %d solves: refactorising\n", *relres, *ns);
+    }
+  }
+  {
+    MxTimer t(h, 2);
+    rc = pgx_nd_factor(h->lu, h->Jv, 1);
+  }
+  if (rc) {
+    h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+    h->lu_factored = false;
+    return rc;
+  }
+  h->lu_factored = true;
+  int ns2 = 0;
+  rc = mx_linear_solve(h, h->rhs, h->dx, opts, &ns2, relres);
+  *ns += ns2;
+  return rc;
+}
+
 // A linear solve whose true relative residual stays above 1e-7 is a failure (SNES_DIVERGED_LINEAR_SOLVE) - unless the
 // residual is at the rounding level of the operator itself: normwise backward error |b - J dx| / (| |J| |dx| | + |b|)
 // <= 1e-13.  (Late Newton steps on very fine meshes have right-hand sides of 1e-8 against |J| |dx| of 1e-1: 1e-7 relative
@@ -337,6 +394,7 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
   const size_t bytes = sizeof(double) * h->ntot;
   int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
   double fnorm = 0, fnorm0 = 0;
+  h->stale_failed = false;
   MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
   h->residual_dev(h->xw, h->F);
   if ((rc = mx_replica_check(h, h->F, "the residual"))) return rc;
@@ -354,18 +412,10 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
       break;
     }
     h->jacobian_dev(h->xw);
-    {
-      MxTimer t(h, 2);
-      rc = pgx_nd_factor(h->lu, h->Jv, 1);
-    }
-    if (rc) {
-      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
-      return rc;
-    }
     mx_axpby(h, -1.0, h->F, 0.0, h->rhs);
     int ns = 0;
     double relres = 0;
-    if ((rc = mx_linear_solve(h, h->rhs, h->dx, opts, &ns, &relres))) return rc;
+    if ((rc = mx_newton_linear(h, opts, its, &ns, &relres))) return rc;
     lin += ns;
     ++its;
     if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
@@ -459,16 +509,18 @@ static int mx_dot(MixedBase* h, const double* a, const double* b, double* out) {
 
 // Right-preconditioned GMRES(m) on the exact operator with the (inaccurate) LU as preconditioner, from the current dx;
 // h->r holds b - J dx on entry.  Modified Gram-Schmidt, Givens rotations, the true residual decides.  At most 3 cycles of 12.
-static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres) {
+static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres,
+                       int max_cycles, int max_m) {
   const int m = 12;
   if (!h->gm_V) {
     const int rca = mx_alloc(h, &h->gm_V, (size_t)(m + 1) * h->ntot);
     if (rca) return rca;
     h->gm_m = m;
   }
+  max_m = std::min(std::max(max_m, 1), m);
   auto V = [&](int j) { return h->gm_V + (size_t)j * h->ntot; };
   int rc = PGX_OK;
-  for (int cycle = 0; cycle < 3; ++cycle) {
+  for (int cycle = 0; cycle < max_cycles; ++cycle) {
     double beta = 0;
     if ((rc = mx_norm(h, h->r, &beta))) return rc;
     if (!(beta > 0.0) || !std::isfinite(beta)) break;
@@ -476,7 +528,7 @@ static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, 
     std::vector<double> H((m + 1) * m, 0.0), cs(m, 0.0), sn(m, 0.0), g(m + 1, 0.0);
     g[0] = beta;
     int k = 0;
-    for (int j = 0; j < m; ++j) {
+    for (int j = 0; j < max_m; ++j) {
       {
         MxTimer t(h, 3);
         if ((rc = pgx_nd_solve(h->lu, V(j), h->z, 1))) {
@@ -555,6 +607,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
   const size_t bytes = sizeof(double) * h->ntot;
   int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
   double fnorm = 0, fnorm0 = 0;
+  h->stale_failed = false;
   MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
   h->residual_dev(h->xw, h->F);
   if ((rc = mx_replica_check(h, h->F, "the residual"))) return rc;
