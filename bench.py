@@ -244,9 +244,18 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
         }
         if not args.no_cpu_baseline and world == 1:
             steps, secs, what = cpu_leg(25.0)
+            n_cpu = args.cpu_n // 8 if args.workload == "ex06" else 14
+            n_gpu = N if args.workload == "ex06" else n
             out["cpu_baseline"] = {"value": steps / secs, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
+                                   # MEASURED here, on the mesh named in `mesh`; `at_workload` carries it to the benchmarked mesh
+                                   "mesh": f"{n_cpu} cells per side", "workload_mesh": f"{n_gpu} cells per side",
                                    "sample": f"{steps} Newton steps ({secs:.1f} s) of {what}: numpy assembly + SuperLU exact "
-                                             "Newton, 1 thread (the oracle; a stand-in for, not a measurement of, FEniCSx+MUMPS)"}
+                                             "Newton, 1 thread (the oracle; a stand-in for, not a measurement of, FEniCSx+MUMPS)",
+                                   **host_info()}
+            ex = extrapolate(steps / secs, n_cpu, n_gpu, _ladder(f"r02_cpu_ladder_{args.workload}.json"))
+            if ex:
+                ex["gpu_over_cpu"] = out["value"] / ex["value"]
+                out["cpu_baseline"]["at_workload"] = ex
     problem.close()
     if comm is not None:
         comm.free()
