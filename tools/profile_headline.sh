@@ -13,7 +13,9 @@ for what in "$@"; do
   case $what in
     stats)
       rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
-      cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv ;;
+      cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+      rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1 || exit 1
+      python3 tools/trace_by_grid.py $OUT/trace > $OUT/trace_by_level.txt; rm -rf $OUT/trace ;;
     spmv)
       rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 tools/spmv_bench.py 2048 > $OUT/pmc_fetch.log 2>&1 || exit 1
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 tools/spmv_bench.py 2048 > $OUT/pmc_write.log 2>&1 || exit 1
@@ -24,7 +26,7 @@ for what in "$@"; do
         --kernel-trace --output-format csv -d $OUT/pmc_sqA -o a -- $BENCH > $OUT/pmc_sqA.log 2>&1 || exit 1
       rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM \
         --kernel-trace --output-format csv -d $OUT/pmc_sqB -o b -- $BENCH > $OUT/pmc_sqB.log 2>&1 || exit 1
-      for k in k_st_smoothK k_st_resid_restrict k_bspmv_stream k_resid_fill_p1; do
+      for k in k_st_smoothR k_st_resid_restrict_r k_bspmv_stream k_resid_fill_p1 k_multiaxpy_norm; do
         python3 tools/pmc_summary.py --kernel $k --out $OUT/pmc_sq_$k.json $OUT/pmc_sqA $OUT/pmc_sqB > /dev/null || true
       done ;;
   esac
