@@ -412,6 +412,14 @@ def main():
     spmv_ms, spmv_bytes = problem.spmv_bench(reps=50)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     n = msh.num_vertices
+    smoother = None
+    if not sharded and args.degree == 1:
+        sm_ms, sm_bytes = problem.smoother_bench(reps=50)
+        smoother = {"kernel": "k_st_smoothR<16,3,POST> on the finest level (three collective-Jacobi sweeps + x + P x_c per launch; 24 % "
+                              "of the solve, the time-dominant kernel; profiles/r02_bench_2048_trace_by_level.txt)",
+                    "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
     prof = problem.profile() if args.profile else None
     if sharded:
         parallelism = (f"sharded: ONE {N}x{N} solve on {world} strips of {N // world} vertex rows (+ ghost rows, "
@@ -476,6 +484,8 @@ def main():
                                             / (spmv_ms * 1e-3) / 1e9,
             },
         }
+        if smoother:
+            out["roofline_dominant"] = smoother
         if prof:
             out["phase_ms"] = prof
         if not args.no_cpu_baseline and world == 1:

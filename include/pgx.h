@@ -147,6 +147,11 @@ int pgx_spmv(pgx_handle* h, const double* x, double* y);
 /* Time `reps` back-to-back SpMV launches on device-resident data with HIP events on the handle's
  * stream; returns average ms per launch and the algorithmic bytes one launch moves. */
 int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+/* The same for the TIME-DOMINANT kernel of the multigrid-preconditioned solve: the fused three-sweep smoother of the finest
+ * level (k_st_smoothR, post-smoothing variant: x + P x_c folded in), at the Jacobian of the last pgx_jacobian_fill.
+ * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,
+ * the new iterate (2) written.  PGX_ESTATE on meshes without a grid hierarchy. */
+int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
 
 /* One nonlinear solve from device `sol` with proximal centre `sol_k`; on reason>0 `sol` is replaced. */
 int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its);

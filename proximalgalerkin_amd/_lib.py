@@ -177,6 +177,7 @@ SYMBOLS = [
      [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
     ("pgx_spmv", C.c_int, [_H, c_double_p, c_double_p]),
     ("pgx_spmv_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_smoother_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
     ("pgx_newton_solve", C.c_int,
      [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pgx_observables", C.c_int, [_H, c_double_p]),

@@ -1856,6 +1856,37 @@ extern "C" int pgx_spmv(pgx_handle* h, const double* x, double* y) {
   return copy_out(h, y, h->w);  // owned rows are J x of the GLOBAL operator; ghost rows are not meaningful
 }
 
+extern "C" int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
+  NEED(h);
+  if (reps < 1 || !avg_ms) return PGX_EINVAL;
+  if (!h->jac_valid || !h->structured || h->lev.size() < 2 || h->dist.on) {
+    h->err = "pgx_smoother_bench needs a structured single-GPU handle with a grid hierarchy and a filled Jacobian";
+    return PGX_ESTATE;
+  }
+  GridLevel& L = h->lev[0];
+  GridLevel& C = h->lev[1];
+  const size_t n = (size_t)L.n;
+  // right-hand side and iterate: any finite data (the kernel's cost does not depend on the values); coarse correction zero
+  pgxk_set(h->st, 2 * n, 1.0, h->rhs);
+  pgxk_set(h->st, 2 * n, 0.5, h->w);
+  HIPCHK(hipMemsetAsync(C.xu, 0, sizeof(double) * C.n, h->st));
+  HIPCHK(hipMemsetAsync(C.xp, 0, sizeof(double) * C.n, h->st));
+  const int remap = h->xcd_remap ? 1 : 0;
+  auto run = [&]() {
+    pgxk_st_smoothK(h->st, 3, 1, L, h->alpha, h->w, h->w + n, &C, C.xu, C.xp, h->rhs, h->rhs + n, 0.8, remap, h->tmp_u, h->tmp_p);
+  };
+  for (int k = 0; k < 3; ++k) run();
+  HIPCHK(hipEventRecord(h->e0, h->st));
+  for (int k = 0; k < reps; ++k) run();
+  HIPCHK(hipEventRecord(h->e1, h->st));
+  HIPCHK(hipEventSynchronize(h->e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
+  *avg_ms = (double)ms / reps;
+  if (bytes) *bytes = 8.0 * (4.0 * n + 2.0 * n + 2.0 * n + 2.0 * C.n + 2.0 * n);
+  return PGX_OK;
+}
+
 extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
   NEED(h);
   if (reps < 1 || !avg_ms) return PGX_EINVAL;

@@ -290,7 +290,65 @@ class MixedSpace:
         return SubSpace(self, i)
 
 
+@dataclass(frozen=True)
+class VectorSpace:
+    """functionspace(mesh, ("Lagrange", degree, (gdim,))) (signorini_dolfinx.py:221): vector-valued Lagrange space on a simplicial
+    mesh (`mesh.geometry` (nv, gdim)); dofs blocked by Cartesian component, [u_x | u_y | u_z] - the layout of include/pgx_sg.h."""
+    mesh: object
+    degree: int
+    dim: int
+    ncomp = 1
+
+    def component_rank(self, i):
+        return 1
+
+    @property
+    def num_dofs(self):
+        if self.degree != 1:
+            raise NotImplementedError("vector Lagrange spaces of degree 1")
+        return self.dim * self.mesh.geometry.shape[0]
+
+
+@dataclass(frozen=True)
+class FacetSubMesh:
+    """dolfinx.mesh.create_submesh(mesh, fdim, facets)[0] (signorini_dolfinx.py:207): the contact surface as a mesh of its own;
+    its vertices are the parent's vertices on those facets, ordered by parent vertex id (the psi ordering of include/pgx_sg.h)."""
+    parent: object
+    facets: np.ndarray  # (nf, 3) parent vertex ids
+
+    @property
+    def vertices(self):
+        return np.unique(self.facets)
+
+
+def create_submesh(mesh, dim, facets):
+    """-> (submesh, submesh_to_mesh entity map) like dolfinx.mesh.create_submesh(...)[0:2]; `facets` are vertex triples."""
+    f = np.ascontiguousarray(facets, dtype=np.int32).reshape(-1, 3)
+    return FacetSubMesh(mesh, f), f
+
+
+@dataclass(frozen=True)
+class FacetSpace:
+    """functionspace(submesh, ("Lagrange", 1)) (signorini_dolfinx.py:222): scalar P1 on the contact surface."""
+    mesh: FacetSubMesh
+    degree: int = 1
+    ncomp = 1
+
+    def component_rank(self, i):
+        return 0
+
+    @property
+    def num_dofs(self):
+        return int(len(self.mesh.vertices))
+
+
 def functionspace(mesh, element=("Lagrange", 1), ncomp=2):
+    if isinstance(mesh, FacetSubMesh):
+        if tuple(element)[:2] != ("Lagrange", 1):
+            raise NotImplementedError("P1 on the contact surface")
+        return FacetSpace(mesh)
+    if isinstance(element, tuple) and len(element) == 3 and isinstance(element[2], tuple):  # ("Lagrange", k, (gdim,))
+        return VectorSpace(mesh, int(element[1]), int(element[2][0]))
     if isinstance(element, tuple) and element and isinstance(element[0], Element):  # a mixed_element([...])
         return MixedSpace(mesh, tuple(element))
     if isinstance(element, Element):
@@ -392,19 +450,31 @@ class Function(_FormOperand):
 
     def interpolate(self, fn):
         """Function.interpolate(callable) for a scalar Lagrange space: nodal values at the dof coordinates
-        (gradient_constraint_dolfinx.py:55-61); fn takes x of shape (2, npts)."""
+        (gradient_constraint_dolfinx.py:55-61); fn takes x of shape (2, npts).  Vector P1 spaces (signorini_dolfinx.py:262):
+        fn returns (gdim, npts)."""
         V = self.function_space
+        if isinstance(V, VectorSpace):
+            vals = np.asarray(fn(np.ascontiguousarray(V.mesh.geometry.T)), dtype=np.float64)
+            self.x.array[:] = vals.reshape(V.dim, -1).ravel()
+            return
         if not isinstance(V, FunctionSpace) or V.ncomp != 1:
             raise NotImplementedError("interpolate: scalar Lagrange spaces")
         self.x.array[:] = np.asarray(fn(np.ascontiguousarray(V.dof_coordinates().T)), dtype=np.float64)
 
 
 class Constant(_FormOperand):
+    """fem.Constant(mesh, value): a scalar, or a vector (signorini_dolfinx.py:236-240: n_g, f) whose `.value` array may be edited."""
+
     def __init__(self, mesh, value):
-        self.value = float(value)
+        v = np.asarray(value, dtype=np.float64)
+        self.value = float(v) if v.ndim == 0 else v.copy()
+
+    @property
+    def rank(self):
+        return 0 if isinstance(self.value, float) else 1
 
     def __float__(self):
-        return self.value
+        return float(self.value)
 
 
 class QuadratureFunction(_FormOperand):
@@ -440,10 +510,20 @@ class DirichletBC:
     sub: int             # which component of the mixed space
 
 
-def dirichletbc(value, dofs, V):
-    """fem.dirichletbc(value=u_bc, dofs=dofs, V=V.sub(0)) (obstacle_pg.py:83)."""
+def locate_dofs_topological(V, dim, facets):
+    """dofs of a P1 vector space on the given facets (vertex triples): one block index per vertex - each carries V.dim components
+    (signorini_dolfinx.py:267)."""
+    return np.unique(np.asarray(facets).ravel()).astype(np.int32)
+
+
+def dirichletbc(value, dofs, V=None):
+    """fem.dirichletbc(value=u_bc, dofs=dofs, V=V.sub(0)) (obstacle_pg.py:83); fem.dirichletbc(u_bc, dofs) with u_bc a Function
+    of a vector space (signorini_dolfinx.py:267): `values` is then (gdim, len(dofs))."""
     sub = V.index if isinstance(V, SubSpace) else 0
     dofs = np.ascontiguousarray(dofs, dtype=np.int32)
+    if isinstance(value, Function) and isinstance(value.function_space, VectorSpace):
+        Vv = value.function_space
+        return DirichletBC(dofs, np.ascontiguousarray(value.x.array.reshape(Vv.dim, -1)[:, dofs]), 0)
     if isinstance(value, Function):
         vals = np.ascontiguousarray(value.x.array[:value.function_space.block_size][dofs])
     else:

@@ -312,6 +312,13 @@ class NonlinearProblem:
                    "pgx_spmv_bench")
         return ms.value, by.value
 
+    def smoother_bench(self, reps=20):
+        """(avg ms, algorithmic bytes) of the finest level's fused smoother launch (include/pgx.h: pgx_smoother_bench)."""
+        ms, by = C.c_double(0), C.c_double(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_smoother_bench(self._h, int(reps), C.byref(ms), C.byref(by)),
+                   "pgx_smoother_bench")
+        return ms.value, by.value
+
     def observables(self):
         """[energy, |complementarity|, feasibility, dual feasibility, H1 increment, latent L2 increment]
         of obstacle_pg.py:145-152,196-201 in one device pass."""

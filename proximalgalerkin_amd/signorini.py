@@ -255,3 +255,117 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
         return it, iterations, x, cv
     problem.close()
     return it, iterations
+
+
+class NonlinearProblem:
+    """dolfinx.fem.petsc.NonlinearProblem(F, [u, psi], bcs=bcs, petsc_options=..., entity_maps=entity_maps, kind="mpi") as
+    signorini_dolfinx.py:283-291 builds it, for the blocked residual FORM of :244-252 stated in proximalgalerkin_amd.ufl (tensor
+    algebra sym / tr / Identity, the `ds` measure over the contact tags, MixedFunctionSpace(V, W) with W on the contact
+    sub-mesh).  The front end recognises the family, reads mu and lambda off the coefficients, the gap off g, the contact facets
+    off the measure; `.solve()` / `.solver` behave like the reference's.  u, psi, psi_k are host Functions."""
+
+    def __init__(self, F, u, bcs=None, petsc_options=None, petsc_options_prefix="", entity_maps=None, kind="mpi", device=0):
+        from . import ufl
+
+        spec = ufl.compile_signorini(F, u)
+        V = spec.u.function_space
+        mesh = V.mesh
+        if V.degree != 1 or V.dim != 3:
+            raise NotImplementedError("HIP backend: degree 1 in 3-D (BASELINE.json config 5)")
+        if not bcs or len(bcs) != 1:
+            raise NotImplementedError("one Dirichlet condition on the displacement surface (signorini_dolfinx.py:255-269)")
+        bc = bcs[0]
+        vals = np.asarray(bc.values)
+        if vals.shape[0] != 3 or np.any(vals[:2] != 0.0) or np.any(vals[2] != vals[2, 0]):
+            raise NotImplementedError("Dirichlet data (0, 0, disp) (signorini_dolfinx.py:257-262)")
+        mu, lam = spec.mu, spec.lmbda
+        E, nu = mu * (3.0 * lam + 2.0 * mu) / (lam + mu), lam / (2.0 * (lam + mu))
+        self.spec = spec
+        self._p = SignoriniProblem(mesh, spec.contact_facets, bc.dofs, E, nu, spec.gap, float(vals[2, 0]), spec.quadrature_degree,
+                                   device=device)
+        assert np.array_equal(self._p.contact_vertices, spec.psi.function_space.mesh.vertices)
+        self.solver = self._p.solver
+        self._nu3 = 3 * mesh.geometry.shape[0]
+
+    def solve(self):
+        p, sp = self._p, self.spec
+        p.set_alpha(sp.alpha.value)
+        p.set_state(np.concatenate([sp.u.x.array, sp.psi.x.array]))
+        p.set_prev(np.concatenate([np.zeros(self._nu3), sp.psi_k.x.array]))  # only psi_k enters the residual (:246)
+        p.solve()
+        if p.solver.getConvergedReason() > 0:
+            x = p.get_state()
+            sp.u.x.array[:] = x[: self._nu3]
+            sp.psi.x.array[:] = x[self._nu3:]
+
+    def close(self):
+        self._p.close()
+
+
+def solve_contact_problem_forms(mesh: TetMesh, facet_tag: MeshTags, boundary_conditions: dict, E: float = 2.0e4, nu: float = 0.3,
+                                gap: float = 0.0, disp: float = -0.25, newton_tol: float = 1e-6, max_iterations: int = 25,
+                                alpha_0: float = 1.0, tol: float = 1e-6, quadrature_degree: int = 4, device: int = 0):
+    """signorini_dolfinx.solve_contact_problem (:156-360) with the problem stated as the reference states it: spaces, sub-mesh,
+    measures, the residual form, NonlinearProblem - through the UFL-subset front end.  alpha doubling.  Returns
+    (it, iterations, u Function)."""
+    from . import ufl
+
+    def epsilon(w):  # :146-147
+        return ufl.sym(ufl.grad(w))
+
+    def sigma(w, mu, lmbda):  # :150-153
+        return 2.0 * mu * epsilon(w) + lmbda * ufl.tr(ufl.grad(w)) * ufl.Identity(gdim)
+
+    contact_facets = np.concatenate([facet_tag.find(m) for m in boundary_conditions["contact"]])  # :199-202
+    gdim, fdim = 3, 2
+    submesh, submesh_to_mesh = fem.create_submesh(mesh, fdim, contact_facets)  # :207
+    ds = ufl.Measure("ds", domain=mesh, subdomain_data=facet_tag, subdomain_id=boundary_conditions["contact"],
+                     metadata={"quadrature_degree": quadrature_degree})  # :211-218
+    V = fem.functionspace(mesh, ("Lagrange", 1, (gdim,)))  # :221
+    W = fem.functionspace(submesh, ("Lagrange", 1))  # :222
+    Q = ufl.MixedFunctionSpace(V, W)  # :225
+    v, w = ufl.TestFunctions(Q)
+    u, psi, psi_k = fem.Function(V, name="displacement"), fem.Function(W), fem.Function(W)
+    mu = E / (2.0 * (1.0 + nu))
+    lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    n_g = fem.Constant(mesh, np.zeros(gdim))
+    n_g.value[-1] = -1
+    alpha = fem.Constant(mesh, alpha_0)
+    f = fem.Constant(mesh, np.zeros(gdim))
+    x = ufl.SpatialCoordinate(mesh)
+    g = x[gdim - 1] + fem.Constant(mesh, -gap)
+    residual = alpha * ufl.inner(sigma(u, mu, lmbda), epsilon(v)) * ufl.dx(domain=mesh) - alpha * ufl.inner(f, v) * ufl.dx(domain=mesh)
+    residual += -ufl.inner(psi - psi_k, ufl.dot(v, n_g)) * ds
+    residual += ufl.inner(ufl.dot(u, n_g), w) * ds
+    residual += ufl.inner(ufl.exp(psi), w) * ds - ufl.inner(g, w) * ds
+    F = ufl.extract_blocks(residual)  # :252
+    u_bc = fem.Function(V)
+
+    def disp_func(xx):  # :257-260
+        values = np.zeros((gdim, xx.shape[1]))
+        values[gdim - 1, :] = disp
+        return values
+
+    u_bc.interpolate(disp_func)
+    bc_facets = np.concatenate([facet_tag.find(d) for d in boundary_conditions["displacement"]])  # :265-266
+    bc = fem.dirichletbc(u_bc, fem.locate_dofs_topological(V, fdim, bc_facets))  # :267
+    solver = NonlinearProblem(F, [u, psi], bcs=[bc], petsc_options={"snes_type": "newtonls", "snes_linesearch_type": "none"},
+                              petsc_options_prefix="signorini_", entity_maps=[submesh_to_mesh], kind="mpi", device=device)
+    u_prev = np.zeros_like(u.x.array)
+    iterations = []
+    it = 0
+    for it in range(1, max_iterations + 1):  # :317-358
+        alpha.value = alpha_0 * 2**it
+        solver_tol = 10 * newton_tol if it < 2 else newton_tol
+        solver.solver.setTolerances(atol=solver_tol, rtol=solver_tol)
+        solver.solve()
+        iterations.append(solver.solver.getIterationNumber())
+        normed_diff = float(np.linalg.norm(u.x.array - u_prev))  # :336-339
+        if normed_diff <= tol:
+            break
+        u_prev[:] = u.x.array
+        psi_k.x.array[:] = psi.x.array
+        if solver.solver.getConvergedReason() <= 0:
+            break
+    solver.close()
+    return it, iterations, u

@@ -22,6 +22,8 @@ from __future__ import annotations
 import itertools
 from dataclasses import dataclass
 
+import numpy as np
+
 from . import fem
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -108,9 +110,28 @@ class Division(Expr):
 
 class Grad(Expr):
     def __init__(self, a):
-        if a.rank:
-            raise NotImplementedError("grad of a vector expression")
-        self.a, self.rank = a, 1
+        if a.rank > 1:
+            raise NotImplementedError("grad of a tensor expression")
+        self.a, self.rank = a, a.rank + 1  # grad of a vector field is a rank-2 tensor (signorini_dolfinx.py:146-153)
+
+
+class Sym(Expr):
+    def __init__(self, a):
+        if a.rank != 2:
+            raise ValueError("sym() of a non-tensor")
+        self.a, self.rank = a, 2
+
+
+class Tr(Expr):
+    def __init__(self, a):
+        if a.rank != 2:
+            raise ValueError("tr() of a non-tensor")
+        self.a, self.rank = a, 0
+
+
+class IdentityTensor(Expr):
+    def __init__(self, dim):
+        self.dim, self.rank = int(dim), 2
 
 
 class Inner(Expr):
@@ -136,13 +157,15 @@ def as_expr(o):
     if isinstance(o, (int, float)):
         return Number(o)
     if isinstance(o, fem.Constant):
-        return Terminal("constant", o)
+        return Terminal("constant", o, 0, o.rank)
     if isinstance(o, fem.QuadratureFunction):
         return Terminal("quadrature", o)
     if isinstance(o, fem.Function):
         V = o.function_space
         if isinstance(V, fem.FunctionSpace) and V.ncomp == 1:  # a coefficient in a scalar space (phi, f of example 06)
             return Terminal("coefficient", o)
+        if isinstance(V, (fem.VectorSpace, fem.FacetSpace)):  # blocked problems: each unknown is a Function of its own space
+            return Terminal("field", o, 0, V.component_rank(0))
         raise TypeError("a mixed Function enters a form through split(function)")
     raise TypeError(f"cannot use {type(o).__name__} in a form")
 
@@ -168,6 +191,35 @@ def grad(a):
 
 def inner(a, b):
     return Inner(as_expr(a), as_expr(b))
+
+
+def sym(a):
+    return Sym(as_expr(a))
+
+
+def tr(a):
+    return Tr(as_expr(a))
+
+
+def Identity(dim):
+    return IdentityTensor(dim)
+
+
+class MixedFunctionSpace:
+    """ufl.MixedFunctionSpace(V, W) (signorini_dolfinx.py:225): a blocked space; TestFunctions(Q) gives one test function per block."""
+
+    def __init__(self, *spaces):
+        self.spaces = spaces
+        self.ncomp = len(spaces)
+
+    def component_rank(self, i):
+        return self.spaces[i].component_rank(0)
+
+
+def extract_blocks(form):
+    """ufl.extract_blocks(residual) (signorini_dolfinx.py:252): the blocked residual; kept as one Form here (the families index the
+    blocks by their test functions)."""
+    return form
 
 
 dot = inner  # real-valued: the same contraction for the ranks supported here
@@ -226,10 +278,11 @@ class Measure:
     """ufl.Measure("dx", domain=msh, metadata={"quadrature_degree": q}) (obstacle_pg.py:115); `ufl.dx` is the default cell
     measure (thermoforming_dolfinx.py:14), whose quadrature degree the family picks."""
 
-    def __init__(self, name="dx", domain=None, metadata=None):
-        if name != "dx":
-            raise NotImplementedError("only the cell measure dx is supported by the front end")
+    def __init__(self, name="dx", domain=None, metadata=None, subdomain_data=None, subdomain_id=None):
+        if name not in ("dx", "ds"):
+            raise NotImplementedError("cell measure dx and exterior-facet measure ds")
         self.name, self.domain = name, domain
+        self.subdomain_data, self.subdomain_id = subdomain_data, subdomain_id  # ds: facet tags + the tags integrated over
         self.degree = None if not metadata else metadata.get("quadrature_degree")
 
     def __rmul__(self, o):
@@ -392,18 +445,44 @@ class _Canon:
                 for cb, sb, vb in self.expand(e.b):
                     s = sa + sb
                     if va is not None:
-                        s = s + ("inner(" + ",".join(sorted((va, vb))) + ")",)
+                        if "I" in (va, vb):  # inner(I, X) = tr(X)
+                            other = vb if va == "I" else va
+                            core = other[4:-1] if other.startswith("sym(") else other
+                            if not core.startswith("grad("):
+                                raise NotImplementedError(f"inner(Identity, {other})")
+                            s = s + ("div(" + core[5:-1] + ")",)
+                        else:
+                            s = s + ("inner(" + ",".join(sorted((va, vb))) + ")",)
                     out.append((ca * cb, tuple(sorted(s)), None))
             return out
         if isinstance(e, Grad):
             out = []
-            for c, s, _ in self.expand(e.a):
+            for c, s, vslot in self.expand(e.a):
+                if vslot is not None:  # gradient of a vector field: a tensor slot
+                    if any(not self._const(f) for f in s):
+                        raise NotImplementedError("grad of a product of fields")
+                    out.append((c, s, "grad(" + vslot + ")"))
+                    continue
                 varying = [f for f in s if not self._const(f)]
                 if len(varying) != 1:
                     raise NotImplementedError("grad of a product of fields or of a constant")
                 rest = tuple(f for f in s if self._const(f))
                 out.append((c, rest, "grad(" + varying[0] + ")"))
             return out
+        if isinstance(e, Sym):
+            return [(c, s, "sym(" + v + ")") for c, s, v in self.expand(e.a)]
+        if isinstance(e, Tr):  # tr(grad(u)) = div(u); tr(sym(grad(u))) = div(u); tr(I) = dim
+            out = []
+            for c, s, v in self.expand(e.a):
+                if v == "I":
+                    raise NotImplementedError("tr(Identity)")
+                core = v[4:-1] if v.startswith("sym(") else v
+                if not core.startswith("grad("):
+                    raise NotImplementedError(f"tr({v})")
+                out.append((c, tuple(sorted(s + ("div(" + core[5:-1] + ")",))), None))
+            return out
+        if isinstance(e, IdentityTensor):
+            return [(1.0, (), "I")]
         if isinstance(e, Func):
             return [(1.0, (e.name + "(" + ",".join(self.text(self.combine(self.expand(a))) for a in e.args) + ")",), None)]
         raise TypeError(f"unsupported expression node {type(e).__name__}")
@@ -426,7 +505,7 @@ class _Canon:
             if it.integrand.rank:
                 raise ValueError("the integrand of a form must be scalar")
             for c, s, v in self.expand(it.integrand):
-                k = (it.measure.degree, s)
+                k = (it.measure.degree, s) if it.measure.name == "dx" else ((it.measure.name, it.measure.degree), s)
                 acc[k] = acc.get(k, 0.0) + it.scale * c
         return {k: c for k, c in acc.items() if c != 0.0}
 
@@ -581,7 +660,7 @@ def canonical_by_position(F: Form):
 
     for t in terminals(F):
         tag = {"component": "fn", "argument": "test", "constant": "c", "quadrature": "q", "coefficient": "coef", "coordinate": "x",
-               "role": "role"}[t.kind]
+               "role": "role", "field": "field"}[t.kind]
         names[t.key()] = (f"{tag}{oid(t.obj)}[{t.index}]", t.kind == "constant")
     return canonical(F, names), objs
 
@@ -718,3 +797,94 @@ def compile_form(F: Form, u: fem.Function, J=None):
             raise NotImplementedError("J must be the derivative of F or of F - eps/alpha*inner(grad(psi),grad(w))*dx")
         eps = rG.get("eps")
     return ThermoformingSpec(u, r["previous"], r["alpha"], r["beta"], r["f"], r["bound0"], r["bound1"], eps, degree)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# example 02: blocked residual with a facet latent variable (signorini_dolfinx.py:211-252)
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class SignoriniSpec:
+    u: fem.Function
+    psi: fem.Function
+    psi_k: fem.Function
+    alpha: fem.Constant
+    mu: float
+    lmbda: float
+    gap: float
+    contact_facets: object  # (nf, 3) vertex triples the ds measure integrates over
+    quadrature_degree: int
+
+
+def compile_signorini(F: Form, unknowns):
+    """Match the blocked residual of signorini_dolfinx.py:244-249 - alpha (sigma(u), eps(v)) dx - alpha (f, v) dx
+    - (psi - psi_k, v.n_g) ds + (u.n_g, w) ds + (exp(psi), w) ds - (g, w) ds with sigma = 2 mu eps + lambda tr(grad u) I,
+    g = x_last + Constant(-gap) - against the family's template.  mu and lambda are plain numbers in the reference: they are READ
+    OFF the coefficients of the two elasticity monomials; everything else must agree term by term."""
+    u, psi = unknowns
+    terms = terminals(F)
+    fields = [t for t in terms if t.kind == "field"]
+    args = [t for t in terms if t.kind == "argument"]
+    consts = [t for t in terms if t.kind == "constant"]
+    coords = [t for t in terms if t.kind == "coordinate"]
+    Q = args[0].obj if args else None
+    if not isinstance(Q, MixedFunctionSpace) or any(t.obj is not Q for t in args) or Q.ncomp != 2:
+        raise NotImplementedError("test functions must come from MixedFunctionSpace(V, W)")
+    others = [t.obj for t in fields if t.obj is not u and t.obj is not psi]
+    if len(others) != 1 or others[0].function_space is not psi.function_space:
+        raise NotImplementedError("expected exactly one more Function of the latent space (the previous iterate psi_k)")
+    psi_k = others[0]
+    dim = u.function_space.dim
+    vec = [t for t in consts if t.rank == 1]
+    sca = [t for t in consts if t.rank == 0]
+    if len(vec) != 2 or len(sca) != 2 or len(coords) != 1 or coords[0].index != dim - 1:
+        raise NotImplementedError("expected the vector Constants n_g and f, the scalar Constants alpha and -gap and the last coordinate")
+    meas = {(it.measure.name, it.measure.degree) for it in F.integrals}
+    dsm = [it.measure for it in F.integrals if it.measure.name == "ds"]
+    if not dsm or any(m.subdomain_data is not dsm[0].subdomain_data or m.subdomain_id != dsm[0].subdomain_id for m in dsm):
+        raise NotImplementedError("one ds measure over the contact tags")
+    ds_deg = dsm[0].degree
+    if meas != {("dx", None), ("ds", ds_deg)} or ds_deg is None:
+        raise NotImplementedError("integrals over ufl.dx(domain=mesh) and one ds measure with a quadrature degree")
+    base = {}
+    for t in fields:
+        base[t.key()] = ({id(u): "u", id(psi): "psi", id(psi_k): "psi_k"}[id(t.obj)], False)
+    for t in args:
+        base[t.key()] = (("v", "w")[t.index], False)
+    base[coords[0].key()] = ("xg", False)
+    # template in roles, with unit elasticity coefficients (their values are read off below)
+    ru, rv, rn, rf = _role("u", 1), _role("v", 1), _role("n_g", 1), _role("f", 1)
+    rpsi, rpsik, rw, ralpha, rgap, rx = (_role(n) for n in ("psi", "psi_k", "w", "alpha", "mgap", "xg"))
+    tdx, tds = Measure("dx"), Measure("ds", metadata={"quadrature_degree": ds_deg})
+    eps = lambda a: sym(grad(a))  # noqa: E731
+    T = (ralpha * inner(eps(ru), eps(rv)) * tdx + ralpha * tr(grad(ru)) * tr(grad(rv)) * tdx - ralpha * inner(rf, rv) * tdx
+         - inner(rpsi - rpsik, dot(rv, rn)) * tds + inner(dot(ru, rn), rw) * tds + inner(exp(rpsi), rw) * tds - inner(rx + rgap, rw) * tds)
+    tmpl = canonical(T, _template_names(T, {"alpha", "mgap", "n_g", "f"}))
+    k_eps = next(k for k in tmpl if any(f.startswith("inner(sym(") for f in k[1]))
+    k_div = next(k for k in tmpl if sum(f.startswith("div(") for f in k[1]) == 2)
+    best = None
+    for vperm in itertools.permutations(("n_g", "f")):
+        for sperm in itertools.permutations(("alpha", "mgap")):
+            names = dict(base)
+            for t, r in zip(vec, vperm):
+                names[t.key()] = (r, True)
+            for t, r in zip(sca, sperm):
+                names[t.key()] = (r, True)
+            got = canonical(F, names)
+            two_mu, lam = got.get(k_eps, 0.0), got.get(k_div, 0.0)
+            diff = {k: got.get(k, 0.0) - tmpl.get(k, 0.0) for k in (set(got) | set(tmpl)) - {k_eps, k_div}}
+            diff = {k: c for k, c in diff.items() if abs(c) > 1e-14}
+            if not diff and two_mu > 0.0 and lam >= 0.0:
+                roles = {r: t.obj for t, r in zip(vec, vperm)}
+                roles.update({r: t.obj for t, r in zip(sca, sperm)})
+                n_g, f = roles["n_g"].value, roles["f"].value
+                e_last = np.zeros(dim)
+                e_last[-1] = -1.0
+                if not np.array_equal(np.asarray(n_g), e_last) or np.any(np.asarray(f) != 0.0):
+                    raise NotImplementedError("HIP backend: n_g = -e_last and f = 0 (the reference's values, signorini_dolfinx.py:236-240)")
+                m = dsm[0]
+                ids = m.subdomain_id if isinstance(m.subdomain_id, (tuple, list)) else (m.subdomain_id,)
+                facets = np.concatenate([m.subdomain_data.find(i) for i in ids])
+                return SignoriniSpec(u, psi, psi_k, roles["alpha"], 0.5 * two_mu, lam, -float(roles["mgap"].value), facets, ds_deg)
+            if best is None or len(diff) < len(best):
+                best = diff
+    raise NotImplementedError("the form is not the Signorini residual of signorini_dolfinx.py:244-249; terms that differ: " + _describe(best or {}))

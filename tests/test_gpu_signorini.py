@@ -69,3 +69,17 @@ def test_full_lvpp_run_matches_oracle(require_gpu, n, gap):
     assert it == it_ref and list(iterations) == list(its_ref)
     nu3 = 3 * prob.nv
     assert _rel(x[:nu3], x_ref[:nu3]) < 1e-10
+
+
+def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
+    """signorini_dolfinx.py:146-153, 199-291 stated through the UFL-subset front end (tensor algebra, ds measure over the contact
+    tags, MixedFunctionSpace with the latent variable on the contact sub-mesh) reproduces the declarative driver."""
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube(5, 4, 4)
+    mt, bcs = G.native_tags(mesh)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, gap=0.02, verbose=False, return_solution=True)
+    it_f, iterations_f, u = G.solve_contact_problem_forms(mesh, mt, bcs, gap=0.02)
+    assert it_f == it and list(iterations_f) == list(iterations)
+    nu3 = 3 * mesh.geometry.shape[0]
+    assert np.linalg.norm(u.x.array - x[:nu3]) <= 1e-12 * np.linalg.norm(x[:nu3])

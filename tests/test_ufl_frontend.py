@@ -91,7 +91,7 @@ def test_measure_and_structure_errors():
     u, psi = ufl.split(sol)
     v, w = ufl.TestFunctions(V)
     with pytest.raises(NotImplementedError):
-        ufl.Measure("ds")
+        ufl.Measure("dS")  # interior-facet integrals: not in the subset
     with pytest.raises(ValueError):
         ufl.grad(u) * ufl.grad(v)
     with pytest.raises(ValueError):
@@ -268,3 +268,71 @@ def test_gateaux_derivative_of_an_energy():
     dE = ufl.derivative(E, sol, zt)
     expect = ufl.inner(ufl.grad(u), ufl.grad(v)) * dx + ufl.inner(psi, w) * dx + ufl.exp(u) * v * dx - f * v * dx
     assert ufl.forms_equal(dE, expect)
+
+
+# ---- example 02: tensor algebra, facet measure, blocked spaces -----------------------------------------------------------------
+def _signorini_forms(E=2.0e4, nu=0.3, gap=0.1, alpha_0=1.0, swap=False):
+    """signorini_dolfinx.py:146-153 and :199-252 verbatim (native 3-D branch)."""
+    from proximalgalerkin_amd import signorini as sg
+
+    mesh = sg.create_unit_cube(3, 2, 2)
+    facet_tag, boundary_conditions = sg.native_tags(mesh)
+
+    def epsilon(w):
+        return ufl.sym(ufl.grad(w))
+
+    def sigma(w, mu, lmbda, gdim):
+        return 2.0 * mu * epsilon(w) + lmbda * ufl.tr(ufl.grad(w)) * ufl.Identity(gdim)
+
+    contact_facets = np.concatenate([facet_tag.find(m) for m in boundary_conditions["contact"]])
+    gdim = 3
+    submesh, submesh_to_mesh = fem.create_submesh(mesh, 2, contact_facets)
+    ds = ufl.Measure("ds", domain=mesh, subdomain_data=facet_tag, subdomain_id=boundary_conditions["contact"],
+                     metadata={"quadrature_degree": 4})
+    V = fem.functionspace(mesh, ("Lagrange", 1, (gdim,)))
+    W = fem.functionspace(submesh, ("Lagrange", 1))
+    Q = ufl.MixedFunctionSpace(V, W)
+    v, w = ufl.TestFunctions(Q)
+    u, psi, psi_k = fem.Function(V, name="displacement"), fem.Function(W), fem.Function(W)
+    mu = E / (2.0 * (1.0 + nu))
+    lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    n_g = fem.Constant(mesh, np.zeros(gdim))
+    n_g.value[-1] = -1
+    alpha = fem.Constant(mesh, alpha_0)
+    f = fem.Constant(mesh, np.zeros(gdim))
+    x = ufl.SpatialCoordinate(mesh)
+    g = x[gdim - 1] + fem.Constant(mesh, -gap)
+    residual = alpha * ufl.inner(sigma(u, mu, lmbda, gdim), epsilon(v)) * ufl.dx(domain=mesh) - alpha * ufl.inner(f, v) * ufl.dx(domain=mesh)
+    residual += -ufl.inner(psi - psi_k, ufl.dot(v, n_g)) * ds
+    residual += ufl.inner(ufl.dot(u, n_g), w) * ds
+    residual += ufl.inner(ufl.exp(psi), w) * ds - ufl.inner(g, w) * ds
+    if swap:
+        residual += 2.0 * ufl.inner(ufl.exp(psi), w) * ds
+    return ufl.extract_blocks(residual), u, psi, psi_k, alpha, mu, lmbda, contact_facets, mesh, facet_tag, boundary_conditions
+
+
+def test_example02_blocked_residual_is_recognised_and_lame_constants_are_read_off():
+    F, u, psi, psi_k, alpha, mu, lmbda, contact, *_ = _signorini_forms()
+    spec = ufl.compile_signorini(F, [u, psi])
+    assert spec.u is u and spec.psi is psi and spec.psi_k is psi_k and spec.alpha is alpha
+    assert spec.mu == pytest.approx(mu, rel=1e-14) and spec.lmbda == pytest.approx(lmbda, rel=1e-14)
+    assert spec.gap == pytest.approx(0.1) and spec.quadrature_degree == 4
+    assert np.array_equal(spec.contact_facets, contact)
+    assert u.function_space.num_dofs == 3 * 36 and psi.function_space.num_dofs == 12
+    with pytest.raises(NotImplementedError):  # e^psi with the wrong sign / weight is not the Signorini residual
+        ufl.compile_signorini(_signorini_forms(swap=True)[0], [u, psi])
+
+
+def test_tensor_identities_of_the_canonical_form():
+    """inner(lambda tr(grad u) I, sym(grad v)) = lambda div(u) div(v); inner(sym(grad u), sym(grad v)) is symmetric in (u, v)."""
+    F, u, psi, *_ = _signorini_forms()
+    V = u.function_space
+    Q = ufl.MixedFunctionSpace(V, psi.function_space)
+    v, w = ufl.TestFunctions(Q)
+    dx = ufl.dx(domain=V.mesh)
+    a = ufl.inner(ufl.tr(ufl.grad(u)) * ufl.Identity(3), ufl.sym(ufl.grad(v))) * dx
+    b = ufl.tr(ufl.grad(u)) * ufl.tr(ufl.sym(ufl.grad(v))) * dx
+    assert ufl.forms_equal(a, b)
+    c = ufl.inner(ufl.sym(ufl.grad(u)), ufl.sym(ufl.grad(v))) * dx
+    d = ufl.inner(ufl.sym(ufl.grad(v)), ufl.sym(ufl.grad(u))) * dx
+    assert ufl.forms_equal(c, d) and not ufl.forms_equal(a, c)
