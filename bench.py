@@ -150,11 +150,11 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
             from oracle import gc_oracle as G
             from oracle import pg_oracle as O
 
-            c, e = O.create_rectangle(args.cpu_n // 8, args.cpu_n // 8, (0.0, 0.0), (1.0, 1.0))
+            c, e = O.create_rectangle(args.cpu_n // 4, args.cpu_n // 4, (0.0, 0.0), (1.0, 1.0))
             prob = G.GradientConstraintP2(c, e)
             t0 = time.perf_counter()
             _, its, _ = G.solve_problem(prob)
-            return int(its.sum()), time.perf_counter() - t0, f"the full LVPP run on a {args.cpu_n // 8}x{args.cpu_n // 8} mesh ({prob.ntot} unknowns)"
+            return int(its.sum()), time.perf_counter() - t0, f"the full LVPP run on a {args.cpu_n // 4}x{args.cpu_n // 4} mesh ({prob.ntot} unknowns)"
     else:
         from proximalgalerkin_amd import signorini as G
 
@@ -183,7 +183,7 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
         def cpu_leg(budget):
             from oracle import sg_oracle as S
 
-            m = 14
+            m = 18
             c, t = S.create_unit_cube_tets(m, m, m)
             prob = S.SignoriniP1(c, t, S.boundary_facets_where(c, t, lambda x: np.isclose(x[:, 2], 0.0)),
                                  np.flatnonzero(np.isclose(c[:, 2], 1.0)))
@@ -244,7 +244,7 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
         }
         if not args.no_cpu_baseline and world == 1:
             steps, secs, what = cpu_leg(25.0)
-            n_cpu = args.cpu_n // 8 if args.workload == "ex06" else 14
+            n_cpu = args.cpu_n // 4 if args.workload == "ex06" else 18
             n_gpu = N if args.workload == "ex06" else n
             out["cpu_baseline"] = {"value": steps / secs, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
                                    # MEASURED here, on the mesh named in `mesh`; `at_workload` carries it to the benchmarked mesh

@@ -14,7 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 struct PgxScatter {
@@ -50,12 +53,28 @@ static inline void pgx_scatter_run(hipStream_t st, const PgxScatter& S, const do
 static inline std::string pgx_scatter_build(const int32_t* dest, int64_t nsrc, int64_t nout, std::vector<void*>& allocs,
                                             PgxScatter* S) {
   if (nsrc > 0x7fffffff || nout > 0x7fffffff) return "scatter table exceeds int32 indices";
+  // Counting sort by destination, threads over DESTINATION ranges: every thread streams the whole table (sequential reads) but
+  // counts / places only the entries of its own range, so the random writes of a thread stay inside its slice and no two threads
+  // touch the same counter.  (Sequential version: 3 s for the 226 M-entry constant-block table of example 06 at 1024^2.)
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, nout / 65536 + 1}));
   std::vector<int32_t> cnt((size_t)nout + 1, 0);
-  for (int64_t k = 0; k < nsrc; ++k) {
-    const int32_t d = dest[k];
-    if (d >= nout) return "scatter destination out of range";
-    if (d >= 0) cnt[(size_t)d + 1]++;
+  std::vector<int> bad(T, 0);
+  auto range = [&](int t) { return std::make_pair((int64_t)t * nout / T, (int64_t)(t + 1) * nout / T); };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const auto [d0, d1] = range(t);
+        for (int64_t k = 0; k < nsrc; ++k) {
+          const int32_t d = dest[k];
+          if (d >= nout) bad[t] = 1;
+          if (d >= d0 && d < d1) cnt[(size_t)d + 1]++;
+        }
+      });
+    for (auto& x : th) x.join();
   }
+  for (int t = 0; t < T; ++t)
+    if (bad[t]) return "scatter destination out of range";
   std::vector<int32_t> dst, ptr;
   int64_t total = 0;
   for (int64_t d = 0; d < nout; ++d)
@@ -69,9 +88,17 @@ static inline std::string pgx_scatter_build(const int32_t* dest, int64_t nsrc, i
   std::vector<int32_t> pos((size_t)nout, -1);
   for (size_t j = 0; j < dst.size(); ++j) pos[(size_t)dst[j]] = ptr[j];
   std::vector<int32_t> src((size_t)total);
-  for (int64_t k = 0; k < nsrc; ++k) {
-    const int32_t d = dest[k];
-    if (d >= 0) src[(size_t)pos[(size_t)d]++] = (int32_t)k;
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const auto [d0, d1] = range(t);
+        for (int64_t k = 0; k < nsrc; ++k) {
+          const int32_t d = dest[k];
+          if (d >= d0 && d < d1) src[(size_t)pos[(size_t)d]++] = (int32_t)k;
+        }
+      });
+    for (auto& x : th) x.join();
   }
   S->nsrc = nsrc;
   S->ndst = (int64_t)dst.size();
