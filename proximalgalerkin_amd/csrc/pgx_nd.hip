@@ -112,6 +112,7 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  int panel_kind = 0;  // PGX_ND_PANEL: 0 MFMA (default), 1 LDS-blocked scalar, 2 register-column scalar panel kernel
   double factor_ms = 0, solve_ms = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<void*> allocs;
@@ -508,6 +509,10 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   }
   s->kcut = kcut;
   s->nsub = nsub;
+  {
+    const char* e = getenv("PGX_ND_PANEL");
+    s->panel_kind = e ? atoi(e) : 0;
+  }
   // large factorisation on one GPU: cut the tree at depth 3 and factorise the (up to) 8 subtrees below one after the other
   {
     const char* e = getenv("PGX_ND_CUT_GB");  // threshold in GB of device storage (default 96); 0 = always, < 0 = never
@@ -1042,6 +1047,226 @@ __global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ arena, in
       }
     }
   }
+}
+
+// Register variant of the panel solves (PGX_ND_PANEL=2; an experiment kept for the comparison in DESIGN.md section 9).  ONE WAVE per 64-wide
+// chunk, the lane's column (row panel) / row (column panel) of the chunk in registers, right-looking substitution
+//     for m < nb:  x[m] final (* 1/U[m][m] for the column panel);  x[i] -= C[m][i] x[m]  for i > m
+// fully unrolled: the nb - m - 1 updates of a step are independent FMAs, their coefficients are WAVE-UNIFORM LDS reads at
+// compile-time offsets (ds_read2_b64 broadcasts, no conflicts) and there is NO barrier inside the solve - the LDS kernel
+// pays 2 barriers per 8 pivots with one of its four waves doing the 8x8 triangles.  Work per chunk is the nb^2/2 x 64 FMAs
+// of the substitution itself.  A workgroup = 4 chunks of ONE panel type sharing the coefficient block C (zero padded to
+// NB so that the unrolled updates past nb are no-ops).  The row panel is column-major along the pivots (a lane's column is
+// contiguous in memory), so its chunks pass through a 16-row LDS slab per wave in both directions: global accesses stay
+// 128-B segments, the slab (stride ND_PS = 66) is conflict-free on both sides.
+#define ND_PS 66
+template <int NB>
+__global__ __launch_bounds__(256) void k_nd_panel_r(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
+                                                    int64_t store_off, int P) {
+  __shared__ __attribute__((aligned(16))) double C[NB * ND_PS];
+  __shared__ double inv[64];
+  __shared__ double Tb[4][16 * ND_PS];
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const int64_t MP = (int64_t)M * P;
+  double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = (int)gridDim.y >> 1;
+  const bool isL = (int)blockIdx.y >= half;
+  const int t = ((int)blockIdx.y - (isL ? half : 0)) * 4 + wave;
+  const int o0 = kb + nb + ND_TS * t;
+  const int wd = min(ND_TS, M - o0);  // <= 0 for the idle waves of the last workgroup
+  const double* Dg = S + (int64_t)kb * M + kb;
+  // coefficient block: C[m][i] multiplies x[m] in equation i > m.  Row panel: L[i][m]; column panel: U[m][i].
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int a = idx % NB, b = idx / NB;  // a runs along memory in both cases
+    if (!isL) {
+      C[b * ND_PS + a] = (a < nb && b < nb && a > b) ? Dg[(int64_t)b * M + a] : 0.0;  // m = b, i = a
+    } else {
+      C[a * ND_PS + b] = (a < nb && b < nb && b > a) ? Dg[(int64_t)b * M + a] : 0.0;  // m = a, i = b
+    }
+  }
+  if (tid < 64) inv[tid] = (isL && tid < nb) ? 1.0 / Dg[(int64_t)tid * M + tid] : 1.0;
+  double x[NB];
+  double* tb = Tb[wave];
+  const int rl = lane & 15, cg = lane >> 4;
+  if (wd > 0) {
+    if (isL) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) x[k] = (k < nb && lane < wd) ? F[(int64_t)(kb + k) * M + o0 + lane] : 0.0;
+    } else {
+#pragma unroll
+      for (int s = 0; s < NB / 16; ++s) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int col = 4 * j + cg, r = 16 * s + rl;
+          v[j] = (16 * s < nb && r < nb && col < wd) ? F[(int64_t)(o0 + col) * M + kb + r] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tb[rl * ND_PS + 4 * j + cg] = v[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) x[16 * s + rr] = tb[rr * ND_PS + lane];
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __syncthreads();
+  if (wd <= 0) return;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    if ((m & 7) == 0 && m >= nb) break;
+    const double xm = x[m] * inv[m];  // inv = 1 for the row panel (unit lower triangle)
+    x[m] = xm;
+#pragma unroll
+    for (int i = m + 1; i < NB; ++i) x[i] -= C[m * ND_PS + i] * xm;
+  }
+  if (isL) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < nb && lane < wd) S[(int64_t)(kb + k) * M + o0 + lane] = x[k];
+  } else {
+#pragma unroll
+    for (int s = 0; s < NB / 16; ++s) {
+      if (16 * s >= nb) break;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) tb[rr * ND_PS + lane] = x[16 * s + rr];
+      __builtin_amdgcn_wave_barrier();
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = tb[rl * ND_PS + 4 * j + cg];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int col = 4 * j + cg, r = 16 * s + rl, c = o0 + col;
+        if (r < nb && col < wd) S[c < P ? (int64_t)c * M + kb + r : MP + (int64_t)(c - P) * P + kb + r] = v[j];
+      }
+    }
+  }
+}
+
+// MFMA variant of the panel solves (default).  The substitution is blocked by 16 pivots,
+//     X_a = inv(T_aa) (B_a - sum_{b<a} T_ab X_b),   a = 0..3,
+// every product a chain of v_mfma_f64_16x16x4_f64 with the 16 x 16 coefficient block as the A operand (one ds_read_b64 per
+// MFMA = 512 B of LDS per 2048 flops; the scalar substitutions above need 512 B per 128 flops and are LDS-bound on it) and
+// the chunk's pivot block as B operand AND accumulator: for this instruction lane l holds B[k = l>>4][n = l&15] and
+// D[m = (l>>4) + 4 reg][n = l&15], so accumulator register s of block b IS the B operand of k-slice s (pivots 16b + 4s +
+// (l>>4)) and a solved block feeds the next products straight from registers - no LDS round trip, no barrier in the solve.
+// The column panel X U^{-1} is the same recurrence on X^T with T = U^T, so one code path serves both with the pivot / line
+// strides swapped.  T is staged NEGATED below the diagonal (the MFMAs accumulate), its four diagonal blocks are inverted
+// in place, one per wave (16 lanes = 16 columns of the inverse by substitution, coefficients broadcast from LDS), and the
+// padding beyond nb is the identity.  A workgroup = one 64-line chunk, wave w = its lines [16w, 16w+16).
+// LDS layouts (r = equation, m = unknown): column panel r*68 + m, row panel m*80 + r - both fill from memory along lanes
+// and give the A-operand reads (r = l&15, m = 4s + (l>>4)) the minimal two passes.
+__global__ __launch_bounds__(256) void k_nd_panel_m(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
+                                                    int64_t store_off, int P) {
+  __shared__ double Lh[64 * 80];
+  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
+  const int64_t MP = (int64_t)M * P;
+  double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, n = l & 15, g = l >> 4;
+  const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
+  const bool isL = (int)blockIdx.y >= nch;
+  const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
+  const int wd = min(ND_TS, M - o0);
+  const double* Dg = S + (int64_t)kb * M + kb;
+  const int sr = isL ? 68 : 1, sm = isL ? 1 : 80;
+  const int nbr = (nb + 15) & ~15;
+  {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q, a = idx & 63, b = idx >> 6;  // a runs along memory
+      const bool in = a < nb && b < nb;
+      const bool off = isL ? a < b : a > b;  // (r, m) = (b, a) for the column panel, (a, b) for the row panel
+      v[q] = (in && (off || (isL && a == b))) ? Dg[(int64_t)b * M + a] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q, a = idx & 63, b = idx >> 6;
+      const bool in = a < nb && b < nb;
+      const double w = a == b ? ((isL && in) ? v[q] : 1.0) : -v[q];
+      if (4 * q < nbr) Lh[isL ? b * 68 + a : b * 80 + a] = w;  // b = 4q + wave: only the rows / columns of the blocks in use
+    }
+  }
+  // the chunk in accumulator layout: block a, register q <-> pivot 16a + (l>>4) + 4q, line 16 wave + (l&15)
+  nd_v4d acc[4];
+  const int line = 16 * wave + n;
+  const int64_t lbase = isL ? (int64_t)kb * M + o0 + line : (int64_t)(o0 + line) * M + kb;
+  const int64_t pstr = isL ? M : 1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = 16 * a + g + 4 * q;
+      acc[a][q] = (p < nb && line < wd) ? F[lbase + p * pstr] : 0.0;
+    }
+  __syncthreads();
+  if (16 * wave < nb) {  // inverse of diagonal block `wave`: lane n solves T y = e_n
+    const int a0 = 16 * wave;
+    double y[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = r == n ? 1.0 : 0.0;
+    const double rd = isL ? 1.0 / Lh[(a0 + n) * (sr + sm)] : 1.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (isL) y[m] *= nd_bcast(rd, m);
+#pragma unroll
+      for (int r = m + 1; r < 16; ++r) y[r] += Lh[(a0 + r) * sr + (a0 + m) * sm] * y[m];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (g == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Lh[(a0 + r) * sr + (a0 + n) * sm] = y[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (16 * a >= nb) break;
+    const double* La = Lh + (16 * a + n) * sr + g * sm;
+#pragma unroll
+    for (int b = 0; b < a; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[(16 * b + 4 * s) * sm], acc[b][s], acc[a], 0, 0, 0);
+    const nd_v4d t = acc[a];
+    nd_v4d x = (nd_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(La[(16 * a + 4 * s) * sm], t[s], x, 0, 0, 0);
+    acc[a] = x;
+  }
+  if (line < wd) {
+    const int c = o0 + line;
+    const int64_t sbase = isL ? lbase : (c < P ? (int64_t)c * M + kb : MP + (int64_t)(c - P) * P + kb);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = 16 * a + g + 4 * q;
+        if (p < nb) S[sbase + p * pstr] = acc[a][q];
+      }
+  }
+}
+
+static void nd_launch_panel(int kind, hipStream_t q, unsigned count, unsigned nch, double* arena, int64_t woff, int M, int kb,
+                            int nb, int64_t poff, int P) {
+  if (kind == 0) {
+    hipLaunchKernelGGL(k_nd_panel_m, dim3(count, 2 * nch), dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+    return;
+  }
+  if (kind == 1) {
+    hipLaunchKernelGGL(k_nd_panel, dim3(count, 2 * nch), dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+    return;
+  }
+  const dim3 grid(count, 2 * ((nch + 3) / 4));
+  if (nb <= 16)
+    hipLaunchKernelGGL(k_nd_panel_r<16>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+  else if (nb <= 32)
+    hipLaunchKernelGGL(k_nd_panel_r<32>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+  else if (nb <= 48)
+    hipLaunchKernelGGL(k_nd_panel_r<48>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+  else
+    hipLaunchKernelGGL(k_nd_panel_r<64>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
 }
 
 // C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
@@ -1645,7 +1870,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.woff, M, kb, nb, s->d_info, Lv.poff, P);
           if (M - ke > 0) {
             const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
-            hipLaunchKernelGGL(k_nd_panel, dim3((unsigned)Lv.count, 2 * nch), dim3(256), 0, q, s->arena, Lv.woff, M, kb, nb, Lv.poff, P);
+            nd_launch_panel(s->panel_kind, q, (unsigned)Lv.count, nch, s->arena, Lv.woff, M, kb, nb, Lv.poff, P);
             nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
             nd_launch_gemm(s, q, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
           }

@@ -15,7 +15,11 @@ with open(f, newline="") as fh:
     for x in csv.DictReader(fh):
         n = x["Kernel_Name"].split("(")[0].replace("void ", "")
         if n.startswith("k_nd") or "fillBuffer" in n:
-            rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), n))
+            def dim(ax):
+                g = x.get("Grid_Size_" + ax) or (x.get("Grid_Size") if ax == "X" else 1) or 1
+                w = x.get("Workgroup_Size_" + ax) or (x.get("Workgroup_Size") if ax == "X" else 1) or 1
+                return int(g) // max(1, int(w))
+            rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), n, (dim("X"), dim("Y"), dim("Z"))))
 rows.sort()
 solve_k = ("k_nd_fwd_assemble", "k_nd_trsv", "k_nd_gemv", "k_nd_bwd_gather", "k_nd_write_x")
 segs, cur = [], []
@@ -37,7 +41,7 @@ for r in seg:
         depths.append(cur)
         cur, seen_elim = [], False
     cur.append(r)
-    if r[2] in ("k_nd_diag", "k_nd_panel") or r[2].startswith("k_nd_gemm"):
+    if r[2] == "k_nd_diag" or r[2].startswith("k_nd_panel") or r[2].startswith("k_nd_gemm"):
         seen_elim = True
 depths.append(cur)
 print(f"factorisation span {(seg[-1][1] - t0) / 1e6:.1f} ms, {len(depths)} depth groups (deepest first)")
@@ -48,3 +52,10 @@ for i, d in enumerate(depths):
     ks = lambda pre: sum(r[1] - r[0] for r in d if r[2].startswith(pre)) / 1e6  # noqa: E731
     print(f"{i:3d} {(s - t0) / 1e6:9.2f} {(e - s) / 1e6:8.2f} {(first - s) / 1e6:8.2f} {(e - first) / 1e6:8.2f} {sum(r[2] == 'k_nd_diag' for r in d):5d} "
           f"{ks('k_nd_panel'):9.2f} {ks('k_nd_gemm'):8.2f} {ks('k_nd_diag'):8.2f} {ks('k_nd_extend'):8.2f}")
+
+# PGX_ND_LAUNCHES=g0,g1,...: every elimination launch of those depth groups (workgroup grid, duration)
+for gi in [int(t) for t in os.environ.get("PGX_ND_LAUNCHES", "").split(",") if t]:
+    print(f"--- launches of depth group {gi}")
+    for r in depths[gi]:
+        if r[2].startswith("k_nd"):
+            print(f"  {(r[0] - t0) / 1e6:9.3f} ms  {r[2]:24s} grid {r[3]}  {(r[1] - r[0]) / 1e3:9.1f} us")
