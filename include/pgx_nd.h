@@ -44,6 +44,9 @@ typedef struct {
   int64_t factor_nnz;                      /* unpadded entries kept (L and U) */
   double flops;                            /* unpadded factorisation flops */
   double flops_padded;                     /* flops the level-batched kernels execute */
+  int64_t perturbed_pivots;                /* (near-)zero pivots the LAST completed factorisation replaced by +-1e-300 (static
+                                            * perturbation, no pivoting): > 0 means its solves are unreliable; pgx_nd_last_error
+                                            * then says so.  pgx_nd_get_stats waits for a factorisation in flight. */
 } pgx_nd_stats;
 
 /* device < 0: symbolic phase only (no GPU touched) - for pgx_nd_get_stats / pgx_nd_export_* on CPU-only machines. */

@@ -91,6 +91,7 @@ class pgx_nd_stats(C.Structure):
         ("factor_nnz", C.c_int64),
         ("flops", C.c_double),
         ("flops_padded", C.c_double),
+        ("perturbed_pivots", C.c_int64),
     ]
 
 

@@ -146,9 +146,13 @@ struct PhaseTimer {
   pgx_handle* h;
   int slot;
   PhaseTimer(pgx_handle* h_, int s) : h(h_), slot(s) {
+    static const char* const names[8] = {"pgx:residual", "pgx:jacobian", "pgx:mg_setup/lu_factor", "pgx:spmv", "pgx:precond",
+                                         "pgx:orthogonalise", "pgx:observables", "pgx:newton_solve"};
+    pgx_roctx(names[s & 7]);
     if (h->prof) hipEventRecord(h->e0, h->st);
   }
   ~PhaseTimer() {
+    pgx_roctx(nullptr);
     if (h->prof) {
       hipEventRecord(h->e1, h->st);
       hipEventSynchronize(h->e1);
@@ -1981,12 +1985,8 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     if (rcl) return rcl;
   }
   const size_t n2 = 2 * (size_t)h->nd;
-  hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (h->prof) {
-    hipEventCreate(&w0);
-    hipEventCreate(&w1);
-    hipEventRecord(w0, h->st);
-  }
+  PgxSolveScope scope(h->st, h->prof, &h->lu_active);
+  PgxRange range("pgx:newton_solve");
   int its = 0, lin = 0, rsn = 0;
   double fnorm = 0, fnorm0 = 0, ttol = 0;
   h->omega_now = 0.0;
@@ -2074,15 +2074,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   if (rsn > 0) HIPCHK(hipMemcpyAsync(h->x, h->xw, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the solve must not pass silently
-  if (h->prof) {
-    hipEventRecord(w1, h->st);
-    hipEventSynchronize(w1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, w0, w1);
-    h->ms[7] += ms;
-    hipEventDestroy(w0);
-    hipEventDestroy(w1);
-  }
+  if (h->prof) h->ms[7] += scope.stop();
   *reason = rsn;
   if (its_out) *its_out = its;
   if (lin_out) *lin_out = lin;

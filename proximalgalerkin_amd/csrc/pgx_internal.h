@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include "pgx_scope.h"
+
 // storage type of the multigrid D(psi) stencils.  They only feed the PRECONDITIONER (the exact operator's CSR D stays
 // fp64), so fp32 would be admissible; measured on MI355X it made the smoother kernels 27 % SLOWER (same Krylov counts),
 // so the stencils stay fp64.

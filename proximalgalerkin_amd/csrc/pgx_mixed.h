@@ -20,6 +20,7 @@
 #include "../../include/pgx.h"
 #include "../../include/pgx_nd.h"
 #include "pgx_comm.h"
+#include "pgx_scope.h"
 
 struct MixedBase {
   int device = 0;
@@ -88,9 +89,12 @@ struct MxTimer {
   MixedBase* h;
   int slot;
   MxTimer(MixedBase* h_, int s) : h(h_), slot(s) {
+    static const char* const names[6] = {"pgx:residual", "pgx:jacobian", "pgx:lu_factor", "pgx:lu_solve", "pgx:spmv", "pgx:newton"};
+    pgx_roctx(names[s < 0 || s > 5 ? 5 : s]);
     if (h->prof) hipEventRecord(h->e0, h->st);
   }
   ~MxTimer() {
+    pgx_roctx(nullptr);
     if (h->prof) {
       hipEventRecord(h->e1, h->st);
       hipEventSynchronize(h->e1);
@@ -385,12 +389,8 @@ static int mx_linear_solve_ok(MixedBase* h, const double* b, const double* dx, d
 // SNES newtonls + linesearch none on device `x` (replaced only when reason > 0: lvpp/problem.py:121-123)
 static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   if (!opts || !reason) return PGX_EINVAL;
-  hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (h->prof) {
-    hipEventCreate(&w0);
-    hipEventCreate(&w1);
-    hipEventRecord(w0, h->st);
-  }
+  PgxSolveScope scope(h->st, h->prof, nullptr);
+  PgxRange range("pgx:newton_solve");
   const size_t bytes = sizeof(double) * h->ntot;
   int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
   double fnorm = 0, fnorm0 = 0;
@@ -449,15 +449,7 @@ static int mx_newton_solve(MixedBase* h, const pgx_snes_opts* opts, int* reason,
   if (rsn > 0) MXHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
   MXHIP(hipStreamSynchronize(h->st));
   MXHIP(hipGetLastError());
-  if (h->prof) {
-    hipEventRecord(w1, h->st);
-    hipEventSynchronize(w1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, w0, w1);
-    h->ms[5] += ms;
-    hipEventDestroy(w0);
-    hipEventDestroy(w1);
-  }
+  if (h->prof) h->ms[5] += scope.stop();
   *reason = rsn;
   if (its_out) *its_out = its;
   if (lin_out) *lin_out = lin;
@@ -598,12 +590,8 @@ static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, 
 // slope uses the same matrix the direction was computed with, as PETSc's MatMult(jac, Y, W) does.
 static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   if (!opts || !reason) return PGX_EINVAL;
-  hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (h->prof) {
-    hipEventCreate(&w0);
-    hipEventCreate(&w1);
-    hipEventRecord(w0, h->st);
-  }
+  PgxSolveScope scope(h->st, h->prof, nullptr);
+  PgxRange range("pgx:newton_solve");
   const size_t bytes = sizeof(double) * h->ntot;
   int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
   double fnorm = 0, fnorm0 = 0;
@@ -727,15 +715,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
   if (rsn > 0) MXHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
   MXHIP(hipStreamSynchronize(h->st));
   MXHIP(hipGetLastError());
-  if (h->prof) {
-    hipEventRecord(w1, h->st);
-    hipEventSynchronize(w1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, w0, w1);
-    h->ms[5] += ms;
-    hipEventDestroy(w0);
-    hipEventDestroy(w1);
-  }
+  if (h->prof) h->ms[5] += scope.stop();
   *reason = rsn;
   if (its_out) *its_out = its;
   if (lin_out) *lin_out = lin;

@@ -47,6 +47,7 @@
 #include "../../include/pgx.h"
 #include "../../include/pgx_nd.h"
 #include "pgx_comm.h"
+#include "pgx_scope.h"
 
 static thread_local std::string g_nd_error;
 
@@ -96,6 +97,9 @@ struct pgx_nd {
   int32_t *d_fp = nullptr, *d_fb = nullptr, *d_parent = nullptr, *d_slot01 = nullptr, *d_child0 = nullptr,
           *d_child1 = nullptr, *d_own_dofs = nullptr, *d_rel = nullptr, *d_fM = nullptr, *d_fP = nullptr;
   int* d_info = nullptr;  // [0] = number of (near-)zero pivots met by the last factorisation
+  int* h_info = nullptr;  // pinned copy, filled by an async D2H at the end of pgx_nd_factor
+  hipEvent_t ev_info = nullptr;
+  bool info_pending = false;
   // distributed factorisation (pgx_nd_create_dist): the 2^kdist subtrees below tree depth kdist live on one rank each,
   // the levels above on rank 0, which also holds GHOST copies of the other ranks' subtree-root fronts (identity pivot
   // block; their Schur block / border vector arrives through pgx_comm::gather0, leaves through scatter0)
@@ -104,6 +108,11 @@ struct pgx_nd {
   // and joined into the main stream per depth (few large fronts near the root cannot fill 256 CUs one class at a time)
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  // the working buffer of depth d - 1 (zero fill, matrix entries, padding) is prepared on its own stream while depth d is
+  // eliminated: it is the buffer depth d + 1 has just vacated (extend-add of depth d + 1 is enqueued before)
+  hipStream_t prep_st = nullptr;
+  hipEvent_t ev_prep_go = nullptr, ev_prep_done = nullptr;
+  bool prep_ahead = true;  // PGX_ND_PREP_AHEAD=0: everything on the main stream
   pgx_comm* comm = nullptr;
   int kbatch = 0;  // distributed: the (single) batch holding the subtree roots at depth kdist
   int rank = 0, size = 1, kdist = 0;
@@ -1694,6 +1703,15 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   hipEventCreate(&s->e0);
   hipEventCreate(&s->e1);
   hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+  hipEventCreateWithFlags(&s->ev_info, hipEventDisableTiming);
+  if (hipHostMalloc((void**)&s->h_info, sizeof(int)) != hipSuccess) s->h_info = nullptr;
+  {
+    const char* e = getenv("PGX_ND_PREP_AHEAD");
+    s->prep_ahead = !e || atoi(e) != 0;
+    if (hipStreamCreateWithFlags(&s->prep_st, hipStreamNonBlocking) != hipSuccess) s->prep_st = nullptr;
+    hipEventCreateWithFlags(&s->ev_prep_go, hipEventDisableTiming);
+    hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
+  }
   for (int i = 0; i < 3; ++i) {
     if (hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking) != hipSuccess) s->side[i] = nullptr;
     hipEventCreateWithFlags(&s->ev_join[i], hipEventDisableTiming);
@@ -1750,6 +1768,11 @@ extern "C" void pgx_nd_destroy(pgx_nd* s) {
     if (s->e0) hipEventDestroy(s->e0);
     if (s->e1) hipEventDestroy(s->e1);
     if (s->ev_fork) hipEventDestroy(s->ev_fork);
+    if (s->ev_info) hipEventDestroy(s->ev_info);
+    if (s->h_info) hipHostFree(s->h_info);
+    if (s->prep_st) hipStreamSynchronize(s->prep_st), hipStreamDestroy(s->prep_st);
+    if (s->ev_prep_go) hipEventDestroy(s->ev_prep_go);
+    if (s->ev_prep_done) hipEventDestroy(s->ev_prep_done);
     for (int i = 0; i < 3; ++i) {
       if (s->side[i]) hipStreamSynchronize(s->side[i]), hipStreamDestroy(s->side[i]);
       if (s->ev_join[i]) hipEventDestroy(s->ev_join[i]);
@@ -1759,8 +1782,20 @@ extern "C" void pgx_nd_destroy(pgx_nd* s) {
   delete s;
 }
 
+// number of perturbed pivots of the last factorisation, once its read-back has arrived (wait: block until it has)
+static void nd_poll_info(pgx_nd* s, bool wait) {
+  if (!s->info_pending || !s->h_info) return;
+  if (wait ? hipEventSynchronize(s->ev_info) != hipSuccess : hipEventQuery(s->ev_info) != hipSuccess) return;
+  s->info_pending = false;
+  s->stats.perturbed_pivots = *s->h_info;
+  if (*s->h_info > 0)
+    s->err = "pgx_nd_factor: " + std::to_string(*s->h_info) + " (near-)zero pivot(s) replaced by +-1e-300: the matrix is singular to working "
+             "precision in the elimination order (no pivoting across fronts); solves with this factorisation are unreliable";
+}
+
 extern "C" int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st) {
   if (!s || !st) return PGX_EINVAL;
+  nd_poll_info(const_cast<pgx_nd*>(s), true);
   *st = s->stats;
   return PGX_OK;
 }
@@ -1810,6 +1845,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     return PGX_ENODEV;
   }
   NDHIP(hipSetDevice(s->device));
+  PgxRange range("pgx_nd:factor");
   const double* dv = vals;
   if (!on_device) {
     NDHIP(hipMemcpyAsync(s->d_vals, vals, (size_t)s->nnz * sizeof(double), hipMemcpyHostToDevice, s->st));
@@ -1820,19 +1856,20 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   const int maxdepth = (int)s->dfirst.size() - 2;
   // the working buffer of a group: zero, matrix entries, identity on the padded pivots.  (Its previous tenants are
   // stored compactly and their Schur blocks have been absorbed by their parents.)
-  auto prep = [&](const pgx_nd::Group& G) -> int {
+  auto prep_on = [&](const pgx_nd::Group& G, hipStream_t ps) -> int {
     if (G.w_len <= 0) return PGX_OK;
-    NDHIP(hipMemsetAsync(s->arena + G.w_off, 0, (size_t)G.w_len * sizeof(double), s->st));
+    NDHIP(hipMemsetAsync(s->arena + G.w_off, 0, (size_t)G.w_len * sizeof(double), ps));
     if (G.nz1 > G.nz0) {
       int blocks = (int)std::min<int64_t>((G.nz1 - G.nz0 + 255) / 256, 256 * 64);
-      hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, s->st, G.nz0, G.nz1, s->d_sdest, s->d_ssrc, dv, s->arena);
+      hipLaunchKernelGGL(k_nd_scatter, dim3(blocks), dim3(256), 0, ps, G.nz0, G.nz1, s->d_sdest, s->d_ssrc, dv, s->arena);
     }
     const int64_t f0 = s->lev[G.l0].start, f1 = s->lev[G.l1 - 1].start + s->lev[G.l1 - 1].count;
     if (f1 > f0)
-      hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, s->st, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase,
+      hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, ps, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase,
                          s->arena);
     return PGX_OK;
   };
+  auto prep = [&](const pgx_nd::Group& G) -> int { return prep_on(G, s->st); };
   // extend-add of the Schur complements of a (factorised) group into its parents' fronts (two conflict-free passes: first
   // children, second children)
   auto extend = [&](const pgx_nd::Group& G) {
@@ -1902,9 +1939,21 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     }
     eliminate(grp(kc, -1));
   }
+  bool ahead = false;  // this depth's buffer has been prepared on prep_st
   for (int d = (kc >= 0 ? kc - 1 : maxdepth); d >= 0; --d) {
-    if ((rcp = prep(grp(d, -1)))) return rcp;
+    if (ahead)
+      hipStreamWaitEvent(s->st, s->ev_prep_done, 0);
+    else if ((rcp = prep(grp(d, -1))))
+      return rcp;
     if (d < maxdepth) extend(grp(d + 1, -1));
+    ahead = false;
+    if (d > 0 && s->prep_ahead && s->prep_st) {  // depth d + 1 has left the buffer depth d - 1 will use
+      hipEventRecord(s->ev_prep_go, s->st);
+      hipStreamWaitEvent(s->prep_st, s->ev_prep_go, 0);
+      if ((rcp = prep_on(grp(d - 1, -1), s->prep_st))) return rcp;
+      hipEventRecord(s->ev_prep_done, s->prep_st);
+      ahead = true;
+    }
     eliminate(grp(d, -1));
     if (s->size > 1 && d == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
       const NdLevel& Lv = s->lev[s->kbatch];
@@ -1931,8 +1980,16 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     hipEventElapsedTime(&ms, s->e0, s->e1);
     s->factor_ms += ms;
   }
+  if (s->h_info) {
+    NDHIP(hipMemcpyAsync(s->h_info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    hipEventRecord(s->ev_info, s->st);
+    s->info_pending = true;
+  }
   NDHIP(hipGetLastError());
-  if (!on_device) NDHIP(hipStreamSynchronize(s->st));
+  if (!on_device) {
+    NDHIP(hipStreamSynchronize(s->st));
+    nd_poll_info(s, true);
+  }
   s->factored = true;
   return PGX_OK;
 }
@@ -1948,6 +2005,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     return PGX_ESTATE;
   }
   NDHIP(hipSetDevice(s->device));
+  PgxRange range("pgx_nd:solve");
   const double* db = b;
   double* dx = x;
   if (!on_device) {
@@ -2062,6 +2120,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
     NDHIP(hipMemcpyAsync(x, s->d_b, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->st));
     NDHIP(hipStreamSynchronize(s->st));
   }
+  nd_poll_info(s, !on_device);
   return PGX_OK;
 }
 

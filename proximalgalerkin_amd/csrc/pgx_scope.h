@@ -1,0 +1,65 @@
+// Scope helpers shared by the solver translation units: the per-solve guard and the optional roctx ranges.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+// roctx ranges around the solver phases (readable rocprofv3 --marker-trace timelines).  Off unless
+// PGX_ROCTX=1; the marker library is opened with dlopen, so libpgx.so has no link-time dependency on the profiler.
+//   pgx_roctx("name") pushes a range, pgx_roctx(nullptr) pops it.
+static inline void pgx_roctx(const char* name) {
+  typedef int (*push_t)(const char*);
+  typedef int (*pop_t)();
+  struct Fns {
+    push_t push = nullptr;
+    pop_t pop = nullptr;
+    Fns() {
+      const char* e = getenv("PGX_ROCTX");
+      if (!e || atoi(e) == 0) return;
+      for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        push = (push_t)dlsym(h, "roctxRangePushA");
+        pop = (pop_t)dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr, pop = nullptr;
+      }
+    }
+  };
+  static const Fns f;  // thread-safe one-time initialisation
+  if (!f.push) return;
+  if (name)
+    f.push(name);
+  else
+    f.pop();
+}
+struct PgxRange {
+  explicit PgxRange(const char* name) { pgx_roctx(name); }
+  ~PgxRange() { pgx_roctx(nullptr); }
+  PgxRange(const PgxRange&) = delete;
+  PgxRange& operator=(const PgxRange&) = delete;
+};
+
+// Wall-clock events of one Newton solve (profiling) + a flag to drop on EVERY exit path: the early `return rc` of a failed
+// collective or HIP call must neither leak the events nor leave "precondition with the factorisation" set on the handle.
+struct PgxSolveScope {
+  hipStream_t st;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  bool* flag;
+  PgxSolveScope(hipStream_t s, bool prof, bool* f) : st(s), flag(f) {
+    if (prof && hipEventCreate(&w0) == hipSuccess && hipEventCreate(&w1) == hipSuccess) hipEventRecord(w0, st);
+  }
+  float stop() {  // elapsed ms so far (0 when not profiling)
+    float ms = 0;
+    if (w0 && w1 && hipEventRecord(w1, st) == hipSuccess && hipEventSynchronize(w1) == hipSuccess) hipEventElapsedTime(&ms, w0, w1);
+    return ms;
+  }
+  ~PgxSolveScope() {
+    if (flag) *flag = false;
+    if (w0) hipEventDestroy(w0);
+    if (w1) hipEventDestroy(w1);
+  }
+  PgxSolveScope(const PgxSolveScope&) = delete;
+  PgxSolveScope& operator=(const PgxSolveScope&) = delete;
+};

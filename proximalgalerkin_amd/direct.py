@@ -8,6 +8,7 @@ examples/06_gradient_constraints/gradient_constraint_dolfinx.py:118-121).  No CP
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -56,6 +57,10 @@ class DirectSolver:
         data = np.ascontiguousarray(data, dtype=np.float64)
         assert data.shape == (int(self.indptr[-1]),)
         self._check(self._lib.pgx_nd_factor(self._h, L.dptr(data), 0), "pgx_nd_factor")
+        bad = self.stats()["perturbed_pivots"]
+        if bad:  # static pivoting replaced (near-)zero pivots: the factorisation does not represent the matrix
+            msg = self._lib.pgx_nd_last_error(self._h)
+            warnings.warn(msg.decode() if msg else f"pgx_nd_factor: {bad} perturbed pivots", RuntimeWarning, stacklevel=2)
 
     def solve(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -92,3 +92,33 @@ def test_subtree_sequencing_gives_the_same_factorisation(require_gpu, monkeypatc
     assert cut["n_levels"] > plain["n_levels"] and cut["arena_doubles"] < plain["arena_doubles"]
     assert cut["flops"] == plain["flops"] and cut["factor_nnz"] == plain["factor_nnz"]
     _check(J, nod, p1.coords, 0)
+
+
+def test_perturbed_pivots_are_reported(require_gpu):
+    """A structurally fine but numerically singular matrix: the static pivot perturbation must not pass silently
+    (pgx_nd_stats.perturbed_pivots, pgx_nd_last_error, RuntimeWarning from the host mirror); a regular matrix reports 0."""
+    import scipy.sparse as sp
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    n = 12
+    idx = np.arange(n * n).reshape(n, n)
+    A = sp.lil_matrix((n * n, n * n))
+    for (di, dj) in ((0, 0), (0, 1), (1, 0), (0, -1), (-1, 0)):
+        src = idx[max(0, -di):n - max(0, di), max(0, -dj):n - max(0, dj)].ravel()
+        dst = idx[max(0, di):n - max(0, -di), max(0, dj):n - max(0, -dj)].ravel()
+        A[src, dst] = 4.0 if (di, dj) == (0, 0) else -1.0
+    A = A.tocsr()
+    A.sort_indices()
+    coords = np.stack(np.meshgrid(np.arange(n, dtype=float), np.arange(n, dtype=float), indexing="ij"), -1).reshape(-1, 2)
+    coords = np.concatenate([coords, np.zeros((n * n, 1))], axis=1)
+    ds = DirectSolver(A.indptr, A.indices, np.arange(n * n), coords, device=0)
+    ds.factor(A.data)
+    assert ds.stats()["perturbed_pivots"] == 0
+    Z = A.copy()
+    Z.data[:] = 0.0  # same pattern, every pivot exactly zero
+    with pytest.warns(RuntimeWarning, match="zero pivot"):
+        ds.factor(Z.data)
+    assert ds.stats()["perturbed_pivots"] > 0
+    ds.factor(A.data)  # and the report is per factorisation
+    assert ds.stats()["perturbed_pivots"] == 0
+    ds.close()

@@ -2,6 +2,7 @@
 """Per-tree-depth wall time of ONE sparse-LU factorisation from a rocprofv3 kernel trace: pgx_nd_factor processes the dissection
 tree depth by depth (deepest first), each depth = prelude on the main stream (memset, scatter, pad, extend-add of the children) +
 elimination of the depth's batches on forked streams.  Depths are delimited by the working-buffer memsets.
+    PGX_ND_PREP_AHEAD=0 rocprofv3 --kernel-trace ... (the depth-ahead buffer preparation would blur the boundaries)
     python tools/nd_depth_timeline.py <dir or kernel_trace.csv> [index of the factorisation, default: the last complete one]"""
 import csv
 import glob
