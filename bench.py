@@ -407,10 +407,20 @@ def main():
     units = 1 if sharded else world  # solves per step over the whole job
     lin_its = problem.solver.getLinearSolveIterations()
 
-    # ---- roofline of the dominant kernel (k_bspmv): HIP events on the library's own stream ----
+    # ---- roofline of the operator-apply kernel ("SpMV"): HIP events on the library's own stream ----
+    # structured P1: the solver applies J matrix-free (k_st_spmv_r, 65 B per vertex); the block-CSR stream kernel (general
+    # meshes, P2; 232 B per P1 row) is timed beside it on the same matrix and reported as `roofline_csr`
     problem.assemble_jacobian()  # Jacobian at the final iterate
+    spmv_kind = problem.spmv_select()
     spmv_ms, spmv_bytes = problem.spmv_bench(reps=50)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    csr_ms = csr_bytes = None
+    if spmv_kind != 0:
+        problem.spmv_select(0)
+        csr_ms, csr_bytes = problem.spmv_bench(reps=50)
+        problem.spmv_select(spmv_kind)
+    else:
+        csr_ms, csr_bytes = spmv_ms, spmv_bytes
     n = msh.num_vertices
     smoother = None
     if not sharded and args.degree == 1:
@@ -431,11 +441,30 @@ def main():
     else:
         parallelism = "single"
 
-    traffic, traffic_source = None, None
-    tj = _ladder("r02_spmv_pmc_traffic.json")
-    if tj and tj.get("cells") == N and args.degree == 1 and not sharded:
-        traffic = tj["hbm_traffic_bytes_per_launch"]
-        traffic_source = {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date", "traffic_over_algorithmic")}
+    def pmc_traffic(fname):  # HBM bytes per launch from a committed rocprofv3 --pmc profile of the same kernel and mesh
+        tj = _ladder(fname)
+        if tj and tj.get("cells") == N and args.degree == 1 and not sharded:
+            return tj["hbm_traffic_bytes_per_launch"], {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date",
+                                                                               "traffic_over_algorithmic")}
+        return None, None
+
+    def spmv_roofline(kind, ms, nbytes):
+        name = {0: "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
+                1: "k_st_spmv_r (matrix-free apply of the Newton matrix [[aK,M],[M,-D]] on the structured mesh: constant K/M "
+                   "stencils, half-stored D(psi) stencil; the outer-Krylov SpMV of this workload)",
+                2: "k_st_apply<0> (generic matrix-free stencil apply)"}[kind]
+        traffic, src = pmc_traffic({0: "r02_spmv_pmc_traffic.json", 1: "r02_stspmv_pmc_traffic.json"}.get(kind, "none"))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+             # HBM bytes per launch of this kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read
+             # correction; tools/pmc_summary.py).  A profile of another run, not of this one: `traffic_source` says which; null
+             # when no committed profile matches the workload.
+             "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
+        if kind == 0:
+            r["mixed_csr_equivalent_GBs"] = (12.0 * 4 * (nbytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n) / (ms * 1e-3) / 1e9
+        return r
+
     out = None
     if rank == 0:
         out = {
@@ -465,25 +494,10 @@ def main():
             "proximal_iterations_per_s": outer_total / dt,
             "last_newton_linear_iterations": lin_its,
             "setup_s": t_setup,
-            "roofline": {
-                "kernel": "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)"
-                          + (", rank 0's strip" if sharded else ""),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                # HBM bytes per launch of THIS kernel build from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
-                # x2 read correction; tools/pmc_summary.py).  A profile of another run, not of this one: `traffic_source`
-                # says which; null when the profile does not match the workload.
-                "traffic": traffic,
-                "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": spmv_bytes,
-                "avg_launch_ms": spmv_ms,
-                "mixed_csr_equivalent_GBs": (12.0 * 4 * (spmv_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n)
-                                            / (spmv_ms * 1e-3) / 1e9,
-            },
+            "roofline": spmv_roofline(spmv_kind, spmv_ms, spmv_bytes),
         }
+        if spmv_kind != 0:
+            out["roofline_csr"] = spmv_roofline(0, csr_ms, csr_bytes)
         if smoother:
             out["roofline_dominant"] = smoother
         if prof:

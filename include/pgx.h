@@ -144,9 +144,18 @@ int pgx_csr_export(pgx_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr,
 
 /* y = J x with J = Jacobian of the last pgx_jacobian_fill, incl. BC rows/cols (identity). */
 int pgx_spmv(pgx_handle* h, const double* x, double* y);
-/* Time `reps` back-to-back SpMV launches on device-resident data with HIP events on the handle's
- * stream; returns average ms per launch and the algorithmic bytes one launch moves. */
+/* Time `reps` SpMV launches on device-resident data with HIP events on the handle's stream, each one COLD (512 MB of idle
+ * solver storage are overwritten between two timed launches, as a V-cycle does between two applies inside a solve: the
+ * matrix-free kernel's footprint would otherwise fit the 256 MB Infinity Cache); returns the average ms per launch and the
+ * algorithmic bytes one launch moves. */
 int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+/* Operator apply of the outer Krylov solver ("SpMV").  kind 1 (default on structured P1 meshes): matrix-free stencil kernel
+ * k_st_spmv_r - K, M are the uniform mesh's constants, D(psi) its half-stored 7-point stencil, 65 B per vertex; kind 0: the
+ * block-CSR stream kernel k_bspmv_stream (what general meshes and P2 always use, 232 B per P1 row); kind 2: generic
+ * one-thread-per-vertex stencil kernel (A/B); kind -1: query only.  *active (may be NULL) receives the kind that will run on
+ * this handle (0 when the mesh has no grid structure).  pgx_spmv / pgx_spmv_bench follow the selection; pgx_spmv_bench's
+ * `bytes` are the algorithmic bytes of the selected kernel. */
+int pgx_spmv_select(pgx_handle* h, int kind, int* active);
 /* The same for the TIME-DOMINANT kernel of the multigrid-preconditioned solve: the fused three-sweep smoother of the finest
  * level (k_st_smoothR, post-smoothing variant: x + P x_c folded in), at the Jacobian of the last pgx_jacobian_fill.
  * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,

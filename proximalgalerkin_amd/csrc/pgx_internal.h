@@ -137,6 +137,8 @@ void pgxk_view_to_global(hipStream_t st, int ns, int n_view, int n_glob, int sx,
 void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha, const double* xu, const double* xp,
                      const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,
                      double omega, int remap, double* yu, double* yp);
+void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp, int remap, double* yu,
+                  double* yp);
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp);

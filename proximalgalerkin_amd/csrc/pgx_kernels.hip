@@ -2086,6 +2086,149 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
                      L.M, L.Dh, make_stconst(L), L.mask, alpha, xu, xp, bu, bp, C.nx, C.ny, C.mask, remap, cbu, cbp);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-mapped matrix-free operator apply  y = J x  on a structured level: the outer-Krylov "SpMV" of structured P1 handles
+// (pgx_api.hip: spmv_dev).  J = [[aK, M], [M, -D(psi)]] is never formed as a CSR matrix here: K and M are the seven
+// constants of the uniform mesh, D(psi) its half-stored stencil (centre + three forward links, 32 B per vertex; the backward
+// links are the neighbours' forward links), so one apply moves x (16 B) + y (16 B) + D (32 B) + mask (1 B) = 65 B per
+// vertex instead of the 232 B per row of the block-CSR stream (k_bspmv_stream: 7 x 28 B + row pointer + x + y).
+// Mapping as in k_st_resid_restrict_r: a workgroup of 8 waves owns 62 x RY vertices; (1) a wave per row stages
+// (u, psi) interleaved on the (RY + 2) x 64 footprint in LDS; (2) a wave per row evaluates both rows of J from the image
+// - interior tiles with the scalar stencils, pair sums and no tests, boundary tiles (blocks [0, nbnd), scheduled first)
+// through the general per-point code with Dirichlet rows / columns as identity.
+// ------------------------------------------------------------------------------------------------
+#define PGX_SPMV_RY 24
+template <bool FAST>
+__device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int n, const double* __restrict__ K,
+                                             const double* __restrict__ M, const dsten_t* __restrict__ Dh, const StConst& sc,
+                                             const uint8_t* __restrict__ mask, double alpha, const double* __restrict__ xu,
+                                             const double* __restrict__ xp, double* __restrict__ yu, double* __restrict__ yp,
+                                             double2* ximg) {
+  constexpr int W = 64, CXS = 62, RY = PGX_SPMV_RY, HX = RY + 2, NW = PGX_ROWMAP_BLOCK / 64;
+  const int sx = nx + 1;
+  const int i0 = tx * CXS - 1, j0 = ty * RY - 1;  // image origin: one halo column / row before the tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  for (int lj = wave; lj < HX; lj += NW) {
+    const int gj = j0 + lj;
+    double a = 0.0, c2 = 0.0;
+    if (FAST) {
+      const unsigned v = (unsigned)(gj * sx + gi);
+      a = xu[v];
+      c2 = xp[v];
+    } else if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+      const int v = gj * sx + gi;
+      a = mask[v] ? 0.0 : xu[v];  // pre-masked image: Dirichlet columns of the u block contribute nothing
+      c2 = xp[v];
+    }
+    ximg[lj * W + lane] = make_double2(a, c2);
+  }
+  __syncthreads();
+  const bool act = lane >= 1 && lane < W - 1;
+  if (FAST) {
+    const double k0 = alpha * sc.K[0], k1 = alpha * 0.5 * (sc.K[1] + sc.K[2]), k3 = alpha * 0.5 * (sc.K[3] + sc.K[4]),
+                 k5 = alpha * 0.5 * (sc.K[5] + sc.K[6]);
+    const double m0 = sc.M[0], m1 = 0.5 * (sc.M[1] + sc.M[2]), m3 = 0.5 * (sc.M[3] + sc.M[4]), m5 = 0.5 * (sc.M[5] + sc.M[6]);
+    const dsten_t* const D1 = Dh + n;
+    const dsten_t* const D2 = Dh + 2 * (size_t)n;
+    const dsten_t* const D3 = Dh + 3 * (size_t)n;
+#pragma unroll
+    for (int k = 0; k < (RY + NW - 1) / NW; ++k) {
+      const int lj = 1 + wave + NW * k;
+      if (lj > RY) continue;  // wave-uniform
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      const double d0 = Dh[v], d1 = D1[v], d2 = D1[v - 1], d3 = D2[v], d4 = D2[v - sx], d5 = D3[v], d6 = D3[v - sx - 1];
+      const int q = lj * W + lane;
+      const double2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                    x6 = ximg[q - W - 1];
+      const double u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+      const double p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+      const double au = k0 * x0.x + k1 * u12 + k3 * u34 + k5 * u56 + m0 * x0.y + m1 * p12 + m3 * p34 + m5 * p56;
+      const double ap = m0 * x0.x + m1 * u12 + m3 * u34 + m5 * u56 -
+                        (d0 * x0.y + d1 * x1.y + d2 * x2.y + d3 * x3.y + d4 * x4.y + d5 * x5.y + d6 * x6.y);
+      if (act) {
+        __builtin_nontemporal_store(au, yu + v);
+        __builtin_nontemporal_store(ap, yp + v);
+      }
+    }
+  } else {
+    for (int lj = 1 + wave; lj <= RY; lj += NW) {
+      const int gj = j0 + lj;
+      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        StCoef c;
+        st_load_coef(v, gi, gj, nx, ny, n, K, M, Dh, sc, mask, c);
+        const int q = lj * W + lane;
+        const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+        double au = 0.0, ap = 0.0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0; links leaving the grid have zero coefficients
+          const double2 xn = ximg[q + off[t]];
+          au += alpha * c.kv[t] * xn.x + c.mv[t] * xn.y;
+          ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
+        }
+        yu[v] = c.rowbc ? xu[v] : au;
+        yp[v] = ap;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, int n, RrGrid g, int nbnd,
+                                                                const double* __restrict__ K, const double* __restrict__ M,
+                                                                const dsten_t* __restrict__ Dh, StConst sc,
+                                                                const uint8_t* __restrict__ mask, double alpha,
+                                                                const double* __restrict__ xu, const double* __restrict__ xp,
+                                                                int remap, double* __restrict__ yu, double* __restrict__ yp) {
+  constexpr int W = 64, HX = PGX_SPMV_RY + 2, PAD = W + 1;
+  __shared__ double2 ximg_[HX * W + 2 * PAD];
+  int b = blockIdx.x;
+  if (b < nbnd) {  // same enumeration of the boundary frame as k_st_resid_restrict_r
+    int tx, ty;
+    const int side = g.ntx - g.nfx;
+    if (b < g.ntx) {
+      tx = b;
+      ty = 0;
+    } else if ((b -= g.ntx) < g.nfy * side) {
+      ty = 1 + b / side;
+      const int r = b % side;
+      tx = r == 0 ? 0 : g.nfx + r;
+    } else {
+      b -= g.nfy * side;
+      ty = g.nfy + 1 + b / g.ntx;
+      tx = b % g.ntx;
+    }
+    st_spmv_tile<false>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
+  } else {
+    b = xcd_block(b - nbnd, gridDim.x - nbnd, remap);
+    st_spmv_tile<true>(1 + b % g.nfx, 1 + b / g.nfx, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
+  }
+}
+
+// y = J x on a structured level, matrix-free (see above); levels without uniform interior stencils take k_st_apply<0>
+void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp, int remap, double* yu,
+                  double* yp) {
+  if (!L.uniform) {
+    pgxk_st_apply(st, 0, L, alpha, xu, xp, nullptr, nullptr, 0.0, remap ? 2 : 0, yu, yp);
+    return;
+  }
+  constexpr int CXS = 62, RY = PGX_SPMV_RY;
+  RrGrid g;
+  g.ntx = (L.nx + CXS) / CXS;  // ceil((nx + 1) / CXS)
+  g.nty = (L.ny + RY) / RY;
+  // interior <=> every vertex of the image is strictly inside the grid: tx CXS - 1 >= 1, tx CXS + 62 <= nx - 1; ty RY - 1 >= 1,
+  // ty RY + RY <= ny - 1
+  g.nfx = (L.nx - 1 - 62) >= CXS ? (L.nx - 1 - 62) / CXS : 0;
+  g.nfy = (L.ny - 1 - RY) >= RY ? (L.ny - 1 - RY) / RY : 0;
+  g.nfx = std::min(g.nfx, g.ntx - 1);
+  g.nfy = std::min(g.nfy, g.nty - 1);
+  if (!L.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
+  const int nfast = g.nfx * g.nfy, nbnd = g.ntx * g.nty - nfast;
+  hipLaunchKernelGGL(k_st_spmv_r, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh,
+                     make_stconst(L), L.mask, alpha, xu, xp, remap, yu, yp);
+}
+
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
                    const double* bu, const double* bp, double omega, int first, double* yu, double* yp) {
   dim3 grid((L.n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);

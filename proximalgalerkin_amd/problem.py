@@ -312,6 +312,13 @@ class NonlinearProblem:
                    "pgx_spmv_bench")
         return ms.value, by.value
 
+    def spmv_select(self, kind=-1):
+        """Select / query the operator-apply kernel of the Krylov solver (include/pgx.h: pgx_spmv_select): 1 matrix-free stencil
+        (default on structured P1 meshes), 0 block-CSR stream, 2 generic stencil kernel; returns the kind that will run."""
+        act = C.c_int(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_spmv_select(self._h, int(kind), C.byref(act)), "pgx_spmv_select")
+        return act.value
+
     def smoother_bench(self, reps=20):
         """(avg ms, algorithmic bytes) of the finest level's fused smoother launch (include/pgx.h: pgx_smoother_bench)."""
         ms, by = C.c_double(0), C.c_double(0)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of the headline workload (2048^2 P1, settings B) on the GPU box; run from the repo root through gpurun.
-#   bash tools/profile_headline.sh <outdir under gpurun_out> [stats|spmv|smoother ...]
+#   bash tools/profile_headline.sh <outdir under gpurun_out> [stats|spmv|stspmv|smoother ...]
 # stats    : rocprofv3 --kernel-trace --stats of `bench.py --steps 3`
 # spmv     : FETCH_SIZE and WRITE_SIZE of k_bspmv_stream in SEPARATE passes (TCC slots) -> profiles/ via tools/pmc_summary.py
 # smoother : two SQ passes over one solve (wait/issue counters; LDS conflict counters)
@@ -17,10 +17,15 @@ for what in "$@"; do
       rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1 || exit 1
       python3 tools/trace_by_grid.py $OUT/trace > $OUT/trace_by_level.txt; rm -rf $OUT/trace ;;
     spmv)
-      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 tools/spmv_bench.py 2048 > $OUT/pmc_fetch.log 2>&1 || exit 1
-      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 tools/spmv_bench.py 2048 > $OUT/pmc_write.log 2>&1 || exit 1
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 tools/spmv_bench.py 2048 0 > $OUT/pmc_fetch.log 2>&1 || exit 1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 tools/spmv_bench.py 2048 0 > $OUT/pmc_write.log 2>&1 || exit 1
       python3 tools/pmc_summary.py --kernel k_bspmv_stream --traffic --cells 2048 --algorithmic-bytes 973570116 \
         --out $OUT/spmv_pmc_traffic.json $OUT/pmc_fetch $OUT/pmc_write > /dev/null || exit 1 ;;
+    stspmv)  # the matrix-free operator apply: 65 B x 2049^2 vertices
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_sfetch -o f -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_sfetch.log 2>&1 || exit 1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_swrite -o w -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_swrite.log 2>&1 || exit 1
+      python3 tools/pmc_summary.py --kernel k_st_spmv_r --traffic --cells 2048 --algorithmic-bytes 272896065 \
+        --out $OUT/stspmv_pmc_traffic.json $OUT/pmc_sfetch $OUT/pmc_swrite > /dev/null || exit 1 ;;
     smoother)
       rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d $OUT/pmc_sqA -o a -- $BENCH > $OUT/pmc_sqA.log 2>&1 || exit 1
