@@ -412,12 +412,12 @@ def main():
     # meshes, P2; 232 B per P1 row) is timed beside it on the same matrix and reported as `roofline_csr`
     problem.assemble_jacobian()  # Jacobian at the final iterate
     spmv_kind = problem.spmv_select()
-    spmv_ms, spmv_bytes = problem.spmv_bench(reps=50)
+    spmv_ms, spmv_bytes = problem.spmv_bench(reps=20)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     csr_ms = csr_bytes = None
     if spmv_kind != 0:
         problem.spmv_select(0)
-        csr_ms, csr_bytes = problem.spmv_bench(reps=50)
+        csr_ms, csr_bytes = problem.spmv_bench(reps=20)
         problem.spmv_select(spmv_kind)
     else:
         csr_ms, csr_bytes = spmv_ms, spmv_bytes

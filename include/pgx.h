@@ -144,10 +144,11 @@ int pgx_csr_export(pgx_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr,
 
 /* y = J x with J = Jacobian of the last pgx_jacobian_fill, incl. BC rows/cols (identity). */
 int pgx_spmv(pgx_handle* h, const double* x, double* y);
-/* Time `reps` SpMV launches on device-resident data with HIP events on the handle's stream, each one COLD (512 MB of idle
- * solver storage are overwritten between two timed launches, as a V-cycle does between two applies inside a solve: the
- * matrix-free kernel's footprint would otherwise fit the 256 MB Infinity Cache); returns the average ms per launch and the
- * algorithmic bytes one launch moves. */
+/* Time `reps` SpMV launches on device-resident data with HIP events on the handle's stream, in the cache state of a solve
+ * rather than back to back (the matrix-free kernel's footprint would fit the 256 MB Infinity Cache): multigrid handles replay
+ * "one V-cycle producing z, then J z" as an FGMRES iteration does and subtract the time of the V-cycles alone; other handles
+ * sweep 512 MB of idle storage between two applies.  Returns the average ms per launch and the algorithmic bytes one launch
+ * moves. */
 int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
 /* Operator apply of the outer Krylov solver ("SpMV").  kind 1 (default on structured P1 meshes): matrix-free stencil kernel
  * k_st_spmv_r - K, M are the uniform mesh's constants, D(psi) its half-stored 7-point stencil, 65 B per vertex; kind 0: the

@@ -103,6 +103,8 @@ struct pgx_handle {
   // replicas stay bitwise identical (the P2 assembly uses atomics) and issue the same collectives.
   pgx_comm* lu_comm = nullptr;
   double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
+  bool dh_interior = false;
+  int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
   bool check_replicas = false;  // PGX_CHECK_REPLICAS=1: assert that the replicas' residuals are bitwise identical
@@ -770,6 +772,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
+  if (const char* e = getenv("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   if (const char* e = getenv("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
   if (const char* e = getenv("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
@@ -1175,6 +1178,12 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
     return;
   }
   // row-parallel, atomic-free, bitwise reproducible; with_d: also fills D(psi) at the same x (Newton driver)
+  if (h->resid_grid && h->structured && !h->lev.empty() && h->lev[0].uniform) {  // uniform structured mesh: LDS-staged element blocks
+    pgxk_resid_fill_grid(h->st, with_d, h->lev[0], h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
+                         h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv, with_d);
+    h->dh_interior = with_d != 0;  // the interior rows of the finest D stencil are in place (consumed by jacobian_dev(have_d))
+    return;
+  }
   pgxk_resid_fill_p1(h->st, with_d, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
                      h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv);
 }
@@ -1196,7 +1205,9 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
   }
   if (h->structured) {
     PhaseTimer t(h, 2);
-    pgxk_csr_to_stencil_h(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].Dh);
+    pgxk_csr_to_stencil_h(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].Dh,
+                          (have_d && h->degree == 1 && h->dh_interior) ? h->lev[0].ny : 0);
+    h->dh_interior = false;
     const int ld = h->dist.on ? h->dist.ldist : 0;
     for (size_t l = 1; l < h->lev.size(); ++l) {
       if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks
@@ -1912,22 +1923,42 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
   const size_t n2 = 2 * (size_t)h->nd;
   pgxk_set(h->st, n2, 1.0, h->V);
   for (int k = 0; k < 3; ++k) spmv_dev(h, h->V, h->w);
-  // COLD launches, as inside a solve (a V-cycle and the orthogonalisation run between two applies): the matrix-free kernel's
-  // whole footprint (273 MB at 2048^2) would otherwise sit in the 256 MB Infinity Cache and a back-to-back loop reports
-  // 42 us where the solves see 49 us.  Between two timed launches 512 MB of the (idle) Z basis are overwritten.
+  // Launches in the cache state of a solve, not back to back: the matrix-free kernel's whole footprint (273 MB at 2048^2) would
+  // otherwise sit in the 256 MB Infinity Cache (42 us per launch in a tight loop, 49-50 us inside the solves per rocprofv3).
+  // Multigrid handles replay the solver's own sequence - one V-cycle producing z, then J z, exactly as in an FGMRES iteration -
+  // and subtract the time of the V-cycles alone; other handles sweep 512 MB of idle storage (a dot product) between two
+  // applies.  Each batch sits between ONE pair of events: a pair around a single 50 us kernel would add the ~50 us of its two
+  // barrier packets.
+  const bool mg = h->structured && h->degree == 1 && !h->dist.on && !h->lu_active && h->lev.size() > 1;
+  pgx_snes_opts od;
+  pgx_default_opts(&od);
   const size_t flush = std::min<size_t>((size_t)h->restart * n2, ((size_t)512 << 20) / sizeof(double));
-  double tot = 0.0;
-  for (int k = 0; k < reps; ++k) {
-    pgxk_set(h->st, flush, 0.0, h->Z);
-    HIPCHK(hipEventRecord(h->e0, h->st));
-    spmv_dev(h, h->V, h->w);
-    HIPCHK(hipEventRecord(h->e1, h->st));
-    HIPCHK(hipEventSynchronize(h->e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
-    tot += ms;
+  // nine rounds of (batch with applies, batch without), median of the differences: clock and power drift between two ~50 ms
+  // batches is of the order of the quantity measured
+  std::vector<double> diff;
+  for (int round = 0; round < 9; ++round) {
+    double t[2] = {0.0, 0.0};
+    for (int pass = 0; pass < 2; ++pass) {
+      HIPCHK(hipEventRecord(h->e0, h->st));
+      for (int k = 0; k < reps; ++k) {
+        if (mg) {
+          const int rc = precond(h, h->V, h->Z, od.mg_nu, od.mg_omega);
+          if (rc) return rc;
+        } else {
+          pgxk_multidot(h->st, flush, 1, h->Z, 0, h->Z, h->partials, h->d_small);
+        }
+        if (pass == 0) spmv_dev(h, mg ? h->Z : h->V, h->w);
+      }
+      HIPCHK(hipEventRecord(h->e1, h->st));
+      HIPCHK(hipEventSynchronize(h->e1));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
+      t[pass] = ms;
+    }
+    diff.push_back((t[0] - t[1]) / reps);
   }
-  *avg_ms = tot / reps;
+  std::sort(diff.begin(), diff.end());
+  *avg_ms = diff[diff.size() / 2];
   if (bytes) {
     if (h->spmv_stencil && h->structured && h->degree == 1)
       // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
@@ -2106,6 +2137,9 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   }
   h->lu_active = false;
   if (rsn > 0) HIPCHK(hipMemcpyAsync(h->x, h->xw, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  // the last residual evaluation refreshed D(psi) at the final iterate on the finest level only (k_resid_fill_grid writes
+  // the interior rows of its stencil in passing): the hierarchy no longer describes ONE matrix until the next fill
+  if (h->dh_interior) h->jac_valid = false;
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the solve must not pass silently
   if (h->prof) h->ms[7] += scope.stop();

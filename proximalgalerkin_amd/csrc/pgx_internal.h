@@ -121,7 +121,7 @@ void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ld
 void pgxk_csr_to_stencil(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm, const double* vals,
                          double* S);
 void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
-                           const double* vals, dsten_t* Sh);
+                           const double* vals, dsten_t* Sh, int frame_ny = 0);
 void pgxk_rap7(hipStream_t st, const GridLevel& f, const double* Sf, const GridLevel& c, double* Sc);
 void pgxk_rap7h(hipStream_t st, const GridLevel& f, const dsten_t* Sfh, const GridLevel& c, dsten_t* Sch);
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
@@ -183,6 +183,10 @@ void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, co
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                         const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
                         const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout);
+void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_t lds_bytes, const int32_t* rowptr,
+                          const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
+                          const double* coords, const uint8_t* mask, const double* gbc, const double* bphi, const double* x,
+                          const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout, int write_sh);
 // CGS2 with fused passes: (w' = w - V h1; [h2; |w'|^2] = [V,w']^T w') in one pass, then v = (w' - V h2)*scale
 void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h1, double* w,
                    double* partials, double* out);

@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows(int n, const int32_t* _
 // pair come out of the same loop at no extra exp cost (b_exp,a = row sum of the D_e row because the hat
 // functions sum to 1).  One launch replaces memset + k_residual_p1 (6 fp64 atomics per cell, ~1 ms at
 // 2048^2) + k_residual_final + k_fill_rows<2>, and the result is bitwise reproducible (no atomics).
-template <bool WRITE_D>
+static inline StConst make_stconst(const GridLevel& L);
+
+template <bool WRITE_D, bool FRAME>
 __global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1(int n, const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ v2c_ptr,
                                                              const int32_t* __restrict__ v2c_ent,
@@ -241,20 +243,28 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1(int n, const int32_
                                                              const double* __restrict__ bphi,
                                                              const double* __restrict__ x,
                                                              const double* __restrict__ xk, double alpha, double f,
-                                                             QuadTab q, double* __restrict__ F,
+                                                             QuadTab q, int sx, int ny, double* __restrict__ F,
                                                              double* __restrict__ Dout) {
+  // FRAME: only the boundary frame of an (sx x (ny+1))-vertex structured grid; the interior rows belong to k_resid_fill_grid.
+  // Every row then zeroes and writes back its own segment of the LDS row image (no block-wide pass over rows it skipped).
   extern __shared__ double acc[];
   const int i0 = blockIdx.x * PGX_BLOCK;
   const int i = i0 + threadIdx.x;
   const int iend = min(i0 + PGX_BLOCK, n);
   const int base = rowptr[i0];
   const int len = rowptr[iend] - base;
-  if (WRITE_D) {
+  if (WRITE_D && !FRAME) {
     for (int k = threadIdx.x; k < len; k += PGX_BLOCK) acc[k] = 0.0;
     __syncthreads();
   }
+  if (FRAME && i < n) {
+    const int gi = i % sx, gj = i / sx;
+    if (gi > 0 && gi < sx - 1 && gj > 0 && gj < ny) return;
+  }
   if (i < n) {
     double* row = acc + (rowptr[i] - base);
+    if (WRITE_D && FRAME)
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) row[k - rowptr[i]] = 0.0;
     double Fu = 0.0, Fp = 0.0;
     const int ke = v2c_ptr[i + 1];
     for (int k = v2c_ptr[i]; k < ke; ++k) {
@@ -294,11 +304,124 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1(int n, const int32_
     }
     F[i] = mask[i] ? x[i] - gbc[i] : Fu;
     F[n + i] = Fp - bphi[i];
+    if (WRITE_D && FRAME)
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) Dout[k] = row[k - rowptr[i]];
   }
-  if (WRITE_D) {
+  if (WRITE_D && !FRAME) {
     __syncthreads();
     for (int k = threadIdx.x; k < len; k += PGX_BLOCK) Dout[base + k] = acc[k];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Structured-grid twin of k_resid_fill_p1 for the INTERIOR vertices of a uniform right-diagonal mesh: element-local
+// evaluation with LDS-staged element blocks.  A workgroup owns 32 x 12 vertices.  Phase A: every triangle of the 33 x 13
+// squares around them is evaluated ONCE - the six entries E_ab = sum_q w_q exp(psi_h(q)) N_a(q) N_b(q) of its symmetric
+// latent block, 12 exp per triangle instead of the 36 the row-parallel kernel spends (each of a triangle's three rows
+// re-evaluates it) - and parked in LDS.  Phase B: a thread per vertex gathers its six triangles in a fixed order (no
+// atomics, bitwise reproducible): the seven entries of the D(psi) row, written in CSR order (SW, S, W, C, E, N, NE - the
+// sorted columns of an interior row), their sum (= int exp(psi_h) phi_i), and the K / M parts of both residual rows from the
+// seven constants of the uniform stencils.  Triangles of square (a, b): LR {(a,b), (a+1,b), (a+1,b+1)} and
+// UL {(a,b), (a+1,b+1), (a,b+1)}; any symmetric quadrature rule gives the same E for any labelling of a triangle's vertices.
+// The boundary frame (first / last row and column) keeps the general kernel (k_resid_fill_p1<., true>).
+// ------------------------------------------------------------------------------------------------
+#define PGX_RF_TX 32
+#define PGX_RF_TY 12
+template <bool WRITE_D>
+__global__ void __launch_bounds__(PGX_RF_TX * PGX_RF_TY) k_resid_fill_grid(
+    int nx, int ny, int n, const int32_t* __restrict__ rowptr, const double* __restrict__ coords, const uint8_t* __restrict__ mask,
+    const double* __restrict__ gbc, const double* __restrict__ bphi, const double* __restrict__ x, const double* __restrict__ xk,
+    double alpha, double f, QuadTab q, StConst sc, double* __restrict__ F, double* __restrict__ Dout,
+    dsten_t* __restrict__ Sh) {
+  constexpr int TX = PGX_RF_TX, TY = PGX_RF_TY, IW = TX + 2, IH = TY + 2, SW = TX + 1, SH = TY + 1;
+  __shared__ double iu[IH * IW], ip[IH * IW], idp[IH * IW];
+  __shared__ double E[2 * SW * SH][6];  // [2 * square + triangle][00, 11, 22, 01, 02, 12]
+  const int sx = nx + 1;
+  const int ntx = (nx - 1 + TX - 1) / TX;
+  const int i1 = 1 + ((int)blockIdx.x % ntx) * TX, j1 = 1 + ((int)blockIdx.x / ntx) * TY;  // first vertex of the tile
+  const int tid = threadIdx.x;
+  for (int t = tid; t < IH * IW; t += TX * TY) {  // images start one vertex before the tile
+    const int gi = i1 - 1 + t % IW, gj = j1 - 1 + t / IW;
+    double u = 0.0, p = 0.0, dp = 0.0;
+    if (gi <= nx && gj <= ny) {
+      const int v = gj * sx + gi;
+      u = mask[v] ? gbc[v] : x[v];
+      p = x[n + v];
+      dp = p - xk[n + v];
+    }
+    iu[t] = u;
+    ip[t] = p;
+    idp[t] = dp;
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * SW * SH; t += TX * TY) {
+    const int sq = t >> 1, a = sq % SW, b = sq / SW;
+    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i1 - 1 + a < nx && j1 - 1 + b < ny) {  // the square exists
+      const int o = b * IW + a;
+      const double p0 = ip[o], p1 = (t & 1) ? ip[o + IW + 1] : ip[o + 1], p2 = (t & 1) ? ip[o + IW] : ip[o + IW + 1];
+      for (int k = 0; k < q.nq; ++k) {
+        const double n0 = q.N[k][0], n1 = q.N[k][1], n2 = q.N[k][2];
+        const double w = q.w[k] * exp(p0 * n0 + p1 * n1 + p2 * n2);
+        e[0] += w * n0 * n0;
+        e[1] += w * n1 * n1;
+        e[2] += w * n2 * n2;
+        e[3] += w * n0 * n1;
+        e[4] += w * n0 * n2;
+        e[5] += w * n1 * n2;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) E[t][c] = e[c];
+  }
+  __syncthreads();
+  const int li = tid % TX, lj = tid / TX, gi = i1 + li, gj = j1 + lj;
+  if (gi >= nx || gj >= ny) return;  // interior vertices only: 1 <= gi <= nx - 1, 1 <= gj <= ny - 1
+  const int v = gj * sx + gi;
+  const double adet = fabs((coords[2] - coords[0]) * (coords[2 * sx + 1] - coords[1]));  // uniform mesh: |det J| of every triangle
+  // squares around the vertex in tile-square coordinates: SW = (li, lj), SE = (li+1, lj), NW = (li, lj+1), NE = (li+1, lj+1)
+  const double* swl = E[2 * (lj * SW + li)];
+  const double* swu = E[2 * (lj * SW + li) + 1];
+  const double* seu = E[2 * (lj * SW + li + 1) + 1];
+  const double* nwl = E[2 * ((lj + 1) * SW + li)];
+  const double* nel = E[2 * ((lj + 1) * SW + li + 1)];
+  const double* neu = E[2 * ((lj + 1) * SW + li + 1) + 1];
+  // E index: 0:00 1:11 2:22 3:01 4:02 5:12.  Local index of the vertex: SW-LR 2, SW-UL 1, SE-UL 2, NW-LR 1, NE-LR 0, NE-UL 0
+  const double dC = adet * (((swl[2] + swu[1]) + (seu[2] + nwl[1])) + (nel[0] + neu[0]));
+  const double dSW = adet * (swl[4] + swu[3]);  // SW-LR (2,0), SW-UL (1,0)
+  const double dS = adet * (swl[5] + seu[4]);   // SW-LR (2,1), SE-UL (2,0)
+  const double dW = adet * (swu[5] + nwl[3]);   // SW-UL (1,2), NW-LR (1,0)
+  const double dE = adet * (seu[5] + nel[3]);   // SE-UL (2,1), NE-LR (0,1)
+  const double dN = adet * (nwl[5] + neu[4]);   // NW-LR (1,2), NE-UL (0,2)
+  const double dNE = adet * (nel[4] + neu[3]);  // NE-LR (0,2), NE-UL (0,1)
+  if (WRITE_D) {
+    double* d = Dout + rowptr[v];
+    d[0] = dSW;
+    d[1] = dS;
+    d[2] = dW;
+    d[3] = dC;
+    d[4] = dE;
+    d[5] = dN;
+    d[6] = dNE;
+    if (Sh) {  // the multigrid's half-stored stencil of the same row: centre + the three forward links
+      Sh[v] = (dsten_t)dC;
+      Sh[(size_t)n + v] = (dsten_t)dE;
+      Sh[2 * (size_t)n + v] = (dsten_t)dN;
+      Sh[3 * (size_t)n + v] = (dsten_t)dNE;
+    }
+  }
+  const int o = (lj + 1) * IW + li + 1;
+  const int off[7] = {0, 1, -1, IW, -IW, IW + 1, -IW - 1};
+  double Ku = 0.0, Mdp = 0.0, Mu = 0.0;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    Ku += sc.K[t] * iu[o + off[t]];
+    Mdp += sc.M[t] * idp[o + off[t]];
+    Mu += sc.M[t] * iu[o + off[t]];
+  }
+  const double load = adet * 2.0 * (q.mref[0] + q.mref[1] + q.mref[2]);  // int phi_i over the six triangles
+  F[v] = mask[v] ? x[v] - gbc[v] : alpha * Ku + Mdp - alpha * f * load;
+  F[n + v] = Mu - (((dSW + dS) + (dW + dC)) + ((dE + dN) + dNE)) - bphi[v];
 }
 
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
@@ -307,11 +430,36 @@ void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, co
                         const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout) {
   dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
   if (write_d)
-    hipLaunchKernelGGL(k_resid_fill_p1<true>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
-                       coords, mask, gbc, bphi, x, xk, alpha, f, q, F, Dout);
+    hipLaunchKernelGGL((k_resid_fill_p1<true, false>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, 0, 0, F, Dout);
   else
-    hipLaunchKernelGGL(k_resid_fill_p1<false>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
-                       coords, mask, gbc, bphi, x, xk, alpha, f, q, F, Dout);
+    hipLaunchKernelGGL((k_resid_fill_p1<false, false>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, 0, 0, F, Dout);
+}
+
+// structured uniform mesh (GridLevel L = the finest level): boundary frame through the general kernel, interior through
+// k_resid_fill_grid
+void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_t lds_bytes, const int32_t* rowptr,
+                          const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
+                          const double* coords, const uint8_t* mask, const double* gbc, const double* bphi, const double* x,
+                          const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout, int write_sh) {
+  const int n = L.n, sx = L.nx + 1;
+  dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (write_d)
+    hipLaunchKernelGGL((k_resid_fill_p1<true, true>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, sx, L.ny, F, Dout);
+  else
+    hipLaunchKernelGGL((k_resid_fill_p1<false, true>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
+                       coords, mask, gbc, bphi, x, xk, alpha, f, q, sx, L.ny, F, Dout);
+  if (L.nx < 2 || L.ny < 2) return;
+  const int ntx = (L.nx - 1 + PGX_RF_TX - 1) / PGX_RF_TX, nty = (L.ny - 1 + PGX_RF_TY - 1) / PGX_RF_TY;
+  const StConst sc = make_stconst(L);
+  if (write_d)
+    hipLaunchKernelGGL(k_resid_fill_grid<true>, dim3(ntx * nty), dim3(PGX_RF_TX * PGX_RF_TY), 0, st, L.nx, L.ny, n, rowptr, coords,
+                       mask, gbc, bphi, x, xk, alpha, f, q, sc, F, Dout, write_sh ? L.Dh : nullptr);
+  else
+    hipLaunchKernelGGL(k_resid_fill_grid<false>, dim3(ntx * nty), dim3(PGX_RF_TX * PGX_RF_TY), 0, st, L.nx, L.ny, n, rowptr, coords,
+                       mask, gbc, bphi, x, xk, alpha, f, q, sc, F, Dout, nullptr);
 }
 
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
@@ -1039,9 +1187,13 @@ __device__ __forceinline__ void ld7h(const dsten_t* __restrict__ Sh, int n, int 
 __global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil_h(int n, int sx, const int32_t* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ colm,
                                                                 const double* __restrict__ vals,
-                                                                dsten_t* __restrict__ Sh) {
+                                                                dsten_t* __restrict__ Sh, int frame_ny) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (frame_ny > 0) {  // boundary frame only: k_resid_fill_grid has written the interior rows
+    const int gi = i % sx, gj = i / sx;
+    if (gi > 0 && gi < sx - 1 && gj > 0 && gj < frame_ny) return;
+  }
   double s[4] = {0, 0, 0, 0};
   for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
     const int o = (colm[k] & 0x7fffffff) - i;
@@ -1055,9 +1207,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_csr_to_stencil_h(int n, int sx, c
   for (int k = 0; k < 4; ++k) Sh[(size_t)k * n + i] = (dsten_t)s[k];
 }
 void pgxk_csr_to_stencil_h(hipStream_t st, int n, int sx, const int32_t* rowptr, const int32_t* colm,
-                           const double* vals, dsten_t* Sh) {
+                           const double* vals, dsten_t* Sh, int frame_ny) {
   hipLaunchKernelGGL(k_csr_to_stencil_h, dim3((n + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, n, sx, rowptr,
-                     colm, vals, Sh);
+                     colm, vals, Sh, frame_ny);
 }
 
 // Galerkin coarsening on symmetric-half storage: only the 4 stored coarse slots are produced.

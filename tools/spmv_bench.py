@@ -13,7 +13,8 @@ x = rng.standard_normal(2 * msh.num_vertices) * 0.1
 problem.assemble_jacobian(x)
 kind = problem.spmv_select(int(sys.argv[2]) if len(sys.argv) > 2 else -1)
 best = None
-for rep in range(5):
-    ms, by = problem.spmv_bench(reps=100)
+for rep in range(3):
+    ms, by = problem.spmv_bench(reps=20)
     best = ms if best is None else min(best, ms)
+    print(f"  rep {rep}: {ms * 1e3:.1f} us")
 print(f"N={N} kind={kind} bytes={by:.0f} stream={os.environ.get('PGX_SPMV_STREAM','1')} remap={os.environ.get('PGX_XCD_REMAP','1')}: {best*1e3:.1f} us  {by/best/1e6:.0f} GB/s  ({by/best/1e6/8000*100:.1f}% of 8 TB/s)")
