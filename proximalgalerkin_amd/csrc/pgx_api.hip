@@ -104,6 +104,7 @@ struct pgx_handle {
   pgx_comm* lu_comm = nullptr;
   double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
   bool dh_interior = false;
+  int k6_max = 0;          // levels with at most this many vertices run 6 sweeps per smoother launch (PGX_K6_MAX)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
@@ -773,6 +774,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = getenv("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
   if (const char* e = getenv("PGX_RESID_GRID")) h->resid_grid = atoi(e);
+  if (const char* e = getenv("PGX_K6_MAX")) h->k6_max = atoi(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   if (const char* e = getenv("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
   if (const char* e = getenv("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
@@ -1284,21 +1286,23 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
     // prolongated coarse correction)   (pgx_kernels.hip, "Fused V-cycle legs", k_st_smoothK)
     GridLevel& C = h->lev[l + 1];
     const int remap = h->xcd_remap ? 1 : 0;
-    const int nl = nu / Kf;
+    // small levels are bound by the latency of a launch's dependent phases, not by its work: all six sweeps of a leg in ONE launch
+    const int Kl = (Kf == 3 && nu % 6 == 0 && L.n <= h->k6_max && pgxk_st_smooth6_ok(L)) ? 6 : Kf;
+    const int nl = nu / Kl;
     double *cu = Bu, *cp = Bp, *ou = Au, *op = Ap;  // current / other buffer pair
-    pgxk_st_smoothK(h->st, Kf, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
+    pgxk_st_smoothK(h->st, Kl, 0, L, h->alpha, nullptr, nullptr, nullptr, nullptr, nullptr, bu, bp, omega, remap, cu, cp);
     for (int s = 1; s < nl; ++s) {
-      pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+      pgxk_st_smoothK(h->st, Kl, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
       std::swap(cu, ou);
       std::swap(cp, op);
     }
     pgxk_st_resid_restrict(h->st, L, h->alpha, cu, cp, bu, bp, C, remap, C.bu, C.bp);
     vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
-    pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, &C, C.xu, C.xp, bu, bp, omega, remap, ou, op);
+    pgxk_st_smoothK(h->st, Kl, 1, L, h->alpha, cu, cp, &C, C.xu, C.xp, bu, bp, omega, remap, ou, op);
     std::swap(cu, ou);
     std::swap(cp, op);
     for (int s = 1; s < nl; ++s) {
-      pgxk_st_smoothK(h->st, Kf, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
+      pgxk_st_smoothK(h->st, Kl, 1, L, h->alpha, cu, cp, nullptr, nullptr, nullptr, bu, bp, omega, remap, ou, op);
       std::swap(cu, ou);
       std::swap(cp, op);
     }

@@ -196,6 +196,7 @@ void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, s
 void pgxk_multiaxpy_norm(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w,
                          double* partials, double* out);
 // K (2 or 3) collective-Jacobi sweeps per launch; see k_st_smoothK
+int pgxk_st_smooth6_ok(const GridLevel& L);
 void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
                      const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
                      const double* bp, double omega, int remap, double* yu, double* yp);

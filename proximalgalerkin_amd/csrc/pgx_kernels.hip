@@ -1686,6 +1686,8 @@ struct RowmapGrid {
 template <int TY, int K>
 static inline RowmapGrid rowmap_grid(int nx, int ny, int fast_ok) {
   constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K;
+  // the tile enumeration takes tx, ty >= 1 as "the image starts inside the grid": tx TX - K >= 1 and ty TY - K >= 1 at tx = ty = 1
+  static_assert(TX - K >= 1 && TY - K >= 1, "first interior tile would read outside the grid");
   RowmapGrid g;
   g.ntx = (nx + TX) / TX;
   g.nty = (ny + TY) / TY;
@@ -1939,22 +1941,31 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_smoothR(int nx, int ny,
                                  bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD);
 }
 
-template <int TYR>
+template <int TYR, int KS = 3>
 static void launch_rowmap(hipStream_t st, int post, const GridLevel& L, const StConst& sc, double alpha, const double* xu,
                           const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
                           const double* bp, double omega, int remap, double* yu, double* yp) {
-  const RowmapGrid g = rowmap_grid<TYR, 3>(L.nx, L.ny, L.interior_free);
+  const RowmapGrid g = rowmap_grid<TYR, KS>(L.nx, L.ny, L.interior_free);
   const int nfast = g.nfx * g.nfy, nbnd = (g.ntx * g.nty - nfast) * (TYR / 4);  // boundary tiles: sub-tiles of 4 rows
   dim3 grid(nbnd + nfast), block(PGX_ROWMAP_BLOCK);
   if (post)
-    hipLaunchKernelGGL((k_st_smoothR<TYR, 3, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask, alpha,
+    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask, alpha,
                        xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
   else
-    hipLaunchKernelGGL((k_st_smoothR<TYR, 3, false>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask,
+    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, false>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask,
                        alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
 }
 
-// post=0: S^K(0);  post=1: S^K((xu,xp) + P (cu,cp)) (cu may be null)   -- out of place; K in {2,3}
+// K = 6 is available on levels with uniform interior stencils (row-mapped kernels only)
+int pgxk_st_smooth6_ok(const GridLevel& L) {
+  static const int rowmap = [] {
+    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+    return e ? atoi(e) : 1;
+  }();
+  return rowmap && L.uniform;
+}
+
+// post=0: S^K(0);  post=1: S^K((xu,xp) + P (cu,cp)) (cu may be null)   -- out of place; K in {2,3,6}
 void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,
                      const double* xp, const GridLevel* C, const double* cu, const double* cp, const double* bu,
                      const double* bp, double omega, int remap, double* yu, double* yp) {
@@ -1967,6 +1978,10 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
     const char* e = getenv("PGX_SMOOTH_ROWMAP");
     return e ? atoi(e) : 1;
   }();
+  if (K == 6) {  // small levels (pgxk_st_smooth6_ok): SIX sweeps per launch - one latency-bound launch instead of two
+    launch_rowmap<8, 6>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    return;
+  }
   if (rowmap && L.uniform) {  // row-mapped kernels: image 64 x (TY + 6), tile 58 x TY; interior tiles + boundary tiles
     // tile height by level size (measured, us per launch at 2049^2 / 1025^2 / 513^2 / 257^2 vertices; PGX_ROWMAP_TY forces one)
     static const int ty_env = [] {
