@@ -1200,6 +1200,13 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
       // Galerkin coarse block T^T D_P2 T == D in the P1 basis with the P2 psi (same quadrature), for the P1 hierarchy
       pgxk_fill_rows_p1_Dp2(h->st, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cdofs, h->coords,
                             x + h->nd, h->q2, h->Dv);
+    } else if (h->resid_grid && h->structured && !h->lev.empty() && h->lev[0].uniform) {
+      // uniform structured mesh: D(psi) comes from the same element kernel the Newton driver uses (its residual output goes to
+      // scratch), so pgx_jacobian_fill + pgx_csr_export put THAT kernel under the entry-wise oracle comparison of the parity tests
+      pgxk_resid_fill_grid(h->st, 1, h->lev[0], h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
+                           h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, h->w, h->Dv, 1);
+      h->dh_interior = true;
+      have_d = true;
     } else {
       pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
                      x + h->n, h->q, h->Dv);
