@@ -390,6 +390,8 @@ def main():
     if args.profile:
         problem.profile(reset=True)
     barrier()
+    if sharded:
+        problem.comm_counts(reset=True)
     t0 = time.perf_counter()
     newton_total, outer_total = 0, 0
     for _ in range(args.steps):
@@ -404,6 +406,7 @@ def main():
             assert nsum == newton_total * world and osum == outer_total * world, "ranks disagree on iteration counts"
         else:
             newton_total, outer_total = nsum, osum
+    comm_counts = problem.comm_counts() if sharded else None  # collectives of the timed solves, this rank
     units = 1 if sharded else world  # solves per step over the whole job
     lin_its = problem.solver.getLinearSolveIterations()
 
@@ -498,6 +501,11 @@ def main():
         }
         if spmv_kind != 0:
             out["roofline_csr"] = spmv_roofline(0, csr_ms, csr_bytes)
+        if comm_counts:
+            kit = max(comm_counts["krylov_iterations"], 1)
+            out["config"]["collectives_per_krylov_iteration"] = {
+                "halo_exchanges": comm_counts["halo_exchanges"] / kit, "allreduces": comm_counts["allreduces"] / kit,
+                "ghost_depth_multiplier": int(os.environ.get("PGX_GHOST_MUL", "3")), "counted": comm_counts}
         if smoother:
             out["roofline_dominant"] = smoother
         if prof:

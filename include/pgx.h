@@ -150,6 +150,9 @@ int pgx_spmv(pgx_handle* h, const double* x, double* y);
  * sweep 512 MB of idle storage between two applies.  Returns the average ms per launch and the algorithmic bytes one launch
  * moves. */
 int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+/* Sharded handles: collectives issued by THIS rank since the last reset - [0] halo exchanges (one grouped send/recv batch with
+ * both strip neighbours each), [1] all-reduces, [2] V-cycles, [3] Krylov iterations.  Zeros on unsharded handles. */
+int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset);
 /* Operator apply of the outer Krylov solver ("SpMV").  kind 1 (default on structured P1 meshes): matrix-free stencil kernel
  * k_st_spmv_r - K, M are the uniform mesh's constants, D(psi) its half-stored 7-point stencil, 65 B per vertex; kind 0: the
  * block-CSR stream kernel k_bspmv_stream (what general meshes and P2 always use, 232 B per P1 row); kind 2: generic

@@ -28,6 +28,7 @@ struct Dist {
   std::vector<DistLevel> L;
   GridLevel view{};  // this rank's rows of the first replicated level (pointers into that level's global arrays)
   int view_row0 = 0, view_glo = 0, view_H = 0, view_own0 = 0;
+  long long n_halo = 0, n_allreduce = 0, n_vcycle = 0, n_krylov = 0;  // collective counts (pgx_comm_counts)
   double* view_S = nullptr;  // [7 * view.n] strip-shaped coarse stencils before they are merged into the global level
   size_t own_off = 0, own_cnt = 0;  // owned entries per field on level 0: [own_off, own_off + own_cnt)
   int cell0 = 0, ncell_own = 0;     // owned cells (row-major cell order)
@@ -456,6 +457,20 @@ static int detect_uniform(pgx_handle* h, GridLevel& L) {
 // ------------------------------------------------------------------------------------------------
 // sharded path: strip partition arithmetic (no GPU needed) and the ghost-row exchange
 // ------------------------------------------------------------------------------------------------
+// Ghost depth multiplier m (PGX_GHOST_MUL, default 3; every rank must see the same value): distributed level l keeps m 2^(ld-l)
+// ghost rows (24 / 12 / 6 for three distributed levels).  An exchange restores validity depth g and a fused smoother launch
+// consumes K = 3 of it, so deeper ghosts trade redundant rows (m 2^ld per strip side on the finest level: +19 % of a 256-row
+// strip at m = 3) for fewer latency-bound exchanges: 14.2 / 9.2 / 6.2 / 6.2 per Krylov iteration at m = 1 / 2 / 3 / 4
+// (pgx_comm_counts, 2048^2 on 4 strips).
+static int ghost_mul() {
+  static const int m = [] {
+    const char* e = getenv("PGX_GHOST_MUL");
+    const int v = e ? atoi(e) : 3;
+    return v >= 1 && v <= 4 ? v : 3;
+  }();
+  return m;
+}
+
 static int partition_resolve(pgx_partition* pt, std::string& err) {
   if (!pt || pt->size < 1 || pt->rank < 0 || pt->rank >= pt->size || pt->global_ny < 1 || pt->dist_levels < 0) {
     err = "pgx_partition: need 0 <= rank < size, global_ny >= 1, dist_levels >= 0";
@@ -467,7 +482,7 @@ static int partition_resolve(pgx_partition* pt, std::string& err) {
   }
   const int Hh = pt->global_ny / pt->size;
   // level l keeps Hh/2^l owned rows and 2^(ld-l) ghost rows: strips must coarsen ld times and still own g+1 = 3 rows
-  auto ok = [&](int l) { return l >= 1 && l <= 8 && Hh % (1 << l) == 0 && (Hh >> (l - 1)) >= 4; };
+  auto ok = [&](int l) { return l >= 1 && l <= 8 && Hh % (1 << l) == 0 && (Hh >> (l - 1)) >= 4 * ghost_mul(); };
   int ld = pt->dist_levels;
   if (ld == 0) {
     for (ld = 3; ld >= 1 && !ok(ld); --ld) {}
@@ -490,7 +505,7 @@ extern "C" int pgx_partition_rows(pgx_partition* pt, int32_t* row0, int32_t* nro
     g_create_error = err;
     return rc;
   }
-  const int Hh = pt->global_ny / pt->size, g0 = 1 << pt->dist_levels;
+  const int Hh = pt->global_ny / pt->size, g0 = ghost_mul() << pt->dist_levels;
   const int r0 = pt->rank * Hh - (pt->rank > 0 ? g0 : 0);
   const int r1 = (pt->rank + 1 < pt->size) ? (pt->rank + 1) * Hh + g0 : pt->global_ny;  // last local vertex row
   if (row0) *row0 = r0;
@@ -507,11 +522,13 @@ static int halo_level(pgx_handle* h, int l, double* fu, double* fp) {
   double* f[2] = {fu, fp};
   const int rc = h->dist.comm->halo(h->st, f, 2, d.glo * sx, (d.g + 1) * sx, 0, d.g * sx, (d.glo + d.H - d.g) * sx,
                                     d.g * sx, (d.glo + d.H) * sx, (d.g + 1) * sx);
+  ++h->dist.n_halo;
   if (rc) h->err = h->dist.comm->err;
   return rc;
 }
 static int allreduce_dev(pgx_handle* h, double* dev, size_t n) {
   const int rc = h->dist.comm->allreduce(h->st, dev, n);
+  ++h->dist.n_allreduce;
   if (rc) h->err = h->dist.comm->err;
   return rc;
 }
@@ -674,14 +691,14 @@ static int build_multigrid_dist(pgx_handle* h) {
   const int sxc = G.nx + 1;
   const int Hh = D.global_ny / D.size;
   D.view_own0 = (D.rank * Hh) >> ld;
-  D.view_glo = D.rank > 0 ? 1 : 0;
+  D.view_glo = D.rank > 0 ? ghost_mul() : 0;  // the last strip level has 2m ghost rows below and 2m + 1 above
   D.view_H = (Hh >> ld) + (D.rank + 1 == D.size ? 1 : 0);
   D.view_row0 = D.view_own0 - D.view_glo;
   GridLevel& V = D.view;
   V = G;
   V.ny = Fl.ny / 2;
   V.n = sxc * (V.ny + 1);
-  if (V.nx * 2 != Fl.nx || D.view_row0 + V.ny > G.ny || V.ny + 1 != D.view_glo + D.view_H + (D.rank + 1 < D.size ? 2 : 0)) {
+  if (V.nx * 2 != Fl.nx || D.view_row0 + V.ny > G.ny || V.ny + 1 != D.view_glo + D.view_H + (D.rank + 1 < D.size ? ghost_mul() + 1 : 0)) {
     h->err = "sharded hierarchy: strip view of the first replicated level is inconsistent";
     return PGX_EINVAL;
   }
@@ -855,7 +872,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     const int Hh = pt.global_ny / pt.size;
     for (int l = 0; l < D.ldist; ++l) {
       DistLevel d;
-      d.g = 1 << (D.ldist - l);
+      d.g = ghost_mul() << (D.ldist - l);
       d.glo = pt.rank > 0 ? d.g : 0;
       d.H = (Hh >> l) + (pt.rank + 1 == pt.size ? 1 : 0);
       d.ghi = pt.rank + 1 < pt.size ? d.g + 1 : 0;
@@ -1611,6 +1628,7 @@ static int precond(pgx_handle* h, const double* b, double* z, int nu, double ome
   }
   if (h->dist.on) {  // b is owned-compact, z local (owned + ghost rows, correct at least one row beyond the strip)
     scatter_owned(h, b, h->dist.sb);
+    ++h->dist.n_vcycle;
     return vcycle_dist(h, 0, h->dist.sb, h->dist.sb + h->n, z, z + h->n, 1, nu, omega);
   }
   if (h->degree == 2)  // P2 level: one more sweep at 0.75*omega (prototype sweep in DESIGN.md section 3); P1 levels as usual
@@ -1780,6 +1798,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       g[j] = cs[j] * g[j];
       res = std::fabs(g[j + 1]);
       ++its;
+      if (dist) ++h->dist.n_krylov;
       if (o->monitor > 1) printf("      ksp %3d  rnorm %.6e  rel %.3e\n", its, res, res / bnorm);
       if (!std::isfinite(res)) {
         *its_out = its;
@@ -1978,6 +1997,17 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
     else  // one pattern (4 B) + three value streams (24 B) per scalar nnz; rowptr; x read once; y written
       *bytes = 28.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
   }
+  return PGX_OK;
+}
+
+extern "C" int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset) {
+  NEED(h);
+  if (!out) return PGX_EINVAL;
+  out[0] = h->dist.n_halo;
+  out[1] = h->dist.n_allreduce;
+  out[2] = h->dist.n_vcycle;
+  out[3] = h->dist.n_krylov;
+  if (reset) h->dist.n_halo = h->dist.n_allreduce = h->dist.n_vcycle = h->dist.n_krylov = 0;
   return PGX_OK;
 }
 

@@ -319,6 +319,12 @@ class NonlinearProblem:
         _lib.check(self._lib, self._h, self._lib.pgx_spmv_select(self._h, int(kind), C.byref(act)), "pgx_spmv_select")
         return act.value
 
+    def comm_counts(self, reset=False):
+        """Collectives this rank issued since the last reset (include/pgx.h: pgx_comm_counts)."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib, self._h, self._lib.pgx_comm_counts(self._h, out, int(reset)), "pgx_comm_counts")
+        return dict(zip(("halo_exchanges", "allreduces", "vcycles", "krylov_iterations"), (int(v) for v in out)))
+
     def smoother_bench(self, reps=20):
         """(avg ms, algorithmic bytes) of the finest level's fused smoother launch (include/pgx.h: pgx_smoother_bench)."""
         ms, by = C.c_double(0), C.c_double(0)
