@@ -105,7 +105,7 @@ typedef struct {
   int32_t ksp_max_it; /* default 200 */
   int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */
   int32_t mg_nu;      /* pre/post smoothing sweeps, default 6 (even values run as fused double sweeps) */
-  double mg_omega;    /* collective-Jacobi damping, default 0.8 */
+  double mg_omega;    /* collective-Jacobi damping, default 0.75 */
   int32_t monitor;    /* 1 = print per-Newton-step residuals (snes_monitor/ksp_monitor) */
   int32_t pc_type;    /* preconditioner of the FGMRES Newton solve: 0 = auto (1 for P1 on a structured mesh, 2 for P2 and for general
                          meshes), 1 = multigrid V-cycle (single-level smoother on general meshes),

@@ -105,6 +105,8 @@ struct pgx_handle {
   pgx_comm* lu_comm = nullptr;
   double* Jmix = nullptr;  // [4 * s_nnz] values of the mixed CSR matrix in the layout lu was created with
   bool dh_interior = false;
+  int stag_its = 12;       // PGX_STAG_ITS / PGX_STAG_GAIN: stagnation test of the smoother damping (fgmres)
+  double stag_gain = 1e-4;
   int k6_max = 0;          // levels with at most this many vertices run 6 sweeps per smoother launch (PGX_K6_MAX)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
@@ -179,7 +181,11 @@ extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->ksp_restart = 30;
   o->mg_nu = 6;  // 2048^2 sweep (profiles/): nu=2 780 ms, 4 707, 6 660, 8 692, 10 763 per solve - more smoothing shrinks the
                   // Krylov space, whose orthogonalisation cost grows with its square
-  o->mg_omega = 0.8;
+  // damping, re-measured in round 2 on the row-mapped kernels (2048^2, ms per solve / Krylov iterations per solve): 0.60 338, 0.65 324,
+  // 0.70 314 / -, 0.72 311 / 252, 0.75 302 / 246, 0.76 - / 248, 0.77 - / 250, 0.78 332 / 265, 0.80 334 / 267, 0.85 359, 0.90 374: the
+  // optimum of the smoothing factor is flat between 0.72 and 0.77; from 0.78 on one late Newton step trips the stagnation
+  // test and finishes at omega_safe.  1024^2 and 512^2 do not care (87-89 ms, 58 ms for 0.70-0.80).  Round 1 used 0.8.
+  o->mg_omega = 0.75;
   o->monitor = 0;
   o->pc_type = 0;  // auto: multigrid for P1, sparse LU for P2
   o->linesearch = 0;
@@ -792,6 +798,8 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = getenv("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
   if (const char* e = getenv("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = getenv("PGX_K6_MAX")) h->k6_max = atoi(e);
+  if (const char* e = getenv("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
+  if (const char* e = getenv("PGX_STAG_GAIN")) h->stag_gain = atof(e);
   if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
   if (const char* e = getenv("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
   if (const char* e = getenv("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
@@ -1809,11 +1817,13 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         ++j;
         break;
       }
-      if (omega > omega_safe && j + 1 == std::min(m, 30) && res > 0.1 * beta) {
+      // Stagnation test.  A healthy solve gains a factor 5-8 per iteration; a smoother that diverges on the rough late iterates
+      // shows within a dozen iterations.  FGMRES tolerates a changing preconditioner, so the damping is switched IN PLACE (no
+      // restart: the basis built so far stays useful) as soon as `stag_its` iterations have gained less than 1e-4 (round 1
+      // waited for a full cycle of 30 that gained < 10x and restarted).
+      if (omega > omega_safe && j + 1 == std::min(m, h->stag_its) && res > h->stag_gain * beta) {
         h->omega_now = omega = omega_safe;  // sticky until pgx_newton_solve returns: later iterates are rough too
         if (o->monitor > 1) printf("      ksp stagnates: smoother damping -> %.2f for the rest of this Newton solve\n", omega);
-        ++j;
-        break;
       }
     }
     // y = H^-1 g (upper triangular), x += Z y
