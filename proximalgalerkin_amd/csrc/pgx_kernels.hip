@@ -1979,7 +1979,14 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
     return e ? atoi(e) : 1;
   }();
   if (K == 6) {  // small levels (pgxk_st_smooth6_ok): SIX sweeps per launch - one latency-bound launch instead of two
-    launch_rowmap<8, 6>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    static const int ty6 = [] {
+      const char* e = getenv("PGX_K6_TY");
+      return e ? atoi(e) : 0;
+    }();
+    if (ty6 == 16)  // measured at 2049^2: 16-row tiles 323 ms per solve, 8-row tiles 298 ms, three-sweep launches (default) 304 ms
+      launch_rowmap<16, 6>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
+    else
+      launch_rowmap<8, 6>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
     return;
   }
   if (rowmap && L.uniform) {  // row-mapped kernels: image 64 x (TY + 6), tile 58 x TY; interior tiles + boundary tiles
