@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--degree", type=int, choices=[1, 2], default=1, help="Lagrange degree (obstacle_pg.py -p)")
     ap.add_argument("--cpu-n", type=int, default=256, help="mesh size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solves-only", action="store_true",
+                    help="profiling aid: skip the roofline microbenchmarks after the timed solves (their V-cycle replays would "
+                         "distort a per-kernel time breakdown); `roofline` is then null")
     ap.add_argument("--profile", action="store_true", help="per-phase device times (adds syncs; not for `value`)")
     ap.add_argument("--opts", default="", help="extra solver options key=val,key=val (e.g. ksp_gmres_restart=20)")
     ap.add_argument("--replicas", action="store_true", help="N>1: N independent solves instead of one sharded solve")
@@ -415,18 +418,18 @@ def main():
     # meshes, P2; 232 B per P1 row) is timed beside it on the same matrix and reported as `roofline_csr`
     problem.assemble_jacobian()  # Jacobian at the final iterate
     spmv_kind = problem.spmv_select()
-    spmv_ms, spmv_bytes = problem.spmv_bench(reps=20)
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    csr_ms = csr_bytes = None
-    if spmv_kind != 0:
-        problem.spmv_select(0)
-        csr_ms, csr_bytes = problem.spmv_bench(reps=20)
-        problem.spmv_select(spmv_kind)
-    else:
-        csr_ms, csr_bytes = spmv_ms, spmv_bytes
+    spmv_ms = spmv_bytes = csr_ms = csr_bytes = None
+    if not args.solves_only:
+        spmv_ms, spmv_bytes = problem.spmv_bench(reps=20)
+        if spmv_kind != 0:
+            problem.spmv_select(0)
+            csr_ms, csr_bytes = problem.spmv_bench(reps=20)
+            problem.spmv_select(spmv_kind)
+        else:
+            csr_ms, csr_bytes = spmv_ms, spmv_bytes
     n = msh.num_vertices
     smoother = None
-    if not sharded and args.degree == 1:
+    if not sharded and args.degree == 1 and not args.solves_only:
         sm_ms, sm_bytes = problem.smoother_bench(reps=50)
         smoother = {"kernel": "k_st_smoothR<16,3,POST> on the finest level (three collective-Jacobi sweeps + x + P x_c per launch; 24 % "
                               "of the solve, the time-dominant kernel; profiles/r02_bench_2048_trace_by_level.txt)",
@@ -497,9 +500,9 @@ def main():
             "proximal_iterations_per_s": outer_total / dt,
             "last_newton_linear_iterations": lin_its,
             "setup_s": t_setup,
-            "roofline": spmv_roofline(spmv_kind, spmv_ms, spmv_bytes),
+            "roofline": spmv_roofline(spmv_kind, spmv_ms, spmv_bytes) if spmv_ms else None,
         }
-        if spmv_kind != 0:
+        if spmv_kind != 0 and csr_ms:
             out["roofline_csr"] = spmv_roofline(0, csr_ms, csr_bytes)
         if comm_counts:
             kit = max(comm_counts["krylov_iterations"], 1)
