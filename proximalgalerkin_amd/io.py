@@ -222,6 +222,29 @@ def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     return mesh, MeshTags(tagged_facets)
 
 
+def write_xdmf_tet(path, mesh, facet_tags, tags=None, name: str = "mesh", tags_name: str = "facet_tags"):
+    """XDMFFile.write_mesh + write_meshtags of `examples/02_signorini/generate_mesh.py:13-17` for a TetMesh and its MeshTags, with
+    inline (Format="XML") data items - the encoding `read_xdmf` accepts (dolfinx: `XDMFFile(..., encoding=XDMFFile.Encoding.ASCII)`)."""
+    path = Path(path)
+    p, t = np.asarray(mesh.geometry), np.asarray(mesh.cells)
+    tags = sorted(facet_tags._t) if tags is None else list(tags)
+    fc = [np.asarray(facet_tags.find(k)) for k in tags]
+    allf = np.concatenate(fc) if fc else np.zeros((0, 3), dtype=np.int32)
+    vals = np.concatenate([np.full(len(f), k) for f, k in zip(fc, tags)]) if fc else np.zeros(0, dtype=np.int64)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n<Grid Name="%s" GridType="Uniform">\n' % name)
+        f.write('<Topology TopologyType="Tetrahedron" NumberOfElements="%d" NodesPerElement="4">\n<DataItem Dimensions="%d 4" NumberType="Int" '
+                'Format="XML">\n%s\n</DataItem></Topology>\n' % (len(t), len(t), "\n".join(" ".join(map(str, c)) for c in t)))
+        f.write('<Geometry GeometryType="XYZ"><DataItem Dimensions="%d 3" Format="XML">\n%s\n</DataItem></Geometry>\n</Grid>\n'
+                % (len(p), "\n".join("%.17g %.17g %.17g" % tuple(x) for x in p)))
+        f.write('<Grid Name="%s" GridType="Uniform">\n<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n'
+                '<DataItem Dimensions="%d 3" NumberType="Int" Format="XML">\n%s\n</DataItem></Topology>\n'
+                % (tags_name, len(allf), len(allf), "\n".join(" ".join(map(str, c)) for c in allf)))
+        f.write('<Attribute Name="%s" AttributeType="Scalar" Center="Cell"><DataItem Dimensions="%d 1" Format="XML">\n%s\n'
+                '</DataItem></Attribute>\n</Grid>\n</Domain></Xdmf>\n' % (tags_name, len(vals), "\n".join(map(str, vals))))
+
+
 def write_vtu(path, points, cells, point_data: dict | None = None, cell_data: dict | None = None, cell_type: str | None = None):
     """VTK XML unstructured grid (ASCII).  cells: (m,3) triangles, (m,6) quadratic triangles in the dof order used here
     (3 vertices, then the edge midpoint OPPOSITE each vertex - reordered to VTK's edge order) or (m,4) tetrahedra."""

@@ -83,3 +83,33 @@ def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
     assert it_f == it and list(iterations_f) == list(iterations)
     nu3 = 3 * mesh.geometry.shape[0]
     assert np.linalg.norm(u.x.array - x[:nu3]) <= 1e-12 * np.linalg.norm(x[:nu3])
+
+
+def test_half_sphere_through_the_mesh_file_workflow(require_gpu, tmp_path):
+    """The reference's own workflow for its flagship contact geometry (examples/02_signorini/generate_mesh.py +
+    `signorini_dolfinx.py file`): half sphere of lvpp.mesh_generation.create_half_sphere (curved surface tagged 2 = contact, flat top
+    tagged 1 = prescribed displacement) -> XDMF file -> read_mesh / read_meshtags -> LVPP solve.  Curved contact facets, unstructured
+    vertex numbering after the file round trip; HIP path vs oracle on the same mesh."""
+    from proximalgalerkin_amd import io, mesh_generation
+    from proximalgalerkin_amd import signorini as G
+
+    mesh0, _, ft0 = mesh_generation.create_half_sphere(res=0.15)
+    path = tmp_path / "meshes" / "half_sphere.xdmf"
+    io.write_xdmf_tet(path, mesh0, ft0)
+    mesh, mt = io.read_tet_mesh(path)
+    bcs = {"contact": (2,), "displacement": (1,)}
+    # disp -0.12 presses the pole 0.02 into the plane z = 0; the reference's default -0.25 ends in SNES_DIVERGED_DTOL on this
+    # coarse P1 mesh in the oracle as well (no line search)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, disp=-0.12, verbose=False, return_solution=True)
+    bcv = np.unique(mt.find(1).ravel())
+    prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), bcv, gap=0.0, disp=-0.12)
+    xr, itr, itsr = S.solve_contact_problem(prob)
+    assert (it, iterations) == (itr, itsr), (it, iterations, itr, itsr)
+    nv = prob.nv
+    assert np.array_equal(np.sort(cv), prob.cverts)
+    assert _rel(x[:3 * nv], xr[:3 * nv]) < 1e-10
+    uz = x[2 * nv:3 * nv]
+    # the pole is pressed 0.02 below the plane z = 0; the constraint holds weakly: nodal penetration of the order h^2 / r (h = 0.15)
+    assert (mesh.geometry[cv, 2] + uz[cv]).min() > -0.02 and (mesh.geometry[cv, 2] + uz[cv]).min() < 0.01
+    top = bcv
+    assert np.all(uz[top] == -0.12) and np.all(x[top] == 0.0)

@@ -1,0 +1,50 @@
+"""proximalgalerkin_amd/mesh_generation.py: native stand-ins for lvpp.mesh_generation (gmsh is not available offline)."""
+import numpy as np
+
+
+def test_half_sphere_is_a_valid_tagged_tetrahedral_mesh(tmp_path):
+    from proximalgalerkin_amd import io, mesh_generation
+
+    r, c = 0.4, (0.0, 0.0, 0.5)
+    prev = None
+    for res in (0.2, 0.1, 0.05):
+        m, ct, ft = mesh_generation.create_half_sphere(res=res, r=r, center=c)
+        X = m.geometry[m.cells]
+        vol = np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2)) / 6.0
+        assert vol.min() > 0.0  # positively oriented, no inverted cells
+        assert np.unique(m.cells).size == m.geometry.shape[0]
+        d = np.linalg.norm(m.geometry - np.asarray(c), axis=1)
+        assert d.max() <= r * (1 + 1e-12) and m.geometry[:, 2].max() <= c[2] + 1e-15 and abs(m.geometry[:, 2].min() - (c[2] - r)) < 1e-12
+
+        def area(f):
+            x = m.geometry[f]
+            return 0.5 * np.linalg.norm(np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]), axis=1).sum()
+
+        flat, sph = ft.find(1), ft.find(2)
+        assert np.allclose(m.geometry[np.unique(flat), 2], c[2]) and np.allclose(d[np.unique(sph)], r)
+        # the two tags partition the boundary: every exterior facet exactly once
+        ext = m.facets_where(lambda x: np.ones(x.shape[1], dtype=bool))
+        assert len(flat) + len(sph) == len(ext)
+        err = (abs(vol.sum() - 2.0 / 3.0 * np.pi * r**3), abs(area(flat) - np.pi * r**2), abs(area(sph) - 2 * np.pi * r**2))
+        if prev is not None:  # second-order convergence of volume and areas to the exact half ball
+            assert all(e < 0.35 * p for e, p in zip(err, prev)), (err, prev)
+        prev = err
+    path = tmp_path / "hs.xdmf"
+    io.write_xdmf_tet(path, m, ft)
+    m2, mt2 = io.read_tet_mesh(path)
+    assert np.array_equal(m2.geometry, m.geometry) and np.array_equal(m2.cells, m.cells)
+    assert np.array_equal(mt2.find(1), ft.find(1)) and np.array_equal(mt2.find(2), ft.find(2))
+
+
+def test_half_disk():
+    from proximalgalerkin_amd import mesh_generation
+
+    m, _, tags = mesh_generation.create_half_disk(c_y=0.4, R=0.3, res=0.02)
+    X = m.geometry[m.cells]
+    a = 0.5 * ((X[:, 1, 0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (X[:, 2, 0] - X[:, 0, 0]) * (X[:, 1, 1] - X[:, 0, 1]))
+    assert a.min() > 0 and abs(a.sum() - 0.5 * np.pi * 0.09) < 2e-4
+    top, arc = tags[1], tags[2]
+    assert np.allclose(m.geometry[np.unique(top), 1], 0.4)
+    assert np.allclose(np.linalg.norm(m.geometry[np.unique(arc)] - np.array([0.0, 0.4]), axis=1), 0.3)
+    length = lambda e: np.linalg.norm(m.geometry[e[:, 0]] - m.geometry[e[:, 1]], axis=1).sum()  # noqa: E731
+    assert abs(length(top) - 0.6) < 1e-12 and abs(length(arc) - np.pi * 0.3) < 1e-3
