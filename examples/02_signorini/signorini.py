@@ -4,7 +4,8 @@ Counterpart of /root/reference/examples/02_signorini/signorini_dolfinx.py with t
 --disp --gap --n-tol --max-iterations --tol --alpha_scheme --alpha_0 --alpha_c and the two mesh branches: `--nx --ny --nz` (native,
 :361-386: a tetrahedral unit cube, BASELINE.json config 5) or `--filename mesh.msh|mesh.xdmf --contact-tag --displacement-tag`
 (file, :406-409: tetrahedra + tagged boundary triangles, e.g. the half sphere of generate_mesh.py; order-2 geometry is reduced to
-its vertices, XDMF must carry inline data).  Degree 1.
+its vertices, XDMF must carry inline data).  `--degree {1,2}`, default 2 as in the reference (:68-73); BASELINE.json config 5 is
+`--degree 1 --nx 70 --ny 70 --nz 70`.
 """
 import argparse
 import sys
@@ -26,6 +27,7 @@ if __name__ == "__main__":
     parser.add_argument("--alpha_scheme", type=str, default="doubling", choices=["constant", "linear", "doubling"])
     parser.add_argument("--alpha_0", type=float, default=1.0)
     parser.add_argument("--alpha_c", type=float, default=1.0)
+    parser.add_argument("--degree", type=int, default=2, choices=[1, 2], help="Degree of primal and latent space")
     parser.add_argument("--nx", type=int, default=16)
     parser.add_argument("--ny", type=int, default=7)
     parser.add_argument("--nz", type=int, default=5)
@@ -41,7 +43,7 @@ if __name__ == "__main__":
     else:
         mesh = create_unit_cube(a.nx, a.ny, a.nz)
         mt, bcs = native_tags(mesh)
-    it, iterations = solve_contact_problem(mesh=mesh, facet_tag=mt, boundary_conditions=bcs, degree=1, E=a.E, nu=a.nu,
+    it, iterations = solve_contact_problem(mesh=mesh, facet_tag=mt, boundary_conditions=bcs, degree=a.degree, E=a.E, nu=a.nu,
                                            gap=a.gap, disp=a.disp, newton_max_its=250, newton_tol=a.newton_tol,
                                            max_iterations=a.max_iterations, alpha_scheme=a.alpha_scheme, alpha_0=a.alpha_0,
                                            alpha_c=a.alpha_c, tol=a.tol, output=a.output)

@@ -4,8 +4,9 @@
  * examples/02_signorini/signorini_dolfinx.py:333, i.e. what the reference delegates to DOLFINx assembly (cell + exterior
  * facet integrals on a submesh, :199-249) + PETSc SNES (newtonls, linesearch none) + MUMPS LU (:271-291).
  *
- * Spaces at degree 1 (BASELINE.json config 5): u in (P1)^3 on a tetrahedral mesh, psi in P1 on the contact facets.
- *        x = [u_x (nv) | u_y (nv) | u_z (nv) | psi (one per contact vertex, ordered by vertex id)]
+ * Spaces at degree 1 (BASELINE.json config 5): u in (P1)^3 on a tetrahedral mesh, psi in P1 on the contact facets; degree 2 (the
+ * reference's default, :68-73; pgx_sg_mesh.degree = 2): u in (P2)^3, psi in P2 on the contact facets, affine cells.
+ *        x = [u_x (nv) | u_y (nv) | u_z (nv) | psi (one per contact node, ordered by node id)],  nv = vertices (degree 1) / P2 nodes
  * Residual (:236-249), n_g = -e_z, g = x_z - gap, f = 0:
  *        R_u   = alpha (sigma(u), eps(v)) - <psi - psi_k, v.n_g>_Gamma
  *        R_psi = <u.n_g, w>_Gamma + <exp(psi), w>_Gamma - <g, w>_Gamma
@@ -38,6 +39,12 @@ typedef struct {
   const int32_t* cells;    /* [n_cells][4] */
   int32_t n_facets;        /* potential-contact facets (facet_tag.find(contact), :186-189) */
   const int32_t* facets;   /* [n_facets][3] vertex ids */
+  int32_t degree;          /* 0 or 1: degree 1 as described above.  2 (the reference's default, :68-73): u in (P2)^3, psi in P2 on the
+                            * contact facets.  Then n_vertices counts the P2 NODES (mesh vertices, then one node per edge; `coords`
+                            * holds the edge midpoints for them), cells is [n_cells][10]: 4 vertices, then the edge nodes of
+                            * (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); facets is [n_facets][6]: 3 vertices, then the edge nodes of
+                            * (0,1) (0,2) (1,2).  Cells stay affine (geometry from the vertices).  bc_dofs: component * n_nodes +
+                            * node; pgx_sg_contact_vertices returns the node of every psi dof. */
 } pgx_sg_mesh;
 
 typedef struct {

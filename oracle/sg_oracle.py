@@ -176,3 +176,127 @@ def solve_contact_problem(prob: SignoriniP1, newton_tol=1e-6, max_iterations=25,
         u_prev = x[: 3 * prob.nv].copy()
         xk = x.copy()
     return x, it, iterations
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# degree 2 (the reference's default, signorini_dolfinx.py:68-73): u in (P2)^3 on the tetrahedra, psi in P2 on the contact
+# facets (:211-216 "degree of primal and latent space").  Conventions (this oracle's own; the HIP path follows them):
+#   nodes     : the mesh vertices, then one node per edge, edges ordered lexicographically by their (min, max) vertex pair;
+#               node coordinates of an edge node = the edge midpoint (affine cells)
+#   tet       : local nodes 0-3 = vertices, 4-9 = edges (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+#   facet     : local nodes 0-2 = vertices, 3-5 = edges (0,1) (0,2) (1,2)
+#   basis     : vertex a: L_a (2 L_a - 1);  edge (a, b): 4 L_a L_b
+#   quadrature: cells - the 4-point degree-2 rule (exact: the integrand is a product of two affine gradients);
+#               facets - the degree-4 rule of the P1 oracle (:67-69 quadrature_degree = 4)
+# ---------------------------------------------------------------------------------------------------------------------
+TET_EDGES = np.array([(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)])
+TRI_EDGES = np.array([(0, 1), (0, 2), (1, 2)])
+
+
+def p2_numbering(cells, facets):
+    """(n_vertices is implied) -> edges (ne,2), cells10 (nc,10), facets6 (nf,6) with edge node ids n_vertices + edge index."""
+    nv = int(cells.max()) + 1
+    pairs = np.sort(np.concatenate([cells[:, e] for e in TET_EDGES]), axis=1)
+    edges, inv = np.unique(pairs, axis=0, return_inverse=True)
+    nc = len(cells)
+    c10 = np.concatenate([cells, nv + inv.reshape(6, nc).T], axis=1).astype(np.int32)
+    key = edges[:, 0].astype(np.int64) * nv + edges[:, 1]
+    fp = np.sort(np.concatenate([facets[:, e] for e in TRI_EDGES]), axis=1) if len(facets) else np.zeros((0, 2), dtype=np.int64)
+    pos = np.searchsorted(key, fp[:, 0].astype(np.int64) * nv + fp[:, 1])
+    f6 = np.concatenate([facets, nv + pos.reshape(3, len(facets)).T], axis=1).astype(np.int32) if len(facets) else np.zeros((0, 6), np.int32)
+    return edges.astype(np.int32), c10, f6
+
+
+def _p2_tri(L):
+    """P2 basis on a triangle at barycentric points L (nq,3) -> (nq,6)"""
+    return np.concatenate([L * (2 * L - 1), np.stack([4 * L[:, a] * L[:, b] for a, b in TRI_EDGES], axis=1)], axis=1)
+
+
+class SignoriniP2:
+    """Same interface as SignoriniP1 with nv := number of P2 nodes."""
+
+    def __init__(self, coords, cells, contact_facets, bc_facets, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25, quadrature="tri_deg4_gj9"):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
+        self.edges, self.cells10, self.facets6 = p2_numbering(cells, facets)
+        self.nvert = len(coords)
+        self.node_coords = np.concatenate([coords, 0.5 * (coords[self.edges[:, 0]] + coords[self.edges[:, 1]])])
+        self.coords, self.cells, self.facets = coords, cells, facets
+        nn = self.nv = len(self.node_coords)
+        self.nc, self.nf = len(cells), len(facets)
+        self.cverts = np.unique(self.facets6.ravel()).astype(np.int32)  # psi dof -> node
+        self.npsi = len(self.cverts)
+        n2psi = np.full(nn, -1, dtype=np.int64)
+        n2psi[self.cverts] = np.arange(self.npsi)
+        self.ntot = 3 * nn + self.npsi
+        self.mu, self.lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+        self.gap, self.disp = float(gap), float(disp)
+        # Dirichlet nodes: every node of the displacement facets (vertices and edge nodes)
+        _, _, bf6 = p2_numbering(cells, np.ascontiguousarray(bc_facets, dtype=np.int32))
+        bn = np.unique(bf6.ravel()).astype(np.int64)
+        self.bc_nodes = bn
+        self.bc = np.concatenate([bn, nn + bn, 2 * nn + bn]).astype(np.int64)
+        self.bc_vals = np.concatenate([np.zeros(len(bn)), np.zeros(len(bn)), np.full(len(bn), self.disp)])
+        self.isbc = np.zeros(3 * nn, dtype=bool)
+        self.isbc[self.bc] = True
+        # elasticity block
+        a_, b_ = 0.5854101966249685, 0.1381966011250105
+        Lq = np.full((4, 4), b_) + (a_ - b_) * np.eye(4)  # barycentric points of the degree-2 rule
+        wq = np.full(4, 1.0 / 24.0)
+        x = coords[cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 3] - x[:, 0]], axis=2)
+        det = np.linalg.det(J)
+        invJ = np.linalg.inv(J)
+        gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+        G1 = np.einsum("ak,ckd->cad", gref, invJ)  # gradients of the barycentric coordinates (nc,4,3)
+        Ae = np.zeros((self.nc, 10, 3, 10, 3))
+        mu, lm = self.mu, self.lmbda
+        for q in range(4):
+            L = Lq[q]
+            G = np.empty((self.nc, 10, 3))
+            for a in range(4):
+                G[:, a] = (4 * L[a] - 1) * G1[:, a]
+            for k, (a, b) in enumerate(TET_EDGES):
+                G[:, 4 + k] = 4 * (L[a] * G1[:, b] + L[b] * G1[:, a])
+            GG = np.einsum("cad,cbd->cab", G, G)
+            Ae += (wq[q] * np.abs(det))[:, None, None, None, None] * (
+                lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G) + mu * np.einsum("cab,ij->caibj", GG, np.eye(3)))
+        c10 = self.cells10
+        rows = (c10[:, :, None, None, None] + nn * np.arange(3)[None, None, :, None, None])
+        cols = (c10[:, None, None, :, None] + nn * np.arange(3)[None, None, None, None, :])
+        rows, cols = np.broadcast_arrays(rows, cols)
+        self.A = sp.coo_matrix((Ae.ravel(), (rows.ravel(), cols.ravel())), shape=(3 * nn, 3 * nn)).tocsr()
+        # contact facets
+        self.Xq, self.wq = O.load_quadrature(quadrature)
+        L3 = np.stack([1 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
+        self.Nq = _p2_tri(L3)  # (nq,6)
+        xf = coords[facets]
+        farea2 = np.linalg.norm(np.cross(xf[:, 1] - xf[:, 0], xf[:, 2] - xf[:, 0]), axis=1)
+        self.wdet = farea2[:, None] * self.wq[None]
+        Mref = np.einsum("q,qa,qb->ab", self.wq, self.Nq, self.Nq)
+        Me = farea2[:, None, None] * Mref[None]
+        f6 = self.facets6
+        pf = n2psi[f6]
+        self.pf = pf
+        r = np.repeat(pf, 6, axis=1).ravel()
+        c = np.tile(f6, (1, 6)).ravel()
+        self.MG = sp.coo_matrix((Me.ravel(), (r, c)), shape=(self.npsi, nn)).tocsr()
+        zq = np.einsum("qa,fa->fq", L3, xf[:, :, 2])
+        self.b_g = np.bincount(pf.ravel(), weights=((self.wdet * (zq - self.gap)) @ self.Nq).ravel(), minlength=self.npsi)
+        self._rp = np.repeat(pf, 6, axis=1).ravel()
+        self._cp = np.tile(pf, (1, 6)).ravel()
+
+    split = SignoriniP1.split
+    residual = SignoriniP1.residual
+    jacobian = SignoriniP1.jacobian
+
+    def exp_terms(self, psi, with_matrix=True):
+        pq = psi[self.pf] @ self.Nq.T
+        with np.errstate(over="ignore", under="ignore"):
+            wE = self.wdet * np.exp(pq)
+        b = np.bincount(self.pf.ravel(), weights=(wE @ self.Nq).ravel(), minlength=self.npsi)
+        if not with_matrix:
+            return b, None
+        De = np.einsum("fq,qa,qb->fab", wE, self.Nq, self.Nq)
+        return b, sp.coo_matrix((De.ravel(), (self._rp, self._cp)), shape=(self.npsi, self.npsi)).tocsr()

@@ -116,6 +116,7 @@ class pgx_sg_mesh(C.Structure):  # include/pgx_sg.h
         ("cells", c_int32_p),
         ("n_facets", C.c_int32),
         ("facets", c_int32_p),
+        ("degree", C.c_int32),
     ]
 
 

@@ -15,13 +15,15 @@
 #define SG_MAXQ 16
 struct SgQuad {
   double L[SG_MAXQ][3], w[SG_MAXQ];
+  double N[SG_MAXQ][6];  // facet basis at the quadrature points: P1 = L; P2 = L_a (2 L_a - 1), then 4 L_a L_b for (0,1) (0,2) (1,2)
   int nq;
 };
 
 static thread_local std::string g_sg_error;
 
 struct pgx_sg_handle : MixedBase {
-  int nv = 0, nc = 0, nf = 0, npsi = 0;
+  int nv = 0, nc = 0, nf = 0, npsi = 0;  // nv = number of NODES (degree 2: vertices + edge midpoints)
+  int npc = 4, npf = 3;                  // nodes per cell / per contact facet: 4 / 3 (degree 1), 10 / 6 (degree 2)
   SgQuad Q{};
   double alpha = 1.0, gap = 0.0, mu = 0.0, lmbda = 0.0;
   double *coords = nullptr, *gbc = nullptr, *bg = nullptr;
@@ -85,13 +87,69 @@ __global__ __launch_bounds__(128) void k_sg_const_cells(int nc, const int32_t* _
     }
 }
 
+// degree 2: A_e[(A,i),(B,j)] = |det J| sum_q w_q (lambda dN_A,i dN_B,j + mu dN_A,j dN_B,i + mu delta_ij dN_A . dN_B) with the
+// 4-point degree-2 rule (exact: gradients of P2 functions are affine).  Local nodes: 0-3 vertices, 4-9 the edges
+// (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); vertex functions L_a (2 L_a - 1), edge functions 4 L_a L_b.  900 entries per cell.
+__global__ __launch_bounds__(64) void k_sg_const_cells_p2(int nc, const int32_t* __restrict__ cells, const double* __restrict__ coords,
+                                                          double mu, double lmbda, double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cv = cells + 10 * (size_t)c;
+  double X[4][3];
+  for (int a = 0; a < 4; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)cv[a] + d];
+  double J[3][3];
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 3; ++k) J[d][k] = X[k + 1][d] - X[0][d];
+  const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+  double inv[3][3];
+  inv[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+  inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+  inv[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+  inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  inv[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+  inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+  inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+  double G1[4][3];  // gradients of the barycentric coordinates
+  for (int d = 0; d < 3; ++d) {
+    G1[1][d] = inv[0][d];
+    G1[2][d] = inv[1][d];
+    G1[3][d] = inv[2][d];
+    G1[0][d] = -(inv[0][d] + inv[1][d] + inv[2][d]);
+  }
+  const int ea[6] = {0, 0, 0, 1, 1, 2}, eb[6] = {1, 2, 3, 2, 3, 3};
+  const double qa = 0.5854101966249685, qb = 0.1381966011250105, wq = fabs(det) / 24.0;
+  for (int A = 0; A < 10; ++A)
+    for (int B = 0; B < 10; ++B) {
+      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int q = 0; q < 4; ++q) {
+        double L[4];
+        for (int a = 0; a < 4; ++a) L[a] = a == q ? qa : qb;
+        double gA[3], gB[3];
+        for (int d = 0; d < 3; ++d) {
+          gA[d] = A < 4 ? (4.0 * L[A] - 1.0) * G1[A][d] : 4.0 * (L[ea[A - 4]] * G1[eb[A - 4]][d] + L[eb[A - 4]] * G1[ea[A - 4]][d]);
+          gB[d] = B < 4 ? (4.0 * L[B] - 1.0) * G1[B][d] : 4.0 * (L[ea[B - 4]] * G1[eb[B - 4]][d] + L[eb[B - 4]] * G1[ea[B - 4]][d]);
+        }
+        const double gg = gA[0] * gB[0] + gA[1] * gB[1] + gA[2] * gB[2];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) acc[i][j] += wq * (lmbda * gA[i] * gB[j] + mu * gA[j] * gB[i] + (i == j ? mu * gg : 0.0));
+      }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) stash[(size_t)((A * 3 + i) * 30 + (B * 3 + j)) * nc + c] = acc[i][j];
+    }
+}
+
 // facet mass coupling (+M on (u_z, psi), -M on (psi, u_z)) and b_g = <g, w>, once
+template <int NPF>
 __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* __restrict__ facets, const int32_t* __restrict__ fpsi,
                                                          const double* __restrict__ coords, double gap, SgQuad Q,
-                                                         double* __restrict__ stash /* [21 * nf]: 18 matrix slots, 3 of b_g */) {
+                                                         double* __restrict__ stash /* [(2 NPF^2 + NPF) * nf]: matrix slots, then b_g */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
-  const int32_t* fv = facets + 3 * (size_t)f;
+  const int32_t* fv = facets + NPF * (size_t)f;  // the first three nodes are the vertices: affine geometry
   double X[3][3];
   for (int a = 0; a < 3; ++a)
     for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
@@ -99,20 +157,24 @@ __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* 
   const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
   const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
   const double area2 = sqrt(cx * cx + cy * cy + cz * cz);
-  double Me[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, g[3] = {0, 0, 0};
+  double Me[NPF][NPF], g[NPF];
+  for (int a = 0; a < NPF; ++a) {
+    g[a] = 0.0;
+    for (int b = 0; b < NPF; ++b) Me[a][b] = 0.0;
+  }
   for (int q = 0; q < Q.nq; ++q) {
     const double wd = Q.w[q] * area2;
     const double zq = Q.L[q][0] * X[0][2] + Q.L[q][1] * X[1][2] + Q.L[q][2] * X[2][2];
-    for (int a = 0; a < 3; ++a) {
-      g[a] += wd * (zq - gap) * Q.L[q][a];
-      for (int b = 0; b < 3; ++b) Me[a][b] += wd * Q.L[q][a] * Q.L[q][b];
+    for (int a = 0; a < NPF; ++a) {
+      g[a] += wd * (zq - gap) * Q.N[q][a];
+      for (int b = 0; b < NPF; ++b) Me[a][b] += wd * Q.N[q][a] * Q.N[q][b];
     }
   }
-  for (int a = 0; a < 3; ++a) {
-    stash[(size_t)(18 + a) * nf + f] = g[a];
-    for (int b = 0; b < 3; ++b) {
-      stash[(size_t)(a * 3 + b) * nf + f] = Me[a][b];       // row u_z(a), col psi(b)
-      stash[(size_t)(9 + a * 3 + b) * nf + f] = -Me[a][b];  // row psi(a), col u_z(b)
+  for (int a = 0; a < NPF; ++a) {
+    stash[(size_t)(2 * NPF * NPF + a) * nf + f] = g[a];
+    for (int b = 0; b < NPF; ++b) {
+      stash[(size_t)(a * NPF + b) * nf + f] = Me[a][b];               // row u_z(a), col psi(b)
+      stash[(size_t)(NPF * NPF + a * NPF + b) * nf + f] = -Me[a][b];  // row psi(a), col u_z(b)
     }
   }
 }
@@ -127,13 +189,14 @@ __global__ void k_sg_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, con
 }
 
 // parks (mode 0) D_e[a][b] = <exp(psi) N_a, N_b> for the Jacobian, (mode 1) b_exp[a] = <exp(psi), N_a> for the residual
+template <int NPF>
 __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const int32_t* __restrict__ facets,
                                                 const int32_t* __restrict__ fpsi, const double* __restrict__ coords,
                                                 const double* __restrict__ x, SgQuad Q, double* __restrict__ stash) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
-  const int32_t* fv = facets + 3 * (size_t)f;
-  const int32_t* fp = fpsi + 3 * (size_t)f;
+  const int32_t* fv = facets + NPF * (size_t)f;
+  const int32_t* fp = fpsi + NPF * (size_t)f;
   double X[3][3];
   for (int a = 0; a < 3; ++a)
     for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
@@ -141,20 +204,26 @@ __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const 
   const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
   const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
   const double area2 = sqrt(cx * cx + cy * cy + cz * cz);
-  const double p0 = x[nu + fp[0]], p1 = x[nu + fp[1]], p2 = x[nu + fp[2]];
-  double De[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, be[3] = {0, 0, 0};
+  double pv[NPF], De[NPF][NPF], be[NPF];
+  for (int a = 0; a < NPF; ++a) {
+    pv[a] = x[nu + fp[a]];
+    be[a] = 0.0;
+    for (int b = 0; b < NPF; ++b) De[a][b] = 0.0;
+  }
   for (int q = 0; q < Q.nq; ++q) {
-    const double e = Q.w[q] * area2 * exp(p0 * Q.L[q][0] + p1 * Q.L[q][1] + p2 * Q.L[q][2]);
-    for (int a = 0; a < 3; ++a) {
-      be[a] += e * Q.L[q][a];
-      for (int b = 0; b < 3; ++b) De[a][b] += e * Q.L[q][a] * Q.L[q][b];
+    double pq = 0.0;
+    for (int a = 0; a < NPF; ++a) pq += pv[a] * Q.N[q][a];
+    const double e = Q.w[q] * area2 * exp(pq);
+    for (int a = 0; a < NPF; ++a) {
+      be[a] += e * Q.N[q][a];
+      for (int b = 0; b < NPF; ++b) De[a][b] += e * Q.N[q][a] * Q.N[q][b];
     }
   }
   if (mode == 0) {
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) stash[(size_t)(a * 3 + b) * nf + f] = De[a][b];
+    for (int a = 0; a < NPF; ++a)
+      for (int b = 0; b < NPF; ++b) stash[(size_t)(a * NPF + b) * nf + f] = De[a][b];
   } else {
-    for (int a = 0; a < 3; ++a) stash[(size_t)a * nf + f] = be[a];
+    for (int a = 0; a < NPF; ++a) stash[(size_t)a * nf + f] = be[a];
   }
 }
 
@@ -205,8 +274,12 @@ void pgx_sg_handle::residual_dev(const double* xin, double* Fout) {
   hipLaunchKernelGGL(k_sg_resid_rows, dim3((unsigned)((h->ntot * 16 + 255) / 256)), dim3(256), 0, h->st, h->ntot, nu, h->rowptr,
                      h->col, h->Jc, h->mask, h->gbc, h->bg, xin, h->xk, h->alpha, Fout);
   if (h->nf > 0) {
-    hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                       h->Q, h->stash);
+    if (h->npf == 6)
+      hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                         h->Q, h->stash);
+    else
+      hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                         h->Q, h->stash);
     pgx_scatter_run(h->st, h->sc_b, h->stash, 1.0, 1, Fout);
   }
 }
@@ -216,15 +289,23 @@ void pgx_sg_handle::jacobian_dev(const double* xin) {
   hipLaunchKernelGGL(k_sg_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
   if (h->nf > 0) {
-    hipLaunchKernelGGL(k_sg_exp, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi, h->coords,
-                       xin, h->Q, h->stash);
+    if (h->npf == 6)
+      hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
+                         h->coords, xin, h->Q, h->stash);
+    else
+      hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
+                         h->coords, xin, h->Q, h->stash);
     pgx_scatter_run(h->st, h->sc_D, h->stash, 1.0, 1, h->Jv);
   }
   h->jac_valid = true;
 }
 
+// NPC / NPF: nodes per cell / per contact facet (4 / 3: degree 1; 10 / 6: degree 2, m->n_vertices = number of NODES)
+template <int NPC, int NPF>
 static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm) {
+  constexpr int ND = 3 * NPC, NE = ND * ND, NF2 = NPF * NPF, NFS = 2 * NF2 + NPF;  // cell dofs, cell slots, facet block, facet slots
   const int nv = m->n_vertices, nc = m->n_cells, nf = m->n_facets;
+  h->npc = NPC, h->npf = NPF;
   const int nu = 3 * nv;
   h->nv = nv, h->nc = nc, h->nf = nf;
   h->comm = comm;
@@ -235,15 +316,22 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   for (int q = 0; q < p->nq; ++q) {
     const double X = p->qpts[2 * q], Y = p->qpts[2 * q + 1];
     h->Q.L[q][0] = 1.0 - X - Y, h->Q.L[q][1] = X, h->Q.L[q][2] = Y, h->Q.w[q] = p->qwts[q];
+    const double* L = h->Q.L[q];
+    if (NPF == 3) {
+      for (int a = 0; a < 3; ++a) h->Q.N[q][a] = L[a];
+    } else {
+      for (int a = 0; a < 3; ++a) h->Q.N[q][a] = L[a] * (2.0 * L[a] - 1.0);
+      h->Q.N[q][3] = 4.0 * L[0] * L[1], h->Q.N[q][4] = 4.0 * L[0] * L[2], h->Q.N[q][5] = 4.0 * L[1] * L[2];
+    }
   }
-  for (size_t k = 0; k < 4 * (size_t)nc; ++k)
+  for (size_t k = 0; k < NPC * (size_t)nc; ++k)
     if (m->cells[k] < 0 || m->cells[k] >= nv) {
       h->err = "cell vertex out of range";
       return PGX_EINVAL;
     }
   // psi dofs = contact vertices ordered by vertex id
   std::vector<int32_t> v2psi(nv, -1);
-  for (size_t k = 0; k < 3 * (size_t)nf; ++k) {
+  for (size_t k = 0; k < NPF * (size_t)nf; ++k) {
     if (m->facets[k] < 0 || m->facets[k] >= nv) {
       h->err = "facet vertex out of range";
       return PGX_EINVAL;
@@ -268,40 +356,40 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
     hmask[d] = 1;
     hg[d] = p->bc_vals ? p->bc_vals[k] : 0.0;
   }
-  std::vector<int32_t> fpsi(3 * (size_t)nf);
+  std::vector<int32_t> fpsi(NPF * (size_t)nf);
   for (size_t k = 0; k < fpsi.size(); ++k) fpsi[k] = v2psi[m->facets[k]];
   // entities: cells (12 mixed dofs: (a,i) -> i*nv + vertex a) and facets (6: u_z of 3 vertices, psi of 3 vertices)
-  auto cell_dofs = [&](int c, int32_t md[12]) {
-    for (int a = 0; a < 4; ++a)
-      for (int i = 0; i < 3; ++i) md[a * 3 + i] = i * nv + m->cells[4 * (size_t)c + a];
+  auto cell_dofs = [&](int c, int32_t md[ND]) {
+    for (int a = 0; a < NPC; ++a)
+      for (int i = 0; i < 3; ++i) md[a * 3 + i] = i * nv + m->cells[NPC * (size_t)c + a];
   };
-  auto facet_dofs = [&](int f, int32_t md[6]) {
-    for (int a = 0; a < 3; ++a) md[a] = 2 * nv + m->facets[3 * (size_t)f + a], md[3 + a] = nu + fpsi[3 * (size_t)f + a];
+  auto facet_dofs = [&](int f, int32_t md[2 * NPF]) {
+    for (int a = 0; a < NPF; ++a) md[a] = 2 * nv + m->facets[NPF * (size_t)f + a], md[NPF + a] = nu + fpsi[NPF * (size_t)f + a];
   };
   std::vector<int64_t> dptr(ntot + 1, 0);
   for (int c = 0; c < nc; ++c) {
-    int32_t md[12];
+    int32_t md[ND];
     cell_dofs(c, md);
-    for (int a = 0; a < 12; ++a) dptr[md[a] + 1]++;
+    for (int a = 0; a < ND; ++a) dptr[md[a] + 1]++;
   }
   for (int f = 0; f < nf; ++f) {
-    int32_t md[6];
+    int32_t md[2 * NPF];
     facet_dofs(f, md);
-    for (int a = 0; a < 6; ++a) dptr[md[a] + 1]++;
+    for (int a = 0; a < 2 * NPF; ++a) dptr[md[a] + 1]++;
   }
   for (int64_t i = 0; i < ntot; ++i) dptr[i + 1] += dptr[i];
   std::vector<int64_t> dent(dptr[ntot]);  // entity id: cells [0,nc), facets [nc, nc+nf)
   {
     std::vector<int64_t> fill(dptr.begin(), dptr.end() - 1);
     for (int c = 0; c < nc; ++c) {
-      int32_t md[12];
+      int32_t md[ND];
       cell_dofs(c, md);
-      for (int a = 0; a < 12; ++a) dent[fill[md[a]]++] = c;
+      for (int a = 0; a < ND; ++a) dent[fill[md[a]]++] = c;
     }
     for (int f = 0; f < nf; ++f) {
-      int32_t md[6];
+      int32_t md[2 * NPF];
       facet_dofs(f, md);
-      for (int a = 0; a < 6; ++a) dent[fill[md[a]]++] = (int64_t)nc + f;
+      for (int a = 0; a < 2 * NPF; ++a) dent[fill[md[a]]++] = (int64_t)nc + f;
     }
   }
   auto gather_row = [&](int64_t r, std::vector<int32_t>& tmp) {
@@ -309,13 +397,13 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
     for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
       const int64_t e = dent[q];
       if (e < nc) {
-        int32_t md[12];
+        int32_t md[ND];
         cell_dofs((int)e, md);
-        tmp.insert(tmp.end(), md, md + 12);
+        tmp.insert(tmp.end(), md, md + ND);
       } else {
-        int32_t md[6];
+        int32_t md[2 * NPF];
         facet_dofs((int)(e - nc), md);
-        tmp.insert(tmp.end(), md, md + 6);
+        tmp.insert(tmp.end(), md, md + 2 * NPF);
       }
     }
     std::sort(tmp.begin(), tmp.end());
@@ -372,25 +460,25 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
       }
   });
   // destination tables, slot-major like the stashes the kernels write: table[slot * n_entities + entity]
-  std::vector<int32_t> d144((size_t)nc * 144), d18((size_t)nf * 18), dD((size_t)nf * 9), dbg((size_t)nf * 3), dbe((size_t)nf * 3);
+  std::vector<int32_t> d144((size_t)nc * NE), d18((size_t)nf * 2 * NF2), dD((size_t)nf * NF2), dbg((size_t)nf * NPF), dbe((size_t)nf * NPF);
   mx_par_for(nc, [&](int64_t a0, int64_t b0) {
     for (int64_t c = a0; c < b0; ++c) {
-      int32_t md[12];
+      int32_t md[ND];
       cell_dofs((int)c, md);
-      for (int a = 0; a < 12; ++a)
-        for (int b = 0; b < 12; ++b) d144[(size_t)(a * 12 + b) * nc + (size_t)c] = find(md[a], md[b]);
+      for (int a = 0; a < ND; ++a)
+        for (int b = 0; b < ND; ++b) d144[(size_t)(a * ND + b) * nc + (size_t)c] = find(md[a], md[b]);
     }
   });
   for (int f = 0; f < nf; ++f) {
-    int32_t md[6];
+    int32_t md[2 * NPF];
     facet_dofs(f, md);
-    for (int a = 0; a < 3; ++a) {
-      dbg[(size_t)a * nf + f] = fpsi[3 * (size_t)f + a];
-      dbe[(size_t)a * nf + f] = nu + fpsi[3 * (size_t)f + a];
-      for (int b = 0; b < 3; ++b) {
-        d18[(size_t)(a * 3 + b) * nf + f] = find(md[a], md[3 + b]);
-        d18[(size_t)(9 + a * 3 + b) * nf + f] = find(md[3 + a], md[b]);
-        dD[(size_t)(a * 3 + b) * nf + f] = find(md[3 + a], md[3 + b]);
+    for (int a = 0; a < NPF; ++a) {
+      dbg[(size_t)a * nf + f] = fpsi[NPF * (size_t)f + a];
+      dbe[(size_t)a * nf + f] = nu + fpsi[NPF * (size_t)f + a];
+      for (int b = 0; b < NPF; ++b) {
+        d18[(size_t)(a * NPF + b) * nf + f] = find(md[a], md[NPF + b]);
+        d18[(size_t)(NF2 + a * NPF + b) * nf + f] = find(md[NPF + a], md[b]);
+        dD[(size_t)(a * NPF + b) * nf + f] = find(md[NPF + a], md[NPF + b]);
       }
     }
   }
@@ -417,9 +505,9 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   }
   int32_t* d_cells = nullptr;
   MXALLOC(h->coords, 3 * (size_t)nv);
-  MXALLOC(h->facets, 3 * (size_t)nf);
-  MXALLOC(h->fpsi, 3 * (size_t)nf);
-  MXALLOC(h->stash, 9 * (size_t)std::max(nf, 1));
+  MXALLOC(h->facets, NPF * (size_t)nf);
+  MXALLOC(h->fpsi, NPF * (size_t)nf);
+  MXALLOC(h->stash, NF2 * (size_t)std::max(nf, 1));
   MXALLOC(h->mask, nu);
   MXALLOC(h->gbc, nu);
   MXALLOC(h->bg, npsi);
@@ -430,7 +518,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXALLOC(h->Jv, tot);
   if ((rc = mx_alloc_state(h))) return rc;
   MXHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 3 * nv, hipMemcpyHostToDevice));
-  MXHIP(hipMemcpy(h->facets, m->facets, sizeof(int32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice));
+  MXHIP(hipMemcpy(h->facets, m->facets, sizeof(int32_t) * NPF * (size_t)nf, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->fpsi, fpsi.data(), sizeof(int32_t) * fpsi.size(), hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->mask, hmask.data(), nu, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nu, hipMemcpyHostToDevice));
@@ -440,8 +528,8 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
   MXHIP(hipMemsetAsync(h->bg, 0, sizeof(double) * npsi, h->st));
   {
-    std::string e1 = pgx_scatter_build(dD.data(), (int64_t)9 * nf, tot, h->allocs, &h->sc_D);
-    if (e1.empty()) e1 = pgx_scatter_build(dbe.data(), (int64_t)3 * nf, ntot, h->allocs, &h->sc_b);
+    std::string e1 = pgx_scatter_build(dD.data(), (int64_t)NF2 * nf, tot, h->allocs, &h->sc_D);
+    if (e1.empty()) e1 = pgx_scatter_build(dbe.data(), (int64_t)NPF * nf, ntot, h->allocs, &h->sc_b);
     if (!e1.empty()) {
       h->err = e1;
       return PGX_ENOMEM;
@@ -450,22 +538,25 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   // constant blocks, once, deterministic: park per entity, sum per destination; tables and stashes are temporary
   std::vector<void*> tmp;
   PgxScatter sc_c, sc_f, sc_g;
-  std::string e1 = pgx_scatter_build(d144.data(), (int64_t)144 * nc, tot, tmp, &sc_c);
-  if (e1.empty()) e1 = pgx_scatter_build(d18.data(), (int64_t)18 * nf, tot, tmp, &sc_f);
-  if (e1.empty()) e1 = pgx_scatter_build(dbg.data(), (int64_t)3 * nf, npsi, tmp, &sc_g);
+  std::string e1 = pgx_scatter_build(d144.data(), (int64_t)NE * nc, tot, tmp, &sc_c);
+  if (e1.empty()) e1 = pgx_scatter_build(d18.data(), (int64_t)2 * NF2 * nf, tot, tmp, &sc_f);
+  if (e1.empty()) e1 = pgx_scatter_build(dbg.data(), (int64_t)NPF * nf, npsi, tmp, &sc_g);
   double *st_c = nullptr, *st_f = nullptr;
-  hipError_t e = e1.empty() ? hipMalloc((void**)&d_cells, sizeof(int32_t) * 4 * (size_t)nc) : hipErrorOutOfMemory;
-  if (e == hipSuccess) e = hipMalloc((void**)&st_c, sizeof(double) * 144 * (size_t)nc);
-  if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * 21 * (size_t)std::max(nf, 1));
-  if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * 4 * (size_t)nc, hipMemcpyHostToDevice);
+  hipError_t e = e1.empty() ? hipMalloc((void**)&d_cells, sizeof(int32_t) * NPC * (size_t)nc) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipMalloc((void**)&st_c, sizeof(double) * NE * (size_t)nc);
+  if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * NFS * (size_t)std::max(nf, 1));
+  if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * NPC * (size_t)nc, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+    if (NPC == 4)
+      hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+    else
+      hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nc + 63) / 64), dim3(64), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
     pgx_scatter_run(h->st, sc_c, st_c, 1.0, 0, h->Jc);
     if (nf > 0) {
-      hipLaunchKernelGGL(k_sg_const_facets, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
+      hipLaunchKernelGGL(k_sg_const_facets<NPF>, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
                          h->Q, st_f);
       pgx_scatter_run(h->st, sc_f, st_f, 1.0, 1, h->Jc);  // the +-M_G slots are disjoint from the elasticity slots
-      pgx_scatter_run(h->st, sc_g, st_f + 18 * (size_t)nf, 1.0, 0, h->bg);
+      pgx_scatter_run(h->st, sc_g, st_f + 2 * NF2 * (size_t)nf, 1.0, 0, h->bg);
     }
     e = hipStreamSynchronize(h->st);
   }
@@ -483,7 +574,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
 static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device, pgx_sg_handle** out) {
   if (!m || !p || !out || !m->coords || !m->cells || m->n_vertices <= 0 || m->n_cells <= 0 || m->n_facets < 0 ||
       (m->n_facets > 0 && !m->facets) || !p->qpts || !p->qwts || p->nq <= 0 || p->nq > SG_MAXQ ||
-      (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5)) {
+      (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5) || m->degree < 0 || m->degree > 2) {
     g_sg_error = "pgx_sg_create: bad arguments";
     return PGX_EINVAL;
   }
@@ -498,7 +589,7 @@ static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* co
   }
   pgx_sg_handle* h = new pgx_sg_handle();
   h->device = device;
-  int rc = sg_create_impl(h, m, p, comm);
+  int rc = (m->degree == 2) ? sg_create_impl<10, 6>(h, m, p, comm) : sg_create_impl<4, 3>(h, m, p, comm);
   if (rc) {
     g_sg_error = h->err;
     pgx_sg_destroy(h);

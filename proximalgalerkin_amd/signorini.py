@@ -6,8 +6,8 @@ reference's signature (:156-174) and loop (:317-358); `SignoriniProblem` stands 
 `.solve()`, `.solver.setTolerances(atol=, rtol=)`, `.solver.getIterationNumber()`, `.solver.getConvergedReason()`
 (:331-335).  Everything below `.solve()` runs in libpgx.so (include/pgx_sg.h).  No CPU fallback.
 
-Degree 1 on tetrahedra (BASELINE.json config 5); the reference's default degree 2 and its hexahedral native mesh are not
-implemented.
+Degrees 1 (BASELINE.json config 5) and 2 (the reference's default, :68-73) on tetrahedra; the reference's native mesh is hexahedral
+(:376-383) - here the same vertex grid split into tetrahedra.  The forms-driven `NonlinearProblem` below states the degree-1 problem.
 """
 from __future__ import annotations
 
@@ -51,6 +51,33 @@ class MeshTags:
         return self._t.get(int(tag), np.zeros((0, 3), dtype=np.int32))
 
 
+_TET_EDGES = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+_TRI_EDGES = ((0, 1), (0, 2), (1, 2))
+
+
+def p2_nodes(mesh: TetMesh, *facet_sets):
+    """Degree-2 node numbering of include/pgx_sg.h: the mesh vertices, then one node per edge (edges ordered by their (min, max)
+    vertex pair), at the edge midpoint.  Returns (node_coords, cells10, [facets6 for every facet set])."""
+    cells = mesh.cells.astype(np.int64)
+    nv = mesh.geometry.shape[0]
+    pairs = np.sort(np.concatenate([cells[:, list(e)] for e in _TET_EDGES]), axis=1)
+    key = pairs[:, 0] * nv + pairs[:, 1]
+    ukey, inv = np.unique(key, return_inverse=True)
+    nc = len(cells)
+    cells10 = np.ascontiguousarray(np.concatenate([cells, nv + inv.reshape(6, nc).T], axis=1), dtype=np.int32)
+    e0, e1 = ukey // nv, ukey % nv
+    coords = np.ascontiguousarray(np.concatenate([mesh.geometry, 0.5 * (mesh.geometry[e0] + mesh.geometry[e1])]))
+    out = []
+    for f in facet_sets:
+        f = np.asarray(f, dtype=np.int64).reshape(-1, 3)
+        fp = np.sort(np.concatenate([f[:, list(e)] for e in _TRI_EDGES]), axis=1) if len(f) else np.zeros((0, 2), dtype=np.int64)
+        pos = np.searchsorted(ukey, fp[:, 0] * nv + fp[:, 1])
+        if len(f) and not np.array_equal(ukey[pos], fp[:, 0] * nv + fp[:, 1]):
+            raise ValueError("a facet edge is not an edge of the mesh")
+        out.append(np.ascontiguousarray(np.concatenate([f, nv + pos.reshape(3, len(f)).T], axis=1), dtype=np.int32))
+    return coords, cells10, out
+
+
 def create_unit_cube(nx, ny, nz) -> TetMesh:
     """nx x ny x nz cubes, six tetrahedra each around the diagonal v0-v7 (dolfinx.mesh.create_unit_cube with
     CellType.tetrahedron [split pattern recalled, not verifiable offline])."""
@@ -78,18 +105,31 @@ def native_tags(mesh: TetMesh) -> tuple[MeshTags, dict]:
 class SignoriniProblem:
     """x = [u_x | u_y | u_z | psi (contact vertices ordered by vertex id)]."""
 
-    def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None):
+    def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None, degree=1,
+                 bc_facets=None):
+        """degree 2 (the reference's default): `bc_facets` (the displacement facets) must be given - their edge nodes are Dirichlet
+        nodes too; `bc_vertices` is then ignored.  State layout [u_x | u_y | u_z | psi] over the P2 NODES (p2_nodes)."""
         self._lib = lib = _lib.load()
         self.mesh = mesh
-        nv = mesh.geometry.shape[0]
+        self.degree = int(degree)
         pts, wts = fem.quadrature_rule("triangle", quadrature_degree)
-        facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
-        bv = np.asarray(bc_vertices, dtype=np.int64)
+        if self.degree == 2:
+            if bc_facets is None:
+                raise ValueError("degree 2 needs the displacement FACETS (their edge nodes are constrained as well)")
+            coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets)
+            bv = np.unique(bf6.ravel()).astype(np.int64)
+        elif self.degree == 1:
+            coords, cells = mesh.geometry, mesh.cells
+            facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
+            bv = np.asarray(bc_vertices, dtype=np.int64)
+        else:
+            raise NotImplementedError("HIP backend: degrees 1 and 2")
+        self.node_coords = coords
+        nv = coords.shape[0]
         bc = np.ascontiguousarray(np.concatenate([bv, nv + bv, 2 * nv + bv]), dtype=np.int32)  # all components (:267)
         vals = np.ascontiguousarray(np.concatenate([np.zeros(len(bv)), np.zeros(len(bv)), np.full(len(bv), float(disp))]))
-        self._keep = (mesh.geometry, mesh.cells, facets, pts, wts, bc, vals)
-        pm = _lib.pgx_sg_mesh(nv, mesh.cells.shape[0], _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), facets.shape[0],
-                              _lib.iptr(facets))
+        self._keep = (coords, cells, facets, pts, wts, bc, vals)
+        pm = _lib.pgx_sg_mesh(nv, cells.shape[0], _lib.dptr(coords), _lib.iptr(cells), facets.shape[0], _lib.iptr(facets), self.degree)
         pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
                                  _lib.iptr(bc), _lib.dptr(vals))
         self._h = C.c_void_p()
@@ -205,12 +245,13 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
                           quadrature_degree: int = 4, verbose: bool = True, return_solution: bool = False, device: int = 0,
                           comm=None):
     """signorini_dolfinx.solve_contact_problem (:156-360): returns (it, iterations) [, final state, problem data]."""
-    if degree != 1:
-        raise NotImplementedError("HIP backend: degree 1 (BASELINE.json config 5); the reference's default is 2")
+    if degree not in (1, 2):
+        raise NotImplementedError("HIP backend: degrees 1 (BASELINE.json config 5) and 2 (the reference's default)")
     contact = np.concatenate([facet_tag.find(t) for t in boundary_conditions["contact"]])  # :186-189
     bc_facets = np.concatenate([facet_tag.find(t) for t in boundary_conditions["displacement"]])  # :265-266
     bc_vertices = np.unique(bc_facets.ravel())
-    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device, comm=comm)
+    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device, comm=comm, degree=degree,
+                               bc_facets=bc_facets)
     iterations = []
     normed_diff = -1.0
     it = 0
@@ -245,7 +286,9 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
 
         xs = problem.get_state()
         nv = problem.nv
-        write_vtu(output / "uh.vtu", mesh.geometry, mesh.cells, {"displacement": np.stack([xs[:nv], xs[nv:2 * nv], xs[2 * nv:3 * nv]], axis=1)})
+        nvert = mesh.geometry.shape[0]  # degree 2: the vertex values (the edge nodes follow them in every component)
+        write_vtu(output / "uh.vtu", mesh.geometry, mesh.cells,
+                  {"displacement": np.stack([xs[:nvert], xs[nv:nv + nvert], xs[2 * nv:2 * nv + nvert]], axis=1)})
     if verbose:
         print(f"num_dofs_u={3 * problem.nv}, num_cells={mesh.cells.shape[0]}")
     if return_solution:
@@ -271,7 +314,7 @@ class NonlinearProblem:
         V = spec.u.function_space
         mesh = V.mesh
         if V.degree != 1 or V.dim != 3:
-            raise NotImplementedError("HIP backend: degree 1 in 3-D (BASELINE.json config 5)")
+            raise NotImplementedError("forms front end: degree 1 in 3-D; degree 2 runs through solve_contact_problem(degree=2)")
         if not bcs or len(bcs) != 1:
             raise NotImplementedError("one Dirichlet condition on the displacement surface (signorini_dolfinx.py:255-269)")
         bc = bcs[0]
