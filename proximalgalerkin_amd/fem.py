@@ -302,11 +302,19 @@ class VectorSpace:
     def component_rank(self, i):
         return 1
 
+    def node_coordinates(self):
+        """(n_nodes, gdim): the mesh vertices, at degree 2 followed by the edge midpoints (signorini.p2_nodes, include/pgx_sg.h)."""
+        if self.degree == 1:
+            return self.mesh.geometry
+        if self.degree == 2 and self.dim == 3:
+            from .signorini import p2_nodes
+
+            return p2_nodes(self.mesh)[0]
+        raise NotImplementedError("vector Lagrange spaces of degree 1, and degree 2 on tetrahedra")
+
     @property
     def num_dofs(self):
-        if self.degree != 1:
-            raise NotImplementedError("vector Lagrange spaces of degree 1")
-        return self.dim * self.mesh.geometry.shape[0]
+        return self.dim * self.node_coordinates().shape[0]
 
 
 @dataclass(frozen=True)
@@ -329,7 +337,8 @@ def create_submesh(mesh, dim, facets):
 
 @dataclass(frozen=True)
 class FacetSpace:
-    """functionspace(submesh, ("Lagrange", 1)) (signorini_dolfinx.py:222): scalar P1 on the contact surface."""
+    """functionspace(submesh, ("Lagrange", degree)) (signorini_dolfinx.py:222): scalar P1 / P2 on the contact surface; dofs ordered by
+    the parent's node id (vertices, then edge nodes)."""
     mesh: FacetSubMesh
     degree: int = 1
     ncomp = 1
@@ -337,16 +346,24 @@ class FacetSpace:
     def component_rank(self, i):
         return 0
 
+    def nodes(self):
+        """parent node id of every dof"""
+        if self.degree == 1:
+            return self.mesh.vertices
+        from .signorini import p2_nodes
+
+        return np.unique(p2_nodes(self.mesh.parent, self.mesh.facets)[2][0])
+
     @property
     def num_dofs(self):
-        return int(len(self.mesh.vertices))
+        return int(len(self.nodes()))
 
 
 def functionspace(mesh, element=("Lagrange", 1), ncomp=2):
     if isinstance(mesh, FacetSubMesh):
-        if tuple(element)[:2] != ("Lagrange", 1):
-            raise NotImplementedError("P1 on the contact surface")
-        return FacetSpace(mesh)
+        if tuple(element)[0] != "Lagrange" or int(tuple(element)[1]) not in (1, 2):
+            raise NotImplementedError("P1 or P2 on the contact surface")
+        return FacetSpace(mesh, int(tuple(element)[1]))
     if isinstance(element, tuple) and len(element) == 3 and isinstance(element[2], tuple):  # ("Lagrange", k, (gdim,))
         return VectorSpace(mesh, int(element[1]), int(element[2][0]))
     if isinstance(element, tuple) and element and isinstance(element[0], Element):  # a mixed_element([...])
@@ -454,7 +471,7 @@ class Function(_FormOperand):
         fn returns (gdim, npts)."""
         V = self.function_space
         if isinstance(V, VectorSpace):
-            vals = np.asarray(fn(np.ascontiguousarray(V.mesh.geometry.T)), dtype=np.float64)
+            vals = np.asarray(fn(np.ascontiguousarray(V.node_coordinates().T)), dtype=np.float64)
             self.x.array[:] = vals.reshape(V.dim, -1).ravel()
             return
         if not isinstance(V, FunctionSpace) or V.ncomp != 1:
@@ -511,8 +528,12 @@ class DirichletBC:
 
 
 def locate_dofs_topological(V, dim, facets):
-    """dofs of a P1 vector space on the given facets (vertex triples): one block index per vertex - each carries V.dim components
-    (signorini_dolfinx.py:267)."""
+    """dofs of a vector Lagrange space on the given facets (vertex triples): one block index per node - each carries V.dim
+    components (signorini_dolfinx.py:267); at degree 2 the facets' edge nodes are included."""
+    if isinstance(V, VectorSpace) and V.degree == 2:
+        from .signorini import p2_nodes
+
+        return np.unique(p2_nodes(V.mesh, facets)[2][0]).astype(np.int32)
     return np.unique(np.asarray(facets).ravel()).astype(np.int32)
 
 

@@ -7,7 +7,7 @@ reference's signature (:156-174) and loop (:317-358); `SignoriniProblem` stands 
 (:331-335).  Everything below `.solve()` runs in libpgx.so (include/pgx_sg.h).  No CPU fallback.
 
 Degrees 1 (BASELINE.json config 5) and 2 (the reference's default, :68-73) on tetrahedra; the reference's native mesh is hexahedral
-(:376-383) - here the same vertex grid split into tetrahedra.  The forms-driven `NonlinearProblem` below states the degree-1 problem.
+(:376-383) - here the same vertex grid split into tetrahedra.  The forms-driven `NonlinearProblem` below takes both degrees.
 """
 from __future__ import annotations
 
@@ -107,17 +107,17 @@ class SignoriniProblem:
 
     def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None, degree=1,
                  bc_facets=None):
-        """degree 2 (the reference's default): `bc_facets` (the displacement facets) must be given - their edge nodes are Dirichlet
-        nodes too; `bc_vertices` is then ignored.  State layout [u_x | u_y | u_z | psi] over the P2 NODES (p2_nodes)."""
+        """degree 2 (the reference's default): the Dirichlet NODES come from `bc_vertices` if given (node ids of p2_nodes), else from
+        `bc_facets` (the displacement facets: vertices and edge nodes).  State layout [u_x | u_y | u_z | psi] over the P2 nodes."""
         self._lib = lib = _lib.load()
         self.mesh = mesh
         self.degree = int(degree)
         pts, wts = fem.quadrature_rule("triangle", quadrature_degree)
         if self.degree == 2:
-            if bc_facets is None:
-                raise ValueError("degree 2 needs the displacement FACETS (their edge nodes are constrained as well)")
-            coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets)
-            bv = np.unique(bf6.ravel()).astype(np.int64)
+            if bc_facets is None and bc_vertices is None:
+                raise ValueError("degree 2 needs the Dirichlet nodes or the displacement FACETS (their edge nodes are constrained as well)")
+            coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets if bc_vertices is None else np.zeros((0, 3), np.int32))
+            bv = (np.unique(bf6.ravel()) if bc_vertices is None else np.asarray(bc_vertices)).astype(np.int64)
         elif self.degree == 1:
             coords, cells = mesh.geometry, mesh.cells
             facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
@@ -250,8 +250,8 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
     contact = np.concatenate([facet_tag.find(t) for t in boundary_conditions["contact"]])  # :186-189
     bc_facets = np.concatenate([facet_tag.find(t) for t in boundary_conditions["displacement"]])  # :265-266
     bc_vertices = np.unique(bc_facets.ravel())
-    problem = SignoriniProblem(mesh, contact, bc_vertices, E, nu, gap, disp, quadrature_degree, device=device, comm=comm, degree=degree,
-                               bc_facets=bc_facets)
+    problem = SignoriniProblem(mesh, contact, bc_vertices if degree == 1 else None, E, nu, gap, disp, quadrature_degree, device=device,
+                               comm=comm, degree=degree, bc_facets=bc_facets)
     iterations = []
     normed_diff = -1.0
     it = 0
@@ -313,8 +313,9 @@ class NonlinearProblem:
         spec = ufl.compile_signorini(F, u)
         V = spec.u.function_space
         mesh = V.mesh
-        if V.degree != 1 or V.dim != 3:
-            raise NotImplementedError("forms front end: degree 1 in 3-D; degree 2 runs through solve_contact_problem(degree=2)")
+        W = spec.psi.function_space
+        if V.degree not in (1, 2) or V.dim != 3 or W.degree != V.degree:
+            raise NotImplementedError("HIP backend: equal degrees 1 or 2 for displacement and latent variable, in 3-D (signorini_dolfinx.py:221-222)")
         if not bcs or len(bcs) != 1:
             raise NotImplementedError("one Dirichlet condition on the displacement surface (signorini_dolfinx.py:255-269)")
         bc = bcs[0]
@@ -325,10 +326,10 @@ class NonlinearProblem:
         E, nu = mu * (3.0 * lam + 2.0 * mu) / (lam + mu), lam / (2.0 * (lam + mu))
         self.spec = spec
         self._p = SignoriniProblem(mesh, spec.contact_facets, bc.dofs, E, nu, spec.gap, float(vals[2, 0]), spec.quadrature_degree,
-                                   device=device)
-        assert np.array_equal(self._p.contact_vertices, spec.psi.function_space.mesh.vertices)
+                                   device=device, degree=V.degree)
+        assert np.array_equal(self._p.contact_vertices, W.nodes())
         self.solver = self._p.solver
-        self._nu3 = 3 * mesh.geometry.shape[0]
+        self._nu3 = V.num_dofs
 
     def solve(self):
         p, sp = self._p, self.spec
@@ -347,7 +348,7 @@ class NonlinearProblem:
 
 def solve_contact_problem_forms(mesh: TetMesh, facet_tag: MeshTags, boundary_conditions: dict, E: float = 2.0e4, nu: float = 0.3,
                                 gap: float = 0.0, disp: float = -0.25, newton_tol: float = 1e-6, max_iterations: int = 25,
-                                alpha_0: float = 1.0, tol: float = 1e-6, quadrature_degree: int = 4, device: int = 0):
+                                alpha_0: float = 1.0, tol: float = 1e-6, quadrature_degree: int = 4, device: int = 0, degree: int = 1):
     """signorini_dolfinx.solve_contact_problem (:156-360) with the problem stated as the reference states it: spaces, sub-mesh,
     measures, the residual form, NonlinearProblem - through the UFL-subset front end.  alpha doubling.  Returns
     (it, iterations, u Function)."""
@@ -364,8 +365,8 @@ def solve_contact_problem_forms(mesh: TetMesh, facet_tag: MeshTags, boundary_con
     submesh, submesh_to_mesh = fem.create_submesh(mesh, fdim, contact_facets)  # :207
     ds = ufl.Measure("ds", domain=mesh, subdomain_data=facet_tag, subdomain_id=boundary_conditions["contact"],
                      metadata={"quadrature_degree": quadrature_degree})  # :211-218
-    V = fem.functionspace(mesh, ("Lagrange", 1, (gdim,)))  # :221
-    W = fem.functionspace(submesh, ("Lagrange", 1))  # :222
+    V = fem.functionspace(mesh, ("Lagrange", degree, (gdim,)))  # :221
+    W = fem.functionspace(submesh, ("Lagrange", degree))  # :222
     Q = ufl.MixedFunctionSpace(V, W)  # :225
     v, w = ufl.TestFunctions(Q)
     u, psi, psi_k = fem.Function(V, name="displacement"), fem.Function(W), fem.Function(W)

@@ -71,17 +71,20 @@ def test_full_lvpp_run_matches_oracle(require_gpu, n, gap):
     assert _rel(x[:nu3], x_ref[:nu3]) < 1e-10
 
 
-def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
+@pytest.mark.parametrize("degree", [1, 2])
+def test_problem_stated_as_forms_runs_the_same_solve(require_gpu, degree):
     """signorini_dolfinx.py:146-153, 199-291 stated through the UFL-subset front end (tensor algebra, ds measure over the contact
-    tags, MixedFunctionSpace with the latent variable on the contact sub-mesh) reproduces the declarative driver."""
+    tags, MixedFunctionSpace with the latent variable on the contact sub-mesh) reproduces the declarative driver, at degree 1 and at
+    the reference's default degree 2 (functionspace(mesh, ("Lagrange", 2, (3,))), functionspace(submesh, ("Lagrange", 2)))."""
     from proximalgalerkin_amd import signorini as G
 
-    mesh = G.create_unit_cube(5, 4, 4)
+    mesh = G.create_unit_cube(5, 4, 4) if degree == 1 else G.create_unit_cube(3, 3, 2)
     mt, bcs = G.native_tags(mesh)
-    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, gap=0.02, verbose=False, return_solution=True)
-    it_f, iterations_f, u = G.solve_contact_problem_forms(mesh, mt, bcs, gap=0.02)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, degree=degree, gap=0.02, verbose=False, return_solution=True)
+    it_f, iterations_f, u = G.solve_contact_problem_forms(mesh, mt, bcs, gap=0.02, degree=degree)
     assert it_f == it and list(iterations_f) == list(iterations)
-    nu3 = 3 * mesh.geometry.shape[0]
+    nu3 = u.x.array.size
+    assert nu3 == 3 * (mesh.geometry.shape[0] if degree == 1 else G.p2_nodes(mesh)[0].shape[0])
     assert np.linalg.norm(u.x.array - x[:nu3]) <= 1e-12 * np.linalg.norm(x[:nu3])
 
 
