@@ -1,0 +1,67 @@
+"""Mid-size goldens of examples 06, 02 (degrees 1, 2) and 01-P2 (tools/make_golden_families.py: CPU oracle runs of minutes, too long to
+repeat inside a GPU test): the HIP path reproduces the per-step Newton counts and the final primal field to 1e-10 relative L2 (ex 01-P2,
+ex 06 up to 48^2) resp. to the accuracy the examples' own Newton tolerances define (see the tests) on
+meshes where its sparse LU works on a deep dissection tree (several size classes per depth, subtree batches)."""
+import pathlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = pathlib.Path(__file__).resolve().parent / "golden"
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def _files(pattern):
+    return sorted(GOLD.glob(pattern))
+
+
+@pytest.mark.parametrize("f", _files("gradient_constraint_p2_n*_defaults_mid.npz"), ids=lambda f: f.stem)
+def test_example06(require_gpu, f):
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    z = np.load(f)
+    N = int(z["N"])
+    its, _, x = solve_problem(N, N, verbose=False, return_solution=True)
+    assert list(its) == list(z["newton"]), (its, z["newton"])
+    n2 = z["u_final"].size
+    # 1e-10 up to 48^2; at 96^2 the two runs differ by 2.2e-10: the late Newton matrices have condition numbers beyond 1e10, the
+    # oracle's SuperLU steps carry no iterative refinement (the HIP path refines every solve to a 1e-12 true residual), and SNES
+    # stops both at rtol = atol = 1e-9 - the field is determined to a few 1e-10 by the problem's own tolerances
+    assert _rel(x[:n2], z["u_final"]) < (1e-10 if N <= 48 else 5e-10)
+
+
+@pytest.mark.parametrize("f", _files("signorini_p*_n*_defaults_mid.npz"), ids=lambda f: f.stem)
+def test_example02(require_gpu, f):
+    from proximalgalerkin_amd import signorini as G
+
+    z = np.load(f)
+    n, degree = int(z["n"]), int(z["degree"])
+    mesh = G.create_unit_cube(n, n, n)
+    mt, bcs = G.native_tags(mesh)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, degree=degree, verbose=False, return_solution=True)
+    assert it == int(z["it"]) and list(iterations) == list(z["newton"])
+    nu3 = z["u_final"].size
+    # measured: 14^3 and 8^3 (degree 2) agree to < 1e-10, 20^3 to 4.1e-10, 12^3 (degree 2) to 6.5e-10.  The reference's Newton
+    # tolerance for this example is 1e-6 (signorini_dolfinx.py:330-332): the last step of either implementation lands wherever
+    # quadratic convergence takes it below that, and the oracle's SuperLU steps are not refined - 1e-9 is what the two share
+    assert _rel(x[:nu3], z["u_final"]) < 1e-9
+
+
+@pytest.mark.parametrize("f", _files("obstacle_p2_n*_settingsB_mid.npz"), ids=lambda f: f.stem)
+def test_example01_p2(require_gpu, f):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    z = np.load(f)
+    N = int(z["N"])
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
+    problem, sol, sol_k, alpha = setup_problem(msh, 2)
+    hist = run_outer_loop(problem, sol, sol_k, alpha, 500, "double_exponential", 1e2, 1e-4)
+    assert list(hist["Newton steps"]) == list(z["newton"]), (hist["Newton steps"], z["newton"])
+    n = z["u_final"].size
+    assert _rel(sol.x.array[:n], z["u_final"]) < 1e-10
+    problem.close()
