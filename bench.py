@@ -469,6 +469,11 @@ def main():
              "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
         if kind == 0:
             r["mixed_csr_equivalent_GBs"] = (12.0 * 4 * (nbytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n) / (ms * 1e-3) / 1e9
+        elif csr_bytes:
+            # SURVEY.md section 8(d) prices the operator as the mixed CSR the reference assembles (12 B per nnz of the 2n x 2n matrix +
+            # 20 B per row = 1.578 GB at 2048^2): what a CSR SpMV would have to stream for the SAME product - a rate of work, not a
+            # bandwidth (this kernel moves 65 B per vertex)
+            r["mixed_csr_equivalent_GBs"] = (12.0 * 4 * (csr_bytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n) / (ms * 1e-3) / 1e9
         return r
 
     out = None
