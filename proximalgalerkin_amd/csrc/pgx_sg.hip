@@ -306,6 +306,10 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   constexpr int ND = 3 * NPC, NE = ND * ND, NF2 = NPF * NPF, NFS = 2 * NF2 + NPF;  // cell dofs, cell slots, facet block, facet slots
   const int nv = m->n_vertices, nc = m->n_cells, nf = m->n_facets;
   h->npc = NPC, h->npf = NPF;
+  if ((double)NE * nc * (sizeof(double) + sizeof(int32_t)) > 96e9) {  // stash + destination table of the one-pass constant-block assembly
+    h->err = "mesh too large for the one-pass assembly of the elasticity block at this degree (" + std::to_string(NE) + " entries per cell)";
+    return PGX_ENOMEM;
+  }
   const int nu = 3 * nv;
   h->nv = nv, h->nc = nc, h->nf = nf;
   h->comm = comm;
