@@ -4,15 +4,16 @@ Counterpart of /root/reference/examples/02_signorini/signorini_dolfinx.py with t
 --disp --gap --n-tol --max-iterations --tol --alpha_scheme --alpha_0 --alpha_c and the two mesh branches: `--nx --ny --nz` (native,
 :361-386: a tetrahedral unit cube, BASELINE.json config 5) or `--filename mesh.msh|mesh.xdmf --contact-tag --displacement-tag`
 (file, :406-409: tetrahedra + tagged boundary triangles, e.g. the half sphere of generate_mesh.py; order-2 geometry is reduced to
-its vertices, XDMF must carry inline data).  `--degree {1,2}`, default 2 as in the reference (:68-73); BASELINE.json config 5 is
-`--degree 1 --nx 70 --ny 70 --nz 70`.
+its vertices, XDMF must carry inline data).  `--degree {1,2}`, default 2 as in the reference (:68-73); the native mesh is hexahedral
+as in the reference (`--cell-type hexahedron`, Q1 / Q2 elements); BASELINE.json config 5 is
+`--cell-type tetrahedron --degree 1 --nx 70 --ny 70 --nz 70`.
 """
 import argparse
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
-from proximalgalerkin_amd.signorini import create_unit_cube, native_tags, solve_contact_problem  # noqa: E402
+from proximalgalerkin_amd.signorini import create_unit_cube, create_unit_cube_hex, native_tags, solve_contact_problem  # noqa: E402
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -28,6 +29,8 @@ if __name__ == "__main__":
     parser.add_argument("--alpha_0", type=float, default=1.0)
     parser.add_argument("--alpha_c", type=float, default=1.0)
     parser.add_argument("--degree", type=int, default=2, choices=[1, 2], help="Degree of primal and latent space")
+    parser.add_argument("--cell-type", dest="cell_type", default="hexahedron", choices=["hexahedron", "tetrahedron"],
+                        help="native mesh: hexahedra as in the reference (:381-386), or the same vertex grid split into tetrahedra")
     parser.add_argument("--nx", type=int, default=16)
     parser.add_argument("--ny", type=int, default=7)
     parser.add_argument("--nz", type=int, default=5)
@@ -41,7 +44,7 @@ if __name__ == "__main__":
         mesh, mt = read_tet_mesh(a.filename)
         bcs = {"contact": (a.ct,), "displacement": (a.dt,)}
     else:
-        mesh = create_unit_cube(a.nx, a.ny, a.nz)
+        mesh = create_unit_cube_hex(a.nx, a.ny, a.nz) if a.cell_type == "hexahedron" else create_unit_cube(a.nx, a.ny, a.nz)
         mt, bcs = native_tags(mesh)
     it, iterations = solve_contact_problem(mesh=mesh, facet_tag=mt, boundary_conditions=bcs, degree=a.degree, E=a.E, nu=a.nu,
                                            gap=a.gap, disp=a.disp, newton_max_its=250, newton_tol=a.newton_tol,

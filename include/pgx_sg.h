@@ -5,7 +5,8 @@
  * facet integrals on a submesh, :199-249) + PETSc SNES (newtonls, linesearch none) + MUMPS LU (:271-291).
  *
  * Spaces at degree 1 (BASELINE.json config 5): u in (P1)^3 on a tetrahedral mesh, psi in P1 on the contact facets; degree 2 (the
- * reference's default, :68-73; pgx_sg_mesh.degree = 2): u in (P2)^3, psi in P2 on the contact facets, affine cells.
+ * reference's default, :68-73; pgx_sg_mesh.degree = 2): u in (P2)^3, psi in P2 on the contact facets, affine cells; hexahedra
+ * (the reference's native mesh, :376-383; pgx_sg_mesh.cell_type = 1) with Q1 / Q2 elements on parallelepipeds.
  *        x = [u_x (nv) | u_y (nv) | u_z (nv) | psi (one per contact node, ordered by node id)],  nv = vertices (degree 1) / P2 nodes
  * Residual (:236-249), n_g = -e_z, g = x_z - gap, f = 0:
  *        R_u   = alpha (sigma(u), eps(v)) - <psi - psi_k, v.n_g>_Gamma
@@ -45,6 +46,11 @@ typedef struct {
                             * (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); facets is [n_facets][6]: 3 vertices, then the edge nodes of
                             * (0,1) (0,2) (1,2).  Cells stay affine (geometry from the vertices).  bc_dofs: component * n_nodes +
                             * node; pgx_sg_contact_vertices returns the node of every psi dof. */
+  int32_t cell_type;       /* 0: tetrahedra (above).  1: hexahedra - the reference's native mesh (:376-383) - with Q_d elements, d = degree
+                            * (0 / 1 -> Q1, 2 -> Q2): cells is [n_cells][(d+1)^3], facets [n_facets][(d+1)^2] (quadrilaterals), local nodes
+                            * numbered lexicographically (xi fastest), basis = tensor Lagrange on the equispaced nodes k/d; cells and facets
+                            * must be affine images of the cube / square (parallelepipeds: true for box grids).  The facet quadrature of
+                            * pgx_sg_problem is then a rule on the unit SQUARE (weights sum to 1). */
 } pgx_sg_mesh;
 
 typedef struct {

@@ -300,3 +300,130 @@ class SignoriniP2:
             return b, None
         De = np.einsum("fq,qa,qb->fab", wE, self.Nq, self.Nq)
         return b, sp.coo_matrix((De.ravel(), (self._rp, self._cp)), shape=(self.npsi, self.npsi)).tocsr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hexahedra - the reference's NATIVE mesh (signorini_dolfinx.py:376-383: create_unit_cube(..., CellType.hexahedron), default
+# 16 x 7 x 5) with Q_d elements, d = 1, 2 (d = 2 is the script's default degree).  Conventions (this oracle's own; the HIP path
+# follows them): the mesh is the structured box grid, so the Q_d nodes are the lattice of (d nx + 1)(d ny + 1)(d nz + 1) points,
+# numbered lexicographically (x fastest); a cell's / facet's local nodes are numbered lexicographically too; basis = tensor
+# products of the 1-D Lagrange polynomials on the equispaced nodes k / d; cells by Gauss-Legendre (d + 1)^3 (exact on boxes),
+# facets by Gauss-Legendre 3 x 3 (degree 5 >= the script's quadrature_degree = 4).
+# ---------------------------------------------------------------------------------------------------------------------
+def _lag1d(d, t):
+    """values (len(t), d+1) and derivatives of the 1-D Lagrange basis on the nodes k/d"""
+    xn = np.arange(d + 1) / d
+    t = np.asarray(t, dtype=float)
+    V = np.ones((len(t), d + 1))
+    D = np.zeros((len(t), d + 1))
+    for i in range(d + 1):
+        for j in range(d + 1):
+            if j != i:
+                V[:, i] *= (t - xn[j]) / (xn[i] - xn[j])
+        for m in range(d + 1):
+            if m == i:
+                continue
+            term = np.full(len(t), 1.0 / (xn[i] - xn[m]))
+            for j in range(d + 1):
+                if j != i and j != m:
+                    term *= (t - xn[j]) / (xn[i] - xn[j])
+            D[:, i] += term
+    return V, D
+
+
+def _gauss01(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
+def hex_lattice(nx, ny, nz, d):
+    """node coordinates (lexicographic, x fastest), cells (nc, (d+1)^3), bottom facets z = 0 and top facets z = 1 (nf, (d+1)^2)"""
+    Nx, Ny, Nz = d * nx + 1, d * ny + 1, d * nz + 1
+    Z, Y, X = np.meshgrid(np.linspace(0, 1, Nz), np.linspace(0, 1, Ny), np.linspace(0, 1, Nx), indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    nid = lambda gx, gy, gz: (gz * Ny + gy) * Nx + gx  # noqa: E731
+    cz, cy, cx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    cx, cy, cz = cx.ravel(), cy.ravel(), cz.ravel()
+    loc = [(ix, iy, iz) for iz in range(d + 1) for iy in range(d + 1) for ix in range(d + 1)]
+    cells = np.stack([nid(d * cx + ix, d * cy + iy, d * cz + iz) for ix, iy, iz in loc], axis=1).astype(np.int32)
+    fy, fx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    fx, fy = fx.ravel(), fy.ravel()
+    floc = [(ix, iy) for iy in range(d + 1) for ix in range(d + 1)]
+    bottom = np.stack([nid(d * fx + ix, d * fy + iy, 0 * fx) for ix, iy in floc], axis=1).astype(np.int32)
+    top = np.stack([nid(d * fx + ix, d * fy + iy, 0 * fx + Nz - 1) for ix, iy in floc], axis=1).astype(np.int32)
+    return coords, cells, bottom, top
+
+
+class SignoriniHex:
+    """Same interface as SignoriniP1 with nv := number of Q_d nodes; cells must be parallelepipeds (the structured grid's are boxes)."""
+
+    def __init__(self, nx, ny, nz, degree=2, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25):
+        d = self.degree = int(degree)
+        coords, cells, bottom, top = hex_lattice(nx, ny, nz, d)
+        self.node_coords, self.cells, self.facets, self.top = coords, cells, bottom, top
+        nn = self.nv = len(coords)
+        npc, npf = (d + 1) ** 3, (d + 1) ** 2
+        self.nc, self.nf = len(cells), len(bottom)
+        self.cverts = np.unique(bottom.ravel()).astype(np.int32)
+        self.npsi = len(self.cverts)
+        n2psi = np.full(nn, -1, dtype=np.int64)
+        n2psi[self.cverts] = np.arange(self.npsi)
+        self.ntot = 3 * nn + self.npsi
+        self.mu, self.lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+        self.gap, self.disp = float(gap), float(disp)
+        bn = np.unique(top.ravel()).astype(np.int64)
+        self.bc_nodes = bn
+        self.bc = np.concatenate([bn, nn + bn, 2 * nn + bn]).astype(np.int64)
+        self.bc_vals = np.concatenate([np.zeros(len(bn)), np.zeros(len(bn)), np.full(len(bn), self.disp)])
+        self.isbc = np.zeros(3 * nn, dtype=bool)
+        self.isbc[self.bc] = True
+        # elasticity block: reference gradients at the tensor Gauss points
+        g, w = _gauss01(d + 1)
+        V, D = _lag1d(d, g)
+        loc = [(ix, iy, iz) for iz in range(d + 1) for iy in range(d + 1) for ix in range(d + 1)]
+        x0 = coords[cells[:, 0]]
+        J = np.stack([coords[cells[:, d]] - x0, coords[cells[:, d * (d + 1)]] - x0, coords[cells[:, d * (d + 1) ** 2]] - x0], axis=2)  # columns
+        det = np.linalg.det(J)
+        invJ = np.linalg.inv(J)
+        Ae = np.zeros((self.nc, npc, 3, npc, 3))
+        mu, lm = self.mu, self.lmbda
+        for qz in range(d + 1):
+            for qy in range(d + 1):
+                for qx in range(d + 1):
+                    gref = np.array([[D[qx, ix] * V[qy, iy] * V[qz, iz], V[qx, ix] * D[qy, iy] * V[qz, iz], V[qx, ix] * V[qy, iy] * D[qz, iz]]
+                                     for ix, iy, iz in loc])  # (npc, 3)
+                    G = np.einsum("ak,ckd->cad", gref, invJ)
+                    GG = np.einsum("cad,cbd->cab", G, G)
+                    wq = w[qx] * w[qy] * w[qz]
+                    Ae += (wq * np.abs(det))[:, None, None, None, None] * (
+                        lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G) + mu * np.einsum("cab,ij->caibj", GG, np.eye(3)))
+        rows = (cells[:, :, None, None, None] + nn * np.arange(3)[None, None, :, None, None])
+        cols = (cells[:, None, None, :, None] + nn * np.arange(3)[None, None, None, None, :])
+        rows, cols = np.broadcast_arrays(rows, cols)
+        self.A = sp.coo_matrix((Ae.ravel(), (rows.ravel(), cols.ravel())), shape=(3 * nn, 3 * nn)).tocsr()
+        # contact facets: 3 x 3 Gauss points on the reference square, bilinear / biquadratic facet basis
+        gq, wq1 = _gauss01(3)
+        Vf, _ = _lag1d(d, gq)
+        self.fq = np.array([(gq[a], gq[b]) for b in range(3) for a in range(3)])  # (9, 2), xi fastest
+        self.fw = np.array([wq1[a] * wq1[b] for b in range(3) for a in range(3)])
+        self.Nq = np.array([[Vf[a, ix] * Vf[b, iy] for iy in range(d + 1) for ix in range(d + 1)] for b in range(3) for a in range(3)])  # (9, npf)
+        xf0 = coords[bottom[:, 0]]
+        e1, e2 = coords[bottom[:, d]] - xf0, coords[bottom[:, d * (d + 1)]] - xf0
+        area = np.linalg.norm(np.cross(e1, e2), axis=1)
+        self.wdet = area[:, None] * self.fw[None]
+        Mref = np.einsum("q,qa,qb->ab", self.fw, self.Nq, self.Nq)
+        Me = area[:, None, None] * Mref[None]
+        pf = n2psi[bottom]
+        self.pf = pf
+        r = np.repeat(pf, npf, axis=1).ravel()
+        c = np.tile(bottom, (1, npf)).ravel()
+        self.MG = sp.coo_matrix((Me.ravel(), (r, c)), shape=(self.npsi, nn)).tocsr()
+        zq = xf0[:, 2:3] + self.fq[None, :, 0] * e1[:, 2:3] + self.fq[None, :, 1] * e2[:, 2:3]
+        self.b_g = np.bincount(pf.ravel(), weights=((self.wdet * (zq - self.gap)) @ self.Nq).ravel(), minlength=self.npsi)
+        self._rp = np.repeat(pf, npf, axis=1).ravel()
+        self._cp = np.tile(pf, (1, npf)).ravel()
+
+    split = SignoriniP1.split
+    residual = SignoriniP1.residual
+    jacobian = SignoriniP1.jacobian
+    exp_terms = SignoriniP2.exp_terms

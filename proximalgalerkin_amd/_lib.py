@@ -117,6 +117,7 @@ class pgx_sg_mesh(C.Structure):  # include/pgx_sg.h
         ("n_facets", C.c_int32),
         ("facets", c_int32_p),
         ("degree", C.c_int32),
+        ("cell_type", C.c_int32),
     ]
 
 

@@ -15,8 +15,10 @@
 #define SG_MAXQ 16
 struct SgQuad {
   double L[SG_MAXQ][3], w[SG_MAXQ];
-  double N[SG_MAXQ][6];  // facet basis at the quadrature points: P1 = L; P2 = L_a (2 L_a - 1), then 4 L_a L_b for (0,1) (0,2) (1,2)
+  double N[SG_MAXQ][9];  // facet basis at the quadrature points: P1 = L; P2 = L_a (2 L_a - 1), then 4 L_a L_b for (0,1) (0,2) (1,2);
+                         // quadrilateral facets: tensor Lagrange basis, lexicographic
   int nq;
+  int g[3];              // local nodes spanning the (affine) facet: x = X[g0] + xi (X[g1] - X[g0]) + eta (X[g2] - X[g0])
 };
 
 static thread_local std::string g_sg_error;
@@ -142,6 +144,60 @@ __global__ __launch_bounds__(64) void k_sg_const_cells_p2(int nc, const int32_t*
     }
 }
 
+// hexahedra (Q1 / Q2; any cell family with an affine map): A_e by quadrature from a TABLE of reference gradients,
+// tab = [nq weights | nq x NPC x 3 reference gradients]; geometry from the four local nodes gn = (origin, +xi, +eta, +zeta):
+// J = [X[g1]-X[g0] | X[g2]-X[g0] | X[g3]-X[g0]].  One thread per cell; gradients are recomputed per (A, B, q) so that nothing but the
+// 3 x 3 accumulator lives in registers (Q2: 6561 entries per cell).
+template <int NPC>
+__global__ __launch_bounds__(64) void k_sg_const_cells_tab(int nc, const int32_t* __restrict__ cells, const double* __restrict__ coords,
+                                                           double mu, double lmbda, int nq, const double* __restrict__ tab, int g0, int g1,
+                                                           int g2, int g3, double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int32_t* cv = cells + NPC * (size_t)c;
+  const int gn[4] = {g0, g1, g2, g3};
+  double X[4][3];
+  for (int a = 0; a < 4; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)cv[gn[a]] + d];
+  double J[3][3];
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 3; ++k) J[d][k] = X[k + 1][d] - X[0][d];
+  const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+  double inv[3][3];
+  inv[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+  inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+  inv[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+  inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  inv[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+  inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+  inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+  const double adet = fabs(det);
+  const double* dN = tab + nq;
+  constexpr int ND = 3 * NPC;
+  for (int A = 0; A < NPC; ++A)
+    for (int B = 0; B < NPC; ++B) {
+      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int q = 0; q < nq; ++q) {
+        const double* ra = dN + ((size_t)q * NPC + A) * 3;
+        const double* rb = dN + ((size_t)q * NPC + B) * 3;
+        double gA[3], gB[3];
+        for (int d = 0; d < 3; ++d) {
+          gA[d] = ra[0] * inv[0][d] + ra[1] * inv[1][d] + ra[2] * inv[2][d];
+          gB[d] = rb[0] * inv[0][d] + rb[1] * inv[1][d] + rb[2] * inv[2][d];
+        }
+        const double wq = tab[q] * adet;
+        const double gg = gA[0] * gB[0] + gA[1] * gB[1] + gA[2] * gB[2];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) acc[i][j] += wq * (lmbda * gA[i] * gB[j] + mu * gA[j] * gB[i] + (i == j ? mu * gg : 0.0));
+      }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) stash[(size_t)((A * 3 + i) * ND + (B * 3 + j)) * nc + c] = acc[i][j];
+    }
+}
+
 // facet mass coupling (+M on (u_z, psi), -M on (psi, u_z)) and b_g = <g, w>, once
 template <int NPF>
 __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* __restrict__ facets, const int32_t* __restrict__ fpsi,
@@ -149,10 +205,10 @@ __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* 
                                                          double* __restrict__ stash /* [(2 NPF^2 + NPF) * nf]: matrix slots, then b_g */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
-  const int32_t* fv = facets + NPF * (size_t)f;  // the first three nodes are the vertices: affine geometry
-  double X[3][3];
+  const int32_t* fv = facets + NPF * (size_t)f;
+  double X[3][3];  // the three nodes spanning the affine facet
   for (int a = 0; a < 3; ++a)
-    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[Q.g[a]] + d];
   const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
   const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
   const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
@@ -199,7 +255,7 @@ __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const 
   const int32_t* fp = fpsi + NPF * (size_t)f;
   double X[3][3];
   for (int a = 0; a < 3; ++a)
-    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[a] + d];
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[3 * (size_t)fv[Q.g[a]] + d];
   const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
   const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
   const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
@@ -277,6 +333,12 @@ void pgx_sg_handle::residual_dev(const double* xin, double* Fout) {
     if (h->npf == 6)
       hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
                          h->Q, h->stash);
+    else if (h->npf == 4)
+      hipLaunchKernelGGL(k_sg_exp<4>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                         h->Q, h->stash);
+    else if (h->npf == 9)
+      hipLaunchKernelGGL(k_sg_exp<9>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
+                         h->Q, h->stash);
     else
       hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
                          h->Q, h->stash);
@@ -292,6 +354,12 @@ void pgx_sg_handle::jacobian_dev(const double* xin) {
     if (h->npf == 6)
       hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
                          h->coords, xin, h->Q, h->stash);
+    else if (h->npf == 4)
+      hipLaunchKernelGGL(k_sg_exp<4>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
+                         h->coords, xin, h->Q, h->stash);
+    else if (h->npf == 9)
+      hipLaunchKernelGGL(k_sg_exp<9>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
+                         h->coords, xin, h->Q, h->stash);
     else
       hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
                          h->coords, xin, h->Q, h->stash);
@@ -300,7 +368,19 @@ void pgx_sg_handle::jacobian_dev(const double* xin) {
   h->jac_valid = true;
 }
 
-// NPC / NPF: nodes per cell / per contact facet (4 / 3: degree 1; 10 / 6: degree 2, m->n_vertices = number of NODES)
+// 1-D Lagrange basis on the equispaced nodes k / d (d = 1, 2): values l[0..d] and derivatives dl[0..d] at t
+static void sg_lagrange1d(int d, double t, double* l, double* dl) {
+  if (d == 1) {
+    l[0] = 1.0 - t, l[1] = t;
+    dl[0] = -1.0, dl[1] = 1.0;
+  } else {
+    l[0] = 2.0 * (t - 0.5) * (t - 1.0), l[1] = -4.0 * t * (t - 1.0), l[2] = 2.0 * t * (t - 0.5);
+    dl[0] = 4.0 * t - 3.0, dl[1] = 4.0 - 8.0 * t, dl[2] = 4.0 * t - 1.0;
+  }
+}
+
+// NPC / NPF: nodes per cell / per contact facet: tetrahedra 4 / 3 (degree 1), 10 / 6 (degree 2); hexahedra 8 / 4 (Q1), 27 / 9 (Q2).
+// m->n_vertices = number of NODES.
 template <int NPC, int NPF>
 static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm) {
   constexpr int ND = 3 * NPC, NE = ND * ND, NF2 = NPF * NPF, NFS = 2 * NF2 + NPF;  // cell dofs, cell slots, facet block, facet slots
@@ -323,10 +403,21 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
     const double* L = h->Q.L[q];
     if (NPF == 3) {
       for (int a = 0; a < 3; ++a) h->Q.N[q][a] = L[a];
-    } else {
+    } else if (NPF == 6) {
       for (int a = 0; a < 3; ++a) h->Q.N[q][a] = L[a] * (2.0 * L[a] - 1.0);
       h->Q.N[q][3] = 4.0 * L[0] * L[1], h->Q.N[q][4] = 4.0 * L[0] * L[2], h->Q.N[q][5] = 4.0 * L[1] * L[2];
+    } else {  // quadrilateral facets: tensor Lagrange basis of degree d on [0,1]^2, lexicographic (xi fastest)
+      const int d = NPF == 4 ? 1 : 2;
+      double lx[3], ly[3], dummy[3];
+      sg_lagrange1d(d, X, lx, dummy);
+      sg_lagrange1d(d, Y, ly, dummy);
+      for (int iy = 0; iy <= d; ++iy)
+        for (int ix = 0; ix <= d; ++ix) h->Q.N[q][iy * (d + 1) + ix] = lx[ix] * ly[iy];
     }
+  }
+  {
+    const int d = (NPF == 4) ? 1 : (NPF == 9 ? 2 : 0);
+    h->Q.g[0] = 0, h->Q.g[1] = d ? d : 1, h->Q.g[2] = d ? d * (d + 1) : 2;
   }
   for (size_t k = 0; k < NPC * (size_t)nc; ++k)
     if (m->cells[k] < 0 || m->cells[k] >= nv) {
@@ -551,10 +642,42 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * NFS * (size_t)std::max(nf, 1));
   if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * NPC * (size_t)nc, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    if (NPC == 4)
+    if (NPC == 4) {
       hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
-    else
+    } else if (NPC == 10) {
       hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nc + 63) / 64), dim3(64), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+    } else {  // hexahedra: Gauss-Legendre (d + 1)^3 on [0,1]^3, tensor Lagrange reference gradients
+      const int d = NPC == 8 ? 1 : 2, n1 = d + 1, nq3 = n1 * n1 * n1;
+      const double gp2[2] = {0.5 - 0.5 / sqrt(3.0), 0.5 + 0.5 / sqrt(3.0)}, gw2[2] = {0.5, 0.5};
+      const double gp3[3] = {0.5 - 0.5 * sqrt(0.6), 0.5, 0.5 + 0.5 * sqrt(0.6)}, gw3[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+      const double* gp = d == 1 ? gp2 : gp3;
+      const double* gw = d == 1 ? gw2 : gw3;
+      std::vector<double> tab((size_t)nq3 + (size_t)nq3 * NPC * 3);
+      int q = 0;
+      for (int qz = 0; qz < n1; ++qz)
+        for (int qy = 0; qy < n1; ++qy)
+          for (int qx = 0; qx < n1; ++qx, ++q) {
+            tab[q] = gw[qx] * gw[qy] * gw[qz];
+            double lx[3], ly[3], lz[3], dx[3], dy[3], dz[3];
+            sg_lagrange1d(d, gp[qx], lx, dx);
+            sg_lagrange1d(d, gp[qy], ly, dy);
+            sg_lagrange1d(d, gp[qz], lz, dz);
+            for (int iz = 0; iz < n1; ++iz)
+              for (int iy = 0; iy < n1; ++iy)
+                for (int ix = 0; ix < n1; ++ix) {
+                  double* r = tab.data() + nq3 + ((size_t)q * NPC + (size_t)(iz * n1 + iy) * n1 + ix) * 3;
+                  r[0] = dx[ix] * ly[iy] * lz[iz], r[1] = lx[ix] * dy[iy] * lz[iz], r[2] = lx[ix] * ly[iy] * dz[iz];
+                }
+          }
+      double* d_tab = nullptr;
+      e = hipMalloc((void**)&d_tab, sizeof(double) * tab.size());
+      if (e == hipSuccess) e = hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        tmp.push_back(d_tab);
+        hipLaunchKernelGGL(k_sg_const_cells_tab<NPC>, dim3((nc + 63) / 64), dim3(64), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda,
+                           nq3, d_tab, 0, d, d * n1, d * n1 * n1, st_c);
+      }
+    }
     pgx_scatter_run(h->st, sc_c, st_c, 1.0, 0, h->Jc);
     if (nf > 0) {
       hipLaunchKernelGGL(k_sg_const_facets<NPF>, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
@@ -578,7 +701,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
 static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device, pgx_sg_handle** out) {
   if (!m || !p || !out || !m->coords || !m->cells || m->n_vertices <= 0 || m->n_cells <= 0 || m->n_facets < 0 ||
       (m->n_facets > 0 && !m->facets) || !p->qpts || !p->qwts || p->nq <= 0 || p->nq > SG_MAXQ ||
-      (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5) || m->degree < 0 || m->degree > 2) {
+      (p->n_bc > 0 && !p->bc_dofs) || !(p->E > 0.0) || !(p->nu > -1.0 && p->nu < 0.5) || m->degree < 0 || m->degree > 2 || m->cell_type < 0 || m->cell_type > 1) {
     g_sg_error = "pgx_sg_create: bad arguments";
     return PGX_EINVAL;
   }
@@ -593,7 +716,11 @@ static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* co
   }
   pgx_sg_handle* h = new pgx_sg_handle();
   h->device = device;
-  int rc = (m->degree == 2) ? sg_create_impl<10, 6>(h, m, p, comm) : sg_create_impl<4, 3>(h, m, p, comm);
+  int rc;
+  if (m->cell_type == 1)
+    rc = (m->degree == 2) ? sg_create_impl<27, 9>(h, m, p, comm) : sg_create_impl<8, 4>(h, m, p, comm);
+  else
+    rc = (m->degree == 2) ? sg_create_impl<10, 6>(h, m, p, comm) : sg_create_impl<4, 3>(h, m, p, comm);
   if (rc) {
     g_sg_error = h->err;
     pgx_sg_destroy(h);

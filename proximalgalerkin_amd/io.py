@@ -24,7 +24,7 @@ import numpy as np
 # gmsh element type -> (name, nodes)
 _GMSH = {1: ("line", 2), 2: ("triangle", 3), 4: ("tetra", 4), 8: ("line3", 3), 9: ("triangle6", 6), 11: ("tetra10", 10),
          15: ("vertex", 1)}
-_VTK = {"triangle": 5, "triangle6": 22, "tetra": 10, "line": 3, "vertex": 1}
+_VTK = {"triangle": 5, "triangle6": 22, "tetra": 10, "line": 3, "vertex": 1, "hexahedron": 12}
 
 
 def read_msh(path):
@@ -253,7 +253,7 @@ def write_vtu(path, points, cells, point_data: dict | None = None, cell_data: di
         points = np.concatenate([points, np.zeros((len(points), 1))], axis=1)
     cells = np.asarray(cells)
     k = cells.shape[1]
-    cell_type = cell_type or {3: "triangle", 6: "triangle6", 4: "tetra"}[k]
+    cell_type = cell_type or {3: "triangle", 6: "triangle6", 4: "tetra", 8: "hexahedron"}[k]  # hexahedron: VTK corner order
     if cell_type == "triangle6":  # VTK: mid(0,1), mid(1,2), mid(2,0); here: opposite 0 = (1,2), opposite 1 = (0,2), opposite 2 = (0,1)
         cells = cells[:, [0, 1, 2, 5, 3, 4]]
 

@@ -6,8 +6,8 @@ reference's signature (:156-174) and loop (:317-358); `SignoriniProblem` stands 
 `.solve()`, `.solver.setTolerances(atol=, rtol=)`, `.solver.getIterationNumber()`, `.solver.getConvergedReason()`
 (:331-335).  Everything below `.solve()` runs in libpgx.so (include/pgx_sg.h).  No CPU fallback.
 
-Degrees 1 (BASELINE.json config 5) and 2 (the reference's default, :68-73) on tetrahedra; the reference's native mesh is hexahedral
-(:376-383) - here the same vertex grid split into tetrahedra.  The forms-driven `NonlinearProblem` below takes both degrees.
+Degrees 1 (BASELINE.json config 5) and 2 (the reference's default, :68-73) on tetrahedra (`TetMesh`) and on the reference's native
+hexahedral box grid (`HexMesh`, :376-383; Q1 / Q2 elements).  The forms-driven `NonlinearProblem` below takes both degrees.
 """
 from __future__ import annotations
 
@@ -78,6 +78,78 @@ def p2_nodes(mesh: TetMesh, *facet_sets):
     return coords, cells10, out
 
 
+@dataclass
+class HexMesh:
+    """dolfinx.mesh.create_unit_cube(comm, nx, ny, nz, CellType.hexahedron) - the reference's NATIVE mesh (signorini_dolfinx.py:376-383):
+    a structured grid of boxes.  `geometry` / `cells` are the vertex lattice (nv, 3) and the 8 corner vertices per cell, numbered
+    lexicographically (x fastest); the Q_d nodes of include/pgx_sg.h are the lattice refined d times (`lattice(d)`)."""
+    nx: int
+    ny: int
+    nz: int
+
+    def _lat(self, d):
+        Nx, Ny, Nz = d * self.nx + 1, d * self.ny + 1, d * self.nz + 1
+        Z, Y, X = np.meshgrid(np.linspace(0, 1, Nz), np.linspace(0, 1, Ny), np.linspace(0, 1, Nx), indexing="ij")
+        return np.ascontiguousarray(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)), (Nx, Ny, Nz)
+
+    @property
+    def geometry(self):
+        return self._lat(1)[0]
+
+    @property
+    def cells(self):
+        return self.lattice(1)[1]
+
+    def lattice(self, d):
+        """(node coordinates, cells [nc][(d+1)^3]) of the Q_d discretisation, local nodes lexicographic"""
+        coords, (Nx, Ny, Nz) = self._lat(d)
+        cz, cy, cx = np.meshgrid(np.arange(self.nz), np.arange(self.ny), np.arange(self.nx), indexing="ij")
+        cx, cy, cz = cx.ravel(), cy.ravel(), cz.ravel()
+        cells = np.stack([((d * cz + iz) * Ny + d * cy + iy) * Nx + d * cx + ix
+                          for iz in range(d + 1) for iy in range(d + 1) for ix in range(d + 1)], axis=1)
+        return coords, np.ascontiguousarray(cells, dtype=np.int32)
+
+    def facets_where(self, pred):
+        """Exterior faces (4 corner vertices of the vertex lattice, lexicographic within the face) whose corners satisfy pred(x)."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        Nx, Ny = nx + 1, ny + 1
+        vid = lambda gx, gy, gz: (gz * Ny + gy) * Nx + gx  # noqa: E731
+        out = []
+        j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+        for gz in (0, nz):
+            out.append(np.stack([vid(i, j, gz), vid(i + 1, j, gz), vid(i, j + 1, gz), vid(i + 1, j + 1, gz)], axis=-1).reshape(-1, 4))
+        k, i = np.meshgrid(np.arange(nz), np.arange(nx), indexing="ij")
+        for gy in (0, ny):
+            out.append(np.stack([vid(i, gy, k), vid(i + 1, gy, k), vid(i, gy, k + 1), vid(i + 1, gy, k + 1)], axis=-1).reshape(-1, 4))
+        k, j = np.meshgrid(np.arange(nz), np.arange(ny), indexing="ij")
+        for gx in (0, nx):
+            out.append(np.stack([vid(gx, j, k), vid(gx, j + 1, k), vid(gx, j, k + 1), vid(gx, j + 1, k + 1)], axis=-1).reshape(-1, 4))
+        faces = np.concatenate(out)
+        on = pred(self.geometry.T)
+        return np.ascontiguousarray(faces[on[faces].all(axis=1)], dtype=np.int32)
+
+    def facet_nodes(self, faces, d):
+        """Q_d nodes (lexicographic within the face) of faces given by their 4 corner vertices"""
+        faces = np.asarray(faces, dtype=np.int64).reshape(-1, 4)
+        Nx1, Ny1 = self.nx + 1, self.ny + 1
+        Nx, Ny = d * self.nx + 1, d * self.ny + 1
+
+        def ijk(v):
+            return np.stack([v % Nx1, (v // Nx1) % Ny1, v // (Nx1 * Ny1)], axis=-1)
+
+        c0, e1, e2 = ijk(faces[:, 0]), ijk(faces[:, 1]) - ijk(faces[:, 0]), ijk(faces[:, 2]) - ijk(faces[:, 0])
+        nodes = []
+        for iy in range(d + 1):
+            for ix in range(d + 1):
+                g = d * c0 + ix * e1 + iy * e2
+                nodes.append((g[:, 2] * Ny + g[:, 1]) * Nx + g[:, 0])
+        return np.ascontiguousarray(np.stack(nodes, axis=1), dtype=np.int32)
+
+
+def create_unit_cube_hex(nx, ny, nz) -> HexMesh:
+    return HexMesh(int(nx), int(ny), int(nz))
+
+
 def create_unit_cube(nx, ny, nz) -> TetMesh:
     """nx x ny x nz cubes, six tetrahedra each around the diagonal v0-v7 (dolfinx.mesh.create_unit_cube with
     CellType.tetrahedron [split pattern recalled, not verifiable offline])."""
@@ -113,7 +185,20 @@ class SignoriniProblem:
         self.mesh = mesh
         self.degree = int(degree)
         pts, wts = fem.quadrature_rule("triangle", quadrature_degree)
-        if self.degree == 2:
+        self.cell_type = 1 if isinstance(mesh, HexMesh) else 0
+        if self.cell_type == 1:  # the reference's native mesh: Q_d on the structured box grid
+            if self.degree not in (1, 2):
+                raise NotImplementedError("HIP backend: degrees 1 and 2")
+            if bc_facets is None:
+                raise ValueError("hexahedral meshes need the displacement FACETS")
+            coords, cells = mesh.lattice(self.degree)
+            facets = mesh.facet_nodes(contact_facets, self.degree)
+            bv = np.unique(mesh.facet_nodes(bc_facets, self.degree).ravel()).astype(np.int64)
+            g, w1 = np.polynomial.legendre.leggauss(3)  # 3 x 3 Gauss-Legendre on the unit square (degree 5 >= quadrature_degree 4)
+            g, w1 = 0.5 * (g + 1.0), 0.5 * w1
+            pts = np.ascontiguousarray([(g[a], g[b]) for b in range(3) for a in range(3)])
+            wts = np.ascontiguousarray([w1[a] * w1[b] for b in range(3) for a in range(3)])
+        elif self.degree == 2:
             if bc_facets is None and bc_vertices is None:
                 raise ValueError("degree 2 needs the Dirichlet nodes or the displacement FACETS (their edge nodes are constrained as well)")
             coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets if bc_vertices is None else np.zeros((0, 3), np.int32))
@@ -129,7 +214,8 @@ class SignoriniProblem:
         bc = np.ascontiguousarray(np.concatenate([bv, nv + bv, 2 * nv + bv]), dtype=np.int32)  # all components (:267)
         vals = np.ascontiguousarray(np.concatenate([np.zeros(len(bv)), np.zeros(len(bv)), np.full(len(bv), float(disp))]))
         self._keep = (coords, cells, facets, pts, wts, bc, vals)
-        pm = _lib.pgx_sg_mesh(nv, cells.shape[0], _lib.dptr(coords), _lib.iptr(cells), facets.shape[0], _lib.iptr(facets), self.degree)
+        pm = _lib.pgx_sg_mesh(nv, cells.shape[0], _lib.dptr(coords), _lib.iptr(cells), facets.shape[0], _lib.iptr(facets), self.degree,
+                              self.cell_type)
         pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
                                  _lib.iptr(bc), _lib.dptr(vals))
         self._h = C.c_void_p()
@@ -250,8 +336,8 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
     contact = np.concatenate([facet_tag.find(t) for t in boundary_conditions["contact"]])  # :186-189
     bc_facets = np.concatenate([facet_tag.find(t) for t in boundary_conditions["displacement"]])  # :265-266
     bc_vertices = np.unique(bc_facets.ravel())
-    problem = SignoriniProblem(mesh, contact, bc_vertices if degree == 1 else None, E, nu, gap, disp, quadrature_degree, device=device,
-                               comm=comm, degree=degree, bc_facets=bc_facets)
+    problem = SignoriniProblem(mesh, contact, bc_vertices if degree == 1 and not isinstance(mesh, HexMesh) else None, E, nu, gap, disp,
+                               quadrature_degree, device=device, comm=comm, degree=degree, bc_facets=bc_facets)
     iterations = []
     normed_diff = -1.0
     it = 0
@@ -286,9 +372,15 @@ def solve_contact_problem(mesh: TetMesh, facet_tag: MeshTags, boundary_condition
 
         xs = problem.get_state()
         nv = problem.nv
-        nvert = mesh.geometry.shape[0]  # degree 2: the vertex values (the edge nodes follow them in every component)
-        write_vtu(output / "uh.vtu", mesh.geometry, mesh.cells,
-                  {"displacement": np.stack([xs[:nvert], xs[nv:nv + nvert], xs[2 * nv:2 * nv + nvert]], axis=1)})
+        if isinstance(mesh, HexMesh):  # all Q_d nodes as a point cloud of first-order cells on the refined lattice
+            co, ce = mesh.lattice(degree)
+            sub = HexMesh(degree * mesh.nx, degree * mesh.ny, degree * mesh.nz)
+            write_vtu(output / "uh.vtu", co, sub.cells[:, [0, 1, 3, 2, 4, 5, 7, 6]],
+                      {"displacement": np.stack([xs[:nv], xs[nv:2 * nv], xs[2 * nv:3 * nv]], axis=1)}, cell_type="hexahedron")
+        else:
+            nvert = mesh.geometry.shape[0]  # degree 2: the vertex values (the edge nodes follow them in every component)
+            write_vtu(output / "uh.vtu", mesh.geometry, mesh.cells,
+                      {"displacement": np.stack([xs[:nvert], xs[nv:nv + nvert], xs[2 * nv:2 * nv + nvert]], axis=1)})
     if verbose:
         print(f"num_dofs_u={3 * problem.nv}, num_cells={mesh.cells.shape[0]}")
     if return_solution:

@@ -51,6 +51,20 @@ def test_example02(require_gpu, f):
     assert _rel(x[:nu3], z["u_final"]) < 1e-9
 
 
+@pytest.mark.parametrize("f", _files("signorini_hex_q*_defaults_mid.npz"), ids=lambda f: f.stem)
+def test_example02_on_the_references_native_hexahedral_mesh(require_gpu, f):
+    """signorini_dolfinx.py with no arguments: create_unit_cube(16, 7, 5, hexahedron), degree 2."""
+    from proximalgalerkin_amd import signorini as G
+
+    z = np.load(f)
+    mesh = G.create_unit_cube_hex(*[int(v) for v in z["n"]])
+    mt, bcs = G.native_tags(mesh)
+    it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, degree=int(z["degree"]), verbose=False, return_solution=True)
+    assert it == int(z["it"]) and list(iterations) == list(z["newton"])
+    nu3 = z["u_final"].size
+    assert _rel(x[:nu3], z["u_final"]) < 1e-9  # Newton tolerance 1e-6, see test_example02
+
+
 @pytest.mark.parametrize("f", _files("obstacle_p2_n*_settingsB_mid.npz"), ids=lambda f: f.stem)
 def test_example01_p2(require_gpu, f):
     from proximalgalerkin_amd import fem

@@ -178,3 +178,38 @@ def test_degree2_full_lvpp_run_matches_oracle(require_gpu, n, gap):
     # the degree-2 displacement agrees with the degree-1 one on a finer mesh to discretisation accuracy (independent discretisations)
     uz = x[2 * prob.nv:3 * prob.nv]
     assert abs(uz[prob.bc_nodes] + 0.25).max() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# hexahedra - the reference's native mesh (signorini_dolfinx.py:376-383), Q1 and Q2 (its default degree)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,degree", [((2, 2, 2), 1), ((4, 3, 2), 1), ((2, 2, 2), 2), ((4, 3, 3), 2)])
+def test_hexahedra_kernels_and_full_run_match_oracle(require_gpu, n, degree):
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube_hex(*n)
+    mt, bcs = G.native_tags(mesh)
+    prob = S.SignoriniHex(*n, degree=degree, gap=0.01)
+    problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.01, -0.25, degree=degree, bc_facets=mt.find(1))
+    assert problem.ndofs == prob.ntot and np.array_equal(problem.contact_vertices, prob.cverts)
+    assert np.array_equal(problem.node_coords, prob.node_coords)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(prob.ntot) * 0.05
+    x[3 * prob.nv:] = -np.abs(rng.standard_normal(prob.npsi)) * np.where(rng.random(prob.npsi) < 0.4, 400.0, 2.0)
+    xk = rng.standard_normal(prob.ntot) * 0.05
+    for alpha in (2.0, 64.0):
+        problem.set_alpha(alpha)
+        problem.set_prev(xk)
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, alpha)
+        assert _rel(F, Fr) < 1e-12
+        J = problem.jacobian(x)
+        Jr = prob.jacobian(x, alpha).tocsr()
+        assert abs(J - Jr).max() <= 1e-12 * abs(Jr).max()
+        nu3 = 3 * prob.nv
+        assert abs(J[nu3:, nu3:] - Jr[nu3:, nu3:]).max() <= 1e-12 * abs(Jr[nu3:, nu3:]).max()
+    problem.close()
+    it, iterations, xs, cv = G.solve_contact_problem(mesh, mt, bcs, degree=degree, gap=0.01, verbose=False, return_solution=True)
+    x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
+    assert it == it_ref and list(iterations) == list(its_ref), (it, iterations, it_ref, its_ref)
+    assert _rel(xs[:3 * prob.nv], x_ref[:3 * prob.nv]) < 1e-10

@@ -3,7 +3,7 @@
 final primal field + per-step Newton counts, at sizes where the GPU path's sparse LU works on a deep dissection tree with several
 size classes per depth (the oracle-compared full runs in tests/test_gpu_*.py stop at N = 20 / 8x6x5 / 32 because the oracle runs
 inside the GPU test).  Generated from the ORACLE (parity unpinned, see the oracle headers).
-    python tools/make_golden_families.py [gc N] [sg n] [sg2 n] [p2 N] ...      default: gc 64  sg 14  sg2 8  p2 96"""
+    python tools/make_golden_families.py [gc N] [sg n] [sg2 n] [p2 N] [hexdefault D] ...      default: gc 64  sg 14  sg2 8  p2 96"""
 import pathlib
 import sys
 import time
@@ -40,6 +40,14 @@ def sg(n, degree):
     return its
 
 
+def sghex(nx, ny, nz, degree):
+    p = S.SignoriniHex(nx, ny, nz, degree=degree)
+    x, it, its = S.solve_contact_problem(p)
+    np.savez_compressed(GOLD / f"signorini_hex_q{degree}_{nx}x{ny}x{nz}_defaults_mid.npz", n=np.array([nx, ny, nz]), degree=degree,
+                        u_final=x[:3 * p.nv], newton=np.asarray(its), it=it)
+    return its
+
+
 def p2(N):
     coords, cells = O.create_rectangle(N, N)
     p = O.ObstacleLagrange(coords, cells, degree=2)
@@ -52,5 +60,6 @@ if __name__ == "__main__":
     a = sys.argv[1:] or ["gc", "64", "sg", "14", "sg2", "8", "p2", "96"]
     for kind, size in zip(a[::2], a[1::2]):
         t = time.perf_counter()
-        its = {"gc": gc, "sg": lambda n: sg(n, 1), "sg2": lambda n: sg(n, 2), "p2": p2}[kind](int(size))
+        its = {"gc": gc, "sg": lambda n: sg(n, 1), "sg2": lambda n: sg(n, 2), "p2": p2,
+               "hexdefault": lambda d: sghex(16, 7, 5, d)}[kind](int(size))  # hexdefault D: the reference's native mesh, degree D
         print(f"{kind} {size}: Newton {list(its)}  ({time.perf_counter() - t:.1f} s)", flush=True)
