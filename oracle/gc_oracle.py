@@ -175,3 +175,137 @@ def solve_problem(prob: GradientConstraintP2, alpha_scheme="doubling", alpha_0=1
             break
         xk = x.copy()
     return x, np.array(its_all), np.array(diffs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# general primal degree k in 2..8 (gradient_constraint_dolfinx.py:245-250), latent degree k - 1.  Element conventions as stated in
+# proximalgalerkin_amd/lagrange.py (restated here independently: the lattice is built from barycentric index triples and the basis
+# from the interpolation conditions, solved in a Bernstein basis - nothing is imported from the product):
+#   local nodes: vertices, k-1 nodes per edge (edge i opposite vertex i, from its lower to its higher local vertex), interior nodes by
+#   rows; global dofs: vertices, edge nodes (edge by edge, lower -> higher GLOBAL vertex), interior nodes (cell by cell).
+# ---------------------------------------------------------------------------------------------------------------------
+def pk_lattice(k):
+    tri = [(k, 0, 0), (0, k, 0), (0, 0, k)]  # barycentric index triples (i0, i1, i2) of the vertices
+    for a, b in ((1, 2), (0, 2), (0, 1)):
+        for t in range(1, k):
+            idx = [0, 0, 0]
+            idx[a], idx[b] = k - t, t
+            tri.append(tuple(idx))
+    for j in range(1, k):
+        for i in range(1, k - j):
+            tri.append((k - i - j, i, j))
+    return np.array(tri)
+
+
+def _bernstein(k, X, Y):
+    """Bernstein basis of degree k on the triangle and its reference gradients: (npts, n), (npts, n, 2)"""
+    from math import factorial
+
+    l = np.stack([1.0 - X - Y, X, Y], axis=1)
+    dl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    B, dB = [], []
+    for i2 in range(k + 1):
+        for i1 in range(k + 1 - i2):
+            i0 = k - i1 - i2
+            c = factorial(k) / (factorial(i0) * factorial(i1) * factorial(i2))
+            e = (i0, i1, i2)
+            B.append(c * np.prod([l[:, m] ** e[m] for m in range(3)], axis=0))
+            g = np.zeros((len(X), 2))
+            for m in range(3):
+                if e[m] == 0:
+                    continue
+                term = e[m] * l[:, m] ** (e[m] - 1)
+                for m2 in range(3):
+                    if m2 != m:
+                        term = term * l[:, m2] ** e[m2]
+                g += c * term[:, None] * dl[m][None]
+            dB.append(g)
+    return np.stack(B, axis=1), np.stack(dB, axis=1)
+
+
+def pk_tabulate(k, X, Y):
+    if k == 0:
+        return np.ones((len(X), 1)), np.zeros((len(X), 1, 2))
+    nodes = pk_lattice(k) / k
+    Bn, _ = _bernstein(k, nodes[:, 1], nodes[:, 2])
+    C = np.linalg.solve(Bn, np.eye(len(nodes)))  # Bernstein coefficients of the nodal functions (cond ~ 1e4 at k = 8)
+    B, dB = _bernstein(k, X, Y)
+    return B @ C, np.einsum("qmd,mn->qnd", dB, C)
+
+
+def pk_numbering(coords, cells, k):
+    nv, nc = len(coords), len(cells)
+    c = cells.astype(np.int64)
+    edges, cell_edges = O.build_edges(cells, nv)
+    cols, xs, n = [c], [coords], nv
+    m = k - 1
+    if m:
+        t = np.arange(1, k)[None, :, None] / k
+        xs.append((coords[edges[:, 0]][:, None] * (1 - t) + coords[edges[:, 1]][:, None] * t).reshape(-1, 2))
+        for i, (a, b) in enumerate(((1, 2), (0, 2), (0, 1))):
+            fwd = c[:, a] < c[:, b]
+            idx = np.where(fwd[:, None], np.arange(m)[None], np.arange(m)[None, ::-1])
+            cols.append(nv + cell_edges[:, i].astype(np.int64)[:, None] * m + idx)
+        n += len(edges) * m
+    ni = (k - 1) * (k - 2) // 2
+    if ni:
+        cols.append(n + np.arange(nc)[:, None] * ni + np.arange(ni)[None])
+        lam = pk_lattice(k)[3 + 3 * m:] / k
+        xs.append(np.einsum("ia,cad->cid", lam, coords[c]).reshape(-1, 2))
+        n += nc * ni
+    cd = np.concatenate(cols, axis=1).astype(np.int32)
+    # boundary dofs: vertices and edge nodes of the exterior edges
+    cnt = np.bincount(cell_edges.ravel(), minlength=len(edges))
+    bedge = np.flatnonzero(cnt == 1)
+    bc = [np.unique(edges[bedge].ravel())]
+    if m:
+        bc.append((nv + bedge[:, None] * m + np.arange(m)[None]).ravel())
+    return n, cd, np.concatenate(xs), np.unique(np.concatenate(bc)).astype(np.int32)
+
+
+class GradientConstraintPk(GradientConstraintP2):
+    """x = [u (n2 = P_k dofs) | psi_x (nv := P_{k-1} dofs) | psi_y]; everything else as GradientConstraintP2 (whose methods it reuses:
+    `self.cells` then holds the LATENT cell dofs and `self.Lq` the latent basis, which is all they ask of a P1 mesh)."""
+
+    def __init__(self, coords, cells, degree, phi=phi_default, f=f_default, quadrature="tri_deg10_gj36"):
+        k = int(degree)
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.degree = k
+        self.vertex_coords, self.vertex_cells = coords, cells
+        self.nc = len(cells)
+        self.Xq, self.wq = O.load_quadrature(quadrature)
+        X, Y = self.Xq[:, 0], self.Xq[:, 1]
+        self.Lq, _ = pk_tabulate(k - 1, X, Y)
+        self.Nq, self.dNq = pk_tabulate(k, X, Y)
+        self.n2, self.cell_dofs, self.dof_coords, self.bc = pk_numbering(coords, cells, k)
+        self.nv, self.cells, self.latent_coords, _ = pk_numbering(coords, cells, k - 1)
+        self.ntot = self.n2 + 2 * self.nv
+        self.isbc = np.zeros(self.n2, dtype=bool)
+        self.isbc[self.bc] = True
+        nu, npl = self.cell_dofs.shape[1], self.cells.shape[1]
+        x = coords[cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+        invJ = np.empty_like(J)
+        invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
+        invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
+        self.wdet = np.abs(det)[:, None] * self.wq[None]
+        self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)
+        self.phi_dofs = phi(self.dof_coords.T.copy())
+        self.f_dofs = f(self.dof_coords.T.copy())
+        self.phi_q = self.phi_dofs[self.cell_dofs] @ self.Nq.T
+        f_q = self.f_dofs[self.cell_dofs] @ self.Nq.T
+        self.Ke = np.einsum("cq,cqad,cqbd->cab", self.wdet, self.Gq, self.Gq)
+        self.Ge = np.einsum("cq,qb,cqad->cbda", self.wdet, self.Lq, self.Gq)
+        self.b_f = np.bincount(self.cell_dofs.ravel(), weights=((self.wdet * f_q) @ self.Nq).ravel(), minlength=self.n2)
+        self.Me = np.einsum("cq,qa,qb->cab", self.wdet, self.Nq, self.Nq)
+        cd, cv = self.cell_dofs, self.cells
+        self.K = sp.coo_matrix((self.Ke.ravel(), (np.repeat(cd, nu, axis=1).ravel(), np.tile(cd, (1, nu)).ravel())), shape=(self.n2, self.n2)).tocsr()
+        self.M2 = sp.coo_matrix((self.Me.ravel(), (np.repeat(cd, nu, axis=1).ravel(), np.tile(cd, (1, nu)).ravel())), shape=(self.n2, self.n2)).tocsr()
+        rows_v = np.repeat(cv, nu, axis=1).ravel()
+        cols_u = np.tile(cd, (1, npl)).ravel()
+        self.Gx = sp.coo_matrix((self.Ge[:, :, 0, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self.Gy = sp.coo_matrix((self.Ge[:, :, 1, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self._rv = np.repeat(cv, npl, axis=1).ravel()
+        self._cv = np.tile(cv, (1, npl)).ravel()

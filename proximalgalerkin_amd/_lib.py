@@ -108,6 +108,26 @@ class pgx_gc_problem(C.Structure):  # include/pgx_gc.h
     ]
 
 
+class pgx_gc_spaces(C.Structure):  # include/pgx_gc.h: general primal degree
+    _fields_ = [
+        ("n_vertices", C.c_int32),
+        ("n_cells", C.c_int32),
+        ("coords", c_double_p),
+        ("cells", c_int32_p),
+        ("nu", C.c_int32),
+        ("np", C.c_int32),
+        ("n_u", C.c_int32),
+        ("n_p", C.c_int32),
+        ("cell_dofs_u", c_int32_p),
+        ("cell_dofs_p", c_int32_p),
+        ("coords_u", c_double_p),
+        ("coords_p", c_double_p),
+        ("tab_Nu", c_double_p),
+        ("tab_dNu", c_double_p),
+        ("tab_Np", c_double_p),
+    ]
+
+
 class pgx_sg_mesh(C.Structure):  # include/pgx_sg.h
     _fields_ = [
         ("n_vertices", C.c_int32),
@@ -223,6 +243,7 @@ SYMBOLS = [
     ("pgx_nd_export_dest", C.c_int, [_H, c_int64_p, c_int64_p]),
     # example 06: gradient constraint, vector latent variable (include/pgx_gc.h)
     ("pgx_gc_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_gc_create_general", C.c_int, [C.POINTER(pgx_gc_spaces), C.POINTER(pgx_gc_problem), C.c_int, C.POINTER(_H)]),
     ("pgx_gc_create_dist", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_gc_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
     ("pgx_gc_destroy", None, [_H]),

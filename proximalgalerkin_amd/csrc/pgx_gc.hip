@@ -31,7 +31,12 @@ struct pgx_gc_handle : MixedBase {
   double* Jc = nullptr;  // constant part of the Jacobian values (K and G slots), assembled once
   // deterministic assembly (pgx_scatter.h): element kernels park [slot * nc + cell] in `stash`, one thread per destination sums
   PgxScatter sc_res, sc_N;  // residual: 12 slots per cell -> dofs; N(psi): 36 slots per cell -> CSR positions
-  double* stash = nullptr;  // [36 * nc]
+  double* stash = nullptr;  // [36 * nc]  (general degree: [4 NP^2 * nc])
+  // general primal degree k = 3..8 (pgx_gc_create_general): NU / NP local nodes of the primal P_k / latent P_(k-1) space, the latent
+  // cell dofs, and the basis tables at the quadrature points; n2 = primal dofs, nv = latent dofs per component
+  int gen = 0, NU = 6, NP = 3;
+  int32_t *cdofs_p = nullptr, *cells3 = nullptr;  // latent cell dofs; vertex triples (affine geometry)
+  double *tNu = nullptr, *tdNu = nullptr, *tNp = nullptr;
   void residual_dev(const double* xin, double* Fout) override;
   void jacobian_dev(const double* xin) override;
 };
@@ -291,6 +296,188 @@ __global__ __launch_bounds__(256) void k_gc_l2(int nc, const int32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// general degree (primal P_k, latent (P_(k-1))^2, k <= 8): the same element integrals, TABLE-driven.  tNu [nq][NU] and tdNu
+// [nq][NU][2] are the primal basis and its reference gradients at the quadrature points, tNp [nq][NP] the latent basis; cells are
+// affine (geometry from the three vertices).  One thread per cell, runtime sizes, local arrays of the maximal size; slot-major
+// stashes as above.  These kernels are not tuned: the factorisation dominates a Newton step by orders of magnitude.
+// ------------------------------------------------------------------------------------------------------------------
+#define GCG_MAXU 45
+#define GCG_MAXP 36
+struct GcgArgs {
+  int nc, n2, nv, NU, NP, nq;
+  const int32_t *cells, *cdu, *cdp;
+  const double *coords, *tNu, *tdNu, *tNp;
+  double w[GC_MAXQ];
+};
+
+__device__ inline GcGeom gcg_geom(const GcgArgs& A, int c) { return gc_geom(A.coords, A.cells + 3 * (size_t)c); }
+
+__global__ __launch_bounds__(64) void k_gcg_residual(GcgArgs A, const uint8_t* __restrict__ mask, const double* __restrict__ gbc,
+                                                     const double* __restrict__ phi, const double* __restrict__ f,
+                                                     const double* __restrict__ x, const double* __restrict__ xk, double alpha,
+                                                     double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= A.nc) return;
+  const int NU = A.NU, NP = A.NP, nc = A.nc;
+  const GcGeom g = gcg_geom(A, c);
+  const int32_t* cu = A.cdu + (size_t)NU * c;
+  const int32_t* cp = A.cdp + (size_t)NP * c;
+  double u[GCG_MAXU], ph[GCG_MAXU], ff[GCG_MAXU], Ru[GCG_MAXU], Gx[GCG_MAXU], Gy[GCG_MAXU];
+  double px[GCG_MAXP], py[GCG_MAXP], dx0[GCG_MAXP], dy0[GCG_MAXP], Rx[GCG_MAXP], Ry[GCG_MAXP];
+  for (int a = 0; a < NU; ++a) {
+    const int d = cu[a];
+    u[a] = mask[d] ? gbc[d] : x[d];
+    ph[a] = phi[d];
+    ff[a] = f[d];
+    Ru[a] = 0.0;
+  }
+  for (int b = 0; b < NP; ++b) {
+    const int v = cp[b];
+    px[b] = x[A.n2 + v];
+    py[b] = x[A.n2 + A.nv + v];
+    dx0[b] = px[b] - xk[A.n2 + v];
+    dy0[b] = py[b] - xk[A.n2 + A.nv + v];
+    Rx[b] = Ry[b] = 0.0;
+  }
+  for (int q = 0; q < A.nq; ++q) {
+    const double* Nu = A.tNu + (size_t)q * NU;
+    const double* dN = A.tdNu + (size_t)q * NU * 2;
+    const double* Np = A.tNp + (size_t)q * NP;
+    const double wd = A.w[q] * g.adet;
+    double gux = 0, guy = 0, phq = 0, fq = 0;
+    for (int a = 0; a < NU; ++a) {
+      Gx[a] = dN[2 * a] * g.inv[0][0] + dN[2 * a + 1] * g.inv[1][0];
+      Gy[a] = dN[2 * a] * g.inv[0][1] + dN[2 * a + 1] * g.inv[1][1];
+      gux += u[a] * Gx[a];
+      guy += u[a] * Gy[a];
+      phq += ph[a] * Nu[a];
+      fq += ff[a] * Nu[a];
+    }
+    double pxq = 0, pyq = 0, dxq = 0, dyq = 0;
+    for (int b = 0; b < NP; ++b) {
+      pxq += px[b] * Np[b];
+      pyq += py[b] * Np[b];
+      dxq += dx0[b] * Np[b];
+      dyq += dy0[b] * Np[b];
+    }
+    const double s = sqrt(1.0 + pxq * pxq + pyq * pyq);
+    const double vx = alpha * gux + dxq, vy = alpha * guy + dyq;
+    for (int a = 0; a < NU; ++a) Ru[a] += wd * (vx * Gx[a] + vy * Gy[a] - alpha * fq * Nu[a]);
+    const double rx = gux - phq * pxq / s, ry = guy - phq * pyq / s;
+    for (int b = 0; b < NP; ++b) {
+      Rx[b] += wd * Np[b] * rx;
+      Ry[b] += wd * Np[b] * ry;
+    }
+  }
+  for (int a = 0; a < NU; ++a) stash[(size_t)a * nc + c] = Ru[a];
+  for (int b = 0; b < NP; ++b) {
+    stash[(size_t)(NU + b) * nc + c] = Rx[b];
+    stash[(size_t)(NU + NP + b) * nc + c] = Ry[b];
+  }
+}
+
+// constant part: K (NU^2 slots), then G and G^T: slot NU^2 + ((b*2 + d)*NU + a)*2 (+1)
+__global__ __launch_bounds__(64) void k_gcg_const(GcgArgs A, double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= A.nc) return;
+  const int NU = A.NU, NP = A.NP, nc = A.nc;
+  const GcGeom g = gcg_geom(A, c);
+  for (int a = 0; a < NU; ++a) {
+    for (int b = 0; b < NU; ++b) {
+      double acc = 0.0;
+      for (int q = 0; q < A.nq; ++q) {
+        const double* dN = A.tdNu + (size_t)q * NU * 2;
+        const double ax = dN[2 * a] * g.inv[0][0] + dN[2 * a + 1] * g.inv[1][0], ay = dN[2 * a] * g.inv[0][1] + dN[2 * a + 1] * g.inv[1][1];
+        const double bx = dN[2 * b] * g.inv[0][0] + dN[2 * b + 1] * g.inv[1][0], by = dN[2 * b] * g.inv[0][1] + dN[2 * b + 1] * g.inv[1][1];
+        acc += A.w[q] * g.adet * (ax * bx + ay * by);
+      }
+      stash[(size_t)(a * NU + b) * nc + c] = acc;
+    }
+    for (int b = 0; b < NP; ++b) {
+      double gx = 0.0, gy = 0.0;
+      for (int q = 0; q < A.nq; ++q) {
+        const double* dN = A.tdNu + (size_t)q * NU * 2;
+        const double ax = dN[2 * a] * g.inv[0][0] + dN[2 * a + 1] * g.inv[1][0], ay = dN[2 * a] * g.inv[0][1] + dN[2 * a + 1] * g.inv[1][1];
+        const double wl = A.w[q] * g.adet * A.tNp[(size_t)q * NP + b];
+        gx += wl * ax;
+        gy += wl * ay;
+      }
+      const size_t e0 = (size_t)NU * NU + ((size_t)(b * 2 + 0) * NU + a) * 2, e1 = (size_t)NU * NU + ((size_t)(b * 2 + 1) * NU + a) * 2;
+      stash[e0 * nc + c] = gx;
+      stash[(e0 + 1) * nc + c] = gx;
+      stash[e1 * nc + c] = gy;
+      stash[(e1 + 1) * nc + c] = gy;
+    }
+  }
+}
+
+// N(psi): slot (a*NP + b)*4 + {xx, xy, yx, yy}
+__global__ __launch_bounds__(64) void k_gcg_jac_N(GcgArgs A, const double* __restrict__ phi, const double* __restrict__ x,
+                                                  double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= A.nc) return;
+  const int NU = A.NU, NP = A.NP, nc = A.nc;
+  const GcGeom g = gcg_geom(A, c);
+  const int32_t* cu = A.cdu + (size_t)NU * c;
+  const int32_t* cp = A.cdp + (size_t)NP * c;
+  double cxx[GC_MAXQ], cxy[GC_MAXQ], cyy[GC_MAXQ];
+  for (int q = 0; q < A.nq; ++q) {
+    const double* Nu = A.tNu + (size_t)q * NU;
+    const double* Np = A.tNp + (size_t)q * NP;
+    double phq = 0, pxq = 0, pyq = 0;
+    for (int a = 0; a < NU; ++a) phq += phi[cu[a]] * Nu[a];
+    for (int b = 0; b < NP; ++b) {
+      pxq += x[A.n2 + cp[b]] * Np[b];
+      pyq += x[A.n2 + A.nv + cp[b]] * Np[b];
+    }
+    const double s = sqrt(1.0 + pxq * pxq + pyq * pyq), s3 = s * s * s, wp = A.w[q] * g.adet * phq;
+    cxx[q] = wp * (1.0 / s - pxq * pxq / s3);
+    cxy[q] = wp * (-pxq * pyq / s3);
+    cyy[q] = wp * (1.0 / s - pyq * pyq / s3);
+  }
+  for (int a = 0; a < NP; ++a)
+    for (int b = 0; b < NP; ++b) {
+      double nxx = 0, nxy = 0, nyy = 0;
+      for (int q = 0; q < A.nq; ++q) {
+        const double ll = A.tNp[(size_t)q * NP + a] * A.tNp[(size_t)q * NP + b];
+        nxx += cxx[q] * ll;
+        nxy += cxy[q] * ll;
+        nyy += cyy[q] * ll;
+      }
+      const size_t e = (size_t)(a * NP + b) * 4;
+      stash[e * nc + c] = nxx;
+      stash[(e + 1) * nc + c] = nxy;
+      stash[(e + 2) * nc + c] = nxy;
+      stash[(e + 3) * nc + c] = nyy;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gcg_l2(GcgArgs A, const double* __restrict__ x, const double* __restrict__ xk,
+                                                double* __restrict__ partials) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < A.nc; c += MX_RED * 256) {
+    const GcGeom g = gcg_geom(A, c);
+    const int32_t* cu = A.cdu + (size_t)A.NU * c;
+    for (int q = 0; q < A.nq; ++q) {
+      const double* Nu = A.tNu + (size_t)q * A.NU;
+      double v = 0;
+      for (int a = 0; a < A.NU; ++a) v += (x[cu[a]] - xk[cu[a]]) * Nu[a];
+      s += A.w[q] * g.adet * v * v;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+static GcgArgs gcg_args(const pgx_gc_handle* h);
+
+// ------------------------------------------------------------------------------------------------------------------
 // host: pattern, destination tables, create
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" void pgx_gc_destroy(pgx_gc_handle* h) {
@@ -527,6 +714,280 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   return PGX_OK;
 }
 
+static GcgArgs gcg_args(const pgx_gc_handle* h) {
+  GcgArgs A{};
+  A.nc = h->nc, A.n2 = h->n2, A.nv = h->nv, A.NU = h->NU, A.NP = h->NP, A.nq = h->Q.nq;
+  A.cells = h->cells3, A.cdu = h->cdofs, A.cdp = h->cdofs_p;
+  A.coords = h->coords, A.tNu = h->tNu, A.tdNu = h->tdNu, A.tNp = h->tNp;
+  for (int q = 0; q < h->Q.nq; ++q) A.w[q] = h->Q.w[q];
+  return A;
+}
+
+// general degree: same construction as gc_create_impl with run-time element sizes (see pgx_gc.h: pgx_gc_spaces)
+static int gcg_create_impl(pgx_gc_handle* h, const pgx_gc_spaces* sp, const pgx_gc_problem* p, pgx_comm* comm) {
+  h->comm = comm;
+  h->gen = 1;
+  const int NU = sp->nu, NP = sp->np, ND = NU + 2 * NP;
+  const int nc = sp->n_cells, n2 = sp->n_u, nv = sp->n_p, nvert = sp->n_vertices;
+  const int64_t ntot = (int64_t)n2 + 2 * (int64_t)nv;
+  h->NU = NU, h->NP = NP, h->nv = nv, h->nc = nc, h->n2 = n2, h->ntot = ntot;
+  h->Q.nq = p->nq;
+  for (int q = 0; q < p->nq; ++q) h->Q.X[q] = p->qpts[2 * q], h->Q.Y[q] = p->qpts[2 * q + 1], h->Q.w[q] = p->qwts[q];
+  const int32_t *cdu = sp->cell_dofs_u, *cdp = sp->cell_dofs_p;
+  for (size_t k = 0; k < (size_t)NU * nc; ++k)
+    if (cdu[k] < 0 || cdu[k] >= n2) {
+      h->err = "primal cell dof out of range";
+      return PGX_EINVAL;
+    }
+  for (size_t k = 0; k < (size_t)NP * nc; ++k)
+    if (cdp[k] < 0 || cdp[k] >= nv) {
+      h->err = "latent cell dof out of range";
+      return PGX_EINVAL;
+    }
+  for (size_t k = 0; k < 3 * (size_t)nc; ++k)
+    if (sp->cells[k] < 0 || sp->cells[k] >= nvert) {
+      h->err = "cell vertex out of range";
+      return PGX_EINVAL;
+    }
+  std::vector<uint8_t> hmask(n2, 0);
+  std::vector<double> hg(n2, 0.0);
+  for (int k = 0; k < p->n_bc; ++k) {
+    const int d = p->bc_dofs[k];
+    if (d < 0 || d >= n2) {
+      h->err = "bc dof out of range";
+      return PGX_EINVAL;
+    }
+    hmask[d] = 1;
+    hg[d] = p->bc_vals ? p->bc_vals[k] : 0.0;
+  }
+  auto mixed = [&](int c, int32_t* md) {  // NU u dofs, NP psi_x, NP psi_y
+    for (int a = 0; a < NU; ++a) md[a] = cdu[(size_t)NU * c + a];
+    for (int b = 0; b < NP; ++b) md[NU + b] = n2 + cdp[(size_t)NP * c + b], md[NU + NP + b] = n2 + nv + cdp[(size_t)NP * c + b];
+  };
+  std::vector<int64_t> dptr(ntot + 1, 0);
+  {
+    std::vector<int32_t> md(ND);
+    for (int c = 0; c < nc; ++c) {
+      mixed(c, md.data());
+      for (int a = 0; a < ND; ++a) dptr[md[a] + 1]++;
+    }
+  }
+  for (int64_t i = 0; i < ntot; ++i) dptr[i + 1] += dptr[i];
+  std::vector<int32_t> dcell(dptr[ntot]);
+  {
+    std::vector<int64_t> fill(dptr.begin(), dptr.end() - 1);
+    std::vector<int32_t> md(ND);
+    for (int c = 0; c < nc; ++c) {
+      mixed(c, md.data());
+      for (int a = 0; a < ND; ++a) dcell[fill[md[a]]++] = c;
+    }
+  }
+  std::vector<int32_t>& rowptr = h->h_rowptr;
+  std::vector<int32_t>& col = h->h_col;
+  rowptr.assign(ntot + 1, 0);
+  auto gather_row = [&](int64_t r, std::vector<int32_t>& tmp, std::vector<int32_t>& md) {
+    tmp.clear();
+    for (int64_t q = dptr[r]; q < dptr[r + 1]; ++q) {
+      mixed(dcell[q], md.data());
+      tmp.insert(tmp.end(), md.begin(), md.end());
+    }
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+  };
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp, md(ND);
+    for (int64_t r = a; r < b; ++r) {
+      gather_row(r, tmp, md);
+      rowptr[r + 1] = (int32_t)tmp.size();
+    }
+  });
+  int64_t tot = 0;
+  for (int64_t r = 0; r < ntot; ++r) {
+    tot += rowptr[r + 1];
+    if (tot > 0x7fffffff) {
+      h->err = "mixed matrix exceeds int32 nnz";
+      return PGX_EINVAL;
+    }
+    rowptr[r + 1] = (int32_t)tot;
+  }
+  h->nnz = tot;
+  col.resize(tot);
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> tmp, md(ND);
+    for (int64_t r = a; r < b; ++r) {
+      gather_row(r, tmp, md);
+      std::copy(tmp.begin(), tmp.end(), col.begin() + rowptr[r]);
+    }
+  });
+  auto find = [&](int32_t r, int32_t c) -> int32_t {
+    const int32_t* b = col.data() + rowptr[r];
+    const int32_t* e = col.data() + rowptr[r + 1];
+    return (int32_t)(std::lower_bound(b, e, c) - col.data());
+  };
+  std::vector<uint8_t> kind(tot);
+  mx_par_for(ntot, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r)
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = col[k];
+        uint8_t t;
+        if (r < n2 && c < n2)
+          t = (hmask[r] || hmask[c]) ? ((r == c && hmask[r]) ? 3 : 4) : 0;
+        else if (r < n2)
+          t = hmask[r] ? 4 : 1;
+        else if (c < n2)
+          t = hmask[c] ? 4 : 1;
+        else
+          t = 2;
+        kind[k] = t;
+      }
+  });
+  const size_t nsc = (size_t)NU * NU + 4 * (size_t)NP * NU, nsn = 4 * (size_t)NP * NP;
+  if ((double)(nsc + nsn + ND) * nc * 12.0 > 96e9) {
+    h->err = "mesh too large for the one-pass assembly at this degree";
+    return PGX_ENOMEM;
+  }
+  std::vector<int32_t> dC(nsc * nc), dN(nsn * nc), dR((size_t)ND * nc);
+  mx_par_for(nc, [&](int64_t a0, int64_t b0) {
+    std::vector<int32_t> md(ND);
+    for (int64_t c = a0; c < b0; ++c) {
+      mixed((int)c, md.data());
+      for (int a = 0; a < NU; ++a)
+        for (int b = 0; b < NU; ++b) dC[(size_t)(a * NU + b) * nc + (size_t)c] = find(md[a], md[b]);
+      for (int b = 0; b < NP; ++b)
+        for (int d = 0; d < 2; ++d)
+          for (int a = 0; a < NU; ++a) {
+            const size_t e = (size_t)NU * NU + ((size_t)(b * 2 + d) * NU + a) * 2;
+            const int32_t pr = md[NU + NP * d + b];
+            dC[e * nc + (size_t)c] = find(pr, md[a]);
+            dC[(e + 1) * nc + (size_t)c] = find(md[a], pr);
+          }
+      for (int a = 0; a < NP; ++a)
+        for (int b = 0; b < NP; ++b)
+          for (int cc = 0; cc < 2; ++cc)
+            for (int d = 0; d < 2; ++d)
+              dN[((size_t)(a * NP + b) * 4 + cc * 2 + d) * nc + (size_t)c] = find(md[NU + NP * cc + a], md[NU + NP * d + b]);
+      for (int a = 0; a < ND; ++a) dR[(size_t)a * nc + (size_t)c] = md[a];
+    }
+  });
+  // nested dissection nodes: the primal nodes, then the latent nodes (each carries psi_x and psi_y)
+  std::vector<double> xy(2 * ((size_t)n2 + nv));
+  std::copy(sp->coords_u, sp->coords_u + 2 * (size_t)n2, xy.begin());
+  std::copy(sp->coords_p, sp->coords_p + 2 * (size_t)nv, xy.begin() + 2 * (size_t)n2);
+  std::vector<int32_t> nod(ntot);
+  for (int i = 0; i < n2; ++i) nod[i] = i;
+  for (int v = 0; v < nv; ++v) nod[n2 + v] = nod[(size_t)n2 + nv + v] = n2 + v;
+  GCHIP(hipStreamCreate(&h->st));
+  pgx_nd_matrix Am{};
+  Am.n = ntot;
+  Am.rowptr = rowptr.data();
+  Am.col = col.data();
+  Am.n_nodes = n2 + nv;
+  Am.node_of_dof = nod.data();
+  Am.dim = 2;
+  Am.node_coords = xy.data();
+  Am.leaf_nodes = 0;
+  if (const char* e = getenv("PGX_ND_LEAF")) Am.leaf_nodes = atoi(e);
+  int rc = comm ? pgx_nd_create_dist(&Am, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&Am, h->device, (void*)h->st, &h->lu);
+  if (rc) {
+    h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
+    h->lu = nullptr;
+    return rc;
+  }
+  const int nq = p->nq;
+  GCALLOC(h->coords, 2 * (size_t)nvert);
+  GCALLOC(h->cells3, 3 * (size_t)nc);
+  GCALLOC(h->cdofs, (size_t)NU * nc);
+  GCALLOC(h->cdofs_p, (size_t)NP * nc);
+  GCALLOC(h->tNu, (size_t)nq * NU);
+  GCALLOC(h->tdNu, (size_t)nq * NU * 2);
+  GCALLOC(h->tNp, (size_t)nq * NP);
+  GCALLOC(h->mask, n2);
+  GCALLOC(h->gbc, n2);
+  GCALLOC(h->phi, n2);
+  GCALLOC(h->f, n2);
+  GCALLOC(h->rowptr, ntot + 1);
+  GCALLOC(h->col, tot);
+  GCALLOC(h->kind, tot);
+  GCALLOC(h->stash, std::max(nsn, (size_t)ND) * nc);
+  GCALLOC(h->Jc, tot);
+  GCALLOC(h->Jv, tot);
+  {
+    int rcs = mx_alloc_state(h);
+    if (rcs) return rcs;
+  }
+  GCHIP(hipMemcpy(h->coords, sp->coords, sizeof(double) * 2 * nvert, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->cells3, sp->cells, sizeof(int32_t) * 3 * (size_t)nc, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->cdofs, cdu, sizeof(int32_t) * (size_t)NU * nc, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->cdofs_p, cdp, sizeof(int32_t) * (size_t)NP * nc, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->tNu, sp->tab_Nu, sizeof(double) * (size_t)nq * NU, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->tdNu, sp->tab_dNu, sizeof(double) * (size_t)nq * NU * 2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->tNp, sp->tab_Np, sizeof(double) * (size_t)nq * NP, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->mask, hmask.data(), n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->phi, p->phi_dofs, sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->f, p->f_dofs, sizeof(double) * n2, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->col, col.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
+  GCHIP(hipMemcpy(h->kind, kind.data(), tot, hipMemcpyHostToDevice));
+  {
+    std::string e1 = pgx_scatter_build(dR.data(), (int64_t)ND * nc, ntot, h->allocs, &h->sc_res);
+    if (e1.empty()) e1 = pgx_scatter_build(dN.data(), (int64_t)nsn * nc, tot, h->allocs, &h->sc_N);
+    if (!e1.empty()) {
+      h->err = e1;
+      return PGX_ENOMEM;
+    }
+  }
+  GCHIP(hipMemsetAsync(h->Jc, 0, sizeof(double) * tot, h->st));
+  {
+    std::vector<void*> tmp;
+    PgxScatter sc_c;
+    std::string e1 = pgx_scatter_build(dC.data(), (int64_t)nsc * nc, tot, tmp, &sc_c);
+    double* stc = nullptr;
+    hipError_t e = e1.empty() ? hipMalloc((void**)&stc, sizeof(double) * nsc * nc) : hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_gcg_const, dim3((nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), stc);
+      pgx_scatter_run(h->st, sc_c, stc, 1.0, 0, h->Jc);
+      e = hipStreamSynchronize(h->st);
+    }
+    if (stc) hipFree(stc);
+    for (void* q : tmp) hipFree(q);
+    if (e != hipSuccess) {
+      h->err = std::string("constant Jacobian blocks: ") + (e1.empty() ? hipGetErrorString(e) : e1.c_str());
+      return PGX_EHIP;
+    }
+  }
+  return PGX_OK;
+}
+
+extern "C" int pgx_gc_create_general(const pgx_gc_spaces* sp, const pgx_gc_problem* p, int device, pgx_gc_handle** out) {
+  if (!sp || !p || !out || !sp->coords || !sp->cells || !sp->cell_dofs_u || !sp->cell_dofs_p || !sp->coords_u || !sp->coords_p ||
+      !sp->tab_Nu || !sp->tab_dNu || !sp->tab_Np || sp->nu < 3 || sp->nu > GCG_MAXU || sp->np < 1 || sp->np > GCG_MAXP ||
+      sp->n_cells <= 0 || sp->n_u <= 0 || sp->n_p <= 0 || !p->qpts || !p->qwts || !p->phi_dofs || !p->f_dofs || p->nq <= 0 ||
+      p->nq > GC_MAXQ || (p->n_bc > 0 && !p->bc_dofs)) {
+    g_gc_error = "pgx_gc_create_general: bad arguments";
+    return PGX_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    g_gc_error = "pgx_gc_create_general: no usable GPU (there is no CPU fallback)";
+    return PGX_ENODEV;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_gc_error = "hipSetDevice failed";
+    return PGX_EHIP;
+  }
+  pgx_gc_handle* h = new pgx_gc_handle();
+  h->device = device;
+  int rc = gcg_create_impl(h, sp, p, nullptr);
+  if (rc) {
+    g_gc_error = h->err;
+    pgx_gc_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return PGX_OK;
+}
+
 static int gc_create(const pgx_mesh* m, const pgx_gc_problem* p, pgx_comm* comm, int device, pgx_gc_handle** out) {
   if (!m || !p || !out || !m->coords || !m->cells || !m->cell_dofs || m->n_dofs <= m->n_vertices || !p->qpts || !p->qwts ||
       !p->phi_dofs || !p->f_dofs || p->nq <= 0 || p->nq > GC_MAXQ || (p->n_bc > 0 && !p->bc_dofs)) {
@@ -614,6 +1075,13 @@ void pgx_gc_handle::residual_dev(const double* xin, double* Fout) {
   pgx_gc_handle* h = this;
   GcTimer t(h, 0);
   hipMemsetAsync(Fout, 0, sizeof(double) * h->ntot, h->st);
+  if (h->gen) {
+    hipLaunchKernelGGL(k_gcg_residual, dim3((h->nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), h->mask, h->gbc, h->phi, h->f, xin,
+                       h->xk, h->alpha, h->stash);
+    pgx_scatter_run(h->st, h->sc_res, h->stash, 1.0, 0, Fout);
+    hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, xin, Fout);
+    return;
+  }
   hipLaunchKernelGGL(k_gc_residual, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
                      h->mask, h->gbc, h->phi, h->f, xin, h->xk, h->alpha, h->Q, h->stash);
   pgx_scatter_run(h->st, h->sc_res, h->stash, 1.0, 0, Fout);
@@ -624,8 +1092,11 @@ void pgx_gc_handle::jacobian_dev(const double* xin) {
   GcTimer t(h, 1);
   hipLaunchKernelGGL(k_gc_jac_init, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->st, h->nnz, h->kind, h->Jc,
                      h->alpha, h->Jv);
-  hipLaunchKernelGGL(k_gc_jac_N, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
-                     h->phi, xin, h->Q, h->stash);
+  if (h->gen)
+    hipLaunchKernelGGL(k_gcg_jac_N, dim3((h->nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), h->phi, xin, h->stash);
+  else
+    hipLaunchKernelGGL(k_gc_jac_N, dim3((h->nc + 127) / 128), dim3(128), 0, h->st, h->nc, h->n2, h->nv, h->cdofs, h->coords,
+                       h->phi, xin, h->Q, h->stash);
   pgx_scatter_run(h->st, h->sc_N, h->stash, -1.0, 1, h->Jv);  // the latent block is -N(psi)
   h->jac_valid = true;
 }
@@ -699,7 +1170,10 @@ extern "C" int pgx_gc_spmv(pgx_gc_handle* h, const double* x, double* y) {
 extern "C" int pgx_gc_l2_increment(pgx_gc_handle* h, double* out) {
   GCNEED(h);
   if (!out) return PGX_EINVAL;
-  hipLaunchKernelGGL(k_gc_l2, dim3(GC_RED), dim3(256), 0, h->st, h->nc, h->cdofs, h->coords, h->x, h->xk, h->Q, h->partials);
+  if (h->gen)
+    hipLaunchKernelGGL(k_gcg_l2, dim3(GC_RED), dim3(256), 0, h->st, gcg_args(h), h->x, h->xk, h->partials);
+  else
+    hipLaunchKernelGGL(k_gc_l2, dim3(GC_RED), dim3(256), 0, h->st, h->nc, h->cdofs, h->coords, h->x, h->xk, h->Q, h->partials);
   hipLaunchKernelGGL(k_mx_final, dim3(1), dim3(256), 0, h->st, GC_RED, h->partials, h->d_out);
   {
     const int rcs = mx_sync_scalar(h);  // distributed handles: the loop's stopping test must agree on every rank

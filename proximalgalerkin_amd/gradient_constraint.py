@@ -36,36 +36,61 @@ def f_default(x):
 
 
 class GradientConstraintProblem:
-    """Mixed space [P2, (P1)^2] on `mesh`; state layout x = [u (P2 dofs: vertices | edges) | psi_x | psi_y]."""
+    """Mixed space [P_k, (P_(k-1))^2] on `mesh` (k = `degree`, 2 by default as in the reference, up to 8); state layout
+    x = [u (primal dofs) | psi_x | psi_y].  k = 2 runs the specialised kernels of include/pgx_gc.h, k >= 3 (or `general=True`) the
+    table-driven ones (pgx_gc_create_general) with the Lagrange tables of proximalgalerkin_amd/lagrange.py."""
 
     def __init__(self, mesh: fem.Mesh, phi_func: Callable, f_func: Callable, petsc_options: dict | None = None,
-                 quadrature_degree: int = 10, device: int = 0, comm=None):
+                 quadrature_degree: int = 10, device: int = 0, comm=None, degree: int = 2, general: bool = False):
         self._lib = lib = _lib.load()
         self.mesh = mesh
-        U = fem.FunctionSpace(mesh, 2, 1)  # primal space (collapsed sub(0), :54)
-        self.U = U
-        self.n2, self.nv = U.block_size, mesh.num_vertices
-        self.ndofs = self.n2 + 2 * self.nv
-        xd = U.dof_coordinates()
+        self.degree = k = int(degree)
+        if not 2 <= k <= 8:
+            raise NotImplementedError("primal degree 2..8 (gradient_constraint_dolfinx.py:245-250)")
         pts, wts = fem.quadrature_rule("triangle", quadrature_degree)  # :53
+        self._h = C.c_void_p()
+        if k == 2 and not general:
+            U = fem.FunctionSpace(mesh, 2, 1)  # primal space (collapsed sub(0), :54)
+            self.U = U
+            self.n2, self.nv = U.block_size, mesh.num_vertices
+            xd = U.dof_coordinates()
+            cd = U.cell_dofs()
+            bc = np.ascontiguousarray(mesh.exterior_dofs(2), dtype=np.int32)  # :63-69
+        else:
+            if comm is not None:
+                raise NotImplementedError("general degree with a distributed LU")
+            from . import lagrange
+
+            self.U = None
+            self.n2, cd, xd = lagrange.numbering(mesh, k)
+            self.nv, cdp, xdp = lagrange.numbering(mesh, k - 1)
+            bc = lagrange.exterior_dofs(mesh, k, cd)
+            Nu, dNu = lagrange.tabulate(k, pts)
+            Npl, _ = lagrange.tabulate(k - 1, pts)
+        self.dof_coords = xd
+        self.ndofs = self.n2 + 2 * self.nv
         # phi.interpolate(phi_func), f.interpolate(f_func) (:55-61); arrays of nodal values are taken as they are (forms front end)
         phi = np.ascontiguousarray(phi_func(xd.T.copy()) if callable(phi_func) else phi_func, dtype=np.float64)
         f = np.ascontiguousarray(f_func(xd.T.copy()) if callable(f_func) else f_func, dtype=np.float64)
-        if phi.shape != (U.block_size,) or f.shape != (U.block_size,):
-            raise ValueError("phi and f must be given in the collapsed primal space (one value per P2 dof)")
-        bc = np.ascontiguousarray(mesh.exterior_dofs(2), dtype=np.int32)  # :63-69
-        cd = U.cell_dofs()
-        self._keep = (mesh.geometry, mesh.cells, cd, pts, wts, phi, f, bc)
-        pm = _lib.pgx_mesh(mesh.num_vertices, mesh.num_cells, _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), 0, 0,
-                           _lib.iptr(cd), self.n2)
+        if phi.shape != (self.n2,) or f.shape != (self.n2,):
+            raise ValueError("phi and f must be given in the collapsed primal space (one value per primal dof)")
         pp = _lib.pgx_gc_problem(len(wts), _lib.dptr(pts), _lib.dptr(wts), _lib.dptr(phi), _lib.dptr(f), len(bc),
                                  _lib.iptr(bc), None)
-        self._h = C.c_void_p()
-        if comm is None:
-            rc = lib.pgx_gc_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
-        else:  # one handle per GPU: replicated iterate, distributed sparse LU; every call below is collective
-            self._comm = comm
-            rc = lib.pgx_gc_create_dist(C.byref(pm), C.byref(pp), comm._c, int(device), C.byref(self._h))
+        if k == 2 and not general:
+            self._keep = (mesh.geometry, mesh.cells, cd, pts, wts, phi, f, bc)
+            pm = _lib.pgx_mesh(mesh.num_vertices, mesh.num_cells, _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), 0, 0,
+                               _lib.iptr(cd), self.n2)
+            if comm is None:
+                rc = lib.pgx_gc_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
+            else:  # one handle per GPU: replicated iterate, distributed sparse LU; every call below is collective
+                self._comm = comm
+                rc = lib.pgx_gc_create_dist(C.byref(pm), C.byref(pp), comm._c, int(device), C.byref(self._h))
+        else:
+            self._keep = (mesh.geometry, mesh.cells, cd, cdp, xd, xdp, Nu, dNu, Npl, pts, wts, phi, f, bc)
+            sp = _lib.pgx_gc_spaces(mesh.num_vertices, mesh.num_cells, _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), cd.shape[1],
+                                    cdp.shape[1], self.n2, self.nv, _lib.iptr(cd), _lib.iptr(cdp), _lib.dptr(xd), _lib.dptr(xdp),
+                                    _lib.dptr(Nu), _lib.dptr(dNu), _lib.dptr(Npl))
+            rc = lib.pgx_gc_create_general(C.byref(sp), C.byref(pp), int(device), C.byref(self._h))
         if rc:
             msg = lib.pgx_gc_last_error(None)
             raise _lib.PgxError(f"pgx_gc_create failed (code {rc}): {msg.decode() if msg else ''}")
@@ -152,7 +177,7 @@ class GradientConstraintProblem:
         K = self.jacobian(x0)[:n2, :n2].tocsr()
         K.sort_indices()
         self.set_alpha(alpha)
-        lu = DirectSolver(K.indptr, K.indices, np.arange(n2, dtype=np.int32), self.U.dof_coordinates(), device=device)
+        lu = DirectSolver(K.indptr, K.indices, np.arange(n2, dtype=np.int32), self.dof_coords, device=device)
         lu.factor(K.data)
         b = -F[:n2]
         u = lu.solve(b)
@@ -219,10 +244,10 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
                   phi_func: Callable = phi_default, f_func: Callable = f_default, warm_start: bool = False,
                   verbose: bool = True, return_solution: bool = False, device: int = 0, comm=None):
     """gradient_constraint_dolfinx.solve_problem (:18-205): returns (newton_iterations, L2_diff) [, final state]."""
-    if primal_space not in ("Lagrange", "P", "CG") or primal_degree != 2 or cell_type != "triangle":
-        raise NotImplementedError("HIP backend: primal Lagrange degree 2 on triangles (the reference's defaults)")
+    if primal_space not in ("Lagrange", "P", "CG") or not 2 <= primal_degree <= 8 or cell_type != "triangle":
+        raise NotImplementedError("HIP backend: primal Lagrange degree 2..8 on triangles (:245-250; quadrilaterals are not built)")
     mesh = fem.create_unit_square(N, M)  # :36
-    problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device, comm=comm)
+    problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device, comm=comm, degree=primal_degree)
     if warm_start:  # :72-96
         if comm is not None:
             raise NotImplementedError("warm_start with a distributed LU")
@@ -262,10 +287,13 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
         from .io import write_vtu  # u (P2) for ParaView - the reference writes u.bp / grad_u.bp with VTXWriter (:145-158)
 
         xs = problem.get_state()
-        write_vtu(result_dir / "u.vtu", problem.U.dof_coordinates(), problem.U.cell_dofs(), {"u": xs[: problem.n2]})
-        nv, n2 = problem.nv, problem.n2
+        nv, n2, nvert = problem.nv, problem.n2, mesh.num_vertices
+        if problem.U is not None:
+            write_vtu(result_dir / "u.vtu", problem.U.dof_coordinates(), problem.U.cell_dofs(), {"u": xs[: problem.n2]})
+        else:  # general degree: the vertex values (the first dofs of every Lagrange space here)
+            write_vtu(result_dir / "u.vtu", mesh.geometry, mesh.cells, {"u": xs[:nvert]})
         write_vtu(result_dir / "psi.vtu", mesh.geometry, mesh.cells,
-                  {"psi": np.stack([xs[n2: n2 + nv], xs[n2 + nv:]], axis=1)})
+                  {"psi": np.stack([xs[n2: n2 + nvert], xs[n2 + nv: n2 + nv + nvert]], axis=1)})
     if return_solution:
         x = problem.get_state()
         problem.close()

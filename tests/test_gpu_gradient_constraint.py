@@ -175,3 +175,57 @@ def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
     assert list(its_f) == list(its)
     assert np.allclose(diffs_f, diffs, rtol=1e-9, atol=1e-14)
     assert np.linalg.norm(sol.x.array - x) <= 1e-12 * np.linalg.norm(x)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# general primal degree (gradient_constraint_dolfinx.py:245-250: 2..8), latent degree k - 1: table-driven kernels
+# ------------------------------------------------------------------------------------------------------------------
+def _general(N, k):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default
+
+    mesh = fem.create_unit_square(N, N)
+    problem = GradientConstraintProblem(mesh, phi_default, f_default, degree=k, general=True)
+    c, e = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintPk(c, e, k)
+    assert problem.ndofs == prob.ntot and problem.n2 == prob.n2 and problem.nv == prob.nv
+    return problem, prob
+
+
+@pytest.mark.parametrize("N,k", [(4, 2), (5, 3), (4, 4), (3, 6), (2, 8)])
+def test_general_degree_kernels_match_oracle(require_gpu, N, k):
+    problem, prob = _general(N, k)
+    rng = np.random.default_rng(20 + k)
+    x = rng.standard_normal(prob.ntot) * 0.3
+    x[prob.n2:] *= np.where(rng.random(2 * prob.nv) < 0.3, 300.0, 1.0)  # some large latent values: s = sqrt(1 + |psi|^2) >> 1
+    xk = rng.standard_normal(prob.ntot) * 0.3
+    for alpha in (1.0, 32.0):
+        problem.set_alpha(alpha)
+        problem.set_prev(xk)
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, alpha)
+        assert np.linalg.norm(F - Fr) <= 1e-11 * np.linalg.norm(Fr), np.linalg.norm(F - Fr) / np.linalg.norm(Fr)
+        J = problem.jacobian(x)
+        Jr = prob.jacobian(x, alpha).tocsr()
+        assert abs(J - Jr).max() <= 1e-11 * abs(Jr).max()
+        n2 = prob.n2
+        assert abs(J[n2:, n2:] - Jr[n2:, n2:]).max() <= 1e-11 * abs(Jr[n2:, n2:]).max()
+    assert abs(problem.l2_increment() - 0.0) >= 0.0
+    problem.close()
+
+
+@pytest.mark.parametrize("N,k", [(6, 2), (16, 3), (12, 4), (3, 5), (8, 6), (4, 8)])
+def test_general_degree_full_run_matches_oracle(require_gpu, N, k):
+    from proximalgalerkin_amd.gradient_constraint import solve_problem
+
+    its, _, x = solve_problem(N, N, primal_degree=k, verbose=False, return_solution=True)
+    c, e = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintPk(c, e, k)
+    xr, its_r, _ = G.solve_problem(prob)
+    assert list(its) == list(its_r), (list(its), list(its_r))
+    n2 = prob.n2
+    # k <= 6: 1e-9 (SNES rtol = atol = 1e-9).  k = 8 agrees to 8e-8 only: the reference's fixed degree-10 rule (:53, 36 points) cannot
+    # resolve the latent block of a (P7)^2 element (72 x 72 per cell from 36 points), the late Newton matrices are singular to working
+    # precision along those modes and two direct solvers pick different representatives - same Newton counts, same u to 7 digits
+    tol = 1e-9 if k <= 6 else 1e-6
+    assert np.linalg.norm(x[:n2] - xr[:n2]) <= tol * np.linalg.norm(xr[:n2])
