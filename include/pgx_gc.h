@@ -55,8 +55,12 @@ typedef struct {
 typedef struct {
   int32_t n_vertices, n_cells;
   const double* coords;         /* [n_vertices][2] */
-  const int32_t* cells;         /* [n_cells][3] vertex ids: affine geometry */
-  int32_t nu, np;               /* local nodes of the primal / latent element: (k+1)(k+2)/2 <= 45, k(k+1)/2 <= 36 */
+  const int32_t* cells;         /* [n_cells][3] vertex ids spanning the AFFINE cell map x0 + (x1-x0) xi + (x2-x0) eta: a triangle's
+                                   vertices, or origin / +xi corner / +eta corner of a parallelogram (--cell_type quadrilateral,
+                                   :229-236: create_unit_square's rectangles; the rule of pgx_gc_problem is then one on the unit
+                                   square, weights summing to 1) */
+  int32_t nu, np;               /* local nodes of the primal / latent element: triangles (k+1)(k+2)/2 <= 45, k(k+1)/2 <= 36;
+                                   quadrilaterals (k+1)^2 <= 81, k^2 <= 64 */
   int32_t n_u, n_p;             /* global dofs of the primal space / of ONE latent component */
   const int32_t* cell_dofs_u;   /* [n_cells][nu] */
   const int32_t* cell_dofs_p;   /* [n_cells][np] */

@@ -309,3 +309,96 @@ class GradientConstraintPk(GradientConstraintP2):
         self.Gy = sp.coo_matrix((self.Ge[:, :, 1, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
         self._rv = np.repeat(cv, npl, axis=1).ravel()
         self._cv = np.tile(cv, (1, npl)).ravel()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# quadrilateral cells (gradient_constraint_dolfinx.py:229-236 `--cell_type quadrilateral`): create_unit_square(N, M, quadrilateral) is
+# the structured grid of rectangles; u in Q_k, psi in (Q_(k-1))^2, tensor-product Lagrange elements on the equispaced nodes i/k.
+# The Q_k dofs are the k-times refined vertex lattice, numbered lexicographically (x fastest); local nodes lexicographic too.
+# Quadrature: Gauss-Legendre 6 x 6 on the unit square (degree 11 >= the script's quadrature_degree = 10).
+# ---------------------------------------------------------------------------------------------------------------------
+def _lag1d_nodes(d, t):
+    xn = np.arange(d + 1) / d if d else np.array([0.5])
+    t = np.asarray(t, dtype=float)
+    V = np.ones((len(t), d + 1))
+    D = np.zeros((len(t), d + 1))
+    for i in range(d + 1):
+        for j in range(d + 1):
+            if j != i:
+                V[:, i] *= (t - xn[j]) / (xn[i] - xn[j])
+        for m in range(d + 1):
+            if m == i:
+                continue
+            term = np.full(len(t), 1.0 / (xn[i] - xn[m]))
+            for j in range(d + 1):
+                if j != i and j != m:
+                    term *= (t - xn[j]) / (xn[i] - xn[j])
+            D[:, i] += term
+    return V, D
+
+
+def qk_tabulate(d, X, Y):
+    Vx, Dx = _lag1d_nodes(d, X)
+    Vy, Dy = _lag1d_nodes(d, Y)
+    N = np.stack([Vx[:, ix] * Vy[:, iy] for iy in range(d + 1) for ix in range(d + 1)], axis=1)
+    dN = np.stack([np.stack([Dx[:, ix] * Vy[:, iy], Vx[:, ix] * Dy[:, iy]], axis=1) for iy in range(d + 1) for ix in range(d + 1)], axis=1)
+    return N, dN
+
+
+def qk_numbering(nx, ny, d):
+    Nx, Ny = d * nx + 1, d * ny + 1
+    Y, X = np.meshgrid(np.linspace(0, 1, Ny), np.linspace(0, 1, Nx), indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+    cy, cx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    cx, cy = cx.ravel(), cy.ravel()
+    cd = np.stack([(d * cy + iy) * Nx + d * cx + ix for iy in range(d + 1) for ix in range(d + 1)], axis=1).astype(np.int32)
+    gy, gx = np.meshgrid(np.arange(Ny), np.arange(Nx), indexing="ij")
+    bc = np.flatnonzero(((gx == 0) | (gx == Nx - 1) | (gy == 0) | (gy == Ny - 1)).ravel()).astype(np.int32)
+    return Nx * Ny, cd, coords, bc
+
+
+class GradientConstraintQk(GradientConstraintPk):
+    def __init__(self, nx, ny, degree, phi=phi_default, f=f_default):
+        k = self.degree = int(degree)
+        self.nc = nx * ny
+        g, w = np.polynomial.legendre.leggauss(6)
+        g, w = 0.5 * (g + 1.0), 0.5 * w
+        self.Xq = np.array([(g[a], g[b]) for b in range(6) for a in range(6)])
+        self.wq = np.array([w[a] * w[b] for b in range(6) for a in range(6)])
+        X, Y = self.Xq[:, 0], self.Xq[:, 1]
+        self.Lq, _ = qk_tabulate(k - 1, X, Y)
+        self.Nq, self.dNq = qk_tabulate(k, X, Y)
+        self.n2, self.cell_dofs, self.dof_coords, self.bc = qk_numbering(nx, ny, k)
+        self.nv, self.cells, self.latent_coords, _ = qk_numbering(nx, ny, k - 1)
+        _, c1, v1, _ = qk_numbering(nx, ny, 1)
+        self.vertex_coords = v1
+        self.corner_cells = np.ascontiguousarray(c1[:, [0, 1, 2]])  # origin, +x, +y corner of every rectangle
+        self.ntot = self.n2 + 2 * self.nv
+        self.isbc = np.zeros(self.n2, dtype=bool)
+        self.isbc[self.bc] = True
+        nu, npl = self.cell_dofs.shape[1], self.cells.shape[1]
+        x = v1[self.corner_cells]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+        invJ = np.empty_like(J)
+        invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
+        invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
+        self.wdet = np.abs(det)[:, None] * self.wq[None]
+        self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)
+        self.phi_dofs = phi(self.dof_coords.T.copy())
+        self.f_dofs = f(self.dof_coords.T.copy())
+        self.phi_q = self.phi_dofs[self.cell_dofs] @ self.Nq.T
+        f_q = self.f_dofs[self.cell_dofs] @ self.Nq.T
+        self.Ke = np.einsum("cq,cqad,cqbd->cab", self.wdet, self.Gq, self.Gq)
+        self.Ge = np.einsum("cq,qb,cqad->cbda", self.wdet, self.Lq, self.Gq)
+        self.b_f = np.bincount(self.cell_dofs.ravel(), weights=((self.wdet * f_q) @ self.Nq).ravel(), minlength=self.n2)
+        self.Me = np.einsum("cq,qa,qb->cab", self.wdet, self.Nq, self.Nq)
+        cd, cv = self.cell_dofs, self.cells
+        self.K = sp.coo_matrix((self.Ke.ravel(), (np.repeat(cd, nu, axis=1).ravel(), np.tile(cd, (1, nu)).ravel())), shape=(self.n2, self.n2)).tocsr()
+        self.M2 = sp.coo_matrix((self.Me.ravel(), (np.repeat(cd, nu, axis=1).ravel(), np.tile(cd, (1, nu)).ravel())), shape=(self.n2, self.n2)).tocsr()
+        rows_v = np.repeat(cv, nu, axis=1).ravel()
+        cols_u = np.tile(cd, (1, npl)).ravel()
+        self.Gx = sp.coo_matrix((self.Ge[:, :, 0, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self.Gy = sp.coo_matrix((self.Ge[:, :, 1, :].ravel(), (rows_v, cols_u)), shape=(self.nv, self.n2)).tocsr()
+        self._rv = np.repeat(cv, npl, axis=1).ravel()
+        self._cv = np.tile(cv, (1, npl)).ravel()

@@ -301,8 +301,11 @@ __global__ __launch_bounds__(256) void k_gc_l2(int nc, const int32_t* __restrict
 // affine (geometry from the three vertices).  One thread per cell, runtime sizes, local arrays of the maximal size; slot-major
 // stashes as above.  These kernels are not tuned: the factorisation dominates a Newton step by orders of magnitude.
 // ------------------------------------------------------------------------------------------------------------------
-#define GCG_MAXU 45
-#define GCG_MAXP 36
+// element sizes: triangles P8 / P7 have 45 / 36 local nodes, quadrilaterals Q8 / Q7 81 / 64 (pgx_gc.h: affine cells of either shape)
+#define GCG_MAXU 81
+#define GCG_MAXP 64
+#define GCG_TRIU 45
+#define GCG_TRIP 36
 struct GcgArgs {
   int nc, n2, nv, NU, NP, nq;
   const int32_t *cells, *cdu, *cdp;
@@ -312,6 +315,7 @@ struct GcgArgs {
 
 __device__ inline GcGeom gcg_geom(const GcgArgs& A, int c) { return gc_geom(A.coords, A.cells + 3 * (size_t)c); }
 
+template <int MAXU, int MAXP>
 __global__ __launch_bounds__(64) void k_gcg_residual(GcgArgs A, const uint8_t* __restrict__ mask, const double* __restrict__ gbc,
                                                      const double* __restrict__ phi, const double* __restrict__ f,
                                                      const double* __restrict__ x, const double* __restrict__ xk, double alpha,
@@ -322,8 +326,8 @@ __global__ __launch_bounds__(64) void k_gcg_residual(GcgArgs A, const uint8_t* _
   const GcGeom g = gcg_geom(A, c);
   const int32_t* cu = A.cdu + (size_t)NU * c;
   const int32_t* cp = A.cdp + (size_t)NP * c;
-  double u[GCG_MAXU], ph[GCG_MAXU], ff[GCG_MAXU], Ru[GCG_MAXU], Gx[GCG_MAXU], Gy[GCG_MAXU];
-  double px[GCG_MAXP], py[GCG_MAXP], dx0[GCG_MAXP], dy0[GCG_MAXP], Rx[GCG_MAXP], Ry[GCG_MAXP];
+  double u[MAXU], ph[MAXU], ff[MAXU], Ru[MAXU], Gx[MAXU], Gy[MAXU];
+  double px[MAXP], py[MAXP], dx0[MAXP], dy0[MAXP], Rx[MAXP], Ry[MAXP];
   for (int a = 0; a < NU; ++a) {
     const int d = cu[a];
     u[a] = mask[d] ? gbc[d] : x[d];
@@ -1076,8 +1080,12 @@ void pgx_gc_handle::residual_dev(const double* xin, double* Fout) {
   GcTimer t(h, 0);
   hipMemsetAsync(Fout, 0, sizeof(double) * h->ntot, h->st);
   if (h->gen) {
-    hipLaunchKernelGGL(k_gcg_residual, dim3((h->nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), h->mask, h->gbc, h->phi, h->f, xin,
-                       h->xk, h->alpha, h->stash);
+    if (h->NU <= GCG_TRIU && h->NP <= GCG_TRIP)
+      hipLaunchKernelGGL((k_gcg_residual<GCG_TRIU, GCG_TRIP>), dim3((h->nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), h->mask, h->gbc,
+                         h->phi, h->f, xin, h->xk, h->alpha, h->stash);
+    else
+      hipLaunchKernelGGL((k_gcg_residual<GCG_MAXU, GCG_MAXP>), dim3((h->nc + 63) / 64), dim3(64), 0, h->st, gcg_args(h), h->mask, h->gbc,
+                         h->phi, h->f, xin, h->xk, h->alpha, h->stash);
     pgx_scatter_run(h->st, h->sc_res, h->stash, 1.0, 0, Fout);
     hipLaunchKernelGGL(k_gc_resid_bc, dim3((h->n2 + 255) / 256), dim3(256), 0, h->st, h->n2, h->mask, h->gbc, xin, Fout);
     return;

@@ -25,6 +25,11 @@ _TABLES = pathlib.Path(__file__).resolve().parent / "tables" / "quadrature.json"
 def quadrature_rule(cell: str, degree: int):
     """(points (nq,2), weights (nq,)) on the reference triangle. Tables live in ONE file shared with
     the oracle (tools/make_quadrature_tables.py)."""
+    if cell == "quadrilateral":  # tensor Gauss-Legendre rule on the unit square, exact to `degree` in each variable
+        g, w = np.polynomial.legendre.leggauss(degree // 2 + 1)
+        g, w = 0.5 * (g + 1.0), 0.5 * w
+        n = len(g)
+        return (np.ascontiguousarray(np.stack([np.tile(g, n), np.repeat(g, n)], axis=1)), np.ascontiguousarray(np.repeat(w, n) * np.tile(w, n)))
     tabs = json.loads(_TABLES.read_text())
     for t in tabs.values():
         if t["cell"] == cell and t["degree"] == degree:
@@ -182,7 +187,51 @@ def create_disk(h: float, radius: float = 1.0):
     return Mesh(pts, tri)
 
 
-def create_unit_square(nx, ny):
+class QuadMesh:
+    """Structured grid of nx x ny rectangles over `box` (dolfinx.mesh.create_unit_square(..., cell_type=quadrilateral),
+    gradient_constraint_dolfinx.py:34-36): vertex v = j (nx+1) + i, cell c = j nx + i with vertices in lattice order
+    (lower-left, lower-right, upper-left, upper-right).  Cells are affine; `affine_corners` (origin, +x corner, +y corner) is what the
+    element kernels take their geometry from."""
+
+    def __init__(self, box, n):
+        (x0, y0), (x1, y1) = box
+        nx, ny = int(n[0]), int(n[1])
+        if nx < 1 or ny < 1:
+            raise ValueError("at least one cell per direction")
+        self.box = ((float(x0), float(y0)), (float(x1), float(y1)))
+        self.structured = (nx, ny)
+        self.partition = None
+        self.geometry = np.ascontiguousarray(np.stack([np.tile(np.linspace(x0, x1, nx + 1), ny + 1),
+                                                       np.repeat(np.linspace(y0, y1, ny + 1), nx + 1)], axis=1))
+        v0 = (np.repeat(np.arange(ny), nx) * (nx + 1) + np.tile(np.arange(nx), ny)).astype(np.int32)
+        self.cells = np.ascontiguousarray(np.stack([v0, v0 + 1, v0 + nx + 1, v0 + nx + 2], axis=1), dtype=np.int32)
+
+    @property
+    def num_vertices(self):
+        return self.geometry.shape[0]
+
+    @property
+    def num_cells(self):
+        return self.cells.shape[0]
+
+    def cell_name(self):
+        return "quadrilateral"
+
+    @property
+    def affine_corners(self):
+        return np.ascontiguousarray(self.cells[:, :3])
+
+    def triangulated(self):
+        """(cells (2 nc, 3)) two triangles per rectangle - for file output only"""
+        c = self.cells
+        return np.ascontiguousarray(np.concatenate([c[:, [0, 1, 3]], c[:, [0, 3, 2]]]))
+
+
+def create_unit_square(nx, ny, cell_type="triangle"):
+    if cell_type == "quadrilateral":
+        return QuadMesh(((0.0, 0.0), (1.0, 1.0)), (nx, ny))
+    if cell_type != "triangle":
+        raise ValueError(f"cell_type {cell_type}")
     return create_rectangle(((0.0, 0.0), (1.0, 1.0)), (nx, ny))
 
 

@@ -47,9 +47,23 @@ class GradientConstraintProblem:
         self.degree = k = int(degree)
         if not 2 <= k <= 8:
             raise NotImplementedError("primal degree 2..8 (gradient_constraint_dolfinx.py:245-250)")
-        pts, wts = fem.quadrature_rule("triangle", quadrature_degree)  # :53
+        quad = mesh.cell_name() == "quadrilateral"  # --cell_type quadrilateral (:229-236): Q_k / (Q_(k-1))^2 on the grid of rectangles
+        pts, wts = fem.quadrature_rule(mesh.cell_name(), quadrature_degree)  # :53
         self._h = C.c_void_p()
-        if k == 2 and not general:
+        if quad:
+            if comm is not None:
+                raise NotImplementedError("quadrilateral cells with a distributed LU")
+            from . import lagrange
+
+            general = True
+            self.U = None
+            self.n2, cd, xd = lagrange.numbering_quad(mesh, k)
+            self.nv, cdp, xdp = lagrange.numbering_quad(mesh, k - 1)
+            bc = lagrange.exterior_dofs_quad(mesh, k)
+            Nu, dNu = lagrange.tabulate_quad(k, pts)
+            Npl, _ = lagrange.tabulate_quad(k - 1, pts)
+            corners = mesh.affine_corners
+        elif k == 2 and not general:
             U = fem.FunctionSpace(mesh, 2, 1)  # primal space (collapsed sub(0), :54)
             self.U = U
             self.n2, self.nv = U.block_size, mesh.num_vertices
@@ -67,6 +81,7 @@ class GradientConstraintProblem:
             bc = lagrange.exterior_dofs(mesh, k, cd)
             Nu, dNu = lagrange.tabulate(k, pts)
             Npl, _ = lagrange.tabulate(k - 1, pts)
+            corners = mesh.cells
         self.dof_coords = xd
         self.ndofs = self.n2 + 2 * self.nv
         # phi.interpolate(phi_func), f.interpolate(f_func) (:55-61); arrays of nodal values are taken as they are (forms front end)
@@ -86,8 +101,8 @@ class GradientConstraintProblem:
                 self._comm = comm
                 rc = lib.pgx_gc_create_dist(C.byref(pm), C.byref(pp), comm._c, int(device), C.byref(self._h))
         else:
-            self._keep = (mesh.geometry, mesh.cells, cd, cdp, xd, xdp, Nu, dNu, Npl, pts, wts, phi, f, bc)
-            sp = _lib.pgx_gc_spaces(mesh.num_vertices, mesh.num_cells, _lib.dptr(mesh.geometry), _lib.iptr(mesh.cells), cd.shape[1],
+            self._keep = (mesh.geometry, corners, cd, cdp, xd, xdp, Nu, dNu, Npl, pts, wts, phi, f, bc)
+            sp = _lib.pgx_gc_spaces(mesh.num_vertices, mesh.num_cells, _lib.dptr(mesh.geometry), _lib.iptr(corners), cd.shape[1],
                                     cdp.shape[1], self.n2, self.nv, _lib.iptr(cd), _lib.iptr(cdp), _lib.dptr(xd), _lib.dptr(xdp),
                                     _lib.dptr(Nu), _lib.dptr(dNu), _lib.dptr(Npl))
             rc = lib.pgx_gc_create_general(C.byref(sp), C.byref(pp), int(device), C.byref(self._h))
@@ -244,9 +259,9 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
                   phi_func: Callable = phi_default, f_func: Callable = f_default, warm_start: bool = False,
                   verbose: bool = True, return_solution: bool = False, device: int = 0, comm=None):
     """gradient_constraint_dolfinx.solve_problem (:18-205): returns (newton_iterations, L2_diff) [, final state]."""
-    if primal_space not in ("Lagrange", "P", "CG") or not 2 <= primal_degree <= 8 or cell_type != "triangle":
-        raise NotImplementedError("HIP backend: primal Lagrange degree 2..8 on triangles (:245-250; quadrilaterals are not built)")
-    mesh = fem.create_unit_square(N, M)  # :36
+    if primal_space not in ("Lagrange", "P", "CG") or not 2 <= primal_degree <= 8 or cell_type not in ("triangle", "quadrilateral"):
+        raise NotImplementedError("HIP backend: primal Lagrange degree 2..8 on triangles or quadrilaterals (:229-250)")
+    mesh = fem.create_unit_square(N, M, cell_type)  # :36
     problem = GradientConstraintProblem(mesh, phi_func, f_func, device=device, comm=comm, degree=primal_degree)
     if warm_start:  # :72-96
         if comm is not None:
@@ -288,12 +303,24 @@ def solve_problem(N: int, M: int, primal_space: str = "Lagrange", primal_degree:
 
         xs = problem.get_state()
         nv, n2, nvert = problem.nv, problem.n2, mesh.num_vertices
-        if problem.U is not None:
+        if mesh.cell_name() == "quadrilateral":  # vertex values: every k-th point of the Q_k lattice, every (k-1)-th of the latent one
+            nx, ny = mesh.structured
+            k = problem.degree
+
+            def at_vertices(vals, d):
+                return vals.reshape(d * ny + 1, d * nx + 1)[::d, ::d].ravel()
+
+            tri = mesh.triangulated()
+            write_vtu(result_dir / "u.vtu", mesh.geometry, tri, {"u": at_vertices(xs[:n2], k)})
+            write_vtu(result_dir / "psi.vtu", mesh.geometry, tri,
+                      {"psi": np.stack([at_vertices(xs[n2: n2 + nv], k - 1), at_vertices(xs[n2 + nv:], k - 1)], axis=1)})
+        elif problem.U is not None:
             write_vtu(result_dir / "u.vtu", problem.U.dof_coordinates(), problem.U.cell_dofs(), {"u": xs[: problem.n2]})
         else:  # general degree: the vertex values (the first dofs of every Lagrange space here)
             write_vtu(result_dir / "u.vtu", mesh.geometry, mesh.cells, {"u": xs[:nvert]})
-        write_vtu(result_dir / "psi.vtu", mesh.geometry, mesh.cells,
-                  {"psi": np.stack([xs[n2: n2 + nvert], xs[n2 + nv: n2 + nv + nvert]], axis=1)})
+        if mesh.cell_name() != "quadrilateral":
+            write_vtu(result_dir / "psi.vtu", mesh.geometry, mesh.cells,
+                      {"psi": np.stack([xs[n2: n2 + nvert], xs[n2 + nv: n2 + nv + nvert]], axis=1)})
     if return_solution:
         x = problem.get_state()
         problem.close()

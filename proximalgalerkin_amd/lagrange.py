@@ -114,3 +114,71 @@ def exterior_dofs(mesh, k: int, cell_dofs) -> np.ndarray:
         if m:
             out.append(cell_dofs[on[:, i]][:, 3 + i * m:3 + (i + 1) * m].ravel())
     return np.unique(np.concatenate(out)).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# quadrilaterals: tensor-product Lagrange elements Q_k on the structured grid of rectangles that
+# `create_unit_square(..., cell_type=quadrilateral)` is (gradient_constraint_dolfinx.py:34-36,229-236).  Conventions (this package's own;
+# oracle/gc_oracle.py's quadrilateral section follows them): the Q_k dofs of an nx x ny grid are the points of the k-times refined
+# vertex lattice, numbered row by row (x fastest); a cell's local nodes run over its (k+1) x (k+1) sub-lattice in the same order; the
+# basis is the product of the one-dimensional Lagrange bases on the equispaced nodes i/k.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _lagrange_1d(k: int, t):
+    """values (npts, k+1) and derivatives of the 1-D Lagrange basis on the nodes i/k, from the linear factors (k t - a) / (i - a)"""
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    if k == 0:
+        return np.ones((len(t), 1)), np.zeros((len(t), 1))
+    V = np.empty((len(t), k + 1))
+    D = np.empty((len(t), k + 1))
+    for i in range(k + 1):
+        val = np.ones_like(t)
+        der = np.zeros_like(t)
+        for a in range(k + 1):
+            if a == i:
+                continue
+            fac = (k * t - a) / (i - a)
+            der = der * fac + val * (k / (i - a))
+            val = val * fac
+        V[:, i], D[:, i] = val, der
+    return V, D
+
+
+def num_nodes_quad(k: int) -> int:
+    return (k + 1) * (k + 1)
+
+
+def tabulate_quad(k: int, pts) -> tuple[np.ndarray, np.ndarray]:
+    """Values (npts, (k+1)^2) and reference gradients (npts, (k+1)^2, 2) of the Q_k basis on the unit square at `pts`."""
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    Vx, Dx = _lagrange_1d(k, pts[:, 0])
+    Vy, Dy = _lagrange_1d(k, pts[:, 1])
+    V = (Vy[:, :, None] * Vx[:, None, :]).reshape(len(pts), -1)  # node (iy, ix) -> iy (k+1) + ix
+    G = np.stack([(Vy[:, :, None] * Dx[:, None, :]).reshape(len(pts), -1), (Dy[:, :, None] * Vx[:, None, :]).reshape(len(pts), -1)],
+                 axis=2)
+    return np.ascontiguousarray(V), np.ascontiguousarray(G)
+
+
+def numbering_quad(mesh, k: int):
+    """-> (n_dofs, cell_dofs (nc, (k+1)^2) int32, dof_coordinates (n_dofs, 2)) of Q_k on a structured quadrilateral `fem.QuadMesh`;
+    k = 0 is the piecewise-constant space (one dof per cell, at its centre)."""
+    nx, ny = mesh.structured
+    (x0, y0), (x1, y1) = mesh.box
+    cx = np.tile(np.arange(nx), ny)
+    cy = np.repeat(np.arange(ny), nx)
+    if k == 0:
+        xc = np.stack([x0 + (cx + 0.5) * (x1 - x0) / nx, y0 + (cy + 0.5) * (y1 - y0) / ny], axis=1)
+        return nx * ny, np.arange(nx * ny, dtype=np.int32)[:, None].copy(), np.ascontiguousarray(xc)
+    Lx, Ly = k * nx + 1, k * ny + 1
+    loc = (np.repeat(np.arange(k + 1), k + 1) * Lx + np.tile(np.arange(k + 1), k + 1))[None, :]
+    cd = (k * cy * Lx + k * cx)[:, None] + loc
+    X = np.stack([np.tile(np.linspace(x0, x1, Lx), Ly), np.repeat(np.linspace(y0, y1, Ly), Lx)], axis=1)
+    return Lx * Ly, np.ascontiguousarray(cd, dtype=np.int32), np.ascontiguousarray(X)
+
+
+def exterior_dofs_quad(mesh, k: int) -> np.ndarray:
+    """lattice points on the boundary of the box (locate_dofs_topological on the exterior facets, :63-69)"""
+    nx, ny = mesh.structured
+    Lx, Ly = k * nx + 1, k * ny + 1
+    ix = np.tile(np.arange(Lx), Ly)
+    iy = np.repeat(np.arange(Ly), Lx)
+    return np.flatnonzero((ix == 0) | (ix == Lx - 1) | (iy == 0) | (iy == Ly - 1)).astype(np.int32)

@@ -44,3 +44,44 @@ def test_numbering_is_conforming_and_agrees_with_the_oracle(k):
     assert no == n and np.array_equal(cdo, cd) and np.allclose(coo, co) and np.array_equal(bco, L.exterior_dofs(mesh, k, cd))
     if k == 2:
         assert np.array_equal(cd, fem.FunctionSpace(mesh, 2, 1).cell_dofs())  # the P2 numbering of pgx_mesh.cell_dofs
+
+
+@pytest.mark.parametrize("k", range(1, 9))
+def test_quadrilateral_basis_is_nodal_complete_and_agrees_with_the_oracle(k):
+    from proximalgalerkin_amd import lagrange as L
+
+    g = np.arange(k + 1) / k
+    P = np.stack([np.tile(g, k + 1), np.repeat(g, k + 1)], axis=1)  # local nodes: the (k+1) x (k+1) lattice, x fastest
+    V, _ = L.tabulate_quad(k, P)
+    assert V.shape[1] == L.num_nodes_quad(k) and np.abs(V - np.eye(len(P))).max() < 1e-12  # nodal
+    pts = np.random.default_rng(k).random((25, 2))
+    V, dV = L.tabulate_quad(k, pts)
+    assert np.abs(V.sum(axis=1) - 1).max() < 1e-12 and np.abs(dV.sum(axis=1)).max() < 1e-10  # partition of unity
+    f = lambda p: p[:, 0] ** k * p[:, 1] ** k + 2 * p[:, 1] ** k  # noqa: E731  (in Q_k, not in P_k)
+    fy = lambda p: k * p[:, 0] ** k * p[:, 1] ** (k - 1) + 2 * k * p[:, 1] ** (k - 1)  # noqa: E731
+    assert np.abs(V @ f(P) - f(pts)).max() < 1e-11 and np.abs(dV[:, :, 1] @ f(P) - fy(pts)).max() < 1e-10
+    Vo, dVo = G.qk_tabulate(k, pts[:, 0], pts[:, 1])
+    assert np.abs(V - Vo).max() < 1e-12 and np.abs(dV - dVo).max() < 1e-10
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8])
+def test_quadrilateral_numbering_is_conforming_and_agrees_with_the_oracle(k):
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd import lagrange as L
+
+    mesh = fem.create_unit_square(4, 3, "quadrilateral")
+    assert mesh.cell_name() == "quadrilateral" and mesh.num_cells == 12 and mesh.num_vertices == 20
+    n, cd, X = L.numbering_quad(mesh, k)
+    no, cdo, Xo, bco = G.qk_numbering(4, 3, k)
+    assert n == no == (4 * k + 1) * (3 * k + 1) and np.array_equal(cd, cdo) and np.abs(X - Xo).max() < 1e-15
+    assert np.array_equal(L.exterior_dofs_quad(mesh, k), bco)
+    assert np.array_equal(np.unique(cd), np.arange(n))  # every dof belongs to a cell
+    # conforming: the physical position of local node a of every cell, through the affine map of its corners, is the dof's coordinate
+    g = np.arange(k + 1) / k
+    ref = np.stack([np.tile(g, k + 1), np.repeat(g, k + 1)], axis=1)
+    c3 = mesh.geometry[mesh.affine_corners]
+    phys = c3[:, None, 0] + ref[None, :, :1] * (c3[:, None, 1] - c3[:, None, 0]) + ref[None, :, 1:] * (c3[:, None, 2] - c3[:, None, 0])
+    assert np.abs(phys - X[cd]).max() < 1e-14
+    # the tensor rule integrates the unit square: weights sum to 1 and x^11 y^11 is exact at degree 10's six points per direction
+    pts, w = fem.quadrature_rule("quadrilateral", 10)
+    assert len(w) == 36 and abs(w.sum() - 1) < 1e-14 and abs(w @ (pts[:, 0] ** 11 * pts[:, 1] ** 11) - 1 / 144) < 1e-15
