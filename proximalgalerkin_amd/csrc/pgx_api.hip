@@ -1147,7 +1147,7 @@ extern "C" int pgx_get_prev(pgx_handle* h, double* x) {
 }
 extern "C" int pgx_advance_prev(pgx_handle* h) {
   NEED(h);
-  HIPCHK(hipMemcpyAsync(h->xk, h->x, sizeof(double) * 2 * (size_t)h->nd, hipMemcpyDeviceToDevice, h->st));
+  pgxk_scale_copy(h->st, 2 * (size_t)h->nd, 1.0, h->x, h->xk);  // a streaming kernel: the runtime's D2D blit ran these 67 MB at 0.5 TB/s
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
@@ -2116,7 +2116,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     gather_owned(h, v, h->dist.wc);
     return dev_norm(h, h->dist.wc, out, nk);
   };
-  HIPCHK(hipMemcpyAsync(h->xw, h->x, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  pgxk_scale_copy(h->st, n2, 1.0, h->x, h->xw);
   residual_dev(h, h->xw, h->F, 1);
   if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
   if (dist) {
@@ -2187,7 +2187,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     }
   }
   h->lu_active = false;
-  if (rsn > 0) HIPCHK(hipMemcpyAsync(h->x, h->xw, n2 * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  if (rsn > 0) pgxk_scale_copy(h->st, n2, 1.0, h->xw, h->x);
   // the last residual evaluation refreshed D(psi) at the final iterate on the finest level only (k_resid_fill_grid writes
   // the interior rows of its stencil in passing): the hierarchy no longer describes ONE matrix until the next fill
   if (h->dh_interior) h->jac_valid = false;

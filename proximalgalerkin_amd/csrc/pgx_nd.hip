@@ -4,8 +4,8 @@
 // gradient_constraint_dolfinx.py:118-121, signorini_dolfinx.py:271-279, thermoforming_dolfinx.py:105-107) for the Newton
 // systems of the LVPP examples.  DESIGN.md section 9 has the measurements.
 //
-// Host (symbolic, once per pattern): node graph -> recursive coordinate bisection (separator = nodes of the lower half
-// adjacent to the upper half, leaves of 16 nodes) -> postorder, border ("struct") sets.  Fronts are grouped into BATCHES =
+// Host (symbolic, once per pattern): node graph -> recursive coordinate bisection (separator = nodes of one half - the lighter choice -
+// adjacent to the other half, leaves of 16 nodes) -> postorder, border ("struct") sets.  Fronts are grouped into BATCHES =
 // one tree depth x one size class (<= 4 classes per depth, chosen to minimise padded flops + storage); every front of a
 // batch is padded to the batch's pivot order P and border B, so a batch is one strided launch set.  Assembly destinations
 // and child -> parent maps are precomputed.
@@ -225,26 +225,46 @@ struct Symbolic {
       });
       na = cnt / 2;
     }
-    // separator: nodes of the lower half adjacent to the upper half
+    // separator: the nodes of ONE half that are adjacent to the other half - whichever side gives fewer dofs.  (On the P2 / Q2
+    // lattices only every second node line is a one-line separator: with the median on a vertex line the lower half's boundary
+    // is TWO lines thick - the edge-midpoint line and the vertex line below it, 1.5x the dofs, 3.4x the flops of that front -
+    // while the upper half's boundary is the vertex line itself.)
+    auto weight = [&](int32_t g) { return nd_ptr[g + 1] - nd_ptr[g]; };
+    auto touches = [&](int32_t g) {
+      for (int64_t q = gptr[g]; q < gptr[g + 1]; ++q)
+        if (mark[gadj[q]] == stamp) return true;
+      return false;
+    };
     ++stamp;
     for (int64_t k = na; k < cnt; ++k) mark[V[k]] = stamp;
-    int32_t* sep_begin = std::stable_partition(V, V + na, [&](int32_t g) {
-      for (int64_t q = gptr[g]; q < gptr[g + 1]; ++q)
-        if (mark[gadj[q]] == stamp) return false;
-      return true;
-    });
-    int64_t nin = sep_begin - V;  // interior of the lower half: V[0,nin); separator V[nin,na); upper half V[na,cnt)
-    T[tid].own.assign(V + nin, V + na);
-    // move the upper half next to the interior so both children own contiguous ranges
-    std::vector<int32_t> upper(V + na, V + cnt);
-    std::copy(upper.begin(), upper.end(), V + nin);
+    int64_t w_lo = 0, w_hi = 0;
+    for (int64_t k = 0; k < na; ++k)
+      if (touches(V[k])) w_lo += weight(V[k]);
+    ++stamp;
+    for (int64_t k = 0; k < na; ++k) mark[V[k]] = stamp;
+    for (int64_t k = na; k < cnt; ++k)
+      if (touches(V[k])) w_hi += weight(V[k]);
+    int64_t n_first, n_second;  // children: V[0, n_first) and V[n_first, n_first + n_second); the separator follows them
+    if (w_hi < w_lo) {          // upper side: [lower | interior of the upper half | separator]
+      int32_t* sep_begin = std::stable_partition(V + na, V + cnt, [&](int32_t g) { return !touches(g); });
+      n_first = na;
+      n_second = (sep_begin - V) - na;
+    } else {  // lower side: [interior of the lower half | separator | upper] -> rotate the separator to the end
+      ++stamp;
+      for (int64_t k = na; k < cnt; ++k) mark[V[k]] = stamp;
+      int32_t* sep_begin = std::stable_partition(V, V + na, [&](int32_t g) { return !touches(g); });
+      n_first = sep_begin - V;
+      n_second = cnt - na;
+      std::rotate(sep_begin, V + na, V + cnt);
+    }
+    T[tid].own.assign(V + n_first + n_second, V + cnt);
     int nc = 0;
-    if (nin > 0) {
-      int c = bisect(V, nin, tid, depth + 1);
+    if (n_first > 0) {
+      int c = bisect(V, n_first, tid, depth + 1);
       T[tid].child[nc++] = c;
     }
-    if (cnt - na > 0) {
-      int c = bisect(V + nin, cnt - na, tid, depth + 1);
+    if (n_second > 0) {
+      int c = bisect(V + n_first, n_second, tid, depth + 1);
       T[tid].child[nc++] = c;
     }
     return tid;
