@@ -85,10 +85,16 @@ struct pgx_nd {
     int l0 = 0, l1 = 0;        // batches lev[l0 .. l1)
     int64_t w_off = 0, w_len = 0;  // its range of a working buffer
     int64_t nz0 = 0, nz1 = 0;      // its range of the group-sorted assembly list
+    bool leaf_fused = false;       // deepest depth, small fronts: assembled + eliminated by k_nd_leaf (no prep, no diag/panel/gemm)
   };
   std::vector<Group> groups;
   std::vector<int> gfirst;  // groups of depth d: groups[gfirst[d]] .. groups[gfirst[d+1] - 1]
   int kcut = -1, nsub = 0;
+  // fused leaves: per-front lists of the matrix entries (front-local position c*M + r, index of the entry), CSR over ALL fronts
+  // (empty rows for the fronts of other groups)
+  int64_t* d_leaf_ptr = nullptr;
+  int32_t *d_leaf_loc = nullptr, *d_leaf_src = nullptr;
+  bool leaf_fuse = true;                // PGX_ND_LEAF_FUSED=0: the level-batched kernels for the leaves too (A/B)
   int64_t* d_sdest = nullptr;           // assembly list sorted by tree depth: destination in the working buffer ...
   int32_t* d_ssrc = nullptr;            // ... and index of the matrix entry
   // device
@@ -1579,6 +1585,127 @@ __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ aren
     }                                                                 \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused LEAF fronts (the deepest tree depth: no children).  The level-batched path moves a leaf's M x M working matrix
+// seven times through HBM (zero fill, scatter, pad, diagonal block, two panel solves, Schur update) for P <= 32 pivots'
+// worth of arithmetic: with hundreds of thousands of leaves that level alone was 11 % of a 2-D factorisation.  Here ONE
+// WAVE owns a front: the matrix entries are assembled in an LDS tile, then every column is pulled into registers
+// (lane = row; rows 64.. in a second register) and eliminated left-looking against the L columns found so far, which stay
+// in registers (<= 32 pivot columns); the pivot-row entries travel by v_readlane.  A column is written once: L\U and L21
+// to the compact store, U12 after them, the Schur block to the working matrix for the parent's extend-add.  HBM traffic:
+// the entries in, the factors and the Schur block out.  P <= ND_LEAF_P, M <= 128; pivots as in k_nd_diag (no pivoting,
+// static perturbation of zero pivots counted in info).
+// ------------------------------------------------------------------------------------------------------------------
+#define ND_LEAF_P 32
+#define ND_LEAF_M 128
+template <bool TWO>  // TWO: M > 64, a lane also owns row 64 + lane
+__global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int64_t lev_off, int64_t store_off, int64_t f0, int M, int P,
+                                                const int32_t* __restrict__ fp, const int64_t* __restrict__ eptr,
+                                                const int32_t* __restrict__ eloc, const int32_t* __restrict__ esrc,
+                                                const double* __restrict__ vals, int* __restrict__ info) {
+  // tile = what a leaf is assembled from: [M x P pivot columns | P x B rows of the border columns]; the B x B block of a leaf
+  // holds no matrix entry (an entry lives in the front that eliminates the earlier of its two dofs).  One wave per workgroup
+  // and <= 17 KB of LDS per front: up to nine fronts per CU in independent phases, so the assembly latencies of one overlap
+  // the arithmetic of the others.
+  extern __shared__ double T[];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x;
+  const int B = M - P, MP = M * P, tile = MP + P * B;
+  const int64_t f = f0 + i;
+  const int64_t e0 = eptr[f];
+  const int ne = (int)(eptr[f + 1] - e0);
+  const int npiv = fp[f];
+  for (int q = lane; q < tile; q += 64) T[q] = 0.0;
+  __syncthreads();
+  // eight entries per lane and round, every load of a round issued before the first use: a round costs two memory
+  // latencies (list, value) instead of two per entry
+  for (int base = 0; base < ne; base += 512) {
+    int loc[8], src[8];
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = base + 64 * q + lane;
+      const bool ok = t < ne;
+      loc[q] = ok ? eloc[e0 + t] : -1;
+      src[q] = ok ? esrc[e0 + t] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = loc[q] >= 0 ? vals[src[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (loc[q] >= 0) T[loc[q]] = v[q];
+  }
+  for (int k = npiv + lane; k < P; k += 64) T[k * M + k] = 1.0;  // identity on the padded pivots (k_nd_pad)
+  __syncthreads();
+  const int r = lane;
+  double* S = arena + store_off + (int64_t)i * ((int64_t)MP + (int64_t)P * B);
+  double* F = arena + lev_off + (int64_t)i * M * M;
+  // L columns: row r in L0 (0 on and above the diagonal, so the updates below need no row mask), row 64 + r in L1
+  double L0[ND_LEAF_P], L1[TWO ? ND_LEAF_P : 1];
+  int bad = 0;
+  // pivot columns: column j against columns 0..j-1, then the multipliers of column j
+#pragma unroll
+  for (int j = 0; j < ND_LEAF_P; ++j) {
+    if (j < P) {
+      double x0 = r < M ? T[j * M + r] : 0.0, x1 = 0.0;
+      if (TWO) x1 = r + 64 < M ? T[j * M + r + 64] : 0.0;
+#pragma unroll
+      for (int k = 0; k < j; ++k) {
+        const double xk = nd_bcast(x0, k);
+        x0 = fma(-L0[k], xk, x0);
+        if (TWO) x1 = fma(-L1[k], xk, x1);
+      }
+      if (r == j && fabs(x0) < 1e-300) {
+        x0 = x0 < 0 ? -1e-300 : 1e-300;
+        bad = 1;
+      }
+      const double piv = nd_bcast(x0, j);
+      L0[j] = r > j ? x0 / piv : 0.0;
+      if (TWO) L1[j] = x1 / piv;
+      if (r < M) S[(int64_t)j * M + r] = r > j ? L0[j] : x0;
+      if (TWO && r + 64 < M) S[(int64_t)j * M + r + 64] = L1[j];
+    } else {
+      L0[j] = 0.0;
+      if (TWO) L1[j] = 0.0;
+    }
+  }
+  // border columns, two at a time (two independent dependency chains per lane): U12 = L11^-1 A12 on the first P rows,
+  // Schur complement 0 - L21 U12 below.  Pivot steps in blocks of eight (steps beyond P multiply by L = 0).
+  const double* TB = T + MP;
+  for (int j = 0; j < B; j += 2) {
+    const bool two = j + 1 < B;
+    const int jb = two ? j + 1 : j;
+    double x0 = r < P ? TB[j * P + r] : 0.0, y0 = r < P ? TB[jb * P + r] : 0.0, x1 = 0.0, y1 = 0.0;
+#pragma unroll
+    for (int k8 = 0; k8 < ND_LEAF_P; k8 += 8) {
+      if (k8 < P) {
+#pragma unroll
+        for (int k = k8; k < k8 + 8; ++k) {
+          const double xk = nd_bcast(x0, k), yk = nd_bcast(y0, k);
+          x0 = fma(-L0[k], xk, x0);
+          y0 = fma(-L0[k], yk, y0);
+          if (TWO) {
+            x1 = fma(-L1[k], xk, x1);
+            y1 = fma(-L1[k], yk, y1);
+          }
+        }
+      }
+    }
+    if (r < P) {
+      S[MP + (int64_t)j * P + r] = x0;
+      if (two) S[MP + (int64_t)jb * P + r] = y0;
+    } else if (r < M) {
+      F[(int64_t)(P + j) * M + r] = x0;
+      if (two) F[(int64_t)(P + jb) * M + r] = y0;
+    }
+    if (TWO && r + 64 < M) {
+      F[(int64_t)(P + j) * M + r + 64] = x1;
+      if (two) F[(int64_t)(P + jb) * M + r + 64] = y1;
+    }
+  }
+  if (bad) atomicAdd(info, 1);
+}
+
 template <typename T>
 static int nd_upload(pgx_nd* s, T** d, const std::vector<T>& h) {
   void* q = nullptr;
@@ -1695,11 +1822,73 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
         sdest[t] = Lv.woff + (s->dest[k] - Lv.off);  // same front-local position: both layouts use M x M fronts here
         ssrc[t] = (int32_t)k;
       }
-    std::vector<int32_t>().swap(bl);
     if ((rc = nd_upload(s, &s->d_sdest, sdest)) || (rc = nd_upload(s, &s->d_ssrc, ssrc))) return fail(rc);
+    std::vector<int64_t>().swap(sdest);
+    std::vector<int32_t>().swap(ssrc);
     for (int64_t f = 0; f < s->nfronts; ++f) {
       const NdLevel& Lv = s->lev[s->flevel[f]];
       s->fbase[f] = Lv.woff + (f - Lv.start) * (int64_t)(Lv.P + Lv.B) * (Lv.P + Lv.B);
+    }
+    // fused leaves (k_nd_leaf): the groups of the deepest depth whose fronts are small enough get per-front entry lists
+    {
+      const char* e = getenv("PGX_ND_LEAF_FUSED");
+      s->leaf_fuse = !e || atoi(e) != 0;
+    }
+    const int maxdepth = (int)s->dfirst.size() - 2;
+    bool any = false;
+    for (int g = 0; g < ng && s->leaf_fuse; ++g) {
+      pgx_nd::Group& G = s->groups[g];
+      if (G.depth != maxdepth) continue;
+      bool ok = true, some = false;
+      for (int l = G.l0; l < G.l1 && ok; ++l) {
+        const NdLevel& Lv = s->lev[l];
+        if (Lv.count == 0) continue;
+        some = true;
+        if (Lv.P > ND_LEAF_P || Lv.P + Lv.B > ND_LEAF_M || Lv.P < 1) ok = false;
+        for (int64_t f = Lv.start; f < Lv.start + Lv.count && ok; ++f)
+          if (s->child0[f] >= 0 || s->child1[f] >= 0) ok = false;
+      }
+      G.leaf_fused = ok && some;
+      any = any || G.leaf_fused;
+    }
+    if (any) {
+      std::vector<int64_t> lptr(s->nfronts + 1, 0);
+      auto front_of = [&](int64_t k, int* loc) -> int64_t {  // front and front-local position of matrix entry k, or -1
+        const int l = bl[k];  // batch of the entry (-1: assembled on another rank)
+        if (l < 0 || !s->groups[group_of[l]].leaf_fused) return -1;
+        const NdLevel& Lv = s->lev[l];
+        const int M = Lv.P + Lv.B;
+        const int64_t MM = (int64_t)M * M, q = s->dest[k] - Lv.off;
+        const int lq = (int)(q % MM), c = lq / M, r = lq % M;  // column-major position in the M x M front
+        // the kernel's tile: pivot columns whole, border columns on the pivot rows only; a leaf has no entry elsewhere
+        *loc = c < Lv.P ? lq : (r < Lv.P ? M * Lv.P + (c - Lv.P) * Lv.P + r : -1);
+        return Lv.start + q / MM;
+      };
+      int loc = 0;
+      for (int64_t k = 0; k < s->nnz; ++k) {
+        const int64_t f = front_of(k, &loc);
+        if (f >= 0) lptr[f + 1]++;
+        if (f >= 0 && loc < 0) {
+          s->err = "pgx_nd_create: a leaf front holds a matrix entry in its border block";
+          return fail(PGX_EINVAL);
+        }
+      }
+      for (int64_t f = 0; f < s->nfronts; ++f) lptr[f + 1] += lptr[f];
+      std::vector<int32_t> lloc(std::max<int64_t>(lptr[s->nfronts], 1)), lsrc(std::max<int64_t>(lptr[s->nfronts], 1));
+      std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
+      for (int64_t k = 0; k < s->nnz; ++k) {
+        const int64_t f = front_of(k, &loc);
+        if (f >= 0) {
+          const int64_t t = fill[f]++;
+          lloc[t] = loc;
+          lsrc[t] = (int32_t)k;
+        }
+      }
+      if ((rc = nd_upload(s, &s->d_leaf_ptr, lptr)) || (rc = nd_upload(s, &s->d_leaf_loc, lloc)) ||
+          (rc = nd_upload(s, &s->d_leaf_src, lsrc)))
+        return fail(rc);
+      hipFuncSetAttribute((const void*)k_nd_leaf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)k_nd_leaf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
   }
 #define UP(d, h)                        \
@@ -1846,6 +2035,7 @@ static void nd_join(pgx_nd* s, int nused) {
 }
 
 // C -= A B on one rectangle of every front of a level: 128 x 128 tiles where both sides are long, 64 x 64 otherwise
+
 static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1) {
   if (r1 <= r0 || c1 <= c0 || k1 <= k0) return;
   const int M = Lv.P + Lv.B;
@@ -1877,7 +2067,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   // the working buffer of a group: zero, matrix entries, identity on the padded pivots.  (Its previous tenants are
   // stored compactly and their Schur blocks have been absorbed by their parents.)
   auto prep_on = [&](const pgx_nd::Group& G, hipStream_t ps) -> int {
-    if (G.w_len <= 0) return PGX_OK;
+    if (G.w_len <= 0 || G.leaf_fused) return PGX_OK;  // fused leaves assemble in LDS and write every entry that is read later
     NDHIP(hipMemsetAsync(s->arena + G.w_off, 0, (size_t)G.w_len * sizeof(double), ps));
     if (G.nz1 > G.nz0) {
       int blocks = (int)std::min<int64_t>((G.nz1 - G.nz0 + 255) / 256, 256 * 64);
@@ -1912,6 +2102,16 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       const int P = Lv.P, B = Lv.B, M = P + B;
       if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
       hipStream_t q = nd_fork(s, used++);
+      if (G.leaf_fused) {  // one wave per front: assemble in LDS, eliminate in registers, write factors + Schur block once
+        const size_t lds = ((size_t)M * P + (size_t)P * B) * sizeof(double);
+        if (M > 64)
+          hipLaunchKernelGGL(k_nd_leaf<true>, dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P,
+                             s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info);
+        else
+          hipLaunchKernelGGL(k_nd_leaf<false>, dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P,
+                             s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info);
+        continue;
+      }
       // Two-level blocked partial LU of the batch.  Outer blocks of <= ND_OUTER pivots; inside one, <= 64-wide panels:
       // diagonal block, both panel solves, then rank-64 updates of the outer block's row and column STRIPS only.  The
       // rest of the trailing pivot block and panels gets ONE rank-ND_OUTER update per outer block (arithmetic intensity
