@@ -1865,18 +1865,17 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
         return Lv.start + q / MM;
       };
       int loc = 0;
-      for (int64_t k = 0; k < s->nnz; ++k) {
+      for (int64_t k = 0; k < s->nnz && any; ++k) {
         const int64_t f = front_of(k, &loc);
         if (f >= 0) lptr[f + 1]++;
-        if (f >= 0 && loc < 0) {
-          s->err = "pgx_nd_create: a leaf front holds a matrix entry in its border block";
-          return fail(PGX_EINVAL);
-        }
+        if (f >= 0 && loc < 0) any = false;  // an entry in a leaf's border block (not with these assembly maps): batched path
       }
+      if (!any)
+        for (auto& G : s->groups) G.leaf_fused = false;
       for (int64_t f = 0; f < s->nfronts; ++f) lptr[f + 1] += lptr[f];
       std::vector<int32_t> lloc(std::max<int64_t>(lptr[s->nfronts], 1)), lsrc(std::max<int64_t>(lptr[s->nfronts], 1));
       std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
-      for (int64_t k = 0; k < s->nnz; ++k) {
+      for (int64_t k = 0; k < s->nnz && any; ++k) {
         const int64_t f = front_of(k, &loc);
         if (f >= 0) {
           const int64_t t = fill[f]++;
@@ -1884,11 +1883,9 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
           lsrc[t] = (int32_t)k;
         }
       }
-      if ((rc = nd_upload(s, &s->d_leaf_ptr, lptr)) || (rc = nd_upload(s, &s->d_leaf_loc, lloc)) ||
-          (rc = nd_upload(s, &s->d_leaf_src, lsrc)))
-        return fail(rc);
-      hipFuncSetAttribute((const void*)k_nd_leaf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)k_nd_leaf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (any && ((rc = nd_upload(s, &s->d_leaf_ptr, lptr)) || (rc = nd_upload(s, &s->d_leaf_loc, lloc)) ||
+                  (rc = nd_upload(s, &s->d_leaf_src, lsrc))))
+        return fail(rc);  // (the tile is at most (128 x 32 + 32 x 96) doubles = 56 KB: no LDS attribute needed)
     }
   }
 #define UP(d, h)                        \
