@@ -1,8 +1,11 @@
 """A/B of the fused leaf kernel (PGX_ND_LEAF_FUSED=0/1) on the sparse-LU workloads: ms per factorisation and per solve.
-python tools/leaf_ab.py  (one GPU; each case runs in a child process so that the environment variable is read at create)"""
+python tools/leaf_ab.py [ENV_VAR]  (one GPU; default switch PGX_ND_LEAF_FUSED; each case runs in a child process so that the environment variable is read at create)"""
 import os
 import subprocess
 import sys
+
+VAR = sys.argv[1] if len(sys.argv) > 1 else "PGX_ND_LEAF_FUSED"  # any 0/1 switch of the library
+AB = ("0", "1")
 
 CASES = {
     "ex06 1024^2": "import runpy, sys; sys.argv = ['tools/gc_scaling.py', '1024', '3']; runpy.run_path('tools/gc_scaling.py', run_name='__main__')",
@@ -20,11 +23,11 @@ print("  P2 1024: Newton", sum(h["Newton steps"]), f"in {time.perf_counter() - t
 """,
 }
 for name, code in CASES.items():
-    for fused in ("0", "1"):
-        env = dict(os.environ, PGX_ND_LEAF_FUSED=fused)
+    for fused in AB:
+        env = dict(os.environ, **{VAR: fused})
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         lines = [l for l in out.stdout.splitlines() if "phases" in l or "total" in l]
-        print(f"{name}  fused={fused}")
+        print(f"{name}  {VAR}={fused}")
         for l in lines:
             print("   ", l.strip())
         if out.returncode:
