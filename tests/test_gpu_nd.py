@@ -122,3 +122,33 @@ def test_perturbed_pivots_are_reported(require_gpu):
     ds.factor(A.data)  # and the report is per factorisation
     assert ds.stats()["perturbed_pivots"] == 0
     ds.close()
+
+
+def test_fused_leaves_agree_with_the_batched_kernels(require_gpu, monkeypatch):
+    """k_nd_leaf (one wave assembles and eliminates a childless front; default) against the level-batched kernels
+    (PGX_ND_LEAF_FUSED=0) on a late ex 06 matrix with zero pivot padding, leaves of mixed size and |psi| up to 1e3: both are LU
+    factorisations without pivoting of the same matrix in the same order - solutions agree to rounding, both backward stable."""
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    N = 24
+    c6, e6 = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    g = G.GradientConstraintP2(c6, e6)
+    its = []
+    G.solve_problem(g, max_iterations=8, iterates=its)
+    J = g.jacobian(its[-1], 128.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(g.n2), np.arange(g.nv), np.arange(g.nv)]).astype(np.int32)
+    b = np.random.default_rng(9).standard_normal(J.shape[0])
+    xs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PGX_ND_LEAF_FUSED", fused)
+        ds = DirectSolver(J.indptr, J.indices, nod, g.dof_coords, device=0)
+        ds.factor(J.data)
+        xs[fused] = ds.solve(b)
+        assert ds.stats()["perturbed_pivots"] == 0
+        assert _berr(J, xs[fused], b) <= 1e-13
+        ds.factor(J.data)  # refactorisation is bitwise reproducible on either path
+        assert np.array_equal(ds.solve(b), xs[fused])
+        ds.close()
+    assert np.linalg.norm(xs["1"] - xs["0"]) <= 1e-9 * np.linalg.norm(xs["0"])
+    assert not np.array_equal(xs["1"], xs["0"])  # different summation order in the leaves: the switch does select another kernel
