@@ -730,9 +730,10 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
   if (pf < 0) return;  // distributed: the parent of a subtree root lives on rank 0
   const int64_t Mp = fM[pf];
   double* dst = arena + fbase[pf];
-  const int64_t total = (int64_t)b * b;
-  for (int64_t idx = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.y * blockDim.x) {
-    const int c = (int)(idx / b), r = (int)(idx - (int64_t)c * b);
+  // 32-bit index arithmetic (b < 65536: a border of that size would be a 34 GB front)
+  const unsigned ub = (unsigned)b, total = ub * ub, step = gridDim.y * blockDim.x;
+  for (unsigned idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += step) {
+    const unsigned c = idx / ub, r = idx - c * ub;
     dst[(int64_t)R[c] * Mp + R[r]] += src[(int64_t)c * Mc + r];
   }
 }
