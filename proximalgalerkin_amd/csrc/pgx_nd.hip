@@ -95,6 +95,10 @@ struct pgx_nd {
   int64_t* d_leaf_ptr = nullptr;
   int32_t *d_leaf_loc = nullptr, *d_leaf_src = nullptr;
   bool leaf_fuse = true;                // PGX_ND_LEAF_FUSED=0: the level-batched kernels for the leaves too (A/B)
+  // parent-centric assembly (k_nd_gather): every entry of a front = sum of its two children's Schur entries, WRITTEN once - no zero
+  // fill, no read-modify-write.  inv[0|1][vbase[f] + p] = index in child 0|1's border of the parent-local index p, or -1.
+  int32_t* d_inv[2] = {nullptr, nullptr};
+  bool gather = true;                   // PGX_ND_GATHER=0: zero fill + push-style extend-add (A/B)
   int64_t* d_sdest = nullptr;           // assembly list sorted by tree depth: destination in the working buffer ...
   int32_t* d_ssrc = nullptr;            // ... and index of the matrix entry
   // device
@@ -736,6 +740,46 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
     const unsigned c = idx / ub, r = idx - c * ub;
     dst[(int64_t)R[c] * Mp + R[r]] += src[(int64_t)c * Mc + r];
   }
+}
+
+// parent-centric assembly of the fronts [f0, f0 + gridDim.x) of one batch: entry (r, c) = S0[inv0[r], inv0[c]] + S1[inv1[r], inv1[c]]
+// with S0 / S1 the Schur blocks of the two children (in the other working buffer) - every entry of the M x M front is written,
+// so the buffer needs no zero fill and no entry is read-modified-written; the matrix entries are ADDED afterwards (k_nd_scatter_add).
+__global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, const int32_t* __restrict__ child0,
+                                                   const int32_t* __restrict__ child1, const int32_t* __restrict__ fM,
+                                                   const int32_t* __restrict__ fP, const int64_t* __restrict__ fbase,
+                                                   const int64_t* __restrict__ vbase, const int32_t* __restrict__ inv0,
+                                                   const int32_t* __restrict__ inv1, double* __restrict__ arena) {
+  const int64_t f = f0 + blockIdx.x;
+  const int c0 = child0[f], c1 = child1[f];
+  double* F = arena + fbase[f];
+  const int32_t* I0 = inv0 + vbase[f];
+  const int32_t* I1 = inv1 + vbase[f];
+  int M0 = 0, M1 = 0;
+  const double *S0 = nullptr, *S1 = nullptr;
+  if (c0 >= 0) M0 = fM[c0], S0 = arena + fbase[c0] + (int64_t)fP[c0] * M0 + fP[c0];
+  if (c1 >= 0) M1 = fM[c1], S1 = arena + fbase[c1] + (int64_t)fP[c1] * M1 + fP[c1];
+  const unsigned uM = (unsigned)M, total = uM * uM, step = gridDim.y * blockDim.x;
+  for (unsigned idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += step) {
+    const unsigned c = idx / uM, r = idx - c * uM;
+    double v = 0.0;
+    if (S0) {
+      const int a = I0[c], b = I0[r];
+      if ((a | b) >= 0) v = S0[(int64_t)a * M0 + b];
+    }
+    if (S1) {
+      const int a = I1[c], b = I1[r];
+      if ((a | b) >= 0) v += S1[(int64_t)a * M1 + b];
+    }
+    F[idx] = v;
+  }
+}
+
+__global__ void k_nd_scatter_add(int64_t t0, int64_t t1, const int64_t* __restrict__ sdest, const int32_t* __restrict__ ssrc,
+                                 const double* __restrict__ vals, double* __restrict__ arena) {
+  int64_t t = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < t1; t += stride) arena[sdest[t]] += vals[ssrc[t]];  // one matrix entry per position: no atomics
 }
 
 // Schur block of one front <-> contiguous B x B buffer (exchange between ranks)
@@ -1897,6 +1941,24 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
 #undef UP
   if ((rc = nd_upload(s, &s->d_fM, fM)) || (rc = nd_upload(s, &s->d_fP, fP)) || (rc = nd_upload(s, &s->d_vbase, vbase)))
     return fail(rc);
+  {  // inverse child -> parent maps of the parent-centric assembly
+    const char* e = getenv("PGX_ND_GATHER");
+    s->gather = !e || atoi(e) != 0;
+    if (s->gather) {
+      std::vector<int32_t> inv[2];
+      inv[0].assign((size_t)std::max<int64_t>(s->vec_len, 1), -1);
+      inv[1].assign((size_t)std::max<int64_t>(s->vec_len, 1), -1);
+      for (int64_t c = 0; c < s->nfronts; ++c) {
+        const int pf = s->parent[c];
+        if (pf < 0) continue;
+        std::vector<int32_t>& I = inv[s->slot01[c] ? 1 : 0];
+        const int32_t* R = s->rel.data() + s->rel_ptr[c];
+        const int64_t nb = s->rel_ptr[c + 1] - s->rel_ptr[c];
+        for (int64_t k = 0; k < nb; ++k) I[vbase[pf] + R[k]] = (int32_t)k;
+      }
+      if ((rc = nd_upload(s, &s->d_inv[0], inv[0])) || (rc = nd_upload(s, &s->d_inv[1], inv[1]))) return fail(rc);
+    }
+  }
   // the maps live on the device from here on: release the host copies of the large ones (8 bytes per matrix entry)
   std::vector<int64_t>().swap(s->dest);
   std::vector<int32_t>().swap(s->own_dofs);
@@ -2078,6 +2140,28 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     return PGX_OK;
   };
   auto prep = [&](const pgx_nd::Group& G) -> int { return prep_on(G, s->st); };
+  // parent-centric assembly of a group whose children (depth + 1) have been eliminated: children's Schur blocks gathered and
+  // written (k_nd_gather), matrix entries added, identity on the padded pivots - instead of prep + extend of the children
+  auto gather = [&](const pgx_nd::Group& G) {
+    for (int l = G.l0; l < G.l1; ++l) {
+      const NdLevel& Lv = s->lev[l];
+      if (Lv.count == 0) continue;
+      const int M = Lv.P + Lv.B;
+      const int64_t per = (int64_t)M * M;
+      unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 2048));
+      while ((int64_t)gy * Lv.count > (int64_t)1 << 22 && gy > 1) gy /= 2;
+      hipLaunchKernelGGL(k_nd_gather, dim3((unsigned)Lv.count, gy), dim3(256), 0, s->st, Lv.start, M, s->d_child0, s->d_child1, s->d_fM,
+                         s->d_fP, s->d_fbase, s->d_vbase, s->d_inv[0], s->d_inv[1], s->arena);
+    }
+    if (G.nz1 > G.nz0) {
+      int blocks = (int)std::min<int64_t>((G.nz1 - G.nz0 + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(k_nd_scatter_add, dim3(blocks), dim3(256), 0, s->st, G.nz0, G.nz1, s->d_sdest, s->d_ssrc, dv, s->arena);
+    }
+    const int64_t f0 = s->lev[G.l0].start, f1 = s->lev[G.l1 - 1].start + s->lev[G.l1 - 1].count;
+    if (f1 > f0)
+      hipLaunchKernelGGL(k_nd_pad, dim3((unsigned)(f1 - f0)), dim3(64), 0, s->st, f0, s->d_fp, s->d_fP, s->d_fM, s->d_fbase, s->arena);
+  };
+  const bool use_gather = s->gather && s->d_inv[0] && s->d_inv[1];
   // extend-add of the Schur complements of a (factorised) group into its parents' fronts (two conflict-free passes: first
   // children, second children)
   auto extend = [&](const pgx_nd::Group& G) {
@@ -2149,8 +2233,12 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     if ((rcp = prep(grp(kc, -1)))) return rcp;
     for (int g = 0; g < s->nsub; ++g) {
       for (int d = maxdepth; d > kc; --d) {
-        if ((rcp = prep(grp(d, g)))) return rcp;
-        if (d < maxdepth) extend(grp(d + 1, g));
+        if (use_gather && d < maxdepth) {
+          gather(grp(d, g));
+        } else {
+          if ((rcp = prep(grp(d, g)))) return rcp;
+          if (d < maxdepth) extend(grp(d + 1, g));
+        }
         eliminate(grp(d, g));
       }
       extend(grp(kc + 1, g));
@@ -2159,13 +2247,17 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   }
   bool ahead = false;  // this depth's buffer has been prepared on prep_st
   for (int d = (kc >= 0 ? kc - 1 : maxdepth); d >= 0; --d) {
-    if (ahead)
-      hipStreamWaitEvent(s->st, s->ev_prep_done, 0);
-    else if ((rcp = prep(grp(d, -1))))
-      return rcp;
-    if (d < maxdepth) extend(grp(d + 1, -1));
+    if (use_gather && d < maxdepth) {  // (nothing is prepared ahead in this mode: a front is written once, from its children)
+      gather(grp(d, -1));
+    } else {
+      if (ahead)
+        hipStreamWaitEvent(s->st, s->ev_prep_done, 0);
+      else if ((rcp = prep(grp(d, -1))))
+        return rcp;
+      if (d < maxdepth) extend(grp(d + 1, -1));
+    }
     ahead = false;
-    if (d > 0 && s->prep_ahead && s->prep_st) {  // depth d + 1 has left the buffer depth d - 1 will use
+    if (!use_gather && d > 0 && s->prep_ahead && s->prep_st) {  // depth d + 1 has left the buffer depth d - 1 will use
       hipEventRecord(s->ev_prep_go, s->st);
       hipStreamWaitEvent(s->prep_st, s->ev_prep_go, 0);
       if ((rcp = prep_on(grp(d - 1, -1), s->prep_st))) return rcp;
