@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-tree-depth wall time of ONE sparse-LU factorisation from a rocprofv3 kernel trace: pgx_nd_factor processes the dissection
 tree depth by depth (deepest first), each depth = prelude on the main stream (memset, scatter, pad, extend-add of the children) +
-elimination of the depth's batches on forked streams.  Depths are delimited by the working-buffer memsets.
+elimination of the depth's batches on forked streams.  Depths are delimited by the first parent-centric gather of a depth (default) or by the working-buffer memsets (PGX_ND_GATHER=0);
+the xadd column is the extend-add / gather kernel time.
     PGX_ND_PREP_AHEAD=0 rocprofv3 --kernel-trace ... (the depth-ahead buffer preparation would blur the boundaries)
     python tools/nd_depth_timeline.py <dir or kernel_trace.csv> [index of the factorisation, default: the last complete one]"""
 import csv
@@ -38,21 +39,21 @@ t0 = seg[0][0]
 # depth boundaries: a fillBuffer that follows elimination kernels starts a new depth
 depths, cur, seen_elim = [], [], False
 for r in seg:
-    if "fillBuffer" in r[2] and seen_elim:
+    if ("fillBuffer" in r[2] or r[2].startswith("k_nd_gather")) and seen_elim:  # zero fill (push mode) or the first gather (default)
         depths.append(cur)
         cur, seen_elim = [], False
     cur.append(r)
-    if r[2] == "k_nd_diag" or r[2].startswith("k_nd_panel") or r[2].startswith("k_nd_gemm"):
+    if r[2] == "k_nd_diag" or r[2].startswith("k_nd_panel") or r[2].startswith("k_nd_gemm") or r[2].startswith("k_nd_leaf"):
         seen_elim = True
 depths.append(cur)
 print(f"factorisation span {(seg[-1][1] - t0) / 1e6:.1f} ms, {len(depths)} depth groups (deepest first)")
 print(f"{'grp':>3s} {'start ms':>9s} {'wall ms':>8s} {'prelude':>8s} {'elim':>8s} {'diag':>5s} {'panel ms':>9s} {'gemm ms':>8s} {'diag ms':>8s} {'xadd ms':>8s}")
 for i, d in enumerate(depths):
     s, e = d[0][0], max(r[1] for r in d)
-    first = next((r[0] for r in d if r[2] == "k_nd_diag"), e)
+    first = next((r[0] for r in d if r[2] == "k_nd_diag" or r[2].startswith("k_nd_leaf")), e)
     ks = lambda pre: sum(r[1] - r[0] for r in d if r[2].startswith(pre)) / 1e6  # noqa: E731
     print(f"{i:3d} {(s - t0) / 1e6:9.2f} {(e - s) / 1e6:8.2f} {(first - s) / 1e6:8.2f} {(e - first) / 1e6:8.2f} {sum(r[2] == 'k_nd_diag' for r in d):5d} "
-          f"{ks('k_nd_panel'):9.2f} {ks('k_nd_gemm'):8.2f} {ks('k_nd_diag'):8.2f} {ks('k_nd_extend'):8.2f}")
+          f"{ks('k_nd_panel'):9.2f} {ks('k_nd_gemm'):8.2f} {ks('k_nd_diag'):8.2f} {ks('k_nd_extend') + ks('k_nd_gather'):8.2f}")
 
 # PGX_ND_LAUNCHES=g0,g1,...: every elimination launch of those depth groups (workgroup grid, duration)
 for gi in [int(t) for t in os.environ.get("PGX_ND_LAUNCHES", "").split(",") if t]:
