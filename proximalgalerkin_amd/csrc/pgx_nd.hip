@@ -745,7 +745,7 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
 // parent-centric assembly of the fronts [f0, f0 + gridDim.x) of one batch: entry (r, c) = S0[inv0[r], inv0[c]] + S1[inv1[r], inv1[c]]
 // with S0 / S1 the Schur blocks of the two children (in the other working buffer) - every entry of the M x M front is written,
 // so the buffer needs no zero fill and no entry is read-modified-written; the matrix entries are ADDED afterwards (k_nd_scatter_add).
-__global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, const int32_t* __restrict__ child0,
+__global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, int P, const int32_t* __restrict__ child0,
                                                    const int32_t* __restrict__ child1, const int32_t* __restrict__ fM,
                                                    const int32_t* __restrict__ fP, const int64_t* __restrict__ fbase,
                                                    const int64_t* __restrict__ vbase, const int32_t* __restrict__ inv0,
@@ -759,9 +759,18 @@ __global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, const int3
   const double *S0 = nullptr, *S1 = nullptr;
   if (c0 >= 0) M0 = fM[c0], S0 = arena + fbase[c0] + (int64_t)fP[c0] * M0 + fP[c0];
   if (c1 >= 0) M1 = fM[c1], S1 = arena + fbase[c1] + (int64_t)fP[c1] * M1 + fP[c1];
-  const unsigned uM = (unsigned)M, total = uM * uM, step = gridDim.y * blockDim.x;
-  for (unsigned idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += step) {
-    const unsigned c = idx / uM, r = idx - c * uM;
+  // the FRAME of the front only: the P pivot columns whole, then the pivot rows of the B border columns; the border block is
+  // assembled by the Schur update itself (GATHER variants of the GEMM kernels)
+  const unsigned uM = (unsigned)M, uP = (unsigned)P, mp = uM * uP, total = mp + uP * (uM - uP), step = gridDim.y * blockDim.x;
+  for (unsigned e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += step) {
+    unsigned c, r;
+    if (e < mp) {
+      c = e / uM, r = e - c * uM;
+    } else {
+      const unsigned q = e - mp;
+      c = uP + q / uP, r = q - (q / uP) * uP;
+    }
+    const unsigned idx = c * uM + r;
     double v = 0.0;
     if (S0) {
       const int a = I0[c], b = I0[r];
@@ -1349,13 +1358,37 @@ static void nd_launch_panel(int kind, hipStream_t q, unsigned count, unsigned nc
     hipLaunchKernelGGL(k_nd_panel_r<64>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
 }
 
+// Parent-centric assembly fused into the Schur update (GATHER variants of the GEMM kernels): the border block of a front is never
+// written by k_nd_gather and read back - the update computes C = (children's Schur entries through the inverse maps) - A B.
+struct NdGatherCtx {
+  int64_t f0;  // first front of the batch
+  const int32_t *child0, *child1, *fM, *fP, *inv0, *inv1;
+  const int64_t *fbase, *vbase;
+};
+struct NdGatherSrc {
+  const double *S0, *S1;
+  const int32_t *I0, *I1;
+  int M0, M1;
+};
+__device__ __forceinline__ NdGatherSrc nd_gather_src(const NdGatherCtx& g, const double* arena, int64_t f) {
+  NdGatherSrc q;
+  const int c0 = g.child0[f], c1 = g.child1[f];
+  q.I0 = g.inv0 + g.vbase[f];
+  q.I1 = g.inv1 + g.vbase[f];
+  q.M0 = q.M1 = 0;
+  q.S0 = q.S1 = nullptr;
+  if (c0 >= 0) q.M0 = g.fM[c0], q.S0 = arena + g.fbase[c0] + (int64_t)g.fP[c0] * q.M0 + g.fP[c0];
+  if (c1 >= 0) q.M1 = g.fM[c1], q.S1 = arena + g.fbase[c1] + (int64_t)g.fP[c1] * q.M1 + g.fP[c1];
+  return q;
+}
+
 // C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
 // B = F[k0:k1, cols); (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of v_mfma_f64_16x16x4_f64, operands swapped
 // (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
 // into registers while the current one feeds the matrix cores.
-template <int WT>
+template <int WT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P) {
+                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
@@ -1412,6 +1445,34 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
     }
   }
   // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
+  if (GATHER) {
+    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
+    int a0[WT], a1[WT];  // the lane's rows in the children's borders
+#pragma unroll
+    for (int ti = 0; ti < WT; ++ti) {
+      const int i = r0 + wi + 16 * ti + (l & 15);
+      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
+      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
+    }
+#pragma unroll
+    for (int tj = 0; tj < WT; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
+        if (j >= cmax) continue;
+        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
+#pragma unroll
+        for (int ti = 0; ti < WT; ++ti) {
+          const int i = r0 + wi + 16 * ti + (l & 15);
+          if (i >= rmax) continue;
+          double v = 0.0;
+          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
+          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
+          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int tj = 0; tj < WT; ++tj)
 #pragma unroll
@@ -1428,8 +1489,9 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
 // 128 x 128 tiles with EIGHT waves (wave tile 64 x 32 = 4 x 2 MFMA tiles): 64 accumulator VGPRs instead of 128, so that
 // two workgroups = 4 waves per SIMD are resident (launch bounds: 4 waves per SIMD -> <= 128 VGPRs) and one wave's LDS staging and
 // barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
+template <bool GATHER>
 __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P) {
+                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
   constexpr int TS = 128, NT = 512;
   constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
   __shared__ double As[ND_KC][TS + 8];
@@ -1483,6 +1545,34 @@ __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena,
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[tj], lf[ti], acc[tj][ti], 0, 0, 0);
     }
+  }
+  if (GATHER) {
+    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
+    int a0[4], a1[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int i = r0 + wi + 16 * ti + (l & 15);
+      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
+      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
+        if (j >= cmax) continue;
+        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          const int i = r0 + wi + 16 * ti + (l & 15);
+          if (i >= rmax) continue;
+          double v = 0.0;
+          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
+          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
+          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
+        }
+      }
+    return;
   }
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -2096,16 +2186,23 @@ static void nd_join(pgx_nd* s, int nused) {
 
 // C -= A B on one rectangle of every front of a level: 128 x 128 tiles where both sides are long, 64 x 64 otherwise
 
-static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1) {
+// cgather: C is not read but assembled from the children's Schur blocks (the border block of a parent-centrically assembled front)
+static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1,
+                           bool cgather = false) {
   if (r1 <= r0 || c1 <= c0 || k1 <= k0) return;
   const int M = Lv.P + Lv.B;
   const bool big = (r1 - r0) >= 256 && (c1 - c0) >= 256;
   const int TS = big ? 128 : 64;
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
-  if (big)
-    hipLaunchKernelGGL(k_nd_gemm8, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
+  NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
+  if (big && cgather)
+    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+  else if (big)
+    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+  else if (cgather)
+    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
   else
-    hipLaunchKernelGGL(k_nd_gemm<2>, grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P);
+    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -2147,10 +2244,10 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       const NdLevel& Lv = s->lev[l];
       if (Lv.count == 0) continue;
       const int M = Lv.P + Lv.B;
-      const int64_t per = (int64_t)M * M;
+      const int64_t per = (int64_t)M * Lv.P + (int64_t)Lv.P * Lv.B;  // the frame; the border block belongs to the Schur update
       unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 2048));
       while ((int64_t)gy * Lv.count > (int64_t)1 << 22 && gy > 1) gy /= 2;
-      hipLaunchKernelGGL(k_nd_gather, dim3((unsigned)Lv.count, gy), dim3(256), 0, s->st, Lv.start, M, s->d_child0, s->d_child1, s->d_fM,
+      hipLaunchKernelGGL(k_nd_gather, dim3((unsigned)Lv.count, gy), dim3(256), 0, s->st, Lv.start, M, Lv.P, s->d_child0, s->d_child1, s->d_fM,
                          s->d_fP, s->d_fbase, s->d_vbase, s->d_inv[0], s->d_inv[1], s->arena);
     }
     if (G.nz1 > G.nz0) {
@@ -2176,7 +2273,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
                            s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel, s->arena);
     }
   };
-  auto eliminate = [&](const pgx_nd::Group& G) {  // the batches of a group on forked streams
+  auto eliminate = [&](const pgx_nd::Group& G, bool cgather = false) {  // the batches of a group on forked streams
     hipEventRecord(s->ev_fork, s->st);
     int used = 0;
     for (int l = G.l1 - 1; l >= G.l0; --l) {
@@ -2221,7 +2318,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
         nd_launch_gemm(s, q, Lv, P, M, oe, P, ob, oe);
         ob = oe;
       }
-      if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P);
+      if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, cgather);
     }
     nd_join(s, used);
   };
@@ -2233,13 +2330,14 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
     if ((rcp = prep(grp(kc, -1)))) return rcp;
     for (int g = 0; g < s->nsub; ++g) {
       for (int d = maxdepth; d > kc; --d) {
-        if (use_gather && d < maxdepth) {
+        const bool pc = use_gather && d < maxdepth;
+        if (pc) {
           gather(grp(d, g));
         } else {
           if ((rcp = prep(grp(d, g)))) return rcp;
           if (d < maxdepth) extend(grp(d + 1, g));
         }
-        eliminate(grp(d, g));
+        eliminate(grp(d, g), pc);
       }
       extend(grp(kc + 1, g));
     }
@@ -2247,7 +2345,8 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   }
   bool ahead = false;  // this depth's buffer has been prepared on prep_st
   for (int d = (kc >= 0 ? kc - 1 : maxdepth); d >= 0; --d) {
-    if (use_gather && d < maxdepth) {  // (nothing is prepared ahead in this mode: a front is written once, from its children)
+    const bool pc = use_gather && d < maxdepth;
+    if (pc) {  // (nothing is prepared ahead in this mode: a front is written once, from its children)
       gather(grp(d, -1));
     } else {
       if (ahead)
@@ -2264,7 +2363,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       hipEventRecord(s->ev_prep_done, s->prep_st);
       ahead = true;
     }
-    eliminate(grp(d, -1));
+    eliminate(grp(d, -1), pc);
     if (s->size > 1 && d == s->kdist) {  // Schur blocks of the subtree roots -> rank 0's ghost fronts
       const NdLevel& Lv = s->lev[s->kbatch];
       const int P = Lv.P, B = Lv.B, M = P + B;
