@@ -231,9 +231,10 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
                        "parallelism": "single" if world == 1 else f"replicated iterate, sparse LU distributed over {world} ranks "
                                                                    "(one dissection subtree each, RCCL gather/scatter + all-reduce)"},
             "setup_s": t_setup,
-            "roofline": {"kernel": "k_nd_gemm<4>/<2> inside pgx_nd_factor (fp64 MFMA GEMM of the multifrontal LU; the figure is the "
-                                   "WHOLE factorisation: algorithmic flops of this rank / its device time, panels and extend-add "
-                                   "included)",
+            "roofline": {"kernel": "k_nd_gemm8 / k_nd_gemm<2> inside pgx_nd_factor (fp64 MFMA GEMM of the multifrontal LU; the figure is "
+                                   "the WHOLE factorisation: algorithmic flops of this rank / its device time - leaf fronts, frame "
+                                   "assembly, diagonal blocks and panel solves included; the deep tree levels of 2-D problems are "
+                                   "HBM-bound, DESIGN.md section 9)",
                          "bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_flops_per_factorisation": st["flops"],
