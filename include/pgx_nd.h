@@ -50,7 +50,7 @@ typedef struct {
 } pgx_nd_stats;
 
 /* device < 0: symbolic phase only (no GPU touched) - for pgx_nd_get_stats / pgx_nd_export_* on CPU-only machines. */
-/* Environment: PGX_ND_CUT_GB (default 96) - a factorisation whose device storage exceeds this many GB cuts the tree at depth 3
+/* Environment: PGX_ND_CUT_GB (default 160) - a factorisation whose device storage exceeds this many GB cuts the tree at depth 3
  * and factorises the subtrees below one after the other, so that the working buffers only hold one subtree's fronts
  * (0: always, negative: never). */
 int pgx_nd_create(const pgx_nd_matrix* A, int device, void* hip_stream /* may be NULL: own stream */, pgx_nd** out);

@@ -554,8 +554,10 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   }
   // large factorisation on one GPU: cut the tree at depth 3 and factorise the (up to) 8 subtrees below one after the other
   {
-    const char* e = getenv("PGX_ND_CUT_GB");  // threshold in GB of device storage (default 96); 0 = always, < 0 = never
-    const double thr = e ? atof(e) : 96.0;
+    // threshold in GB of device storage; 0 = always, < 0 = never.  Default 160 of the 288 GB: the uncut schedule is the faster one
+    // while it fits (2048^2 P2, 115 GB: factorisations -4 %, solves -31 % against the cut at 96 GB; tools/p2_cut_ab.py)
+    const char* e = getenv("PGX_ND_CUT_GB");
+    const double thr = e ? atof(e) : 160.0;
     const int kc = 3;
     if (attempt == 0 && dsize == 1 && thr >= 0 && maxd >= kc + 3 && (double)s->arena_len * 8 > thr * 1e9) {
       nsub = 0;

@@ -74,7 +74,7 @@ def test_ex06_newton_matrix(require_gpu):
 
 def test_subtree_sequencing_gives_the_same_factorisation(require_gpu, monkeypatch):
     """Large factorisations cut the tree at depth 3 and factorise the subtrees one after the other (PGX_ND_CUT_GB, default
-    96 GB of device storage); forced here on a small matrix: same solutions as SuperLU, less storage than without the cut."""
+    160 GB of device storage); forced here on a small matrix: same solutions as SuperLU, less storage than without the cut."""
     from proximalgalerkin_amd.direct import DirectSolver
 
     N = 48
