@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -297,12 +298,20 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
       s->err = "node_of_dof out of range";
       return PGX_EINVAL;
     }
+  const bool ptime = getenv("PGX_ND_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  auto t_0 = tnow();
   S.build_graph();
+  auto t_1 = tnow();
   S.mark.assign(nn, 0);
   std::vector<int32_t> ids(nn);
   std::iota(ids.begin(), ids.end(), 0);
   S.T.reserve(4 * (size_t)(nn / S.leaf + 2));
   S.bisect(ids.data(), nn, -1, 0);
+  auto t_2 = tnow();
   std::vector<TNode>& T = S.T;
   const int nt = (int)T.size();
   // postorder
@@ -628,6 +637,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   s->own_dofs.resize(s->dof_ptr[nloc]);
   s->rel.resize(s->rel_ptr[nloc]);
   s->nnz = A->rowptr[n];
+  auto t_3 = tnow();
   s->dest.assign(s->nnz, -1);
   // local indices, child -> parent maps, assembly destinations
   std::vector<int32_t> loc(n, -1), loc_owner(n, -1);
@@ -699,6 +709,11 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
         s->err = "matrix pattern is not structurally symmetric (or columns are not sorted)";
         return PGX_EINVAL;
       }
+  if (ptime) {
+    auto t_4 = tnow();
+    fprintf(stderr, "pgx_nd symbolic: node graph %.0f ms, dissection %.0f ms, fronts / batches / layout %.0f ms, maps + destinations %.0f ms\n",
+            tms(t_0, t_1), tms(t_1, t_2), tms(t_2, t_3), tms(t_3, t_4));
+  }
   return PGX_OK;
 }
 
