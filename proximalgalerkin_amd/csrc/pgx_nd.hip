@@ -34,7 +34,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -640,68 +643,100 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   auto t_3 = tnow();
   s->dest.assign(s->nnz, -1);
   // local indices, child -> parent maps, assembly destinations
-  std::vector<int32_t> loc(n, -1), loc_owner(n, -1);
   auto find_entry = [&](int32_t row, int32_t colv) -> int64_t {
     const int32_t* b = A->col + A->rowptr[row];
     const int32_t* e = A->col + A->rowptr[row + 1];
     const int32_t* it = std::lower_bound(b, e, colv);
     return (it != e && *it == colv) ? (int64_t)(it - A->col) : -1;
   };
-  for (int t : post) {
-    if (state[t] != 1) continue;  // ghosts are neither assembled nor eliminated here; their maps into the parent are built below
-    const int f = slot_of[t];
-    const NdLevel& Lv = s->lev[tbatch[t]];
-    const int64_t M = Lv.P + Lv.B;
-    int k = 0;
-    int64_t w = s->dof_ptr[f];
-    for (int32_t g : T[t].own)
-      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
-        int32_t i = S.nd_dofs[q];
-        loc[i] = k++;
-        loc_owner[i] = t;
-        s->own_dofs[w++] = i;
-      }
-    k = Lv.P;
-    for (int32_t g : T[t].border)
-      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
-        int32_t i = S.nd_dofs[q];
-        loc[i] = k++;
-        loc_owner[i] = t;
-      }
-    for (int c = 0; c < 2; ++c) {
-      int ct = T[t].child[c];
-      if (ct < 0 || slot_of[ct] < 0) continue;
-      int64_t r = s->rel_ptr[slot_of[ct]];
-      for (int32_t g : T[ct].border)
-        for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
-          int32_t i = S.nd_dofs[q];
-          if (loc_owner[i] != t) {
-            s->err = "symbolic inconsistency: child border not contained in the parent front";
-            return PGX_EINVAL;
+  // One front at a time needs the local index of every dof it holds: `loc` / `loc_owner`, indexed by dof.  The fronts are
+  // independent (every output range - own_dofs, rel, the destinations of the entries of its own rows and of the mirrored entries -
+  // belongs to one front), so worker threads take them in chunks, each with its private pair of index arrays.
+  std::vector<int> work;
+  work.reserve(post.size());
+  for (int t : post)
+    if (state[t] == 1) work.push_back(t);  // ghosts are neither assembled nor eliminated here; their maps into the parent are built by the parent
+  const char* sym_err = nullptr;
+  std::mutex err_mu;
+  std::atomic<int64_t> next{0};
+  auto worker = [&]() {
+    std::vector<int32_t> loc(n, -1), loc_owner(n, -1);
+    for (;;) {
+      const int64_t w0 = next.fetch_add(256);
+      if (w0 >= (int64_t)work.size()) break;
+      for (int64_t wi = w0; wi < std::min<int64_t>(w0 + 256, (int64_t)work.size()); ++wi) {
+        const int t = work[wi];
+        const int f = slot_of[t];
+        const NdLevel& Lv = s->lev[tbatch[t]];
+        const int64_t M = Lv.P + Lv.B;
+        int k = 0;
+        int64_t w = s->dof_ptr[f];
+        for (int32_t g : T[t].own)
+          for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+            int32_t i = S.nd_dofs[q];
+            loc[i] = k++;
+            loc_owner[i] = t;
+            s->own_dofs[w++] = i;
           }
-          s->rel[r++] = loc[i];
+        k = Lv.P;
+        for (int32_t g : T[t].border)
+          for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+            int32_t i = S.nd_dofs[q];
+            loc[i] = k++;
+            loc_owner[i] = t;
+          }
+        for (int c = 0; c < 2; ++c) {
+          int ct = T[t].child[c];
+          if (ct < 0 || slot_of[ct] < 0) continue;
+          int64_t r = s->rel_ptr[slot_of[ct]];
+          for (int32_t g : T[ct].border)
+            for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+              int32_t i = S.nd_dofs[q];
+              if (loc_owner[i] != t) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                sym_err = "symbolic inconsistency: child border not contained in the parent front";
+                return;
+              }
+              s->rel[r++] = loc[i];
+            }
         }
+        for (int32_t g : T[t].own)
+          for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
+            const int32_t i = S.nd_dofs[q];
+            const int64_t r = loc[i];
+            for (int32_t e = A->rowptr[i]; e < A->rowptr[i + 1]; ++e) {
+              const int32_t j = A->col[e];
+              const int tj = tnode[A->node_of_dof[j]];
+              if (order_of[tj] < order_of[t]) continue;  // assembled from the other side (earlier front)
+              if (loc_owner[j] != t) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                sym_err = "symbolic inconsistency: coupled dof missing from the front";
+                return;
+              }
+              const int64_t c = loc[j];
+              s->dest[e] = s->fbase[f] + c * M + r;
+              if (tj != t) {
+                int64_t et = find_entry(j, i);
+                if (et >= 0) s->dest[et] = s->fbase[f] + r * M + c;
+              }
+            }
+          }
+      }
     }
-    for (int32_t g : T[t].own)
-      for (int64_t q = S.nd_ptr[g]; q < S.nd_ptr[g + 1]; ++q) {
-        const int32_t i = S.nd_dofs[q];
-        const int64_t r = loc[i];
-        for (int32_t e = A->rowptr[i]; e < A->rowptr[i + 1]; ++e) {
-          const int32_t j = A->col[e];
-          const int tj = tnode[A->node_of_dof[j]];
-          if (order_of[tj] < order_of[t]) continue;  // assembled from the other side (earlier front)
-          if (loc_owner[j] != t) {
-            s->err = "symbolic inconsistency: coupled dof missing from the front";
-            return PGX_EINVAL;
-          }
-          const int64_t c = loc[j];
-          s->dest[e] = s->fbase[f] + c * M + r;
-          if (tj != t) {
-            int64_t et = find_entry(j, i);
-            if (et >= 0) s->dest[et] = s->fbase[f] + r * M + c;
-          }
-        }
-      }
+  };
+  {
+    // private index arrays cost 8 bytes per dof and thread: at most 8 threads, fewer on small problems
+    int nthr = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u),
+                                     std::max<int64_t>(1, (int64_t)work.size() / 2048));
+    if (const char* e = getenv("PGX_ND_THREADS")) nthr = std::max(1, atoi(e));
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nthr; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+  if (sym_err) {
+    s->err = sym_err;
+    return PGX_EINVAL;
   }
   if (dsize == 1)  // (on a distributed handle the entries of other ranks' fronts legitimately stay unassigned)
     for (int64_t e = 0; e < s->nnz; ++e)
