@@ -1932,7 +1932,14 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     s->comm = comm, s->rank = comm->rank, s->size = comm->size;
   else
     s->rank = sym_rank, s->size = sym_size;  // symbolic-only view of one rank of a distributed factorisation (tests)
+  const bool ptime = getenv("PGX_ND_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto c_0 = tnow();
   int rc = nd_symbolic(s, A);
+  const auto c_1 = tnow();
   if (rc) {
     g_nd_error = s->err;
     delete s;
@@ -1991,24 +1998,53 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     std::vector<int> group_of(L, 0);
     for (int g = 0; g < ng; ++g)
       for (int l = s->groups[g].l0; l < s->groups[g].l1; ++l) group_of[l] = g;
+    // a parallel counting sort by group, stable in the entry index: contiguous chunks of entries, one histogram per chunk, the
+    // chunks' offsets in chunk order - the lists do not depend on the number of threads
     std::vector<int64_t> gnz(ng + 1, 0);
     std::vector<int32_t> bl(s->nnz, -1);
-    for (int64_t k = 0; k < s->nnz; ++k)
-      if (s->dest[k] >= 0) {
-        bl[k] = batch_of(s->dest[k]);
-        gnz[group_of[bl[k]] + 1]++;
-      }
+    int nthr = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u),
+                                     std::max<int64_t>(1, s->nnz / (1 << 20)));
+    if (const char* e = getenv("PGX_ND_THREADS")) nthr = std::max(1, atoi(e));
+    const int64_t chunk = (s->nnz + nthr - 1) / nthr;
+    std::vector<std::vector<int64_t>> hist(nthr, std::vector<int64_t>(ng, 0));
+    auto run_threads = [&](const std::function<void(int)>& fn) {
+      std::vector<std::thread> pool;
+      for (int i = 1; i < nthr; ++i) pool.emplace_back(fn, i);
+      fn(0);
+      for (auto& th : pool) th.join();
+    };
+    run_threads([&](int ti) {
+      std::vector<int64_t>& hg = hist[ti];
+      for (int64_t k = ti * chunk; k < std::min(s->nnz, (ti + 1) * chunk); ++k)
+        if (s->dest[k] >= 0) {
+          bl[k] = batch_of(s->dest[k]);
+          hg[group_of[bl[k]]]++;
+        }
+    });
+    for (int g = 0; g < ng; ++g)
+      for (int ti = 0; ti < nthr; ++ti) gnz[g + 1] += hist[ti][g];
     for (int g = 0; g < ng; ++g) gnz[g + 1] += gnz[g];
     for (int g = 0; g < ng; ++g) s->groups[g].nz0 = gnz[g], s->groups[g].nz1 = gnz[g + 1];
-    std::vector<int64_t> cur(gnz.begin(), gnz.end() - 1), sdest(gnz[ng]);
-    std::vector<int32_t> ssrc(gnz[ng]);
-    for (int64_t k = 0; k < s->nnz; ++k)
-      if (bl[k] >= 0) {
-        const NdLevel& Lv = s->lev[bl[k]];
-        const int64_t t = cur[group_of[bl[k]]]++;
-        sdest[t] = Lv.woff + (s->dest[k] - Lv.off);  // same front-local position: both layouts use M x M fronts here
-        ssrc[t] = (int32_t)k;
+    for (int g = 0; g < ng; ++g) {  // hist[ti][g] <- first slot of chunk ti in group g
+      int64_t at = gnz[g];
+      for (int ti = 0; ti < nthr; ++ti) {
+        const int64_t c = hist[ti][g];
+        hist[ti][g] = at;
+        at += c;
       }
+    }
+    std::vector<int64_t> sdest(gnz[ng]);
+    std::vector<int32_t> ssrc(gnz[ng]);
+    run_threads([&](int ti) {
+      std::vector<int64_t>& cur = hist[ti];
+      for (int64_t k = ti * chunk; k < std::min(s->nnz, (ti + 1) * chunk); ++k)
+        if (bl[k] >= 0) {
+          const NdLevel& Lv = s->lev[bl[k]];
+          const int64_t t = cur[group_of[bl[k]]]++;
+          sdest[t] = Lv.woff + (s->dest[k] - Lv.off);  // same front-local position: both layouts use M x M fronts here
+          ssrc[t] = (int32_t)k;
+        }
+    });
     if ((rc = nd_upload(s, &s->d_sdest, sdest)) || (rc = nd_upload(s, &s->d_ssrc, ssrc))) return fail(rc);
     std::vector<int64_t>().swap(sdest);
     std::vector<int32_t>().swap(ssrc);
@@ -2075,6 +2111,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
         return fail(rc);  // (the tile is at most (128 x 32 + 32 x 96) doubles = 56 KB: no LDS attribute needed)
     }
   }
+  const auto c_2 = tnow();
 #define UP(d, h)                        \
   if ((rc = nd_upload(s, &s->d, h))) return fail(rc);
   UP(d_dof_ptr, s->dof_ptr) UP(d_rel_ptr, s->rel_ptr) UP(d_fbase, s->fbase) UP(d_fp, s->fp) UP(d_fb, s->fb)
@@ -2131,6 +2168,11 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     const NdLevel& Lk = s->lev[s->kbatch];
     const size_t nb = (size_t)Lk.B * Lk.B, mult = s->rank == 0 ? (size_t)s->size : 1;
     if ((rc = nd_alloc(s, &s->d_xbuf, mult * nb)) || (rc = nd_alloc(s, &s->d_vbuf, mult * (size_t)Lk.B))) return fail(rc);
+  }
+  if (ptime) {
+    hipDeviceSynchronize();
+    fprintf(stderr, "pgx_nd create: symbolic %.0f ms, assembly / leaf lists %.0f ms, maps, uploads, device allocations %.0f ms\n", tms(c_0, c_1),
+            tms(c_1, c_2), tms(c_2, tnow()));
   }
   *out = s;
   return PGX_OK;
