@@ -122,3 +122,27 @@ def test_distributed_symbolic_views_reproduce_lu(R):
     xr = spla.splu(J.tocsc()).solve(b)
     assert np.linalg.norm(J @ x - b) <= 1e-10 * np.linalg.norm(b)
     assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
+
+
+def test_threaded_maps_do_not_depend_on_the_thread_count(monkeypatch):
+    """The index maps and assembly destinations are built by worker threads, one front at a time (PGX_ND_THREADS; private index
+    arrays): every output belongs to exactly one front, so 1, 3 and 8 threads export identical structures.  Also pins the
+    lighter-side separators: on a P2 lattice (nodes = vertices and edge midpoints) the root separator is ONE node line."""
+    N = 16
+    coords, cells = O.create_rectangle(N, N)
+    p2 = O.ObstacleLagrange(coords, cells, degree=2)
+    J = p2.jacobian(0.3 * np.random.default_rng(2).standard_normal(2 * p2.n), 3.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p2.n)] * 2)
+    syms = []
+    for nthr in ("1", "3", "8"):
+        monkeypatch.setenv("PGX_ND_THREADS", nthr)
+        ds = DirectSolver(J.indptr, J.indices, nod, p2.dof_coords, leaf_nodes=8, device=-1)
+        syms.append(ds.export_symbolic())
+        ds.close()
+    for other in syms[1:]:
+        for key in ("lev_start", "P", "B", "fp", "fb", "parent", "slot01", "dof_ptr", "own_dofs", "rel_ptr", "rel", "dest"):
+            assert np.array_equal(syms[0][key], other[key]), key
+    # root front: one lattice line of the (2N+1)^2 P2 nodes, two dofs (u, psi) per node - not the two lines a one-sided rule takes
+    root = int(np.flatnonzero(syms[0]["parent"] < 0)[0])
+    assert syms[0]["fp"][root] == 2 * (2 * N + 1), syms[0]["fp"][root]
