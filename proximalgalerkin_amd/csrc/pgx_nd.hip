@@ -13,13 +13,20 @@
 // assembled and eliminated in lives in one of two WORKING buffers chosen by the parity of its tree depth and reused two
 // depths further up, once the parents have absorbed the Schur blocks - 2-D problems need ~1/2 of the storage of keeping
 // every front whole (ex 06 1024^2: 77 -> 42 GB, ex 02 70^3: 139 -> 76 GB).
-// Device (numeric, every Newton step), depth by depth, deepest first: zero the depth's working buffer, scatter its CSR
-// values to their frontal positions (conflict-free; the assembly list is sorted by depth), extend-add the children's Schur
-// complements (two conflict-free passes, no atomics -> bitwise reproducible), then for every batch of the depth - on
-// forked HIP streams, joined per depth - a two-level blocked partial LU without pivoting across nodes; solved panels are
-// written to the compact store only, which is also where the trailing updates read their operands:
+// Device (numeric, every Newton step), depth by depth, deepest first.  Assembly is PARENT-CENTRIC: every entry of a front is
+// written once as the sum of its two children's Schur entries, found through inverse index maps (no zero fill, no
+// read-modify-write, no atomics -> bitwise reproducible) - k_nd_gather does this for the FRAME of a front (pivot columns and
+// pivot rows), where the CSR values are then added (k_nd_scatter_add; the assembly list is sorted by depth); the border block
+// is assembled by the Schur-update GEMM itself, which takes its C operand through the same maps (GATHER variants).  The
+// childless fronts of the deepest depth are assembled and eliminated by one wave each (k_nd_leaf: LDS tile, L columns in
+// registers, pivot rows by v_readlane).  (PGX_ND_GATHER=0 / PGX_ND_LEAF_FUSED=0: zero fill + scatter + push-style
+// k_nd_extend_add in two conflict-free passes, and the batched kernels for the leaves - the subtree cut of very large
+// factorisations still uses the push path at the cut depth.)  Then for every batch of the depth - on forked HIP streams,
+// joined per depth - a two-level blocked partial LU without pivoting across nodes; solved panels are written to the compact
+// store only, which is also where the trailing updates read their operands:
 //   k_nd_diag   LU of one <= 64-wide diagonal block in LDS (8-column panels by one wave with lane shuffles)
-//   k_nd_panel  both triangular panel solves against that block, 64-wide chunks, blocked by 8 in LDS
+//   k_nd_panel_m both triangular panel solves against that block on the matrix cores (16-pivot blocked substitution; k_nd_panel:
+//               the LDS-blocked scalar version)
 //   k_nd_gemm   C -= A B on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 64^2 tiles by 4 waves x (2x2) MFMA tiles
 //               (k_nd_gemm<2>) and 128^2 tiles by 8 waves x (4x2) MFMA tiles at 4 waves per SIMD (k_nd_gemm8), operands swapped (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes;
 //               rank-64 updates touch only the strips of the current 256-pivot outer block, the rest of the trailing
