@@ -152,3 +152,35 @@ def test_fused_leaves_agree_with_the_batched_kernels(require_gpu, monkeypatch):
         ds.close()
     assert np.linalg.norm(xs["1"] - xs["0"]) <= 1e-9 * np.linalg.norm(xs["0"])
     assert not np.array_equal(xs["1"], xs["0"])  # different summation order in the leaves: the switch does select another kernel
+
+
+def test_assembly_variants_agree_on_an_unstructured_p2_matrix(require_gpu, monkeypatch):
+    """Parent-centric assembly (k_nd_gather + the GATHER Schur updates, default) against zero fill + push-style extend-add
+    (PGX_ND_GATHER=0) on the P2 Newton matrix of a DISK mesh: an unbalanced dissection tree with leaves at several depths,
+    fronts without a second child and padded batches.  Same factorisation order, different summation order of the children's
+    contributions: solutions agree to rounding, both are backward stable, each is bitwise reproducible."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    msh = fem.create_disk(0.06)
+    p2 = O.ObstacleLagrange(msh.geometry, msh.cells, degree=2)
+    rng = np.random.default_rng(4)
+    x = 0.3 * rng.standard_normal(2 * p2.n)
+    x[p2.n:] -= 60.0 * (np.hypot(*p2.dof_coords.T) < 0.35)  # exp(psi) underflows towards 0 in a contact zone
+    J = p2.jacobian(x, 20.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(p2.n)] * 2).astype(np.int32)
+    b = rng.standard_normal(J.shape[0])
+    xs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PGX_ND_GATHER", mode)
+        ds = DirectSolver(J.indptr, J.indices, nod, p2.dof_coords, device=0)
+        ds.factor(J.data)
+        xs[mode] = ds.solve(b)
+        assert _berr(J, xs[mode], b) <= 1e-13, _berr(J, xs[mode], b)
+        ds.factor(J.data)
+        assert np.array_equal(ds.solve(b), xs[mode])
+        ds.close()
+    xr = spla.splu(J.tocsc()).solve(b)
+    assert np.linalg.norm(xs["1"] - xr) <= 1e-7 * np.linalg.norm(xr)
+    assert np.linalg.norm(xs["1"] - xs["0"]) <= 1e-9 * np.linalg.norm(xs["0"])
