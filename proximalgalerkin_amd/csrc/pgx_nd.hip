@@ -97,6 +97,7 @@ struct pgx_nd {
     int64_t w_off = 0, w_len = 0;  // its range of a working buffer
     int64_t nz0 = 0, nz1 = 0;      // its range of the group-sorted assembly list
     bool leaf_fused = false;       // deepest depth, small fronts: assembled + eliminated by k_nd_leaf (no prep, no diag/panel/gemm)
+    bool frame_fused = false;      // small fronts WITH children: frame gathered + eliminated by k_nd_leaf<.,true>, border block by the GATHER GEMM
   };
   std::vector<Group> groups;
   std::vector<int> gfirst;  // groups of depth d: groups[gfirst[d]] .. groups[gfirst[d+1] - 1]
@@ -919,6 +920,30 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 #define ND_OUTER 256 // pivots per outer block of the factorisation (rank of the big trailing updates)
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
+// Parent-centric assembly fused into the Schur update (GATHER variants of the GEMM kernels): the border block of a front is never
+// written by k_nd_gather and read back - the update computes C = (children's Schur entries through the inverse maps) - A B.
+struct NdGatherCtx {
+  int64_t f0;  // first front of the batch
+  const int32_t *child0, *child1, *fM, *fP, *inv0, *inv1;
+  const int64_t *fbase, *vbase;
+};
+struct NdGatherSrc {
+  const double *S0, *S1;
+  const int32_t *I0, *I1;
+  int M0, M1;
+};
+__device__ __forceinline__ NdGatherSrc nd_gather_src(const NdGatherCtx& g, const double* arena, int64_t f) {
+  NdGatherSrc q;
+  const int c0 = g.child0[f], c1 = g.child1[f];
+  q.I0 = g.inv0 + g.vbase[f];
+  q.I1 = g.inv1 + g.vbase[f];
+  q.M0 = q.M1 = 0;
+  q.S0 = q.S1 = nullptr;
+  if (c0 >= 0) q.M0 = g.fM[c0], q.S0 = arena + g.fbase[c0] + (int64_t)g.fP[c0] * q.M0 + g.fP[c0];
+  if (c1 >= 0) q.M1 = g.fM[c1], q.S1 = arena + g.fbase[c1] + (int64_t)g.fP[c1] * q.M1 + g.fP[c1];
+  return q;
+}
+
 // broadcast of one lane's double to the wave when the lane index is wave-uniform: two v_readlane_b32 (scalar result) instead
 // of the two ds_bpermute_b32 round trips through the LDS crossbar that __shfl compiles to - these broadcasts sit on the
 // serial chains of the diagonal-block LU and of the triangular solves
@@ -1417,30 +1442,6 @@ static void nd_launch_panel(int kind, hipStream_t q, unsigned count, unsigned nc
     hipLaunchKernelGGL(k_nd_panel_r<64>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
 }
 
-// Parent-centric assembly fused into the Schur update (GATHER variants of the GEMM kernels): the border block of a front is never
-// written by k_nd_gather and read back - the update computes C = (children's Schur entries through the inverse maps) - A B.
-struct NdGatherCtx {
-  int64_t f0;  // first front of the batch
-  const int32_t *child0, *child1, *fM, *fP, *inv0, *inv1;
-  const int64_t *fbase, *vbase;
-};
-struct NdGatherSrc {
-  const double *S0, *S1;
-  const int32_t *I0, *I1;
-  int M0, M1;
-};
-__device__ __forceinline__ NdGatherSrc nd_gather_src(const NdGatherCtx& g, const double* arena, int64_t f) {
-  NdGatherSrc q;
-  const int c0 = g.child0[f], c1 = g.child1[f];
-  q.I0 = g.inv0 + g.vbase[f];
-  q.I1 = g.inv1 + g.vbase[f];
-  q.M0 = q.M1 = 0;
-  q.S0 = q.S1 = nullptr;
-  if (c0 >= 0) q.M0 = g.fM[c0], q.S0 = arena + g.fbase[c0] + (int64_t)g.fP[c0] * q.M0 + g.fP[c0];
-  if (c1 >= 0) q.M1 = g.fM[c1], q.S1 = arena + g.fbase[c1] + (int64_t)g.fP[c1] * q.M1 + g.fP[c1];
-  return q;
-}
-
 // C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
 // B = F[k0:k1, cols); (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of v_mfma_f64_16x16x4_f64, operands swapped
 // (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
@@ -1792,11 +1793,13 @@ __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ aren
 // ------------------------------------------------------------------------------------------------------------------
 #define ND_LEAF_P 32
 #define ND_LEAF_M 128
-template <bool TWO>  // TWO: M > 64, a lane also owns row 64 + lane
+// CHILD: a front WITH children - its frame (same tile) is first gathered from the children's Schur blocks through the inverse maps,
+// the matrix entries are added, and only L\\U, L21 and U12 are produced: the border block belongs to the GATHER Schur update.
+template <bool TWO, bool CHILD>  // TWO: M > 64, a lane also owns row 64 + lane
 __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int64_t lev_off, int64_t store_off, int64_t f0, int M, int P,
                                                 const int32_t* __restrict__ fp, const int64_t* __restrict__ eptr,
                                                 const int32_t* __restrict__ eloc, const int32_t* __restrict__ esrc,
-                                                const double* __restrict__ vals, int* __restrict__ info) {
+                                                const double* __restrict__ vals, int* __restrict__ info, NdGatherCtx gc) {
   // tile = what a leaf is assembled from: [M x P pivot columns | P x B rows of the border columns]; the B x B block of a leaf
   // holds no matrix entry (an entry lives in the front that eliminates the earlier of its two dofs).  One wave per workgroup
   // and <= 17 KB of LDS per front: up to nine fronts per CU in independent phases, so the assembly latencies of one overlap
@@ -1809,7 +1812,30 @@ __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int6
   const int64_t e0 = eptr[f];
   const int ne = (int)(eptr[f + 1] - e0);
   const int npiv = fp[f];
-  for (int q = lane; q < tile; q += 64) T[q] = 0.0;
+  if (CHILD) {
+    const NdGatherSrc g = nd_gather_src(gc, arena, f);
+    for (int e = lane; e < tile; e += 64) {
+      int c, r;
+      if (e < MP) {
+        c = e / M, r = e - c * M;
+      } else {
+        const int q = e - MP;
+        c = P + q / P, r = q - (q / P) * P;
+      }
+      double v = 0.0;
+      if (g.S0) {
+        const int a = g.I0[c], b = g.I0[r];
+        if ((a | b) >= 0) v = g.S0[(int64_t)a * g.M0 + b];
+      }
+      if (g.S1) {
+        const int a = g.I1[c], b = g.I1[r];
+        if ((a | b) >= 0) v += g.S1[(int64_t)a * g.M1 + b];
+      }
+      T[e] = v;
+    }
+  } else {
+    for (int q = lane; q < tile; q += 64) T[q] = 0.0;
+  }
   __syncthreads();
   // eight entries per lane and round, every load of a round issued before the first use: a round costs two memory
   // latencies (list, value) instead of two per entry
@@ -1827,7 +1853,7 @@ __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int6
     for (int q = 0; q < 8; ++q) v[q] = loc[q] >= 0 ? vals[src[q]] : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (loc[q] >= 0) T[loc[q]] = v[q];
+      if (loc[q] >= 0) T[loc[q]] = CHILD ? T[loc[q]] + v[q] : v[q];  // one entry per position
   }
   for (int k = npiv + lane; k < P; k += 64) T[k * M + k] = 1.0;  // identity on the padded pivots (k_nd_pad)
   __syncthreads();
@@ -1878,7 +1904,7 @@ __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int6
           const double xk = nd_bcast(x0, k), yk = nd_bcast(y0, k);
           x0 = fma(-L0[k], xk, x0);
           y0 = fma(-L0[k], yk, y0);
-          if (TWO) {
+          if (TWO && !CHILD) {
             x1 = fma(-L1[k], xk, x1);
             y1 = fma(-L1[k], yk, y1);
           }
@@ -1888,11 +1914,11 @@ __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int6
     if (r < P) {
       S[MP + (int64_t)j * P + r] = x0;
       if (two) S[MP + (int64_t)jb * P + r] = y0;
-    } else if (r < M) {
+    } else if (!CHILD && r < M) {
       F[(int64_t)(P + j) * M + r] = x0;
       if (two) F[(int64_t)(P + jb) * M + r] = y0;
     }
-    if (TWO && r + 64 < M) {
+    if (!CHILD && TWO && r + 64 < M) {
       F[(int64_t)(P + j) * M + r + 64] = x1;
       if (two) F[(int64_t)(P + jb) * M + r + 64] = y1;
     }
@@ -2066,26 +2092,36 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     }
     const int maxdepth = (int)s->dfirst.size() - 2;
     bool any = false;
+    // ... and, with the parent-centric assembly, the groups of small fronts WITH children (not the push-mode depth of a subtree
+    // cut): their frame is gathered and eliminated by the same kernel (PGX_ND_FRAME_FUSED=0: k_nd_gather + diag + panel)
+    bool frame_fuse = s->leaf_fuse;
+    {
+      const char* e = getenv("PGX_ND_GATHER");
+      if (e && atoi(e) == 0) frame_fuse = false;
+      const char* e2 = getenv("PGX_ND_FRAME_FUSED");
+      if (e2 && atoi(e2) == 0) frame_fuse = false;
+    }
     for (int g = 0; g < ng && s->leaf_fuse; ++g) {
       pgx_nd::Group& G = s->groups[g];
-      if (G.depth != maxdepth) continue;
+      const bool deepest = G.depth == maxdepth;
+      if (!deepest && (!frame_fuse || G.depth == s->kcut)) continue;
       bool ok = true, some = false;
       for (int l = G.l0; l < G.l1 && ok; ++l) {
         const NdLevel& Lv = s->lev[l];
         if (Lv.count == 0) continue;
         some = true;
         if (Lv.P > ND_LEAF_P || Lv.P + Lv.B > ND_LEAF_M || Lv.P < 1) ok = false;
-        for (int64_t f = Lv.start; f < Lv.start + Lv.count && ok; ++f)
+        for (int64_t f = Lv.start; f < Lv.start + Lv.count && ok && deepest; ++f)
           if (s->child0[f] >= 0 || s->child1[f] >= 0) ok = false;
       }
-      G.leaf_fused = ok && some;
-      any = any || G.leaf_fused;
+      (deepest ? G.leaf_fused : G.frame_fused) = ok && some;
+      any = any || (ok && some);
     }
     if (any) {
       std::vector<int64_t> lptr(s->nfronts + 1, 0);
       auto front_of = [&](int64_t k, int* loc) -> int64_t {  // front and front-local position of matrix entry k, or -1
         const int l = bl[k];  // batch of the entry (-1: assembled on another rank)
-        if (l < 0 || !s->groups[group_of[l]].leaf_fused) return -1;
+        if (l < 0 || !(s->groups[group_of[l]].leaf_fused || s->groups[group_of[l]].frame_fused)) return -1;
         const NdLevel& Lv = s->lev[l];
         const int M = Lv.P + Lv.B;
         const int64_t MM = (int64_t)M * M, q = s->dest[k] - Lv.off;
@@ -2101,7 +2137,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
         if (f >= 0 && loc < 0) any = false;  // an entry in a leaf's border block (not with these assembly maps): batched path
       }
       if (!any)
-        for (auto& G : s->groups) G.leaf_fused = false;
+        for (auto& G : s->groups) G.leaf_fused = G.frame_fused = false;
       for (int64_t f = 0; f < s->nfronts; ++f) lptr[f + 1] += lptr[f];
       std::vector<int32_t> lloc(std::max<int64_t>(lptr[s->nfronts], 1)), lsrc(std::max<int64_t>(lptr[s->nfronts], 1));
       std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
@@ -2341,6 +2377,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   // parent-centric assembly of a group whose children (depth + 1) have been eliminated: children's Schur blocks gathered and
   // written (k_nd_gather), matrix entries added, identity on the padded pivots - instead of prep + extend of the children
   auto gather = [&](const pgx_nd::Group& G) {
+    if (G.frame_fused) return;  // k_nd_leaf<., true> gathers the frame itself
     for (int l = G.l0; l < G.l1; ++l) {
       const NdLevel& Lv = s->lev[l];
       if (Lv.count == 0) continue;
@@ -2382,14 +2419,27 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       const int P = Lv.P, B = Lv.B, M = P + B;
       if (Lv.count == 0) continue;  // distributed: the levels above the subtrees live on rank 0
       hipStream_t q = nd_fork(s, used++);
-      if (G.leaf_fused) {  // one wave per front: assemble in LDS, eliminate in registers, write factors + Schur block once
+      if (G.leaf_fused || (cgather && G.frame_fused)) {
+        // one wave per front: assemble in LDS, eliminate in registers; a leaf writes factors + Schur block once, a front with
+        // children its factors - its border block comes from the GATHER Schur update below
         const size_t lds = ((size_t)M * P + (size_t)P * B) * sizeof(double);
-        if (M > 64)
-          hipLaunchKernelGGL(k_nd_leaf<true>, dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P,
-                             s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info);
-        else
-          hipLaunchKernelGGL(k_nd_leaf<false>, dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P,
-                             s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info);
+        const NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
+#define ND_LEAF(TWO, CH)                                                                                                          \
+  hipLaunchKernelGGL((k_nd_leaf<TWO, CH>), dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P, \
+                     s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info, gc)
+        if (G.leaf_fused) {
+          if (M > 64)
+            ND_LEAF(true, false);
+          else
+            ND_LEAF(false, false);
+        } else {
+          if (M > 64)
+            ND_LEAF(true, true);
+          else
+            ND_LEAF(false, true);
+          if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, true);
+        }
+#undef ND_LEAF
         continue;
       }
       // Two-level blocked partial LU of the batch.  Outer blocks of <= ND_OUTER pivots; inside one, <= 64-wide panels:
