@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""HBM traffic of the sparse-LU kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - separate passes, both in KB,
+FETCH_SIZE doubled: gfx950 tallies a 128-B request as 64 B; MI355X_MICROARCH.md) over the same program, with the kernel durations of
+the first pass's kernel trace:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d F -o f -- python3 tools/gc_scaling.py 1024 1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d W -o w -- python3 tools/gc_scaling.py 1024 1
+    python tools/nd_traffic.py F W > profiles/rNN_nd_traffic.json
+Per kernel name: launches, summed bytes, summed duration (counter collection serialises the kernels, so durations are per-kernel
+device times without overlap), bytes / duration."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def counters(d, name):
+    acc = defaultdict(float)
+    cnt = defaultdict(int)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if row["Counter_Name"] == name:
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                acc[k] += float(row["Counter_Value"])
+                cnt[k] += 1
+    return acc, cnt
+
+
+def durations(d):
+    acc = defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+    return acc
+
+
+fetch, cnt = counters(sys.argv[1], "FETCH_SIZE")
+write, _ = counters(sys.argv[2], "WRITE_SIZE")
+dur = durations(sys.argv[1])
+out = {}
+for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
+    if not k.startswith("k_nd"):
+        continue
+    rd, wr = 2.0 * fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
+    out[k] = {"launches": cnt[k], "read_GB": round(rd / 1e9, 3), "written_GB": round(wr / 1e9, 3), "device_ms": round(dur.get(k, 0.0) * 1e3, 2),
+              "TB_per_s": round((rd + wr) / dur[k] / 1e12, 2) if dur.get(k) else None}
+json.dump({"note": "sums over one tools/gc_scaling.py 1024 1 run (5 factorisations, 11 solves); FETCH_SIZE doubled per MI355X_MICROARCH.md",
+           "kernels": out}, sys.stdout, indent=1)
+print()
