@@ -25,7 +25,10 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("-N", type=int, default=64)
     ap.add_argument("--disk", type=float, default=0.0, help="mesh size of a unit-disk Delaunay mesh (the reference's domain)")
-    ap.add_argument("-f", "--infile", type=pathlib.Path, default=None, help="gmsh .msh or inline-data .xdmf file")
+    ap.add_argument("-f", "--infile", "-P", "--path", dest="infile", type=pathlib.Path, default=None,
+                    help="gmsh .msh or inline-data .xdmf file (-P / --path: the reference's flag, compare_all.py:24-31)")
+    ap.add_argument("-O", "--results", dest="result_dir", type=pathlib.Path, default=None,
+                    help="directory for the solutions of the five solvers as VTU files (the reference writes them with VTXWriter, :32-39)")
     ap.add_argument("--max_iter", type=int, default=500)  # compare_all.py:32
     ap.add_argument("--tol", type=float, default=1e-4)  # compare_all.py:31
     ap.add_argument("--first-order-max-iter", type=int, default=20000)
@@ -47,6 +50,12 @@ def main():
     u_vi, it_vi = vi_newton_solver(S, M @ f, bounds[0], bounds[1], coords=coords)
     n = mesh.num_vertices
     print(f"vertices {n}, smallest |u_PG(P1) - u_VI|_inf = {np.abs(u1.x.array[:n] - u_vi).max():.2e}, |u_TR - u_VI|_inf = {np.abs(x_g - u_vi).max():.2e}")
+    if a.result_dir is not None:
+        a.result_dir.mkdir(parents=True, exist_ok=True)
+        fields = {"galahad": x_g, "llvp_first_order": u1.x.array[:n], "ipopt_slot_first_order_method": x_f, "snes": u_vi}
+        for nm, v in fields.items():
+            io.write_vtu(a.result_dir / f"{nm}.vtu", mesh.geometry, mesh.cells, {nm: np.asarray(v)[:n]})
+        io.write_vtu(a.result_dir / "llvp_second_order_at_vertices.vtu", mesh.geometry, mesh.cells, {"llvp_second_order": u2.x.array[:n]})
     name = a.infile or (f"disk h={a.disk}" if a.disk > 0 else f"square N={a.N}")
     print(f"{name} trust-region (projected Newton, GPU LU) iterations: {it_g}")
     print(f"{name} llvp iterations: (P=1) {it_p1}")

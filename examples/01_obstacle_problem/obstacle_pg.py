@@ -18,7 +18,7 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="Run examples from paper",
                                      formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument("-N", dest="N", type=int, default=64, help="cells per side of the square mesh")
-    parser.add_argument("--path", "-f", dest="filename", type=Path, default=None,
+    parser.add_argument("--file-path", "--path", "-f", dest="filename", type=Path, default=None,
                         help="gmsh MSH (2.2 / 4.1 ASCII) file with a triangle mesh - the reference's -f takes the XDMF file its "
                              "gmsh script writes (obstacle_pg.py:276-280); HDF5 is not available offline")
     parser.add_argument("--disk", dest="disk_h", type=float, default=0.0,
