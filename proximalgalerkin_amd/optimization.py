@@ -194,6 +194,16 @@ def galahad_solver(problem, x_init, bounds, log_level: int = 1, use_hessian: boo
                       **kw)
 
 
+def ipopt_solver(problem, x_init, bounds, log_level: int = 5, max_iter: int = 100, tol: float = 1e-6, activate_hessian: bool = True, **kw):
+    """The call of lvpp.optimization.ipopt_solver (src/lvpp/optimization.py:115-166: same arguments, returns x only; the iteration
+    count is left in `problem.total_iteration_count`, which is where the reference's callers read it, compare_all.py:100-108).  The
+    bound-constrained problem is solved by `trb_solver`: projected Newton with `activate_hessian`, projected gradient without - the
+    first-order method the reference compares against is IPOPT with its limited-memory Hessian approximation."""
+    x, _ = trb_solver(problem, x_init, bounds, log_level=1 if log_level > 5 else 0, use_hessian=activate_hessian, max_iter=max_iter,
+                      tol=tol, **kw)
+    return x
+
+
 def vi_newton_solver(S, b, lower, upper=None, x_init=None, max_it: int = 1000, c: float = 1.0, coords=None, device: int = 0,
                      monitor: bool = False):
     """Variational inequality  u >= lower,  S u - b >= 0,  (u - lower)^T (S u - b) = 0  (+ fixed dofs where lower == upper) by the

@@ -54,6 +54,20 @@ def test_trust_region_slot_matches_the_cpu_twin_and_the_vi_solution(require_gpu,
     assert np.abs(x - u).max() <= 1e-8  # two methods, one discrete problem
 
 
+def test_ipopt_slot_has_the_reference_call_shape(require_gpu):
+    """lvpp.optimization.ipopt_solver(problem, x_init, bounds, log_level, max_iter, tol, activate_hessian) -> x, the iteration count
+    read from problem.total_iteration_count (compare_all.py:100-135): same solution as the trust-region slot."""
+    from proximalgalerkin_amd.optimization import galahad_solver, ipopt_solver
+
+    mesh, S, M, f, (lo, up), coords, problem = _setup(24)
+    x = ipopt_solver(problem, np.zeros(len(f)), (lo, up), log_level=0, max_iter=100, tol=1e-10, activate_hessian=True, coords=coords)
+    it = problem.total_iteration_count
+    xg, itg = galahad_solver(problem, np.zeros(len(f)), (lo, up), log_level=0, tol=1e-10, coords=coords)
+    assert isinstance(x, np.ndarray) and it == itg and np.array_equal(x, xg)
+    x1 = ipopt_solver(problem, np.zeros(len(f)), (lo, up), log_level=0, max_iter=20000, tol=1e-5, activate_hessian=False)
+    assert problem.total_iteration_count > it and np.abs(x1 - x).max() < 1e-3  # first-order method: many more iterations, same minimiser
+
+
 def test_iteration_table_and_agreement_with_proximal_galerkin(require_gpu):
     """compare_all.py's experiment on one mesh: every solver converges, the second-order methods in a handful of iterations, and
     the proximal-Galerkin solution (quadrature of exp(psi), a different discrete constraint) agrees with the VI solution to
