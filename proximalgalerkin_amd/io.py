@@ -222,6 +222,20 @@ def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     return mesh, MeshTags(tagged_facets)
 
 
+def write_xdmf_mesh(path, mesh, name: str = "mesh"):
+    """XDMFFile.write_mesh (generate_mesh_gmsh.py:41-43) for a triangular fem.Mesh, inline (Format="XML") data items - the encoding
+    `read_xdmf` / `read_mesh` accept."""
+    path = Path(path)
+    p, t = np.asarray(mesh.geometry), np.asarray(mesh.cells)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n<Grid Name="%s" GridType="Uniform">\n' % name)
+        f.write('<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n<DataItem Dimensions="%d 3" NumberType="Int" '
+                'Format="XML">\n%s\n</DataItem></Topology>\n' % (len(t), len(t), "\n".join(" ".join(map(str, c)) for c in t)))
+        f.write('<Geometry GeometryType="XY"><DataItem Dimensions="%d 2" Format="XML">\n%s\n</DataItem></Geometry>\n</Grid>\n</Domain></Xdmf>\n'
+                % (len(p), "\n".join("%.17g %.17g" % tuple(x) for x in p)))
+
+
 def write_xdmf_tet(path, mesh, facet_tags, tags=None, name: str = "mesh", tags_name: str = "facet_tags"):
     """XDMFFile.write_mesh + write_meshtags of `examples/02_signorini/generate_mesh.py:13-17` for a TetMesh and its MeshTags, with
     inline (Format="XML") data items - the encoding `read_xdmf` accepts (dolfinx: `XDMFFile(..., encoding=XDMFFile.Encoding.ASCII)`)."""

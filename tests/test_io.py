@@ -144,3 +144,27 @@ def test_hdf5_backed_xdmf_is_refused_with_instructions(tmp_path):
         assert "Encoding.ASCII" in str(e)
     else:
         raise AssertionError("an HDF5-backed file must not be read silently")
+
+
+def test_generate_disk_writes_the_reference_named_xdmf_files(tmp_path):
+    """examples/01_obstacle_problem/generate_mesh_gmsh.py: `generate_disk(filename, res, order, refinement_level)` writes
+    `<stem>_<level>.xdmf` (the reference's naming, generate_mesh_gmsh.py:40), every refinement level halves the mesh size, and the
+    file reads back as the mesh `fem.create_disk` makes (inline-data XDMF through io.write_xdmf_mesh / io.read_mesh)."""
+    import importlib.util
+    import pathlib
+
+    from proximalgalerkin_amd import fem, io
+
+    src = pathlib.Path(__file__).resolve().parents[1] / "examples" / "01_obstacle_problem" / "generate_mesh_gmsh.py"
+    spec = importlib.util.spec_from_file_location("generate_mesh_gmsh", src)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sizes = []
+    for level in (0, 1):
+        out = mod.generate_disk(tmp_path / "meshes" / "disk.xdmf", res=0.4, order=2, refinement_level=level)
+        assert out.name == f"disk_{level}.xdmf" and out.exists()
+        m = io.read_mesh(out)
+        ref = fem.create_disk(0.4 / 2**level)
+        assert np.array_equal(m.cells, ref.cells) and np.abs(m.geometry - ref.geometry).max() == 0.0
+        sizes.append(m.num_cells)
+    assert 3.0 < sizes[1] / sizes[0] < 5.0  # h halves: about four times the cells
