@@ -29,7 +29,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("-N", type=int, default=64)
     ap.add_argument("--disk", type=float, default=0.0)
-    ap.add_argument("-f", "--infile", type=pathlib.Path, default=None)
+    ap.add_argument("-f", "--infile", "-P", "--path", dest="infile", type=pathlib.Path, default=None,
+                    help="mesh file (-P / --path: the reference's flag, obstacle_snes.py:26-33)")
     a = ap.parse_args()
     mesh = io.read_mesh(a.infile) if a.infile else fem.create_disk(a.disk) if a.disk > 0 else fem.create_rectangle(
         ((-1.0, -1.0), (1.0, 1.0)), (a.N, a.N))
