@@ -63,37 +63,53 @@ def extrapolate(v_measured, n_measured, n_workload, ladder, size_key="N"):
                       f"measurement at {size_key} = {n_measured}"}
 
 
-def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 25.0):
-    """Oracle (numpy assembly + SuperLU exact Newton, 1 thread) timed on this host: the SAME LVPP run at a
-    reduced mesh size n_sample, cut off after ~budget_s of CPU work.  Timed region = the loop of
-    obstacle_pg.py:173-227 (residual + Jacobian assembly, factorisation, solves, observables)."""
-    import scipy.sparse.linalg as spla
+def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads: int = 1):
+    """Oracle (numpy assembly + exact Newton with the nested-dissection multifrontal LU of oracle/nd_lu.py - the ordering class and
+    the BLAS-3 structure a CPU user gets from `pc_type lu` / MUMPS, obstacle_pg.py:129-131) timed on this host with `threads` BLAS
+    threads (1 = the reference's OMP_NUM_THREADS=1): the SAME LVPP run on an n_sample^2 mesh, stopped after the first Newton step that
+    ends beyond budget_s.  Timed region = the loop of obstacle_pg.py:173-227 (residual + Jacobian assembly, numeric factorisation,
+    solves with iterative refinement, observables); untimed, like the GPU side's setup: mesh / pattern construction and the
+    symbolic analysis of the pattern (done once per mesh by any direct solver)."""
+    from threadpoolctl import threadpool_limits
 
+    from oracle import nd_lu as ND  # CPU baseline leg only
     from oracle import pg_oracle as O  # CPU baseline leg only
 
+    t_setup = time.perf_counter()
     coords, cells = O.create_rectangle(n_sample, n_sample)
     prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(n_sample, n_sample))
     x = np.zeros(2 * prob.n)
     xk = x.copy()
+    ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    ls.nd = ND.NDLU(prob.jacobian(x, 1.0), ls.node_of_dof, ls.node_coords, ls.leaf_nodes)
+    ls.nd.aoff = np.concatenate(([0], np.cumsum(ls.nd.p * ls.nd.p + 2 * ls.nd.p * ls.nd.b)))
+    ls.nd.arena = np.ones(int(ls.nd.aoff[-1]))  # factor storage allocated and touched before the clock starts
+    t_setup = time.perf_counter() - t_setup
     sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
+    ND.MAX_THREADS = threads
     steps, t0 = 0, time.perf_counter()
     over = lambda: time.perf_counter() - t0 > budget_s  # noqa: E731
-    for k in range(settings["max_outer"]):
-        alpha = sched.update(k)
-        F = prob.residual(x, xk, alpha)
-        f0 = np.linalg.norm(F)
-        for _ in range(100):
-            lu = spla.splu(prob.jacobian(x, alpha).tocsc())
-            x = x + lu.solve(-F)
-            steps += 1
+    with threadpool_limits(threads):
+        for k in range(settings["max_outer"]):
+            alpha = sched.update(k)
             F = prob.residual(x, xk, alpha)
-            if np.linalg.norm(F) <= 1e-6 * f0 or over():
+            f0 = np.linalg.norm(F)
+            for _ in range(100):
+                x = x + ls(prob.jacobian(x, alpha), -F)
+                steps += 1
+                F = prob.residual(x, xk, alpha)
+                if np.linalg.norm(F) <= 1e-6 * f0 or over():
+                    break
+            if over() or prob.observables(x, xk, alpha)[4] < settings["tol_exit"]:
                 break
-        if over() or prob.observables(x, xk, alpha)[4] < settings["tol_exit"]:
-            break
-        xk = x.copy()
+            xk = x.copy()
     dt = time.perf_counter() - t0
-    return steps / dt, steps, dt
+    ND.MAX_THREADS = 0
+    detail = {"setup_s_untimed": t_setup, "symbolic_s": ls.nd.symbolic_s, "factor_s": ls.t_factor, "solve_refine_s": ls.t_solve,
+              "assembly_and_rest_s": dt - ls.t_factor - ls.t_solve, "factor_gflops": ls.nd.flops / 1e9,
+              "factor_gflops_per_s": ls.nd.flops * ls.n_factor / max(ls.t_factor, 1e-9) / 1e9,
+              "factor_storage_GB": 8e-9 * ls.nd.factor_entries}
+    return steps / dt, steps, dt, detail
 
 
 def host_info():
@@ -288,6 +304,23 @@ def reduce_over_ranks(dist, dt, newton_total, outer_total, device):
     return float(t.item()), int(c[0].item()), int(c[1].item())
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py --gpus N ...` as a child process; its stdout/stderr pass through, its return code is ours."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher environment, starting " + " ".join(cmd) + "\n")
+    sys.stderr.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,7 +330,8 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=2048, help="cells per side (BASELINE config: 2048)")
     ap.add_argument("--settings", choices=["A", "B"], default="B")
     ap.add_argument("--degree", type=int, choices=[1, 2], default=1, help="Lagrange degree (obstacle_pg.py -p)")
-    ap.add_argument("--cpu-n", type=int, default=256, help="mesh size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=1024, help="mesh size of the bounded CPU-baseline sample (cells per side)")
+    ap.add_argument("--cpu-threads", type=int, default=1, help="BLAS threads of the CPU baseline (1 = the reference's OMP_NUM_THREADS=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solves-only", action="store_true",
                     help="profiling aid: skip the roofline microbenchmarks after the timed solves (their V-cycle replays would "
@@ -311,9 +345,17 @@ def main():
                     help="ex01 = BASELINE metric (config 2); ex06 / ex02 = configs 4 / 5 through the sparse LU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the launcher ourselves, as a CHILD process and before anything in
+        # this process has touched the GPU (never exec), relay its one JSON line and its return code
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to print a line "
+                         f"whose n_gpus would not be what was asked for\n")
+        raise SystemExit(2)
     import torch
 
     dist = None
@@ -520,27 +562,33 @@ def main():
         if prof:
             out["phase_ms"] = prof
         if not args.no_cpu_baseline and world == 1:
-            v, steps, secs = cpu_baseline(args.cpu_n, S)
-            ladder = _ladder("r02_cpu_ladder.json") if args.degree == 1 else None
+            cpu_n = min(args.cpu_n, N)
+            v, steps, secs, detail = cpu_baseline(cpu_n, S, threads=args.cpu_threads)
+            ladder = _ladder("r03_cpu_ladder_nd.json") if args.degree == 1 else None
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "Newton iterations/s",
-                "cores": 1,
+                "cores": args.cpu_threads,
                 "kind": "port",
-                # `value` is MEASURED, here, now - but on the mesh named in `mesh`, not on the benchmarked one: SuperLU on the
-                # 2048^2 saddle point needs hours per Newton step and > 100 GB.  `at_workload` carries it to the benchmarked
-                # mesh with the exponent of the committed ladder and says so.
-                "mesh": f"{args.cpu_n}x{args.cpu_n}",
+                # `value` is MEASURED, here, now, on the mesh named in `mesh`.  When that is smaller than the benchmarked mesh,
+                # `at_workload` carries it there with the exponent of the committed ladder (2-D nested dissection: flops ~ N^3)
+                # and says so; `--cpu-n 2048` measures on the workload itself (about 25 GB of factors, minutes per Newton step).
+                "mesh": f"{cpu_n}x{cpu_n}",
                 "workload_mesh": f"{N}x{N}",
-                "sample": f"{steps} Newton steps ({secs:.1f} s) of the same LVPP run (settings {args.settings}) on a "
-                          f"{args.cpu_n}x{args.cpu_n} mesh: numpy assembly + SuperLU(COLAMD) exact Newton, 1 thread (the "
-                          f"oracle; a stand-in for, not a measurement of, FEniCSx+MUMPS)",
+                "sample": f"{steps} Newton step(s) ({secs:.1f} s) of the same LVPP run (settings {args.settings}) on a "
+                          f"{cpu_n}x{cpu_n} mesh: numpy assembly + exact Newton with a nested-dissection multifrontal LU on "
+                          f"LAPACK/BLAS (oracle/nd_lu.py), {args.cpu_threads} thread(s); symbolic analysis and mesh setup untimed "
+                          f"(as on the GPU side).  The oracle - a stand-in for, not a measurement of, FEniCSx+MUMPS",
+                "detail": detail,
                 **host_info(),
             }
-            ex = extrapolate(v, args.cpu_n, N, ladder)
-            if ex:
-                ex["gpu_over_cpu"] = out["value"] / ex["value"]
-                out["cpu_baseline"]["at_workload"] = ex
+            if cpu_n != N:
+                ex = extrapolate(v, cpu_n, N, ladder)
+                if ex:
+                    ex["gpu_over_cpu"] = out["value"] / ex["value"]
+                    out["cpu_baseline"]["at_workload"] = ex
+            else:
+                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / v
     problem.close()
     if comm is not None:
         comm.free()

@@ -1184,10 +1184,27 @@ extern "C" int pgx_set_alpha(pgx_handle* h, double a) {
 // ------------------------------------------------------------------------------------------------
 // 2-norm of a device vector.  Sharded handles pass OWNED-COMPACT vectors (len = 2 * own_cnt): the squared norms of
 // the ranks are summed by one all-reduce before the square root.
+// Replicas of a distributed-LU handle (pgx_create_lu_dist) compute every steering scalar redundantly - norms, Gram-Schmidt
+// coefficients, observables.  The kernels are deterministic, so the copies agree bitwise today; but a rank that ever took a
+// different branch would issue different collectives and RCCL has no timeout.  So the few doubles that DECIDE control flow are
+// always taken from rank 0 (one tiny all-reduce of "mine if rank 0 else zero"); only the O(n) residual comparison stays behind
+// PGX_CHECK_REPLICAS.  No-op on ordinary and on sharded handles.
+static int replica_agree(pgx_handle* h, double* dev, size_t n) {
+  if (!h->lu_comm || h->lu_comm->size == 1) return PGX_OK;
+  if (h->lu_comm->rank != 0) HIPCHK(hipMemsetAsync(dev, 0, n * sizeof(double), h->st));
+  const int rc = h->lu_comm->allreduce(h->st, dev, n);
+  if (rc) h->err = "replica agreement: " + h->lu_comm->err;
+  return rc;
+}
+
 static int dev_norm(pgx_handle* h, const double* v, double* out, size_t len = 0) {
   pgxk_multidot(h->st, len ? len : 2 * (size_t)h->nd, 1, v, 0, v, h->partials, h->d_small);
   if (h->dist.on) {
     const int rc = allreduce_dev(h, h->d_small, 1);
+    if (rc) return rc;
+  }
+  {
+    const int rc = replica_agree(h, h->d_small, 1);
     if (rc) return rc;
   }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -1748,6 +1765,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
           // lean second pass: w' = w - V h1 and |w'|^2; V^T w' (for the second projection) only if the test below asks for it
           pgxk_multiaxpy_norm(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials, d_h2 + j + 1);
           if (dist && (rc = allreduce_dev(h, d_h2 + j + 1, 1))) return rc;
+          if ((rc = replica_agree(h, h->d_small, 2 * (size_t)(m + 2)))) return rc;
           HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
           HIPCHK(hipStreamSynchronize(h->st));
           for (int i = 0; i <= j; ++i) h1h1 += h->h_small[i] * h->h_small[i];
@@ -1758,6 +1776,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
           if (second) {
             pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h2);
             if (dist && (rc = allreduce_dev(h, d_h2, j + 1))) return rc;
+            if ((rc = replica_agree(h, d_h2, (size_t)(j + 1)))) return rc;
             HIPCHK(hipMemcpyAsync(h->h_small + (m + 2), d_h2, sizeof(double) * (j + 1), hipMemcpyDeviceToHost, h->st));
             HIPCHK(hipStreamSynchronize(h->st));
           }
@@ -1769,6 +1788,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
             pgxk_multidot(h->st, nk, j + 2, h->V, nk, wj, h->partials, d_h2);
           }
           if (dist && (rc = allreduce_dev(h, d_h2, j + 2))) return rc;
+          if ((rc = replica_agree(h, h->d_small, 2 * (size_t)(m + 2)))) return rc;
           HIPCHK(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * (2 * (m + 2)), hipMemcpyDeviceToHost, h->st));
           HIPCHK(hipStreamSynchronize(h->st));
           wp2 = h->h_small[(m + 2) + j + 1];
@@ -2052,7 +2072,8 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
     }
   }
   {
-    const int rcb = replica_check(h, h->d_out6, 6, "the observables");  // fixed-shape reductions: identical on every replica
+    int rcb = replica_check(h, h->d_out6, 6, "the observables");  // fixed-shape reductions: identical on every replica
+    if (!rcb) rcb = replica_agree(h, h->d_out6, 6);                // the stopping test of the proximal loop reads these
     if (rcb) return rcb;
   }
   HIPCHK(hipMemcpyAsync(h->h_small, h->d_out6, sizeof(double) * 6, hipMemcpyDeviceToHost, h->st));

@@ -59,3 +59,17 @@ def test_bench_cli_parses_and_flags_survive_torchrun_abbreviation_rules():
     for o in ours:
         clashes = [t for t in theirs if t.startswith(o)]
         assert not clashes, (o, clashes)
+
+
+def test_bench_refuses_a_world_size_that_is_not_what_gpus_asks_for():
+    """bench.py --gpus 4 under a launcher that started 2 ranks would print n_gpus = 2 for a run the driver files under 4: it must
+    exit non-zero instead (before any GPU or torch work - this runs on the CPU-only container)."""
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

@@ -79,3 +79,18 @@ def test_a_dead_rank_stops_the_job_instead_of_hanging_it(require_gpu):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launches_itself_when_asked_for_more_than_one_gpu(require_gpu):
+    """`python bench.py --gpus 2` WITHOUT a launcher must not silently measure one GPU: it starts torch.distributed.run as a child
+    (before touching the GPU, never exec) and relays the one JSON line; n_gpus is what was asked for."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_COMM="shm", PGX_COMM_TIMEOUT="120")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--cells", "256", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--watchdog", "500"], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
