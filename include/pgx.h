@@ -165,6 +165,11 @@ int pgx_spmv_select(pgx_handle* h, int kind, int* active);
  * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,
  * the new iterate (2) written.  PGX_ESTATE on meshes without a grid hierarchy. */
 int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+/* Measurement aid: average device time (HIP events on the handle's stream, launches back to back) of the part of one V(nu,nu)
+ * cycle that starts on multigrid level `level` (0 = the whole preconditioner application; -1 = the fused tail launch only) with the
+ * default nu and damping.  *n_level receives the vertex count of that level.  bench.py reports the "coarse part" (levels of at most
+ * 513^2 vertices) with it.  Same preconditions as pgx_smoother_bench. */
+int pgx_vcycle_bench(pgx_handle* h, int level, int reps, double* avg_ms, int* n_level);
 
 /* One nonlinear solve from device `sol` with proximal centre `sol_k`; on reason>0 `sol` is replaced. */
 int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its);

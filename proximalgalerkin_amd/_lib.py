@@ -201,6 +201,7 @@ SYMBOLS = [
     ("pgx_spmv", C.c_int, [_H, c_double_p, c_double_p]),
     ("pgx_spmv_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
     ("pgx_smoother_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_vcycle_bench", C.c_int, [_H, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     ("pgx_spmv_select", C.c_int, [_H, C.c_int, C.POINTER(C.c_int)]),
     ("pgx_comm_counts", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int]),
     ("pgx_newton_solve", C.c_int,

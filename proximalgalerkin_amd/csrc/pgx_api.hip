@@ -568,6 +568,7 @@ static void setup_tail(pgx_handle* h, int first) {
         T.sc.M[s] = L.Mc[s];
       }
       T.sc.uniform = L.uniform;
+      T.interior_free = L.interior_free;
       T.mask = L.mask;
       T.xu = L.xu;
       T.xp = L.xp;
@@ -791,6 +792,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   pgx_handle* h = new pgx_handle();
   if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
   if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
+  if (const char* e = getenv("PGX_TAIL2")) pgxk_mg_tail_select(atoi(e));
   if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
   if (const char* e = getenv("PGX_FUSED_K3")) h->fused_k3 = atoi(e);
   if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
@@ -1970,6 +1972,35 @@ extern "C" int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, doubl
   HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
   *avg_ms = (double)ms / reps;
   if (bytes) *bytes = 8.0 * (4.0 * n + 2.0 * n + 2.0 * n + 2.0 * C.n + 2.0 * n);
+  return PGX_OK;
+}
+
+extern "C" int pgx_vcycle_bench(pgx_handle* h, int level, int reps, double* avg_ms, int* n_level) {
+  NEED(h);
+  if (reps < 1 || !avg_ms) return PGX_EINVAL;
+  if (!h->jac_valid || !h->structured || h->lev.size() < 2 || h->dist.on || h->degree != 1) {
+    h->err = "pgx_vcycle_bench needs a structured single-GPU P1 handle with a grid hierarchy and a filled Jacobian";
+    return PGX_ESTATE;
+  }
+  if (level < 0) level = h->tail_start > 0 ? h->tail_start : (int)h->lev.size() - 1;
+  if (level >= (int)h->lev.size()) return PGX_EINVAL;
+  pgx_snes_opts od;
+  pgx_default_opts(&od);
+  GridLevel& L = h->lev[level];
+  double *bu = level == 0 ? h->rhs : L.bu, *bp = level == 0 ? h->rhs + L.n : L.bp;
+  double *xu = level == 0 ? h->w : L.xu, *xp = level == 0 ? h->w + L.n : L.xp;
+  pgxk_set(h->st, (size_t)L.n, 1.0, bu);
+  pgxk_set(h->st, (size_t)L.n, 1.0, bp);
+  auto run = [&]() { vcycle(h, level, bu, bp, xu, xp, od.mg_nu, od.mg_omega); };
+  for (int k = 0; k < 3; ++k) run();
+  HIPCHK(hipEventRecord(h->e0, h->st));
+  for (int k = 0; k < reps; ++k) run();
+  HIPCHK(hipEventRecord(h->e1, h->st));
+  HIPCHK(hipEventSynchronize(h->e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
+  *avg_ms = (double)ms / reps;
+  if (n_level) *n_level = L.n;
   return PGX_OK;
 }
 

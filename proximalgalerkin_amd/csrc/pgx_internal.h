@@ -72,6 +72,8 @@ struct StConst {
 #define PGX_TAIL_VERTS 17000  // 129x129 vertices and below
 struct TailLevel {
   int nx, ny, n;
+  int interior_free;  // GridLevel::interior_free
+  double ic[8];       // k_mg_tail2: alpha K (4) and M (4) interior stencils with the symmetric link pairs summed, set per launch
   const double *K, *M;
   const dsten_t* Dh;
   StConst sc;
@@ -84,6 +86,7 @@ struct TailArgs {
   TailLevel L[PGX_TAIL_MAX];
 };
 void pgxk_mg_tail(hipStream_t st, const TailArgs& A);
+void pgxk_mg_tail_select(int v);  // 1 (default): k_mg_tail2; 0: the round-2 kernels
 
 // ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
 // stash: [4 * nc] scratch (element contributions parked at cell * 4 + a, summed per vertex through the v2c lists: no atomics)

@@ -2701,7 +2701,440 @@ __global__ void __launch_bounds__(512) k_mg_tail_lds(TailArgs A) {
 #undef TL
 }
 
-void pgxk_mg_tail(hipStream_t st, const TailArgs& A) {
+// ------------------------------------------------------------------------------------------------
+// k_mg_tail2 (round 3): the same V-cycle of the tail levels, restructured around what the trace of k_mg_tail_lds showed - 91 us
+// per call for ~15 us of arithmetic: nine level visits that each start with a round trip to L2 for the level's stencil
+// coefficients (7 D links, mask flags, boundary K / M rows: ~2 us per visit), three vertices per thread on the largest level and
+// eight scalar LDS arrays.  Here
+//  * EVERYTHING the cycle reads is staged into LDS by one batch of global loads at the start (right-hand side of the first
+//    level; D half-stencils, Dirichlet flags and the K / M rows of the boundary vertices of every level): one memory latency
+//    per launch instead of one per level visit;
+//  * 1024 threads, at most two vertices per thread, so a sweep of the 33^2 level is one pass;
+//  * (u, psi) interleaved as double2 (half the LDS instructions) and the residual written into the idle half of the solution
+//    ping-pong pair, which frees the LDS for the staged coefficients.
+// Same arithmetic per vertex as k_mg_tail_lds (st_rows / st_jacobi).  Requires uniform interior stencils on every tail level
+// (the host checks; otherwise the kernels above run).
+struct Tail2Off {
+  int x0, x1, b, d, km, mk;  // byte offsets of a level's arrays in the dynamic LDS
+  int vbase;                 // first index of the level in the concatenated vertex list of all tail levels
+};
+__host__ __device__ inline int tail2_nbnd(int nx, int ny) { return 2 * (nx + 1) + 2 * (ny - 1); }
+__host__ __device__ inline size_t tail2_layout(const TailArgs& A, Tail2Off* off) {
+  size_t acc = 0;
+  int vb = 0;
+  for (int l = 0; l < A.nlev; ++l) {
+    const size_t n = (size_t)A.L[l].n;
+    Tail2Off o;
+    o.x0 = (int)acc;
+    acc += 16 * n;
+    o.x1 = (int)acc;
+    acc += 16 * n;
+    o.b = (int)acc;
+    acc += 16 * n;
+    o.d = (int)acc;
+    acc += 32 * n;
+    o.km = (int)acc;
+    acc += (size_t)14 * 8 * tail2_nbnd(A.L[l].nx, A.L[l].ny);
+    o.mk = (int)acc;
+    acc += (n + 15) & ~(size_t)15;
+    o.vbase = vb;
+    vb += (int)n;
+    if (off) off[l] = o;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ int tail2_bidx(int i, int j, int nx, int ny) {
+  return j == 0 ? i : (j == ny ? (nx + 1) + i : (i == 0 ? 2 * (nx + 1) + (j - 1) : 2 * (nx + 1) + (ny - 1) + (j - 1)));
+}
+__device__ __forceinline__ void tail2_bvertex(int t, int nx, int ny, int& i, int& j) {
+  if (t < nx + 1) {
+    i = t;
+    j = 0;
+  } else if (t < 2 * (nx + 1)) {
+    i = t - (nx + 1);
+    j = ny;
+  } else if (t < 2 * (nx + 1) + (ny - 1)) {
+    i = 0;
+    j = t - 2 * (nx + 1) + 1;
+  } else {
+    i = nx;
+    j = t - 2 * (nx + 1) - (ny - 1) + 1;
+  }
+}
+
+__global__ void __launch_bounds__(512) k_mg_tail2(TailArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+  constexpr int NT = 512, SV = 3, IV = 2;  // 8 waves: 256 VGPRs per thread keep every coefficient of a level visit in registers
+  const int tid = threadIdx.x;
+  // level tables live in LDS: a private array indexed by the (runtime) level would sit in scratch memory
+  __shared__ Tail2Off off[PGX_TAIL_MAX];
+  __shared__ int cur[PGX_TAIL_MAX];
+  if (tid == 0) tail2_layout(A, off);
+  __syncthreads();
+  // ---- stage: ONE batch of global loads.  The vertices of all levels form one list (1493 entries for 33^2 ... 3^2); a thread
+  // takes entries tid, tid + 512, tid + 1024 and has every load of both in flight before the first LDS store (a loop over the levels
+  // would pay one memory latency per level: 10 of the first version's 63 us).
+  {
+    int sl[SV], sv[SV];
+    double d[SV][4];
+    uint8_t m[SV] = {};
+    int total = 0;
+    for (int l = 0; l < A.nlev; ++l) total += A.L[l].n;
+#pragma unroll
+    for (int k = 0; k < SV; ++k) {
+      const int e = tid + k * NT;
+      sl[k] = -1;
+      sv[k] = 0;
+      if (e < total) {
+        int l = 0;
+        while (l + 1 < A.nlev && e >= off[l + 1].vbase) ++l;
+        sl[k] = l;
+        sv[k] = e - off[l].vbase;
+        const TailLevel& L = A.L[l];
+        const size_t n = (size_t)L.n;
+        d[k][0] = L.Dh[sv[k]];
+        d[k][1] = L.Dh[n + sv[k]];
+        d[k][2] = L.Dh[2 * n + sv[k]];
+        d[k][3] = L.Dh[3 * n + sv[k]];
+        m[k] = L.mask[sv[k]];
+      }
+    }
+    // boundary rows: entry e of the concatenated boundary lists, one per thread (248 entries in all)
+    int btotal = 0;
+    for (int l = 0; l < A.nlev; ++l) btotal += tail2_nbnd(A.L[l].nx, A.L[l].ny);
+    double kq[14];
+    int bl = -1, bt = 0;
+    if (tid < btotal) {
+      int l = 0, base = 0;
+      while (l + 1 < A.nlev && tid >= base + tail2_nbnd(A.L[l].nx, A.L[l].ny)) {
+        base += tail2_nbnd(A.L[l].nx, A.L[l].ny);
+        ++l;
+      }
+      bl = l;
+      bt = tid - base;
+      const TailLevel& L = A.L[l];
+      int i, j;
+      tail2_bvertex(bt, L.nx, L.ny, i, j);
+      const size_t v = (size_t)j * (L.nx + 1) + i, n = (size_t)L.n;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        kq[s] = L.K[s * n + v];
+        kq[7 + s] = L.M[s * n + v];
+      }
+    }
+    double2 b0[SV];
+#pragma unroll
+    for (int k = 0; k < SV; ++k) {
+      const int v = tid + k * NT;
+      if (v < A.L[0].n) b0[k] = make_double2(A.L[0].bu[v], A.L[0].bp[v]);
+    }
+    // ---- all loads are in flight; now the stores ----
+#pragma unroll
+    for (int k = 0; k < SV; ++k)
+      if (sl[k] >= 0) {
+        const int l = sl[k], n = A.L[l].n, v = sv[k];
+        double* D = (double*)(lds2 + off[l].d);
+        D[v] = d[k][0];
+        D[n + v] = d[k][1];
+        D[2 * n + v] = d[k][2];
+        D[3 * n + v] = d[k][3];
+        (lds2 + off[l].mk)[v] = m[k];
+      }
+    if (bl >= 0) {
+      double* q = (double*)(lds2 + off[bl].km) + 14 * bt;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        q[s] = A.alpha * kq[s];  // premultiplied
+        q[7 + s] = kq[7 + s];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SV; ++k) {
+      const int v = tid + k * NT;
+      if (v < A.L[0].n) ((double2*)(lds2 + off[0].b))[v] = b0[k];
+    }
+    // (host: every level's boundary list and the list of all levels' boundary vertices fit 1024 threads)
+  }
+  __syncthreads();
+
+  // Vertex -> thread mapping of a level visit: thread t owns INTERIOR vertices t and t + 512 (uniform K / M stencils, pair-summed
+  // and premultiplied on the host: scalar registers; the 7 D links and the 2x2 Jacobi block of each sit in vector registers), the
+  // LAST 2(nx+1)+2(ny-1) threads own the BOUNDARY vertices (their whole rows in registers as well) - other waves than the
+  // interior ones wherever the level is small, so the two instruction streams overlap.  The PMC profile of the first
+  // version (profiles/r03_tail_pmc.json) showed the kernel bound by the dependent instruction stream of the one to four waves
+  // that work on the small levels (76 % of all wave cycles waiting at barriers), hence: the damped inverse of the 2x2 vertex
+  // block is formed ONCE per level visit (four multiply-adds per sweep instead of a reciprocal and ~25 instructions) and the row
+  // sums run in independent chains.
+  // Dirichlet columns need no masking here: on every level of the tail b_u is 0 on Dirichlet rows (the restriction masks it) and
+  // the cycle starts from 0, so u stays exactly 0 there (the host requires `interior_free` levels, i.e. Dirichlet dofs on the
+  // boundary only, whose interpolation parents are Dirichlet as well).
+  double cd[IV][7];  // D links of the thread's (up to two) interior vertices
+  double ig[IV][4];  // omega * inverse of the vertex block [[aK0, M0], [M0, -D0]] (identity row for a Dirichlet u)
+  int irow[IV] = {0, 0}, iv[IV] = {-1, -1};
+  double bg[4], ck[7], cm[7], bd[7];
+  unsigned bok = 0;  // bit s: link s stays inside the grid
+  int brow = 0, bv = -1, bt = 0;
+  int xoff[2] = {0, 0}, boff = 0, doff = 0, kmoff = 0;  // LDS offsets of the current level (registers, not the LDS table)
+  auto jac_block = [&](double a, double bm, double dd, int rowbc, double g[4]) {
+    double om_u = A.omega;
+    if (rowbc) {
+      a = 1.0;
+      bm = 0.0;
+      om_u = 1.0;
+    }
+    const double det = -a * dd - bm * bm;
+    g[0] = g[1] = g[2] = g[3] = 0.0;
+    if (det != 0.0) {
+      const double r = 1.0 / det;
+      g[0] = om_u * (-dd * r);
+      g[1] = om_u * (-bm * r);
+      g[2] = A.omega * (-bm * r);
+      g[3] = A.omega * (a * r);
+    } else if (rowbc) {
+      g[0] = 1.0;
+    }
+  };
+  auto load_level = [&](int l) {
+    const TailLevel& L = A.L[l];
+    const int nx = L.nx, ny = L.ny, n = L.n, sx = nx + 1;
+    xoff[0] = off[l].x0;
+    xoff[1] = off[l].x1;
+    boff = off[l].b;
+    doff = off[l].d;
+    kmoff = off[l].km;
+    const double* D = (const double*)(lds2 + doff);
+    const uint8_t* mk = lds2 + off[l].mk;
+    bv = -1;
+    const int nint = (nx > 1 && ny > 1) ? (nx - 1) * (ny - 1) : 0;
+    const int nb = tail2_nbnd(nx, ny);
+#pragma unroll
+    for (int k = 0; k < IV; ++k) {
+      iv[k] = -1;
+      const int t = tid + k * NT;
+      if (t < nint) {
+        const int i = 1 + t % (nx - 1), j = 1 + t / (nx - 1);
+        const int v = j * sx + i;
+        iv[k] = v;
+        cd[k][0] = D[v];
+        cd[k][1] = D[n + v];
+        cd[k][2] = D[n + v - 1];
+        cd[k][3] = D[2 * n + v];
+        cd[k][4] = D[2 * n + v - sx];
+        cd[k][5] = D[3 * n + v];
+        cd[k][6] = D[3 * n + v - sx - 1];
+        irow[k] = mk[v];
+        jac_block(L.ic[0], L.ic[4], cd[k][0], irow[k], ig[k]);
+      }
+    }
+    if (tid >= NT - nb) {
+      int i, j;
+      const int t = tid - (NT - nb);
+      tail2_bvertex(t, nx, ny, i, j);
+      const int v = j * sx + i;
+      bv = v;
+      bt = t;
+      bok = 1u | (i < nx ? 2u : 0u) | (i > 0 ? 4u : 0u) | (j < ny ? 8u : 0u) | (j > 0 ? 16u : 0u) | ((i < nx && j < ny) ? 32u : 0u) |
+            ((i > 0 && j > 0) ? 64u : 0u);
+      brow = mk[v];
+      const double* q = (const double*)(lds2 + kmoff) + 14 * t;
+      jac_block(q[0], q[7], D[v], brow, bg);
+      const int dsl[7] = {v, n + v, n + v - 1, 2 * n + v, 2 * n + v - sx, 3 * n + v, 3 * n + v - sx - 1};
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        ck[s] = q[s];
+        cm[s] = q[7 + s];
+        bd[s] = ((bok >> s) & 1u) ? D[dsl[s]] : 0.0;
+      }
+    }
+  };
+  // one vertex: mode 0 = Jacobi update (from_zero: iterate taken as 0), mode 1 = residual
+  auto interior_vertex = [&](int k, const TailLevel& L, int mode, bool from_zero, const double2* X, const double2* B, double2* Y) {
+    const int v = iv[k], sx = L.nx + 1;
+    double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+    if (!from_zero) {
+      const double2 x0 = X[v], x1 = X[v + 1], x2 = X[v - 1], x3 = X[v + sx], x4 = X[v - sx], x5 = X[v + sx + 1], x6 = X[v - sx - 1];
+      const double u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+      const double p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+      au = (L.ic[0] * x0.x + L.ic[1] * u12) + (L.ic[2] * u34 + L.ic[3] * u56) +
+           ((L.ic[4] * x0.y + L.ic[5] * p12) + (L.ic[6] * p34 + L.ic[7] * p56));
+      ap = ((L.ic[4] * x0.x + L.ic[5] * u12) + (L.ic[6] * u34 + L.ic[7] * u56)) -
+           (((cd[k][0] * x0.y + cd[k][1] * x1.y) + (cd[k][2] * x2.y + cd[k][3] * x3.y)) +
+            ((cd[k][4] * x4.y + cd[k][5] * x5.y) + cd[k][6] * x6.y));
+      xur = x0.x;
+      xpr = x0.y;
+    }
+    const double2 bq = B[v];
+    if (irow[k]) au = xur;
+    const double su = bq.x - au, sp = bq.y - ap;
+    if (mode == 1) {
+      Y[v] = make_double2(su, sp);
+      return;
+    }
+    Y[v] = make_double2(xur + fma(ig[k][0], su, ig[k][1] * sp), xpr + fma(ig[k][2], su, ig[k][3] * sp));
+  };
+  auto boundary_vertex = [&](const TailLevel& L, int mode, bool from_zero, const double2* X, const double2* B, double2* Y) {
+    const int v = bv, sx = L.nx + 1;
+    const int o7[7] = {0, 1, -1, sx, -sx, sx + 1, -sx - 1};
+    double au = 0.0, ap = 0.0, xur = 0.0, xpr = 0.0;
+    if (!from_zero) {
+      double2 t[7];
+#pragma unroll
+      for (int s = 0; s < 7; ++s) t[s] = X[((bok >> s) & 1u) ? v + o7[s] : v];
+      double au1 = 0.0, ap1 = 0.0;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {  // links that leave the grid carry zero coefficients
+        if (s & 1) {
+          au1 = fma(ck[s], t[s].x, fma(cm[s], t[s].y, au1));
+          ap1 = fma(cm[s], t[s].x, fma(-bd[s], t[s].y, ap1));
+        } else {
+          au = fma(ck[s], t[s].x, fma(cm[s], t[s].y, au));
+          ap = fma(cm[s], t[s].x, fma(-bd[s], t[s].y, ap));
+        }
+      }
+      au += au1;
+      ap += ap1;
+      xur = t[0].x;
+      xpr = t[0].y;
+    }
+    const double2 bq = B[v];
+    if (brow) au = xur;
+    const double su = bq.x - au, sp = bq.y - ap;
+    if (mode == 1) {
+      Y[v] = make_double2(su, sp);
+      return;
+    }
+    Y[v] = make_double2(xur + fma(bg[0], su, bg[1] * sp), xpr + fma(bg[2], su, bg[3] * sp));
+  };
+  auto sweeps = [&](int l, int count, bool from_zero, int& buf) {
+    const TailLevel& L = A.L[l];
+    const double2* B = (const double2*)(lds2 + boff);
+    for (int s = 0; s < count; ++s) {
+      const double2* X = (const double2*)(lds2 + xoff[buf]);
+      double2* Y = (double2*)(lds2 + xoff[buf ^ 1]);
+      const bool fz = from_zero && s == 0;
+#pragma unroll
+      for (int k = 0; k < IV; ++k)
+        if (iv[k] >= 0) interior_vertex(k, L, 0, fz, X, B, Y);
+      if (bv >= 0) boundary_vertex(L, 0, fz, X, B, Y);
+      __syncthreads();
+      buf ^= 1;
+    }
+  };
+#define T2X(l, k) ((double2*)(lds2 + ((k) ? off[l].x1 : off[l].x0)))
+#define T2B(l) ((double2*)(lds2 + off[l].b))
+#define T2M(l) ((uint8_t*)(lds2 + off[l].mk))
+  // ---- down leg ----
+  for (int l = 0; l < A.nlev; ++l) {
+    const TailLevel& L = A.L[l];
+    const bool last = (l + 1 == A.nlev);
+    load_level(l);
+    int buf = 0;
+    sweeps(l, last ? A.coarse_sweeps : A.nu, true, buf);
+    if (tid == 0) cur[l] = buf;  // read again on the way up, many barriers later
+    if (!last) {
+      const double2* X = T2X(l, buf);
+      double2* R = T2X(l, buf ^ 1);  // the idle half of the ping-pong pair holds the residual until it is restricted
+      const double2* B = T2B(l);
+#pragma unroll
+      for (int k = 0; k < IV; ++k)
+        if (iv[k] >= 0) interior_vertex(k, L, 1, false, X, B, R);
+      if (bv >= 0) boundary_vertex(L, 1, false, X, B, R);
+      __syncthreads();
+      const TailLevel& C = A.L[l + 1];
+      const int sxc = C.nx + 1, sxf = L.nx + 1;
+      const uint8_t* mkc = T2M(l + 1);
+      double2* Bc = T2B(l + 1);
+      constexpr int OX[7] = {0, 1, -1, 0, 0, 1, -1};
+      constexpr int OY[7] = {0, 0, 0, 1, -1, 1, -1};
+      for (int cv = tid; cv < C.n; cv += NT) {
+        const int I = cv % sxc, J = cv / sxc;
+        double su = 0.0, sp = 0.0;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+          const int ax = 2 * I + OX[o], ay = 2 * J + OY[o];
+          if (ax < 0 || ax > L.nx || ay < 0 || ay > L.ny) continue;
+          const double2 r = R[ay * sxf + ax];
+          const double w = pw(OX[o], OY[o]);
+          su += w * r.x;
+          sp += w * r.y;
+        }
+        Bc[cv] = make_double2(mkc[cv] ? 0.0 : su, sp);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- up leg ----
+  for (int l = A.nlev - 2; l >= 0; --l) {
+    const TailLevel& L = A.L[l];
+    const TailLevel& C = A.L[l + 1];
+    int buf = cur[l];
+    {
+      double2* X = T2X(l, buf);
+      const double2* Xc = T2X(l + 1, cur[l + 1]);
+      const int sxf = L.nx + 1, sxc = C.nx + 1;
+      for (int v = tid; v < L.n; v += NT) {
+        const int i = v % sxf, j = v / sxf;
+        const int i0 = i >> 1, j0 = j >> 1;
+        const double2 a = Xc[j0 * sxc + i0], bq = Xc[(j0 + (j & 1)) * sxc + (i0 + (i & 1))];
+        double2 x = X[v];
+        x.x += 0.5 * (a.x + bq.x);
+        x.y += 0.5 * (a.y + bq.y);
+        X[v] = x;
+      }
+    }
+    load_level(l);
+    __syncthreads();
+    sweeps(l, A.nu, false, buf);
+    if (tid == 0) cur[l] = buf;
+    __syncthreads();
+  }
+  {
+    const double2* X = T2X(0, cur[0]);
+    for (int v = tid; v < A.L[0].n; v += NT) {
+      const double2 x = X[v];
+      A.L[0].xu[v] = x.x;
+      A.L[0].xp[v] = x.y;
+    }
+  }
+#undef T2X
+#undef T2B
+#undef T2M
+}
+
+static int g_tail2 = 1;  // pgx_tuning: 0 = the round-2 kernels (A/B)
+void pgxk_mg_tail_select(int v) { g_tail2 = v; }
+
+void pgxk_mg_tail(hipStream_t st, const TailArgs& A0) {
+  TailArgs A = A0;
+  if (g_tail2) {
+    bool ok = true;  // uniform interior stencils, Dirichlet dofs on the boundary only, every vertex list fits the 512 threads' slots
+    int ntot = 0, nbtot = 0;
+    for (int l = 0; l < A.nlev; ++l) {
+      TailLevel& T = A.L[l];
+      ok = ok && T.sc.uniform && T.interior_free && T.nx >= 1 && T.ny >= 1 && (T.nx - 1) * (T.ny - 1) <= 1024 &&
+           tail2_nbnd(T.nx, T.ny) <= 512;
+      ntot += T.n;
+      nbtot += tail2_nbnd(T.nx, T.ny);
+      // interior stencils of this launch: alpha K and M, symmetric link pairs pre-summed (scalar registers in the kernel)
+      T.ic[0] = A.alpha * T.sc.K[0];
+      T.ic[1] = A.alpha * 0.5 * (T.sc.K[1] + T.sc.K[2]);
+      T.ic[2] = A.alpha * 0.5 * (T.sc.K[3] + T.sc.K[4]);
+      T.ic[3] = A.alpha * 0.5 * (T.sc.K[5] + T.sc.K[6]);
+      T.ic[4] = T.sc.M[0];
+      T.ic[5] = 0.5 * (T.sc.M[1] + T.sc.M[2]);
+      T.ic[6] = 0.5 * (T.sc.M[3] + T.sc.M[4]);
+      T.ic[7] = 0.5 * (T.sc.M[5] + T.sc.M[6]);
+    }
+    ok = ok && ntot <= 3 * 512 && nbtot <= 512;
+    const size_t need = tail2_layout(A, nullptr);
+    if (ok && need <= 159 * 1024) {  // + 300 B of static LDS (level tables) under the 160 KB of a CU
+      if (first_use_on_device(3))
+        hipFuncSetAttribute((const void*)k_mg_tail2, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+      hipLaunchKernelGGL(k_mg_tail2, dim3(1), dim3(512), need, st, A);
+      return;
+    }
+  }
   size_t total = 0;
   for (int l = 0; l < A.nlev; ++l) total += (size_t)8 * A.L[l].n * sizeof(double);
   if (A.L[0].n <= 1536 && total <= 150 * 1024) {

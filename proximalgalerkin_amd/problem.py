@@ -332,6 +332,14 @@ class NonlinearProblem:
                    "pgx_smoother_bench")
         return ms.value, by.value
 
+    def vcycle_bench(self, level, reps=50):
+        """(avg ms, vertices of that level): the part of one V-cycle from multigrid level `level` down and back up, launches back
+        to back (include/pgx.h: pgx_vcycle_bench; level -1 = the fused tail launch)."""
+        ms, nl = C.c_double(0), C.c_int(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_vcycle_bench(self._h, int(level), int(reps), C.byref(ms), C.byref(nl)),
+                   "pgx_vcycle_bench")
+        return ms.value, nl.value
+
     def observables(self):
         """[energy, |complementarity|, feasibility, dual feasibility, H1 increment, latent L2 increment]
         of obstacle_pg.py:145-152,196-201 in one device pass."""
