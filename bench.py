@@ -462,11 +462,14 @@ def main():
     problem.assemble_jacobian()  # Jacobian at the final iterate
     spmv_kind = problem.spmv_select()
     spmv_ms = spmv_bytes = csr_ms = csr_bytes = None
+    cold_ms = {}
     if not args.solves_only:
         spmv_ms, spmv_bytes = problem.spmv_bench(reps=20)
+        cold_ms[spmv_kind] = problem.spmv_bench_cold(reps=20)[0]
         if spmv_kind != 0:
             problem.spmv_select(0)
             csr_ms, csr_bytes = problem.spmv_bench(reps=20)
+            cold_ms[0] = problem.spmv_bench_cold(reps=20)[0]
             problem.spmv_select(spmv_kind)
         else:
             csr_ms, csr_bytes = spmv_ms, spmv_bytes
@@ -474,11 +477,27 @@ def main():
     smoother = None
     if not sharded and args.degree == 1 and not args.solves_only:
         sm_ms, sm_bytes = problem.smoother_bench(reps=50)
-        smoother = {"kernel": "k_st_smoothR<16,3,POST> on the finest level (three collective-Jacobi sweeps + x + P x_c per launch; 24 % "
-                              "of the solve, the time-dominant kernel; profiles/r02_bench_2048_trace_by_level.txt)",
+        smoother = {"kernel": "k_st_smoothR<16,3,POST> on the finest level (three collective-Jacobi sweeps + x + P x_c per launch; the "
+                              "time-dominant kernel of the solve: profiles/r03_bench_2048_trace_by_level.txt)",
                     "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
+    coarse = None
+    if not sharded and args.degree == 1 and not args.solves_only:
+        # the part of one V-cycle on the levels of at most 513^2 vertices, launches back to back
+        lv, part = 0, []
+        while True:
+            try:
+                ms_l, n_l = problem.vcycle_bench(lv, reps=30)
+            except Exception:
+                break
+            part.append((lv, n_l, ms_l))
+            lv += 1
+        tail_ms, tail_n = problem.vcycle_bench(-1, reps=30)
+        first = next((p for p in part if p[1] <= 513 * 513), None)
+        coarse = {"whole_vcycle_us": 1e3 * part[0][2], "from_level_us": {f"{n_l} vertices": 1e3 * ms_l for _, n_l, ms_l in part if n_l >= tail_n},
+                  "levels_up_to_513x513_us": 1e3 * first[2] if first else None, "fused_tail_launch_us": 1e3 * tail_ms,
+                  "how": "pgx_vcycle_bench: HIP events around 30 back-to-back sub-cycles starting on each level"}
     prof = problem.profile() if args.profile else None
     if sharded:
         parallelism = (f"sharded: ONE {N}x{N} solve on {world} strips of {N // world} vertex rows (+ ghost rows, "
@@ -510,6 +529,14 @@ def main():
              # correction; tools/pmc_summary.py).  A profile of another run, not of this one: `traffic_source` says which; null
              # when no committed profile matches the workload.
              "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
+        if src:
+            src["note"] = ("FETCH_SIZE counts requests that reach the memory side of the fabric, Infinity-Cache (MALL) hits included: "
+                           "it bounds re-reads, it does not separate HBM from MALL traffic (MI355X_MICROARCH.md)")
+        if kind in cold_ms and cold_ms[kind]:
+            # `frac` is measured in the cache state of a solve (the vector the operator reads was just written by the V-cycle and
+            # the 273 MB operator straddles the 256 MB Infinity Cache); `cold_frac` after a 512 MB sweep of unrelated storage
+            r["cold_avg_launch_ms"] = cold_ms[kind]
+            r["cold_frac"] = nbytes / (cold_ms[kind] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if kind == 0:
             r["mixed_csr_equivalent_GBs"] = (12.0 * 4 * (nbytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n) / (ms * 1e-3) / 1e9
         elif csr_bytes:
@@ -559,6 +586,8 @@ def main():
                 "ghost_depth_multiplier": int(os.environ.get("PGX_GHOST_MUL", "3")), "counted": comm_counts}
         if smoother:
             out["roofline_dominant"] = smoother
+        if coarse:
+            out["vcycle_parts"] = coarse
         if prof:
             out["phase_ms"] = prof
         if not args.no_cpu_baseline and world == 1:

@@ -150,6 +150,10 @@ int pgx_spmv(pgx_handle* h, const double* x, double* y);
  * sweep 512 MB of idle storage between two applies.  Returns the average ms per launch and the algorithmic bytes one launch
  * moves. */
 int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+/* The same measurement with every apply preceded by a 512 MB sweep of unrelated device storage: the kernel's operands come from
+ * HBM, not from the 256 MB Infinity Cache (the operator of the 2048^2 benchmark, 273 MB, would otherwise mostly sit in it).
+ * bench.py reports it as roofline.cold_frac next to the in-solve figure. */
+int pgx_spmv_bench_cold(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
 /* Sharded handles: collectives issued by THIS rank since the last reset - [0] halo exchanges (one grouped send/recv batch with
  * both strip neighbours each), [1] all-reduces, [2] V-cycles, [3] Krylov iterations.  Zeros on unsharded handles. */
 int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset);
@@ -165,6 +169,15 @@ int pgx_spmv_select(pgx_handle* h, int kind, int* active);
  * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,
  * the new iterate (2) written.  PGX_ESTATE on meshes without a grid hierarchy. */
 int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, double* algorithmic_bytes);
+
+/* Tuning / A-B / test switches (kernel variants, tile sizes, thresholds, consistency checks such as PGX_CHECK_REPLICAS).
+ * libpgx.so never reads them from the environment: they exist only in a process-wide table filled through this call
+ * (value NULL clears the key; keys start with "PGX_").  Most are read when a handle is created.  The environment variables the
+ * library itself honours are the three documented run-time options: PGX_COMM_TIMEOUT (seconds a transport wait may take),
+ * PGX_ROCTX (roctx ranges around the solver phases) and PGX_ND_THREADS (host threads of the symbolic factorisation).
+ * tools/ and tests/ opt in to the old behaviour through the Python loader (PGX_TUNING_FROM_ENV=1 copies PGX_* variables into the
+ * table before each create). */
+int pgx_tuning_set(const char* key, const char* value);
 /* Measurement aid: average device time (HIP events on the handle's stream, launches back to back) of the part of one V(nu,nu)
  * cycle that starts on multigrid level `level` (0 = the whole preconditioner application; -1 = the fused tail launch only) with the
  * default nu and damping.  *n_level receives the vertex count of that level.  bench.py reports the "coarse part" (levels of at most

@@ -200,6 +200,8 @@ SYMBOLS = [
      [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
     ("pgx_spmv", C.c_int, [_H, c_double_p, c_double_p]),
     ("pgx_spmv_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_spmv_bench_cold", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
+    ("pgx_tuning_set", C.c_int, [C.c_char_p, C.c_char_p]),
     ("pgx_smoother_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
     ("pgx_vcycle_bench", C.c_int, [_H, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     ("pgx_spmv_select", C.c_int, [_H, C.c_int, C.POINTER(C.c_int)]),
@@ -308,12 +310,44 @@ SYMBOLS = [
 ]
 
 _lib = None
+_forwarded: dict = {}
+
+# environment variables libpgx.so itself reads (documented run-time options, include/pgx.h); everything else named PGX_* that the
+# library understands is a TUNING key and reaches it only through pgx_tuning_set
+_RUNTIME_ENV = {"PGX_COMM_TIMEOUT", "PGX_ROCTX", "PGX_ND_THREADS", "PGX_LIB", "PGX_TUNING_FROM_ENV"}
+
+
+def tuning_set(key: str, value=None):
+    """Set (value=None: clear) one tuning / A-B / test switch of the library (include/pgx.h: pgx_tuning_set).  Switches are read
+    when a handle is created (a few at every call), never from the environment."""
+    lib = load()
+    rc = lib.pgx_tuning_set(key.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise PgxError(f"pgx_tuning_set({key!r}) failed (code {rc})")
+
+
+def _sync_tuning_from_env(lib):
+    """Opt-in bridge for tools/ and tests/: with PGX_TUNING_FROM_ENV=1 the PGX_* variables of the environment are copied into the
+    library's tuning table before each handle is created (and removed again when they disappear).  Without it - the default - the
+    environment has no influence on the library's behaviour."""
+    if _os.environ.get("PGX_TUNING_FROM_ENV") != "1":
+        return
+    now = {k: v for k, v in _os.environ.items() if k.startswith("PGX_") and k not in _RUNTIME_ENV}
+    for k in list(_forwarded):
+        if k not in now:
+            lib.pgx_tuning_set(k.encode(), None)
+            del _forwarded[k]
+    for k, v in now.items():
+        if _forwarded.get(k) != v:
+            lib.pgx_tuning_set(k.encode(), v.encode())
+            _forwarded[k] = v
 
 
 def load():
     """Load libpgx.so (built by `make -C proximalgalerkin_amd/csrc` / __graft_entry__.build())."""
     global _lib
     if _lib is not None:
+        _sync_tuning_from_env(_lib)
         return _lib
     if not LIB_PATH.exists():
         raise PgxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -324,6 +358,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _sync_tuning_from_env(lib)
     return lib
 
 

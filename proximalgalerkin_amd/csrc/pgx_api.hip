@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,6 +72,13 @@ struct pgx_handle {
   double *p2_xu = nullptr, *p2_xp = nullptr, *p2_ru = nullptr, *p2_rp = nullptr;
   double* p2_stash = nullptr;  // [16 * nc] element residual vectors of the P2 assembly (deterministic scatter, pgx_p2.hip)
   double *c1_bu = nullptr, *c1_bp = nullptr, *c1_xu = nullptr, *c1_xp = nullptr;
+  // vertex-star patch smoother of the P2 level (pgx_patch.hip): NN = slots per patch (0: vertex degree > 7, smoother unavailable)
+  int patch_nn = 0, p2_patch = 1, patch_nu = 2;
+  double patch_omega = 1.0;
+  bool patch_fresh = false;  // pinv holds the inverses of the current Jacobian
+  std::vector<int32_t> patch_dof_host;
+  int32_t *pdof = nullptr, *ppos = nullptr;
+  double *pinv = nullptr, *p2_su = nullptr, *p2_sp = nullptr;
   // state
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
   // Krylov workspace
@@ -169,6 +178,30 @@ struct PhaseTimer {
     }
   }
 };
+
+// ---- tuning table (pgx_scope.h: pgx_tune) ----
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, std::string>& tune_table() {
+  static std::map<std::string, std::string> t;
+  return t;
+}
+}  // namespace
+const char* pgx_tune(const char* name) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  auto& t = tune_table();
+  auto it = t.find(name);
+  return it == t.end() ? nullptr : it->second.c_str();
+}
+extern "C" int pgx_tuning_set(const char* key, const char* value) {
+  if (!key || strncmp(key, "PGX_", 4) != 0) return PGX_EINVAL;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  if (value)
+    tune_table()[key] = value;
+  else
+    tune_table().erase(key);
+  return PGX_OK;
+}
 
 extern "C" void pgx_default_opts(pgx_snes_opts* o) {
   o->snes_rtol = 1e-8;
@@ -396,6 +429,20 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
   std::vector<int32_t> colm(col.size());
   for (size_t k = 0; k < col.size(); ++k) colm[k] = col[k] | (hmask[col[k]] ? (int32_t)0x80000000 : 0);
   DALLOC(h->s_rowptr, n + 1);
+  {  // vertex-star patches: slot 0 = the vertex, then the edge dofs that meet in it (pgx_patch.hip)
+    int maxdeg = 0;
+    for (int v = 0; v < nv; ++v) maxdeg = std::max(maxdeg, eptr[v + 1] - eptr[v]);
+    h->patch_nn = maxdeg + 1 <= 7 ? 7 : (maxdeg + 1 <= 8 ? 8 : 0);
+    if (h->patch_nn) {
+      const int NN = h->patch_nn;
+      h->patch_dof_host.assign((size_t)nv * NN, -1);
+      for (int v = 0; v < nv; ++v) {
+        int32_t* d = h->patch_dof_host.data() + (size_t)v * NN;
+        d[0] = v;
+        for (int k = eptr[v]; k < eptr[v + 1]; ++k) d[1 + k - eptr[v]] = elist[k];
+      }
+    }
+  }
   DALLOC(h->s_colm, colm.size());
   DALLOC(h->p2_v2c_ptr, n + 1);
   DALLOC(h->p2_v2c_ent, vent.size());
@@ -470,7 +517,7 @@ static int detect_uniform(pgx_handle* h, GridLevel& L) {
 // (pgx_comm_counts, 2048^2 on 4 strips).
 static int ghost_mul() {
   static const int m = [] {
-    const char* e = getenv("PGX_GHOST_MUL");
+    const char* e = pgx_tune("PGX_GHOST_MUL");
     const int v = e ? atoi(e) : 3;
     return v >= 1 && v <= 4 ? v : 3;
   }();
@@ -545,7 +592,7 @@ static void setup_tail(pgx_handle* h, int first) {
   {  // a coarsest grid that could not be coarsened to a handful of vertices (odd cell counts) gets a sweep
      // count that grows with its size: Jacobi is then a poor but non-trivial coarse solver
     const GridLevel& Lc = h->lev.back();
-    if (nl > 1 && Lc.n > 100 && !getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = std::min(400, 4 * std::max(Lc.nx, Lc.ny));
+    if (nl > 1 && Lc.n > 100 && !pgx_tune("PGX_COARSE_SWEEPS")) h->coarse_sweeps = std::min(400, 4 * std::max(Lc.nx, Lc.ny));
   }
   for (int l = std::max(first, 1); l < nl; ++l)
     if (h->lev[l].n <= h->tail_verts && nl - l <= PGX_TAIL_MAX) {
@@ -790,22 +837,28 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     return PGX_EINVAL;
   }
   pgx_handle* h = new pgx_handle();
-  if (const char* e = getenv("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
-  if (const char* e = getenv("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
-  if (const char* e = getenv("PGX_TAIL2")) pgxk_mg_tail_select(atoi(e));
-  if (const char* e = getenv("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
-  if (const char* e = getenv("PGX_FUSED_K3")) h->fused_k3 = atoi(e);
-  if (const char* e = getenv("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
-  if (const char* e = getenv("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
-  if (const char* e = getenv("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
-  if (const char* e = getenv("PGX_RESID_GRID")) h->resid_grid = atoi(e);
-  if (const char* e = getenv("PGX_K6_MAX")) h->k6_max = atoi(e);
-  if (const char* e = getenv("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
-  if (const char* e = getenv("PGX_STAG_GAIN")) h->stag_gain = atof(e);
-  if (const char* e = getenv("PGX_FUSED_MIN")) h->fused_min = atoi(e);
-  if (const char* e = getenv("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
-  if (const char* e = getenv("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
-  if (const char* e = getenv("PGX_COARSE_SWEEPS")) h->coarse_sweeps = atoi(e);
+  if (const char* e = pgx_tune("PGX_XCD_REMAP")) h->xcd_remap = atoi(e) ? 2 : 0;
+  if (const char* e = pgx_tune("PGX_TAIL_VERTS")) h->tail_verts = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_PATCH")) h->p2_patch = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_PATCH_NU")) h->patch_nu = std::max(1, atoi(e));
+  if (const char* e = pgx_tune("PGX_P2_PATCH_OMEGA")) h->patch_omega = atof(e);
+  {
+    const char* e = pgx_tune("PGX_TAIL2");  // 0: the round-2 tail kernels (A/B)
+    pgxk_mg_tail_select(e ? atoi(e) : 1);
+  }
+  if (const char* e = pgx_tune("PGX_FUSED_LEGS")) h->fused_legs = atoi(e);
+  if (const char* e = pgx_tune("PGX_FUSED_K3")) h->fused_k3 = atoi(e);
+  if (const char* e = pgx_tune("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
+  if (const char* e = pgx_tune("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
+  if (const char* e = pgx_tune("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
+  if (const char* e = pgx_tune("PGX_RESID_GRID")) h->resid_grid = atoi(e);
+  if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
+  if (const char* e = pgx_tune("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
+  if (const char* e = pgx_tune("PGX_STAG_GAIN")) h->stag_gain = atof(e);
+  if (const char* e = pgx_tune("PGX_FUSED_MIN")) h->fused_min = atoi(e);
+  if (const char* e = pgx_tune("PGX_CGS_SELECTIVE")) h->cgs_selective = atoi(e);
+  if (const char* e = pgx_tune("PGX_CGS_ETA2")) h->cgs_eta2 = atof(e);
+  if (const char* e = pgx_tune("PGX_COARSE_SWEEPS")) h->coarse_sweeps = atoi(e);
   auto fail = [&](int rc) {
     g_create_error = h->err;
     pgx_destroy(h);
@@ -1034,7 +1087,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       // PGX_P2_BASIS_GB (default 24): the sparse LU is the default P2 preconditioner (1-2 iterations per Newton step), the
       // long basis only matters for "pc_type": "pgx_mg"; 96 GB reproduces the pre-LU behaviour
       double budget = 24e9;
-      if (const char* e = getenv("PGX_P2_BASIS_GB")) budget = 1e9 * atof(e);
+      if (const char* e = pgx_tune("PGX_P2_BASIS_GB")) budget = 1e9 * atof(e);
       const double per_vec = 2.0 * (double)n2 * sizeof(double);
       h->restart = (int)std::max(50.0, std::min(300.0, budget / per_vec));
     }
@@ -1078,7 +1131,7 @@ extern "C" int pgx_create_lu_dist(const pgx_mesh* m, const pgx_problem* p, pgx_c
   int rc = create_impl(m, p, device, nullptr, nullptr, out);
   if (rc) return rc;
   (*out)->lu_comm = comm;
-  if (const char* e = getenv("PGX_CHECK_REPLICAS")) (*out)->check_replicas = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_CHECK_REPLICAS")) (*out)->check_replicas = atoi(e) != 0;
   return PGX_OK;
 }
 extern "C" int pgx_create_sharded(const pgx_mesh* m, const pgx_problem* p, const pgx_partition* part, pgx_comm* comm,
@@ -1094,7 +1147,7 @@ extern "C" void pgx_destroy(pgx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
-  if (h->cgs_selective && getenv("PGX_CGS_REPORT"))
+  if (h->cgs_selective && pgx_tune("PGX_CGS_REPORT"))
     fprintf(stderr, "pgx: selective CGS2 skipped the second projection in %ld of %ld Krylov iterations\n", h->cgs_skipped, h->cgs_total);
   if (h->lu) pgx_nd_destroy(h->lu);
   for (void* p : h->allocs) hipFree(p);
@@ -1281,6 +1334,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
     }
   }
   h->jac_valid = true;
+  h->patch_fresh = false;
   return PGX_OK;
 }
 
@@ -1487,6 +1541,54 @@ static void scatter_owned(pgx_handle* h, const double* cmp, double* loc) {
 
 // P2: two-level cycle.  Smoother = collective damped Jacobi on the P2 block CSR (k_bspmv<2>); coarse space =
 // the P1 subspace with its full multigrid hierarchy (one V-cycle); T = P1->P2 interpolation.
+// Patch data of the P2 level: tables on first use, inverses once per Jacobian (alpha and D(psi) change every Newton step)
+static int ensure_patches(pgx_handle* h) {
+  const int NN = h->patch_nn, nv = h->n, nd = h->nd, P = 2 * NN;
+  if (!h->pdof) {
+    DALLOC(h->pdof, (size_t)nv * NN);
+    DALLOC(h->ppos, (size_t)nv * NN * NN);
+    DALLOC(h->pinv, (size_t)nv * P * P);
+    DALLOC(h->p2_su, (size_t)2 * (nd - nv));
+    DALLOC(h->p2_sp, (size_t)2 * (nd - nv));
+    HIPCHK(hipMemcpy(h->pdof, h->patch_dof_host.data(), sizeof(int32_t) * h->patch_dof_host.size(), hipMemcpyHostToDevice));
+    std::vector<int32_t>().swap(h->patch_dof_host);
+    pgxk_patch_positions(h->st, nv, NN, h->pdof, h->s_rowptr, h->s_colm, h->ppos);
+  }
+  if (!h->patch_fresh) {
+    pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv);
+    h->patch_fresh = true;
+  }
+  return PGX_OK;
+}
+
+// Two-level cycle with the vertex-star patch smoother (round 3): patch_nu additive sweeps | P1 hierarchy on T^T (b - J x) |
+// patch_nu sweeps.  A sweep = residual (block-CSR SpMV) + one pass over the patch inverses.
+static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, double* xu, double* xp, int nu, double omega) {
+  const int nd = h->nd, nv = h->n, NN = h->patch_nn;
+  auto resid = [&]() {
+    pgxk_bspmv(h->st, 1, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, 0.0, h->xcd_remap,
+               h->p2_ru, h->p2_rp);
+  };
+  auto patch = [&](const double* ru, const double* rp) {
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+  };
+  hipMemsetAsync(xu, 0, sizeof(double) * nd, h->st);
+  hipMemsetAsync(xp, 0, sizeof(double) * nd, h->st);
+  patch(bu, bp);  // x = 0: the residual is b
+  for (int s2 = 1; s2 < h->patch_nu; ++s2) {
+    resid();
+    patch(h->p2_ru, h->p2_rp);
+  }
+  resid();
+  pgxk_p2_restrict(h->st, nv, nd, h->v2e_ptr, h->v2e, h->mask, h->p2_ru, h->p2_rp, h->c1_bu, h->c1_bp);
+  vcycle(h, 0, h->c1_bu, h->c1_bp, h->c1_xu, h->c1_xp, nu, omega);
+  pgxk_p2_prolong_add(h->st, nv, nd, h->edge_ends, h->c1_xu, h->c1_xp, xu, xp);
+  for (int s2 = 0; s2 < h->patch_nu; ++s2) {
+    resid();
+    patch(h->p2_ru, h->p2_rp);
+  }
+}
+
 static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double* outu, double* outp, int nu,
                       double omega) {
   const int nd = h->nd;
@@ -1595,7 +1697,7 @@ static int ensure_lu(pgx_handle* h) {
   A.dim = 2;
   A.node_coords = xy.data();
   A.leaf_nodes = 0;
-  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  if (const char* e = pgx_tune("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
   int rc = h->lu_comm ? pgx_nd_create_dist(&A, h->lu_comm, h->device, (void*)h->st, &h->lu)
                       : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
@@ -1658,7 +1760,11 @@ static int precond(pgx_handle* h, const double* b, double* z, int nu, double ome
     ++h->dist.n_vcycle;
     return vcycle_dist(h, 0, h->dist.sb, h->dist.sb + h->n, z, z + h->n, 1, nu, omega);
   }
-  if (h->degree == 2)  // P2 level: one more sweep at 0.75*omega (prototype sweep in DESIGN.md section 3); P1 levels as usual
+  if (h->degree == 2 && h->p2_patch && h->patch_nn) {  // vertex-star patch smoother on the P2 level, P1 hierarchy below
+    const int rc = ensure_patches(h);
+    if (rc) return rc;
+    pcycle_p2_patch(h, b, b + h->nd, z, z + h->nd, nu, omega);
+  } else if (h->degree == 2)  // round-1 cycle: point-collective Jacobi on the P2 level (meshes with vertex degree > 7, A/B)
     pcycle_p2(h, b, b + h->nd, z, z + h->nd, nu, omega);
   else
     vcycle(h, 0, b, b + h->n, z, z + h->n, nu, omega);
@@ -2004,7 +2110,7 @@ extern "C" int pgx_vcycle_bench(pgx_handle* h, int level, int reps, double* avg_
   return PGX_OK;
 }
 
-extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
+static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* bytes, bool cold) {
   NEED(h);
   if (reps < 1 || !avg_ms) return PGX_EINVAL;
   if (!h->jac_valid) {
@@ -2020,7 +2126,8 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
   // and subtract the time of the V-cycles alone; other handles sweep 512 MB of idle storage (a dot product) between two
   // applies.  Each batch sits between ONE pair of events: a pair around a single 50 us kernel would add the ~50 us of its two
   // barrier packets.
-  const bool mg = h->structured && h->degree == 1 && !h->dist.on && !h->lu_active && h->lev.size() > 1;
+  // cold: every apply follows a 512 MB sweep of unrelated storage, so neither x nor the stencils sit in the 256 MB Infinity Cache
+  const bool mg = !cold && h->structured && h->degree == 1 && !h->dist.on && !h->lu_active && h->lev.size() > 1;
   pgx_snes_opts od;
   pgx_default_opts(&od);
   const size_t flush = std::min<size_t>((size_t)h->restart * n2, ((size_t)512 << 20) / sizeof(double));
@@ -2059,6 +2166,12 @@ extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* b
       *bytes = 28.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
   }
   return PGX_OK;
+}
+extern "C" int pgx_spmv_bench(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
+  return spmv_bench_impl(h, reps, avg_ms, bytes, false);
+}
+extern "C" int pgx_spmv_bench_cold(pgx_handle* h, int reps, double* avg_ms, double* bytes) {
+  return spmv_bench_impl(h, reps, avg_ms, bytes, true);
 }
 
 extern "C" int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset) {

@@ -655,7 +655,7 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
   A.dim = 2;
   A.node_coords = xy.data();
   A.leaf_nodes = 0;
-  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  if (const char* e = pgx_tune("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
   int rc = comm ? pgx_nd_create_dist(&A, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);
@@ -890,7 +890,7 @@ static int gcg_create_impl(pgx_gc_handle* h, const pgx_gc_spaces* sp, const pgx_
   Am.dim = 2;
   Am.node_coords = xy.data();
   Am.leaf_nodes = 0;
-  if (const char* e = getenv("PGX_ND_LEAF")) Am.leaf_nodes = atoi(e);
+  if (const char* e = pgx_tune("PGX_ND_LEAF")) Am.leaf_nodes = atoi(e);
   int rc = comm ? pgx_nd_create_dist(&Am, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&Am, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);

@@ -181,6 +181,14 @@ void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdo
                                const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
                                int nblocks);
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6);
+// vertex-star patch smoother of the P2 level (pgx_patch.hip)
+void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* rowptr, const int32_t* colm,
+                          int32_t* ppos);
+void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
+                       const double* D, const uint8_t* mask, double alpha, double* pinv);
+void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
+                      const double* pinv, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
+                      double* sp);
 // fused, atomic-free residual (+ optional D(psi) fill) for P1: see k_resid_fill_p1
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,

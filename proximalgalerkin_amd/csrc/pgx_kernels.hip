@@ -1958,8 +1958,8 @@ static void launch_rowmap(hipStream_t st, int post, const GridLevel& L, const St
 
 // K = 6 is available on levels with uniform interior stencils (row-mapped kernels only)
 int pgxk_st_smooth6_ok(const GridLevel& L) {
-  static const int rowmap = [] {
-    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+  const int rowmap = [] {
+    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
     return e ? atoi(e) : 1;
   }();
   return rowmap && L.uniform;
@@ -1974,13 +1974,13 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
     return;
   }
   const StConst sc = make_stconst(L);
-  static const int rowmap = [] {
-    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+  const int rowmap = [] {
+    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
     return e ? atoi(e) : 1;
   }();
   if (K == 6) {  // small levels (pgxk_st_smooth6_ok): SIX sweeps per launch - one latency-bound launch instead of two
-    static const int ty6 = [] {
-      const char* e = getenv("PGX_K6_TY");
+    const int ty6 = [] {
+      const char* e = pgx_tune("PGX_K6_TY");
       return e ? atoi(e) : 0;
     }();
     if (ty6 == 16)  // measured at 2049^2: 16-row tiles 323 ms per solve, 8-row tiles 298 ms, three-sweep launches (default) 304 ms
@@ -1991,8 +1991,8 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
   }
   if (rowmap && L.uniform) {  // row-mapped kernels: image 64 x (TY + 6), tile 58 x TY; interior tiles + boundary tiles
     // tile height by level size (measured, us per launch at 2049^2 / 1025^2 / 513^2 / 257^2 vertices; PGX_ROWMAP_TY forces one)
-    static const int ty_env = [] {
-      const char* e = getenv("PGX_ROWMAP_TY");
+    const int ty_env = [] {
+      const char* e = pgx_tune("PGX_ROWMAP_TY");
       return e ? atoi(e) : 0;
     }();
     const int ty = ty_env ? ty_env : (L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4);
@@ -2233,8 +2233,8 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_resid_restrict_r(int nx
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp) {
-  static const int rowmap = [] {
-    const char* e = getenv("PGX_SMOOTH_ROWMAP");
+  const int rowmap = [] {
+    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
     return e ? atoi(e) : 1;
   }();
   if (rowmap && L.uniform) {

@@ -181,8 +181,8 @@ static int mx_sync_scalar(MixedBase* h) {
 // bitwise identical.  PGX_CHECK_REPLICAS=1 asserts it (tests): rank 0's copy of v must equal the local one exactly.  Collective.
 static int mx_replica_check(MixedBase* h, const double* v, const char* what) {
   if (!h->comm || h->comm->size == 1) return PGX_OK;
-  static const bool on = [] {
-    const char* e = getenv("PGX_CHECK_REPLICAS");
+  const bool on = [] {
+    const char* e = pgx_tune("PGX_CHECK_REPLICAS");
     return e && atoi(e) != 0;
   }();
   if (!on) return PGX_OK;
@@ -242,15 +242,15 @@ static int mx_alloc_state(MixedBase* h) {
   MXHIP(hipMemsetAsync(h->xk, 0, sizeof(double) * h->ntot, h->st));
   hipEventCreate(&h->e0);
   hipEventCreate(&h->e1);
-  if (const char* e = getenv("PGX_LAZY_LU")) h->lazy_lu = atoi(e);
-  if (const char* e = getenv("PGX_LAZY_BUDGET")) h->lazy_budget = std::max(1, atoi(e));
+  if (const char* e = pgx_tune("PGX_LAZY_LU")) h->lazy_lu = atoi(e);
+  if (const char* e = pgx_tune("PGX_LAZY_BUDGET")) h->lazy_budget = std::max(1, atoi(e));
   return PGX_OK;
 }
 
 static void mx_release(MixedBase* h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
-  if (getenv("PGX_LAZY_REPORT"))
+  if (pgx_tune("PGX_LAZY_REPORT"))
     fprintf(stderr, "pgx: lazy refactorisation: %ld Newton systems solved with a stale LU (%ld LU solves), %ld attempts fell back\n",
             h->lazy_hits, h->lazy_its, h->lazy_misses);
   if (h->lu) pgx_nd_destroy(h->lu);
@@ -315,7 +315,7 @@ static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_
     ++*nsolves;
     mx_axpby(h, 1.0, h->z, 1.0, dx);
   }
-  const char* ea = getenv("PGX_MX_GMRES_ALWAYS");  // test hook: polish with GMRES whenever refinement stops above tol
+  const char* ea = pgx_tune("PGX_MX_GMRES_ALWAYS");  // test hook: polish with GMRES whenever refinement stops above tol
   const bool always = ea && atoi(ea);
   if (std::isfinite(*relres) && *relres > 1e-7 && !always) {  // at the rounding level of J itself?  Then GMRES cannot help.
     bool ok = false;

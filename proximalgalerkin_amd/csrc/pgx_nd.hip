@@ -309,7 +309,7 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
       s->err = "node_of_dof out of range";
       return PGX_EINVAL;
     }
-  const bool ptime = getenv("PGX_ND_TIMING") != nullptr;
+  const bool ptime = pgx_tune("PGX_ND_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
@@ -569,14 +569,14 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
   s->kcut = kcut;
   s->nsub = nsub;
   {
-    const char* e = getenv("PGX_ND_PANEL");
+    const char* e = pgx_tune("PGX_ND_PANEL");
     s->panel_kind = e ? atoi(e) : 0;
   }
   // large factorisation on one GPU: cut the tree at depth 3 and factorise the (up to) 8 subtrees below one after the other
   {
     // threshold in GB of device storage; 0 = always, < 0 = never.  Default 160 of the 288 GB: the uncut schedule is the faster one
     // while it fits (2048^2 P2, 115 GB: factorisations -4 %, solves -31 % against the cut at 96 GB; tools/p2_cut_ab.py)
-    const char* e = getenv("PGX_ND_CUT_GB");
+    const char* e = pgx_tune("PGX_ND_CUT_GB");
     const double thr = e ? atof(e) : 160.0;
     const int kc = 3;
     if (attempt == 0 && dsize == 1 && thr >= 0 && maxd >= kc + 3 && (double)s->arena_len * 8 > thr * 1e9) {
@@ -1965,7 +1965,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     s->comm = comm, s->rank = comm->rank, s->size = comm->size;
   else
     s->rank = sym_rank, s->size = sym_size;  // symbolic-only view of one rank of a distributed factorisation (tests)
-  const bool ptime = getenv("PGX_ND_TIMING") != nullptr;
+  const bool ptime = pgx_tune("PGX_ND_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
@@ -2087,7 +2087,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     }
     // fused leaves (k_nd_leaf): the groups of the deepest depth whose fronts are small enough get per-front entry lists
     {
-      const char* e = getenv("PGX_ND_LEAF_FUSED");
+      const char* e = pgx_tune("PGX_ND_LEAF_FUSED");
       s->leaf_fuse = !e || atoi(e) != 0;
     }
     const int maxdepth = (int)s->dfirst.size() - 2;
@@ -2096,9 +2096,9 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     // cut): their frame is gathered and eliminated by the same kernel (PGX_ND_FRAME_FUSED=0: k_nd_gather + diag + panel)
     bool frame_fuse = s->leaf_fuse;
     {
-      const char* e = getenv("PGX_ND_GATHER");
+      const char* e = pgx_tune("PGX_ND_GATHER");
       if (e && atoi(e) == 0) frame_fuse = false;
-      const char* e2 = getenv("PGX_ND_FRAME_FUSED");
+      const char* e2 = pgx_tune("PGX_ND_FRAME_FUSED");
       if (e2 && atoi(e2) == 0) frame_fuse = false;
     }
     for (int g = 0; g < ng && s->leaf_fuse; ++g) {
@@ -2164,7 +2164,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if ((rc = nd_upload(s, &s->d_fM, fM)) || (rc = nd_upload(s, &s->d_fP, fP)) || (rc = nd_upload(s, &s->d_vbase, vbase)))
     return fail(rc);
   {  // inverse child -> parent maps of the parent-centric assembly
-    const char* e = getenv("PGX_ND_GATHER");
+    const char* e = pgx_tune("PGX_ND_GATHER");
     s->gather = !e || atoi(e) != 0;
     if (s->gather) {
       std::vector<int32_t> inv[2];
@@ -2197,7 +2197,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   hipEventCreateWithFlags(&s->ev_info, hipEventDisableTiming);
   if (hipHostMalloc((void**)&s->h_info, sizeof(int)) != hipSuccess) s->h_info = nullptr;
   {
-    const char* e = getenv("PGX_ND_PREP_AHEAD");
+    const char* e = pgx_tune("PGX_ND_PREP_AHEAD");
     s->prep_ahead = !e || atoi(e) != 0;
     if (hipStreamCreateWithFlags(&s->prep_st, hipStreamNonBlocking) != hipSuccess) s->prep_st = nullptr;
     hipEventCreateWithFlags(&s->ev_prep_go, hipEventDisableTiming);

@@ -1,0 +1,207 @@
+// Vertex-star (patch) smoother for the P2 Newton matrices of example 01 - gfx950.
+//
+// Reference: the reference solves the P2 systems of `obstacle_pg.py -p 2` exactly (/root/reference/examples/01_obstacle_problem/
+// obstacle_pg.py:68-70,129-131,288).  Here they are solved by FGMRES with a two-level cycle: a smoother on the P2 level + the P1
+// hierarchy as coarse space (pgx_api.hip: pcycle_p2).  The collective point-Jacobi smoother of rounds 1-2 is not robust there: on
+// the late proximal steps e^psi spans tens of orders of magnitude inside one element and the Krylov counts grow with N (30-90 at
+// 64^2-128^2, hundreds at 256^2).  The remedy (prototype: oracle/p2_patch_proto.py, 8-18 iterations at 16^2 ... 256^2 on the same
+// systems) is an ADDITIVE VERTEX-STAR SCHWARZ smoother: for every mesh vertex the dofs (u, psi) on the vertex and on the edges that
+// meet in it - 2 (1 + deg) <= 16 unknowns - are solved for EXACTLY, the corrections of overlapping patches are averaged
+// (an edge dof belongs to the patches of its two end vertices).
+//
+// Data (per handle, HBM): pdof [np][NN] patch dofs (-1 = unused slot), ppos [np][NN][NN] positions of the patch's scalar-block
+// entries in the P2 block-CSR (-1 = structurally zero), pinv [np][P][P] (P = 2 NN) the inverses of the patch matrices, row-major,
+// rebuilt once per Newton step (only D(psi) and alpha change).  At 2048^2 P2: 4.2 M patches, 6.6 GB of inverses.
+//
+// Mapping: a group of 16 lanes owns one patch, lane l its row l (four patches per 64-wide wavefront); rows meet through
+// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 1568 B per patch and sweep.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgx_internal.h"
+
+namespace {
+
+constexpr int GRP = 16;  // lanes per patch
+
+// ppos[p][i][j] = position of (row dof_i, column dof_j) in the scalar CSR pattern, or -1
+__global__ void __launch_bounds__(256) k_patch_positions(int np, int NN, const int32_t* __restrict__ pdof,
+                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colm,
+                                                         int32_t* __restrict__ ppos) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)np * NN) return;
+  const int p = (int)(t / NN), i = (int)(t % NN);
+  const int32_t* d = pdof + (size_t)p * NN;
+  int32_t* out = ppos + ((size_t)p * NN + i) * NN;
+  for (int j = 0; j < NN; ++j) out[j] = -1;
+  const int row = d[i];
+  if (row < 0) return;
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+    const int c = colm[k] & 0x7fffffff;
+    for (int j = 0; j < NN; ++j)
+      if (d[j] == c) out[j] = k;
+  }
+}
+
+// Patch matrix [[aK, M], [M, -D]] restricted to the patch dofs with the Dirichlet rows / columns of u replaced by identity
+// (the contract of src/lvpp/problem.py:69-77) and unused slots as identity, inverted in place by Gauss-Jordan WITHOUT pivoting:
+// u rows first (aK_pp is SPD), then the psi rows whose Schur complement -D_pp - M_pp (aK_pp)^-1 M_pp is negative definite - the
+// quasi-definite ordering that pgx_nd relies on as well.
+template <int NN>
+__global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __restrict__ pdof, const int32_t* __restrict__ ppos,
+                                                      const double* __restrict__ K, const double* __restrict__ M,
+                                                      const double* __restrict__ D, const uint8_t* __restrict__ mask, double alpha,
+                                                      double* __restrict__ pinv) {
+  constexpr int P = 2 * NN;
+  const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
+  const int l = threadIdx.x & (GRP - 1);
+  const bool live = p < np;
+  const int pp = live ? p : np - 1;  // idle groups repeat the last patch (their shuffles must still run) and do not store
+  const int32_t* d = pdof + (size_t)pp * NN;
+  int dof[NN];
+  bool bc[NN];
+#pragma unroll
+  for (int j = 0; j < NN; ++j) {
+    dof[j] = d[j];
+    bc[j] = dof[j] >= 0 && mask[dof[j]];
+  }
+  double a[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) a[j] = 0.0;
+  if (l < P) {
+    const int i = l < NN ? l : l - NN;
+    const bool urow = l < NN;
+    if (dof[i] < 0 || (urow && bc[i])) {
+      a[l] = 1.0;  // identity row (unused slot / Dirichlet dof of u)
+    } else {
+      const int32_t* pos = ppos + ((size_t)pp * NN + i) * NN;
+#pragma unroll
+      for (int j = 0; j < NN; ++j) {
+        const int k = pos[j];
+        if (k < 0 || dof[j] < 0) continue;
+        if (urow) {
+          a[j] = bc[j] ? 0.0 : alpha * K[k];
+          a[NN + j] = M[k];
+        } else {
+          a[j] = bc[j] ? 0.0 : M[k];
+          a[NN + j] = -D[k];
+        }
+      }
+    }
+  } else {
+    a[0] = 0.0;  // lanes P..15 hold no row
+  }
+  // in-place Gauss-Jordan: after step k column k holds the k-th column of the inverse of the leading block
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    double pr[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) pr[j] = __shfl(a[j], k, GRP);  // pivot row to every lane of the group
+    const double piv = 1.0 / pr[k];
+    if (l == k) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) a[j] = (j == k) ? piv : pr[j] * piv;
+    } else if (l < P) {
+      const double f = a[k];
+#pragma unroll
+      for (int j = 0; j < P; ++j) a[j] = (j == k) ? -f * piv : a[j] - f * (pr[j] * piv);
+    }
+  }
+  if (live && l < P) {
+    double* out = pinv + ((size_t)p * P + l) * P;
+#pragma unroll
+    for (int j = 0; j < P; ++j) out[j] = a[j];
+  }
+}
+
+// One additive sweep: y_p = A_p^-1 r_p for every patch; the vertex dof of a patch belongs to it alone (x += omega y), an edge dof
+// to the patches of its two end vertices: their contributions are parked in stash[2 e + side] and averaged by k_patch_edges
+// (no atomics: bitwise reproducible).
+template <int NN>
+__global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, const int32_t* __restrict__ pdof,
+                                                     const int32_t* __restrict__ edge_ends, const double* __restrict__ pinv,
+                                                     const double* __restrict__ ru, const double* __restrict__ rp, double omega,
+                                                     double* __restrict__ xu, double* __restrict__ xp, double* __restrict__ su,
+                                                     double* __restrict__ sp) {
+  constexpr int P = 2 * NN;
+  const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
+  const int l = threadIdx.x & (GRP - 1);
+  const bool live = p < np;
+  const int pp = live ? p : np - 1;
+  const int i = l < NN ? l : l - NN;
+  int dof = -1;
+  double r = 0.0;
+  double row[P];
+  if (l < P) {
+    dof = pdof[(size_t)pp * NN + i];
+    if (dof >= 0) r = (l < NN) ? ru[dof] : rp[dof];
+    const double* in = pinv + ((size_t)pp * P + l) * P;
+#pragma unroll
+    for (int j = 0; j < P; ++j) row[j] = __builtin_nontemporal_load(in + j);  // streamed once per sweep
+  } else {
+#pragma unroll
+    for (int j = 0; j < P; ++j) row[j] = 0.0;
+  }
+  double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const double rj = __shfl(r, j, GRP);
+    if (j & 1)
+      y1 = fma(row[j], rj, y1);
+    else
+      y0 = fma(row[j], rj, y0);
+  }
+  const double y = y0 + y1;
+  if (!live || l >= P || dof < 0) return;
+  const int v = pp;  // patch p = vertex p
+  if (i == 0) {
+    if (l < NN)
+      xu[v] += omega * y;
+    else
+      xp[v] += omega * y;
+  } else {
+    const int e = dof - nv;
+    const int side = (edge_ends[2 * e] == v) ? 0 : 1;
+    (l < NN ? su : sp)[2 * (size_t)e + side] = y;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_patch_edges(int ne, int nv, double omega, const double* __restrict__ su,
+                                                     const double* __restrict__ sp, double* __restrict__ xu, double* __restrict__ xp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const double2 a = ((const double2*)su)[e], b = ((const double2*)sp)[e];
+  xu[nv + e] += omega * 0.5 * (a.x + a.y);
+  xp[nv + e] += omega * 0.5 * (b.x + b.y);
+}
+
+}  // namespace
+
+void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* rowptr, const int32_t* colm,
+                          int32_t* ppos) {
+  const int64_t t = (int64_t)np * NN;
+  hipLaunchKernelGGL(k_patch_positions, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, np, NN, pdof, rowptr, colm, ppos);
+}
+
+void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
+                       const double* D, const uint8_t* mask, double alpha, double* pinv) {
+  const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
+  if (NN <= 7)
+    hipLaunchKernelGGL((k_patch_invert<7>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, pinv);
+  else
+    hipLaunchKernelGGL((k_patch_invert<8>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, pinv);
+}
+
+void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
+                      const double* pinv, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
+                      double* sp) {
+  const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
+  if (NN <= 7)
+    hipLaunchKernelGGL((k_patch_apply<7>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, pinv, ru, rp, omega, xu, xp,
+                       su, sp);
+  else
+    hipLaunchKernelGGL((k_patch_apply<8>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, pinv, ru, rp, omega, xu, xp,
+                       su, sp);
+  const int ne = nd - nv;
+  hipLaunchKernelGGL(k_patch_edges, dim3((ne + 255) / 256), dim3(256), 0, st, ne, nv, omega, su, sp, xu, xp);
+}

@@ -366,7 +366,7 @@ static int qvi_create_impl(pgx_qvi_handle* h, const pgx_mesh* m, const pgx_qvi_p
   A.dim = 2;
   A.node_coords = m->coords;
   A.leaf_nodes = 0;
-  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  if (const char* e = pgx_tune("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
   int rc = pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);

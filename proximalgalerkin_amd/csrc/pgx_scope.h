@@ -5,6 +5,12 @@
 
 #include <cstdlib>
 
+// Tuning / A-B / test switches (kernel variants, tile sizes, thresholds, consistency checks).  libpgx.so NEVER reads them from the
+// environment: the table is filled only through the C ABI (include/pgx.h: pgx_tuning_set), so a deployed library behaves the same
+// whatever PGX_* variables happen to be set.  nullptr = not set.  The environment variables the library does read are the three
+// documented run-time options PGX_COMM_TIMEOUT, PGX_ROCTX and PGX_ND_THREADS.
+const char* pgx_tune(const char* name);
+
 // roctx ranges around the solver phases (readable rocprofv3 --marker-trace timelines).  Off unless
 // PGX_ROCTX=1; the marker library is opened with dlopen, so libpgx.so has no link-time dependency on the profiler.
 //   pgx_roctx("name") pushes a range, pgx_roctx(nullptr) pops it.

@@ -591,7 +591,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   A.dim = 3;
   A.node_coords = m->coords;
   A.leaf_nodes = 0;
-  if (const char* e = getenv("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
+  if (const char* e = pgx_tune("PGX_ND_LEAF")) A.leaf_nodes = atoi(e);
   int rc = comm ? pgx_nd_create_dist(&A, comm, h->device, (void*)h->st, &h->lu) : pgx_nd_create(&A, h->device, (void*)h->st, &h->lu);
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(nullptr);

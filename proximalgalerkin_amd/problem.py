@@ -312,6 +312,13 @@ class NonlinearProblem:
                    "pgx_spmv_bench")
         return ms.value, by.value
 
+    def spmv_bench_cold(self, reps=20):
+        """Like spmv_bench, every apply after a 512 MB sweep (operands from HBM, not the Infinity Cache): pgx_spmv_bench_cold."""
+        ms, by = C.c_double(0), C.c_double(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_spmv_bench_cold(self._h, int(reps), C.byref(ms), C.byref(by)),
+                   "pgx_spmv_bench_cold")
+        return ms.value, by.value
+
     def spmv_select(self, kind=-1):
         """Select / query the operator-apply kernel of the Krylov solver (include/pgx.h: pgx_spmv_select): 1 matrix-free stencil
         (default on structured P1 meshes), 0 block-CSR stream, 2 generic stencil kernel; returns the kind that will run."""

@@ -3,7 +3,12 @@ import sys
 
 import pytest
 
+import os
+
 ROOT = pathlib.Path(__file__).resolve().parents[1]
+# tests switch kernel variants / thresholds through PGX_* variables (monkeypatch.setenv): the Python loader copies them into the
+# library's tuning table (include/pgx.h: pgx_tuning_set) only with this opt-in - libpgx.so itself never reads them
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 

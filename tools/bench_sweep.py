@@ -5,6 +5,7 @@ boxes of the pool, so every A/B runs in ONE gpurun call).
 Empty env / args parts are allowed ("base::")."""
 import json
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import subprocess
 import sys
 

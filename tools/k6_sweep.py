@@ -2,6 +2,7 @@
 python tools/k6_sweep.py [cells]"""
 import json
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import subprocess
 import sys
 

@@ -1,5 +1,6 @@
 """A/B of lazy refactorisation (PGX_LAZY_LU) on examples 06 and 02: python tools/lazy_lu_ab.py ex06 1024 | ex02 70"""
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import subprocess
 import sys
 

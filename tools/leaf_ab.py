@@ -1,6 +1,7 @@
 """A/B of the fused leaf kernel (PGX_ND_LEAF_FUSED=0/1) on the sparse-LU workloads: ms per factorisation and per solve.
 python tools/leaf_ab.py [ENV_VAR]  (one GPU; default switch PGX_ND_LEAF_FUSED; each case runs in a child process so that the environment variable is read at create)"""
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import subprocess
 import sys
 

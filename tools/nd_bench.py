@@ -1,5 +1,7 @@
 """Time the direct solver on the ex 01 P1 Newton matrix of an N x N mesh (a late-step-like state):
 python tools/nd_bench.py N [leaf_nodes] [reps]"""
+import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys
 import time
 

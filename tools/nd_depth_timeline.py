@@ -8,6 +8,7 @@ the xadd column is the extend-add / gather kernel time.
 import csv
 import glob
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys
 
 src = sys.argv[1]

@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys
 from collections import defaultdict
 

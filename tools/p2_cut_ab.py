@@ -1,6 +1,8 @@
 """Example 01 P2 on an N x N mesh through the sparse LU, settings A, six proximal steps, with per-phase device times - run under
 PGX_ND_CUT_GB=96 / -1 to compare the subtree-sequenced schedule of large factorisations with the plain one:
     PGX_ND_CUT_GB=-1 python tools/p2_cut_ab.py 2048"""
+import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys, time
 sys.path.insert(0, ".")
 from proximalgalerkin_amd import fem

@@ -2,6 +2,7 @@
 scalar) on synthetic grid matrices: factorisation time (pgx_nd_timing), normwise backward error and the difference between the
 solutions.  python tools/panel_ab.py [2d N dofs | 3d n dofs] ...   (default: 2d 640 3, 3d 48 3)"""
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys
 import time
 

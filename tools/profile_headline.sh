@@ -8,6 +8,7 @@ set -o pipefail
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
+export PGX_TUNING_FROM_ENV=1
 BENCH="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --solves-only"
 for what in "$@"; do
   case $what in

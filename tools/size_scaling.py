@@ -1,6 +1,7 @@
 """Single-GPU size scaling table of DESIGN.md section 3: python tools/size_scaling.py [sizes...]"""
 import json
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import subprocess
 import sys
 

@@ -1,5 +1,7 @@
 """SpMV microbenchmark (GPU): python tools/spmv_bench.py N [kind]  -> ms, GB/s of the operator-apply kernel
 (kind: 1 matrix-free stencil k_st_spmv_r (default), 0 block-CSR stream k_bspmv_stream, 2 generic stencil; PGX_SPMV_* env as set)."""
+import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

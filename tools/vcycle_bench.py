@@ -2,6 +2,7 @@
 """Device time of the V-cycle part that starts on each multigrid level (pgx_vcycle_bench; launches back to back), 2048^2 P1 by
 default:  python tools/vcycle_bench.py [cells]   - level 0 is the whole preconditioner application, the last line the fused tail."""
 import os
+os.environ.setdefault("PGX_TUNING_FROM_ENV", "1")  # PGX_* switches reach the library through the loader's opt-in bridge
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
