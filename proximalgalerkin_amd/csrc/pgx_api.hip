@@ -74,7 +74,8 @@ struct pgx_handle {
   double *c1_bu = nullptr, *c1_bp = nullptr, *c1_xu = nullptr, *c1_xp = nullptr;
   // vertex-star patch smoother of the P2 level (pgx_patch.hip): NN = slots per patch (0: vertex degree > 7, smoother unavailable)
   int patch_nn = 0, p2_patch = 1, patch_nu = 2;
-  double patch_omega = 1.0;
+  int p2_fallback_its = 60, p2_fallbacks = 0;  // patch cycle -> sparse LU after this many Krylov iterations without convergence
+  double patch_omega = 0.8;
   bool patch_fresh = false;  // pinv holds the inverses of the current Jacobian
   std::vector<int32_t> patch_dof_host;
   int32_t *pdof = nullptr, *ppos = nullptr;
@@ -842,6 +843,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH")) h->p2_patch = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_NU")) h->patch_nu = std::max(1, atoi(e));
   if (const char* e = pgx_tune("PGX_P2_PATCH_OMEGA")) h->patch_omega = atof(e);
+  if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
     const char* e = pgx_tune("PGX_TAIL2");  // 0: the round-2 tail kernels (A/B)
     pgxk_mg_tail_select(e ? atoi(e) : 1);
@@ -2259,7 +2261,14 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // pc_type: 0 auto (geometric multigrid for P1 on a structured mesh; sparse LU for P2, whose two-level cycle is not robust
   // on the late large-alpha systems, and for general meshes, which have no grid hierarchy - e.g. the reference's own gmsh
   // disk, obstacle_pg.py:64-65), 1 multigrid V-cycle, 2 sparse LU (what the reference asks PETSc/MUMPS for)
-  const bool use_lu = h->lu_comm || optv.pc_type == 2 || (optv.pc_type == 0 && (h->degree == 2 || !h->structured) && !h->dist.on);
+  // P2 on a structured mesh (round 3): the two-level cycle with the vertex-star patch smoother first (pcycle_p2_patch: 8-20
+  // iterations per Newton step at every size, a fifth of a factorisation's time) and the sparse LU only for a Newton solve in
+  // which that cycle stagnates - the overshot iterates of settings B's large alpha jumps, where exp(psi) is rough on the mesh
+  // scale; the LU then stays in place for the rest of that pgx_newton_solve call.
+  const bool mg_first = optv.pc_type == 0 && h->degree == 2 && h->structured && h->lev.size() > 1 && h->patch_nn && h->p2_patch &&
+                        !h->dist.on && !h->lu_comm;
+  bool use_lu = h->lu_comm || optv.pc_type == 2 ||
+                (optv.pc_type == 0 && (h->degree == 2 || !h->structured) && !h->dist.on && !mg_first);
   h->lu_active = false;
   if (use_lu) {
     int rcl = ensure_lu(h);
@@ -2312,8 +2321,28 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     pgxk_scale_copy(h->st, nk, -1.0, dist ? h->rhs : h->F, h->rhs);
     int kits = 0;
     double relres = 0;
-    rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
-    if (rc) return rc;
+    if (mg_first && !use_lu) {
+      pgx_snes_opts ol = optv;
+      ol.ksp_max_it = std::min(optv.ksp_max_it, h->p2_fallback_its);
+      rc = fgmres(h, h->rhs, h->dx, &ol, &kits, &relres);
+      if (rc) return rc;
+      // stagnation = the iteration cap was reached without convergence (an early exit at the attainable accuracy, a few 1e-10
+      // after 10-15 iterations on the late systems, is not): factorise, and keep the factorisation for this solve
+      if (kits >= ol.ksp_max_it && !(relres <= 10.0 * optv.ksp_rtol)) {
+        if (opts->monitor) printf("    KSP (patch multigrid) %d its, rel residual %.3e: sparse LU for the rest of this solve\n", kits, relres);
+        lin += kits;
+        if ((rc = ensure_lu(h))) return rc;
+        if ((rc = lu_factor(h))) return rc;
+        h->lu_active = true;
+        use_lu = true;
+        ++h->p2_fallbacks;
+        rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
+        if (rc) return rc;
+      }
+    } else {
+      rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
+      if (rc) return rc;
+    }
     lin += kits;
     ++its;
     if (opts->monitor) printf("    KSP its %d  rel residual %.3e\n", kits, relres);

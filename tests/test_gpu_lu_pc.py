@@ -47,11 +47,52 @@ def test_p1_lu_and_multigrid_agree(require_gpu):
     assert _rel(xl[:n], xm[:n]) < 1e-10
 
 
-def test_p2_auto_lu_matches_oracle_where_multigrid_failed(require_gpu):
-    """P2, N = 48: the automatic choice for degree 2 is the sparse LU (the two-level P2 cycle is not robust on the late
-    large-alpha systems: DESIGN.md section 3)."""
+@pytest.mark.parametrize("mode", ["auto", "pgx_mg", "fallback"])
+def test_p2_patch_multigrid_matches_oracle(require_gpu, monkeypatch, mode):
+    """P2, N = 48 (round 3): the two-level cycle with the vertex-star patch smoother (pgx_patch.hip) - forced (`pgx_mg`), as the
+    automatic choice for degree 2 on a structured mesh (`auto`: patch multigrid first, sparse LU for a Newton solve in which it
+    stagnates), and with the stagnation threshold lowered to 3 iterations so that the LU fallback path itself runs (`fallback`).
+    Same Newton counts and primal field as the exact-Newton oracle in all three."""
+    if mode == "fallback":
+        monkeypatch.setenv("PGX_P2_FALLBACK_ITS", "3")
     N = 48
-    x, hist, _ = _run(N, 2, None)
+    x, hist, _ = _run(N, 2, dict(OPTS, pc_type="pgx_mg") if mode == "pgx_mg" else None)
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleLagrange(coords, cells, 2)
+    x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+    assert hist["Newton steps"] == h_ref["Newton steps"]
+    assert _rel(x[: prob.n], x_ref[: prob.n]) < 1e-10
+
+
+def test_p2_patch_multigrid_iteration_counts_do_not_grow(require_gpu):
+    """The point of the patch smoother: Krylov iterations per Newton step stay bounded as the mesh is refined (settings A, where no
+    iterate overshoots: 8-11 per step at every size; the point-Jacobi cycle of rounds 1-2 needed 30-90 at 64^2-128^2)."""
+    per_step = {}
+    for N in (32, 128):
+        from proximalgalerkin_amd import fem
+        from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+        msh = fem.create_rectangle(DOMAIN, (N, N))
+        problem, sol, sol_k, alpha = setup_problem(msh, 2, petsc_options=dict(OPTS, pc_type="pgx_mg"))
+        lin = []
+        orig = problem.solve
+
+        def solve(orig=orig, problem=problem, lin=lin):
+            r = orig()
+            lin.append(problem.solver.getLinearSolveIterations())
+            return r
+
+        problem.solve = solve
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "constant", 1e5, 1e-6)
+        problem.close()
+        per_step[N] = max(k / n for k, n in zip(lin, hist["Newton steps"]))
+    assert per_step[32] <= 14 and per_step[128] <= 14, per_step
+
+
+def test_p2_sparse_lu_matches_oracle(require_gpu):
+    """P2, N = 48 through the sparse LU (`pc_type pgx_lu`, the reference's literal choice and round 2's default for degree 2)."""
+    N = 48
+    x, hist, _ = _run(N, 2, OPTS)
     coords, cells = O.create_rectangle(N, N)
     prob = O.ObstacleLagrange(coords, cells, 2)
     x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)

@@ -22,7 +22,7 @@ S = {"A": ("constant", 1e5, 1e-6), "B": ("double_exponential", 1e2, 1e-4)}[setti
 def run(N, pc):
     msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N))
     t0 = time.perf_counter()
-    problem, sol, sol_k, alpha = setup_problem(msh, 2, petsc_options=dict(BASE, pc_type=pc))
+    problem, sol, sol_k, alpha = setup_problem(msh, 2, petsc_options=dict(BASE, pc_type=pc) if pc else dict(BASE))
     ts = time.perf_counter() - t0
     lin = []
     orig = problem.solve
@@ -46,8 +46,9 @@ def run(N, pc):
 
 
 for N in sizes:
-    xm, hm, lm, tm, sm, okm = run(N, "pgx_mg")
-    print(f"N={N} settings {settings} pgx_mg (patch): {tm:7.2f} s (setup {sm:.1f}) newton {hm['Newton steps']} krylov(last per solve) {lm}", flush=True)
+    mode = None if "--auto" in sys.argv else "pgx_mg"  # auto: patch multigrid first, sparse LU for a solve in which it stagnates
+    xm, hm, lm, tm, sm, okm = run(N, mode)
+    print(f"N={N} settings {settings} {mode or 'auto'} (patch): {tm:7.2f} s (setup {sm:.1f}) newton {hm['Newton steps']} krylov(last per solve) {lm}", flush=True)
     if "--no-lu" in sys.argv:
         continue
     xl, hl, ll, tl, sl, okl = run(N, "pgx_lu")
