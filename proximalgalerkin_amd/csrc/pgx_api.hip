@@ -64,6 +64,8 @@ struct pgx_handle {
   double *s_K = nullptr, *s_M = nullptr, *s_D = nullptr;
   int s_nnz = 0;
   size_t s_fill_lds = 0;
+  int32_t* s_blk = nullptr;  // P2: row blocks of the nnz-balanced stream kernel (k_bspmv_bal), s_nblk + 1 entries
+  int s_nblk = 0, spmv_bal = 1;
   std::vector<int32_t> s_h_rowptr, s_h_col;
   // P2 extras: cell dofs, inverted lists of the P2 plan, P1<->P2 transfers, two-level cycle scratch
   QuadTab2 q2{};
@@ -393,6 +395,17 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
     const int i1 = std::min(i0 + PGX_BLOCK, n);
     maxlen = std::max(maxlen, (size_t)(rowptr[i1] - rowptr[i0]));
   }
+  std::vector<int32_t> blk{0};
+  for (int r = 0; r < n;) {  // greedy: as many rows as fit PGX_BAL_CAP entries (a P2 row has at most 23), at most PGX_BLOCK rows
+    int e = r;
+    while (e < n && e - r < PGX_BLOCK && rowptr[e + 1] - rowptr[r] <= PGX_BAL_CAP_HOST) ++e;
+    if (e == r) {
+      blk.clear();  // a single row beyond the capacity: keep the unbalanced kernel
+      break;
+    }
+    blk.push_back(e);
+    r = e;
+  }
   h->s_fill_lds = maxlen * sizeof(double);
   if (h->s_fill_lds > 60 * 1024) {
     h->err = "row block too dense for the LDS-staged fill";
@@ -443,6 +456,11 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
         for (int k = eptr[v]; k < eptr[v + 1]; ++k) d[1 + k - eptr[v]] = elist[k];
       }
     }
+  }
+  if (blk.size() > 1) {
+    h->s_nblk = (int)blk.size() - 1;
+    DALLOC(h->s_blk, blk.size());
+    HIPCHK(hipMemcpy(h->s_blk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
   }
   DALLOC(h->s_colm, colm.size());
   DALLOC(h->p2_v2c_ptr, n + 1);
@@ -852,6 +870,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_FUSED_K3")) h->fused_k3 = atoi(e);
   if (const char* e = pgx_tune("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
+  if (const char* e = pgx_tune("PGX_SPMV_BAL")) h->spmv_bal = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
   if (const char* e = pgx_tune("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
@@ -1351,7 +1370,10 @@ static void spmv_dev(pgx_handle* h, const double* x, double* y) {
       pgxk_st_spmv(h->st, h->lev[0], h->alpha, x, x + h->nd, h->xcd_remap ? 1 : 0, y, y + h->nd);
     return;
   }
-  if (h->spmv_stream && 2 * h->s_fill_lds <= 100 * 1024)
+  if (h->spmv_stream && h->spmv_bal && h->s_blk)
+    pgxk_bspmv_bal(h->st, h->nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, x,
+                   x + h->nd, nullptr, nullptr, h->xcd_remap ? 1 : 0, y, y + h->nd);
+  else if (h->spmv_stream && 2 * h->s_fill_lds <= 100 * 1024)
     pgxk_bspmv_stream(h->st, h->nd, h->s_fill_lds, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, x,
                       x + h->nd, h->xcd_remap ? 1 : 0, y, y + h->nd);
   else
@@ -1568,8 +1590,12 @@ static int ensure_patches(pgx_handle* h) {
 static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, double* xu, double* xp, int nu, double omega) {
   const int nd = h->nd, nv = h->n, NN = h->patch_nn;
   auto resid = [&]() {
-    pgxk_bspmv(h->st, 1, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, 0.0, h->xcd_remap,
-               h->p2_ru, h->p2_rp);
+    if (h->spmv_bal && h->s_blk)
+      pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, xu, xp, bu,
+                     bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
+    else
+      pgxk_bspmv(h->st, 1, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, 0.0, h->xcd_remap,
+                 h->p2_ru, h->p2_rp);
   };
   auto patch = [&](const double* ru, const double* rp) {
     pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);

@@ -145,6 +145,11 @@ void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp);
+// nnz-balanced CSR-stream kernel (blocks blk[b] .. blk[b+1] of <= PGX_BAL_CAP entries and <= 256 rows); bu != nullptr: b - J x
+#define PGX_BAL_CAP_HOST 2048
+void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
+                    const double* K, const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu,
+                    const double* xp, const double* bu, const double* bp, int remap, double* yu, double* yp);
 // CSR-stream form of y = Jx (256 rows per block through LDS); mask = Dirichlet flags of the u block
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,

@@ -620,6 +620,66 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
   __builtin_nontemporal_store(ap, yp + row);
 }
 
+// k_bspmv_bal (round 3): the CSR-stream kernel with NNZ-balanced blocks.  k_bspmv_stream gives every block 256 rows and the LDS of
+// the densest block: on P2 (19 nnz per vertex row, 9 per edge row) that is 78 KB per block = 2 blocks = 8 waves per CU, and the
+// kernel sat at 0.33 of the HBM peak.  Here the host cuts the rows into blocks of at most CAP entries
+// (blk[b] .. blk[b+1], never more than 256 rows), so every block parks <= CAP products per field: 32 KB of LDS, 5 blocks per CU,
+// equal work per block.  bu != nullptr: the residual b - J x instead of J x (the patch smoother's sweeps, pgx_patch.hip).
+#define PGX_BAL_CAP 2048
+__global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* __restrict__ blk, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ colm, const double* __restrict__ K,
+                                                         const double* __restrict__ M, const double* __restrict__ D, double alpha,
+                                                         const uint8_t* __restrict__ mask, const double* __restrict__ xu,
+                                                         const double* __restrict__ xp, const double* __restrict__ bu,
+                                                         const double* __restrict__ bp, int remap, double* __restrict__ yu,
+                                                         double* __restrict__ yp) {
+  __shared__ double su[PGX_BAL_CAP], sp[PGX_BAL_CAP];
+  __shared__ int srp[PGX_BLOCK + 1];
+  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
+  const int r0 = blk[b], nr = blk[b + 1] - r0;
+  const int tid = threadIdx.x;
+  if (tid < nr) srp[tid] = rowptr[r0 + tid];
+  if (tid == 0) srp[nr] = rowptr[r0 + nr];  // nr can be PGX_BLOCK: one entry more than there are threads
+  __syncthreads();
+  const int base = srp[0];
+  const int len = srp[nr] - base;
+  const int32_t* cb = colm + base;
+  const double *Kb = K + base, *Mb = M + base, *Db = D + base;
+#pragma unroll 4
+  for (int k = tid; k < len; k += PGX_BLOCK) {
+    const int cm = __builtin_nontemporal_load(cb + k);
+    const int c = cm & 0x7fffffff;
+    const double kv = __builtin_nontemporal_load(Kb + k), mv = __builtin_nontemporal_load(Mb + k),
+                 dv = __builtin_nontemporal_load(Db + k);
+    const double xuv = (cm < 0) ? 0.0 : xu[c];
+    const double xpv = xp[c];
+    su[k] = alpha * kv * xuv + mv * xpv;
+    sp[k] = mv * xuv - dv * xpv;
+  }
+  __syncthreads();
+  if (tid >= nr) return;
+  const int row = r0 + tid;
+  double au = 0.0, ap = 0.0;
+  for (int k = srp[tid] - base, e = srp[tid + 1] - base; k < e; ++k) {
+    au += su[k];
+    ap += sp[k];
+  }
+  if (mask[row]) au = xu[row];
+  if (bu) {
+    au = bu[row] - au;
+    ap = bp[row] - ap;
+  }
+  __builtin_nontemporal_store(au, yu + row);
+  __builtin_nontemporal_store(ap, yp + row);
+}
+
+void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
+                    const double* K, const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu,
+                    const double* xp, const double* bu, const double* bp, int remap, double* yu, double* yp) {
+  hipLaunchKernelGGL(k_bspmv_bal, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, D, alpha, mask, xu, xp, bu, bp,
+                     remap, yu, yp);
+}
+
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
                        const double* xu, const double* xp, int remap, double* yu, double* yp) {

@@ -103,3 +103,23 @@ def test_p2_unstructured_numbering(require_gpu):
     assert problem.solver.getIterationNumber() == its_ref
     assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-9
     problem.close()
+
+
+@pytest.mark.parametrize("N,M", [(40, 40), (96, 33), (257, 5)])
+def test_p2_nnz_balanced_spmv_matches_oracle_and_the_row_block_kernel(require_gpu, monkeypatch, N, M):
+    """k_bspmv_bal (blocks of at most 2048 entries; the sparse boundary rows make blocks of exactly 256 rows, the case in which the
+    kernel needs one row pointer more than it has threads) against the oracle's J @ v and against the 256-rows-per-block kernel."""
+    out = {}
+    for bal in ("1", "0"):
+        monkeypatch.setenv("PGX_SPMV_BAL", bal)
+        problem, sol, sol_k, alpha, prob = _setup(N, M)
+        x, xk = _iterates(2 * prob.n, 11)
+        alpha.value = 3.5
+        sol_k.x.array[:] = xk
+        problem.assemble_jacobian(x)
+        v = np.random.default_rng(7).standard_normal(2 * prob.n)
+        out[bal] = problem.spmv(v)
+        if bal == "1":
+            assert _rel(out[bal], prob.jacobian(x, 3.5) @ v) < 1e-12
+        problem.close()
+    assert _rel(out["1"], out["0"]) < 1e-14
