@@ -403,8 +403,6 @@ def main():
     sharded = (world > 1 and not args.replicas) or force_sharded
     comm = None
     if sharded:
-        if args.degree != 1:
-            raise SystemExit("bench.py: the sharded path covers P1; use --replicas for --degree 2")
         comm = make_comm(local_rank)  # id / segment-name broadcast through the torch.distributed group
     msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N), comm=comm, dist_levels=args.dist_levels)
     petsc_options = None

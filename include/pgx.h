@@ -262,6 +262,10 @@ int pgx_create_sharded(const pgx_mesh* local_mesh, const pgx_problem* local_prob
 int pgx_create_lu_dist(const pgx_mesh* mesh, const pgx_problem* prob, pgx_comm* comm, int device, pgx_handle** out);
 /* owned entries of a local vector: fields [0,n) and [n,2n) each hold owned entries at [offset, offset+count) */
 int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count);
+/* P2 handles: the owned EDGE dofs of each field block as (offset within the field block, count); the vertex dofs are what
+ * pgx_owned_range reports.  An edge belongs to the rank that owns its lower vertex; edge dofs are numbered by their lower vertex,
+ * row by row, so the owned ones are contiguous.  Unsharded handles own every edge dof. */
+int pgx_owned_edge_range(const pgx_handle* h, int64_t* offset, int64_t* count);
 /* refresh the ghost entries of device `sol` and `sol_k` from their owners (after pgx_set_state / pgx_set_prev
  * with host arrays whose ghost entries are stale) */
 int pgx_sync_ghosts(pgx_handle* h);

@@ -228,6 +228,7 @@ SYMBOLS = [
      [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.POINTER(pgx_partition), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_create_lu_dist", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_owned_range", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("pgx_owned_edge_range", C.c_int, [_H, c_int64_p, c_int64_p]),
     ("pgx_sync_ghosts", C.c_int, [_H]),
     # sparse direct solver (include/pgx_nd.h)
     ("pgx_nd_create", C.c_int, [C.POINTER(pgx_nd_matrix), C.c_int, C.c_void_p, C.POINTER(_H)]),

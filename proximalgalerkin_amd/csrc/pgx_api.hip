@@ -33,6 +33,11 @@ struct Dist {
   long long n_halo = 0, n_allreduce = 0, n_vcycle = 0, n_krylov = 0;  // collective counts (pgx_comm_counts)
   double* view_S = nullptr;  // [7 * view.n] strip-shaped coarse stencils before they are merged into the global level
   size_t own_off = 0, own_cnt = 0;  // owned entries per field on level 0: [own_off, own_off + own_cnt)
+  // P2 on strips: the edge dofs follow the vertex dofs of a field, ordered by their LOWER vertex (row-major), so the edges whose
+  // lower vertex lies in one vertex row form one contiguous block of eb = 3 nx + 1 dofs (nx in the last local row).  An edge is
+  // owned by the rank that owns its lower vertex: owned edges = [eown_off, eown_off + eown_cnt) of the edge part.
+  size_t eb = 0, eown_off = 0, eown_cnt = 0;
+  size_t nk_field() const { return own_cnt + eown_cnt; }  // owned dofs per field (Krylov vectors are owned-compact)
   int cell0 = 0, ncell_own = 0;     // owned cells (row-major cell order)
   double *sb = nullptr, *wc = nullptr;  // local scatter buffer (2n), owned-compact scratch (2*own_cnt)
 };
@@ -434,6 +439,20 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
     eptr[ends[2 * e] + 1]++;
     eptr[ends[2 * e + 1] + 1]++;
   }
+  if (h->dist.on) {  // sharded P2 addresses the edges of a vertex row as one contiguous block (Dist::eb)
+    const int sx = h->nx + 1;
+    std::vector<int> per_row(h->ny + 1, 0);
+    bool sorted = true;
+    for (int e = 0; e < ne; ++e) {
+      if (e && ends[2 * e] < ends[2 * (e - 1)]) sorted = false;
+      per_row[ends[2 * e] / sx]++;
+    }
+    for (int j = 0; j <= h->ny && sorted; ++j) sorted = per_row[j] == (j < h->ny ? 3 * h->nx + 1 : h->nx);
+    if (!sorted) {
+      h->err = "pgx_create_sharded (P2): edge dofs must be numbered by their lower vertex, row by row (3 nx + 1 per vertex row)";
+      return PGX_EINVAL;
+    }
+  }
   for (int i = 0; i < nv; ++i) eptr[i + 1] += eptr[i];
   std::vector<int32_t> elist(eptr[nv]), ef(eptr.begin(), eptr.end() - 1);
   for (int e = 0; e < ne; ++e) {
@@ -594,6 +613,21 @@ static int halo_level(pgx_handle* h, int l, double* fu, double* fp) {
   double* f[2] = {fu, fp};
   const int rc = h->dist.comm->halo(h->st, f, 2, d.glo * sx, (d.g + 1) * sx, 0, d.g * sx, (d.glo + d.H - d.g) * sx,
                                     d.g * sx, (d.glo + d.H) * sx, (d.g + 1) * sx);
+  ++h->dist.n_halo;
+  if (rc) h->err = h->dist.comm->err;
+  return rc;
+}
+// ghost entries of a SOLUTION-SPACE pair (fu, fp) - each [vertex dofs | edge dofs] for P2 - from their owners
+static int halo_solution(pgx_handle* h, double* fu, double* fp) {
+  int rc = halo_level(h, 0, fu, fp);
+  if (rc || h->degree != 2) return rc;
+  // edge part: g full row blocks below and above (the last local row's horizontal edges stay behind: they lie on the outermost,
+  // never-valid ghost line)
+  const DistLevel& d = h->dist.L[0];
+  const size_t eb = h->dist.eb, nv = (size_t)h->n;
+  double* f[2] = {fu + nv, fp + nv};
+  rc = h->dist.comm->halo(h->st, f, 2, d.glo * eb, d.g * eb, 0, d.g * eb, (size_t)(d.glo + d.H - d.g) * eb, d.g * eb,
+                          (size_t)(d.glo + d.H) * eb, d.g * eb);
   ++h->dist.n_halo;
   if (rc) h->err = h->dist.comm->err;
   return rc;
@@ -930,8 +964,8 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       h->err = "pgx_create_sharded: communicator rank/size differ from the partition's";
       return fail(PGX_EINVAL);
     }
-    if (!h->structured || p->degree != 1) {
-      h->err = "pgx_create_sharded: only structured P1 meshes are sharded (strip decomposition)";
+    if (!h->structured || (p->degree != 1 && p->degree != 2)) {
+      h->err = "pgx_create_sharded: structured P1 / P2 meshes are sharded (strip decomposition)";
       return fail(PGX_EINVAL);
     }
     if (h->ny + 1 != nrows || h->nx % (1 << pt.dist_levels)) {
@@ -968,6 +1002,13 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     const int cell_rows = (pt.rank + 1 == pt.size) ? D.L[0].H - 1 : D.L[0].H;
     D.cell0 = 2 * h->nx * D.L[0].glo;
     D.ncell_own = 2 * h->nx * cell_rows;
+    if (p->degree == 2) {
+      D.eb = 3 * (size_t)h->nx + 1;
+      const size_t last = (size_t)h->ny;  // the last local vertex row carries its nx horizontal edges only
+      auto E = [&](size_t row) { return row <= last ? row * D.eb : last * D.eb + (size_t)h->nx; };
+      D.eown_off = E(D.L[0].glo);
+      D.eown_cnt = E((size_t)D.L[0].glo + D.L[0].H) - D.eown_off;
+    }
   }
   // quadrature tables
   h->q.nq = p->nq;
@@ -1128,7 +1169,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     DALLOC(h->d_out6, 6);
     if (h->dist.on) {
       DALLOC(h->dist.sb, n2);
-      DALLOC(h->dist.wc, 2 * h->dist.own_cnt + 2);
+      DALLOC(h->dist.wc, 2 * h->dist.nk_field() + 2);
     }
     const int r = h->dist.on ? build_multigrid_dist(h) : build_multigrid(h);
     if (r) return r;
@@ -1237,14 +1278,20 @@ extern "C" int pgx_zero_state(pgx_handle* h) {
 extern "C" int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count) {
   if (!h) return PGX_EINVAL;
   if (offset) *offset = h->dist.on ? (int64_t)h->dist.own_off : 0;
-  if (count) *count = h->dist.on ? (int64_t)h->dist.own_cnt : (int64_t)h->nd;
+  if (count) *count = h->dist.on ? (int64_t)h->dist.own_cnt : (int64_t)(h->degree == 2 ? h->n : h->nd);
+  return PGX_OK;
+}
+extern "C" int pgx_owned_edge_range(const pgx_handle* h, int64_t* offset, int64_t* count) {
+  if (!h) return PGX_EINVAL;
+  if (offset) *offset = (int64_t)h->n + (h->dist.on ? (int64_t)h->dist.eown_off : 0);
+  if (count) *count = h->dist.on ? (int64_t)h->dist.eown_cnt : (int64_t)(h->nd - h->n);
   return PGX_OK;
 }
 extern "C" int pgx_sync_ghosts(pgx_handle* h) {
   NEED(h);
   if (!h->dist.on) return PGX_OK;
-  int rc = halo_level(h, 0, h->x, h->x + h->n);
-  if (!rc) rc = halo_level(h, 0, h->xk, h->xk + h->n);
+  int rc = halo_solution(h, h->x, h->x + h->nd);
+  if (!rc) rc = halo_solution(h, h->xk, h->xk + h->nd);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
@@ -1554,13 +1601,23 @@ static int vcycle_dist(pgx_handle* h, int l, double* bu, double* bp, double* out
 // owned entries of a local (u | psi) vector <-> owned-compact vector [u_owned | psi_owned]
 static void gather_owned(pgx_handle* h, const double* loc, double* cmp) {
   const Dist& D = h->dist;
-  hipMemcpyAsync(cmp, loc + D.own_off, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
-  hipMemcpyAsync(cmp + D.own_cnt, loc + h->n + D.own_off, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+  const size_t nf = D.nk_field(), nd = (size_t)h->nd, nv = (size_t)h->n;
+  for (int f = 0; f < 2; ++f) {
+    hipMemcpyAsync(cmp + f * nf, loc + f * nd + D.own_off, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+    if (D.eown_cnt)
+      hipMemcpyAsync(cmp + f * nf + D.own_cnt, loc + f * nd + nv + D.eown_off, sizeof(double) * D.eown_cnt, hipMemcpyDeviceToDevice,
+                     h->st);
+  }
 }
 static void scatter_owned(pgx_handle* h, const double* cmp, double* loc) {
   const Dist& D = h->dist;
-  hipMemcpyAsync(loc + D.own_off, cmp, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
-  hipMemcpyAsync(loc + h->n + D.own_off, cmp + D.own_cnt, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+  const size_t nf = D.nk_field(), nd = (size_t)h->nd, nv = (size_t)h->n;
+  for (int f = 0; f < 2; ++f) {
+    hipMemcpyAsync(loc + f * nd + D.own_off, cmp + f * nf, sizeof(double) * D.own_cnt, hipMemcpyDeviceToDevice, h->st);
+    if (D.eown_cnt)
+      hipMemcpyAsync(loc + f * nd + nv + D.eown_off, cmp + f * nf + D.own_cnt, sizeof(double) * D.eown_cnt, hipMemcpyDeviceToDevice,
+                     h->st);
+  }
 }
 
 // P2: two-level cycle.  Smoother = collective damped Jacobi on the P2 block CSR (k_bspmv<2>); coarse space =
@@ -1615,6 +1672,59 @@ static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, d
     resid();
     patch(h->p2_ru, h->p2_rp);
   }
+}
+
+// The same cycle on a strip (sharded P2, round 3).  Validity depth = number of ghost vertex rows on which a local vector equals the
+// global one.  An exchange (halo_solution) restores depth g; a residual b - J x reads one row further out than it writes (-1); a patch
+// solve needs the residual on its whole star and an edge average both end patches (-1): a sweep = residual + patches costs 2 rows.
+// The P1 hierarchy below is vcycle_dist, which exchanges for itself.  Exchanges are issued only when the depth runs out - with the
+// default ghost depth (24 rows at three distributed levels) that is the one exchange of the right-hand side.
+static int pcycle_p2_patch_dist(pgx_handle* h, double* bu, double* bp, double* xu, double* xp, int nu, double omega) {
+  const int nd = h->nd, nv = h->n, NN = h->patch_nn;
+  const int g = h->dist.L[0].g;
+  int rc = halo_solution(h, bu, bp);  // the Krylov vector is correct on owned dofs only
+  if (rc) return rc;
+  int xv = 0;  // validity depth of (xu, xp)
+  auto need = [&](int depth) -> int {
+    if (xv >= depth) return PGX_OK;
+    const int r = halo_solution(h, xu, xp);
+    xv = g;
+    return r;
+  };
+  auto resid = [&]() {
+    pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, xu, xp, bu, bp,
+                   h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
+    xv -= 1;
+  };
+  auto patch = [&](const double* ru, const double* rp) {
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+    xv -= 1;
+  };
+  if (!h->s_blk) {
+    h->err = "sharded P2: no balanced SpMV blocks";
+    return PGX_ESTATE;
+  }
+  hipMemsetAsync(xu, 0, sizeof(double) * nd, h->st);
+  hipMemsetAsync(xp, 0, sizeof(double) * nd, h->st);
+  xv = g;  // zero is right everywhere
+  patch(bu, bp);
+  for (int s2 = 1; s2 < h->patch_nu; ++s2) {
+    if ((rc = need(3))) return rc;
+    resid();
+    patch(h->p2_ru, h->p2_rp);
+  }
+  if ((rc = need(3))) return rc;
+  resid();  // valid to depth >= 2: the P1 restriction reads the residual one row out on the owned coarse rows
+  pgxk_p2_restrict(h->st, nv, nd, h->v2e_ptr, h->v2e, h->mask, h->p2_ru, h->p2_rp, h->c1_bu, h->c1_bp);
+  if ((rc = vcycle_dist(h, 0, h->c1_bu, h->c1_bp, h->c1_xu, h->c1_xp, g, nu, omega))) return rc;
+  pgxk_p2_prolong_add(h->st, nv, nd, h->edge_ends, h->c1_xu, h->c1_xp, xu, xp);
+  xv = std::min(xv, g - 1);  // the edge part of T x_c reads both end vertices
+  for (int s2 = 0; s2 < h->patch_nu; ++s2) {
+    if ((rc = need(3))) return rc;
+    resid();
+    patch(h->p2_ru, h->p2_rp);
+  }
+  return need(2);  // the operator apply that follows reads one row beyond the strip
 }
 
 static void pcycle_p2(pgx_handle* h, const double* bu, const double* bp, double* outu, double* outp, int nu,
@@ -1786,6 +1896,15 @@ static int precond(pgx_handle* h, const double* b, double* z, int nu, double ome
   if (h->dist.on) {  // b is owned-compact, z local (owned + ghost rows, correct at least one row beyond the strip)
     scatter_owned(h, b, h->dist.sb);
     ++h->dist.n_vcycle;
+    if (h->degree == 2) {
+      if (!h->patch_nn) {
+        h->err = "sharded P2 needs the vertex-star patch smoother (vertex degree <= 7)";
+        return PGX_EINVAL;
+      }
+      int rc = ensure_patches(h);
+      if (rc) return rc;
+      return pcycle_p2_patch_dist(h, h->dist.sb, h->dist.sb + h->nd, z, z + h->nd, nu, omega);
+    }
     return vcycle_dist(h, 0, h->dist.sb, h->dist.sb + h->n, z, z + h->n, 1, nu, omega);
   }
   if (h->degree == 2 && h->p2_patch && h->patch_nn) {  // vertex-star patch smoother on the P2 level, P1 hierarchy below
@@ -1807,7 +1926,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
   // tuned vector kernels run unchanged and every dot product is "local partial + one all-reduce"); the operators work
   // on local vectors with ghost rows (Z_j, x), with a gather after every SpMV.
   const bool dist = h->dist.on;
-  const size_t nk = dist ? 2 * h->dist.own_cnt : n2;
+  const size_t nk = dist ? 2 * h->dist.nk_field() : n2;
   double* const wk = dist ? h->dist.wc : h->w;
   // P2: the two-level preconditioner is weaker on the late large-alpha systems (30-60 its): use the full basis
   const int m = (h->degree == 2) ? h->restart : std::min(std::max(o->ksp_restart, 1), h->restart);
@@ -2015,7 +2134,7 @@ extern "C" int pgx_residual(pgx_handle* h, const double* x, double* F, double* f
     int rc;
     if (h->dist.on) {  // collective: 2-norm over the owned entries of all ranks
       gather_owned(h, h->F, h->dist.wc);
-      rc = dev_norm(h, h->dist.wc, fnorm, 2 * h->dist.own_cnt);
+      rc = dev_norm(h, h->dist.wc, fnorm, 2 * h->dist.nk_field());
     } else {
       rc = dev_norm(h, h->F, fnorm);
     }
@@ -2073,7 +2192,7 @@ extern "C" int pgx_spmv(pgx_handle* h, const double* x, double* y) {
   }
   int rc = copy_in(h, h->V, x);
   if (rc) return rc;
-  if (h->dist.on && (rc = halo_level(h, 0, h->V, h->V + h->n))) return rc;  // ghost entries from their owners
+  if (h->dist.on && (rc = halo_solution(h, h->V, h->V + h->nd))) return rc;  // ghost entries from their owners
   spmv_dev(h, h->V, h->w);
   return copy_out(h, y, h->w);  // owned rows are J x of the GLOBAL operator; ghost rows are not meaningful
 }
@@ -2226,10 +2345,17 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
   if (!out) return PGX_EINVAL;
   {
     PhaseTimer t(h, 6);
-    if (h->degree == 2) {
+    if (h->degree == 2 && !h->dist.on) {
       pgxk_observables_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->x, h->xk, h->alpha, h->f, h->q2,
                                 h->obs_partials, h->obs_blocks);
       pgxk_observables_final(h->st, h->obs_blocks, h->obs_partials, h->d_out6);
+    } else if (h->dist.on && h->degree == 2) {
+      const Dist& D = h->dist;  // P2 on a strip: the owned cells' partial sums, one packed all-reduce (raw sums, as below)
+      pgxk_observables_p2_cells(h->st, D.ncell_own, h->nd, h->cdofs + 6 * (size_t)D.cell0, h->coords, h->x, h->xk, h->alpha, h->f,
+                                h->q2, h->obs_partials, pgxk_observables_blocks(D.ncell_own));
+      pgxk_observables_final_raw(h->st, pgxk_observables_blocks(D.ncell_own), h->obs_partials, h->d_out6);
+      const int rc = allreduce_dev(h, h->d_out6, 6);
+      if (rc) return rc;
     } else if (h->dist.on) {
       // owned cells only (a contiguous range in row-major cell order), raw sums, ONE packed all-reduce for the six
       // scalars (the reference all-reduces each one separately, obstacle_pg.py:196-201), then abs / sqrt
@@ -2310,7 +2436,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // Sharded: x, xw, dx, F are local vectors (owned + ghost rows); norms run on owned-compact copies (rhs doubles as the
   // compact copy of F), and the ghost rows of the iterate are refreshed after every update, before the next assembly.
   const bool dist = h->dist.on;
-  const size_t nk = dist ? 2 * h->dist.own_cnt : n2;
+  const size_t nk = dist ? 2 * h->dist.nk_field() : n2;
   auto owned_norm = [&](const double* v, double* out) -> int {
     if (!dist) return dev_norm(h, v, out);
     gather_owned(h, v, h->dist.wc);
@@ -2377,7 +2503,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
       break;
     }
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
-    if (dist && (rc = halo_level(h, 0, h->xw, h->xw + h->n))) return rc;
+    if (dist && (rc = halo_solution(h, h->xw, h->xw + h->nd))) return rc;
     residual_dev(h, h->xw, h->F, 1);
     if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
     if (dist) {

@@ -186,6 +186,7 @@ void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdo
                                const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
                                int nblocks);
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6);
+void pgxk_observables_final_raw(hipStream_t st, int nblocks, const double* partials, double* out6);  // plain sums (sharded)
 // vertex-star patch smoother of the P2 level (pgx_patch.hip)
 void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* rowptr, const int32_t* colm,
                           int32_t* ppos);

@@ -779,6 +779,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_final(int nblocks, co
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6) {
   hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6, 0);
 }
+void pgxk_observables_final_raw(hipStream_t st, int nblocks, const double* partials, double* out6) {
+  hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6, 1);
+}
 
 int pgxk_observables_blocks(int nc) {
   int b = (nc + PGX_BLOCK - 1) / PGX_BLOCK;

@@ -83,7 +83,15 @@ class Mesh:
             return bv
         edges, cell_edges = self.edges()
         cnt = np.bincount(cell_edges.ravel(), minlength=len(edges))
-        return np.concatenate([bv, self.num_vertices + np.flatnonzero(cnt == 1)]).astype(np.int32)
+        on_boundary = cnt == 1
+        if self.partition is not None and self.structured:
+            # a strip: the edges of the cut lines belong to one LOCAL cell only, but only the global boundary is exterior
+            nx, _ = self.structured
+            i, j = edges % (nx + 1), edges // (nx + 1) + self.partition.row0
+            gy = self.partition.global_ny
+            on_boundary &= ((i[:, 0] == i[:, 1]) & ((i[:, 0] == 0) | (i[:, 0] == nx))) | \
+                           ((j[:, 0] == j[:, 1]) & ((j[:, 0] == 0) | (j[:, 0] == gy)))
+        return np.concatenate([bv, self.num_vertices + np.flatnonzero(on_boundary)]).astype(np.int32)
 
     def exterior_vertices(self):
         """Vertices on exterior facets (edges that belong to exactly one cell):

@@ -355,6 +355,13 @@ class NonlinearProblem:
         _lib.check(self._lib, self._h, self._lib.pgx_observables(self._h, _lib.dptr(out)), "pgx_observables")
         return out
 
+    def owned_edge_range(self):
+        """(offset, count): owned EDGE dofs within each field block of a P2 local vector (include/pgx.h: pgx_owned_edge_range)."""
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib, self._h, self._lib.pgx_owned_edge_range(self._h, C.byref(off), C.byref(cnt)),
+                   "pgx_owned_edge_range")
+        return off.value, cnt.value
+
     def owned_range(self):
         """(offset, count): owned entries of each field block of a local vector (everything for an unsharded mesh)."""
         off, cnt = C.c_int64(0), C.c_int64(0)

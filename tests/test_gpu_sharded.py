@@ -231,3 +231,49 @@ def test_bench_sharded_branch_runs_over_rccl_with_one_rank(require_gpu):
     assert d["config"]["mixed_unknowns"] == 2 * 257 * 257
     assert d["config"]["newton_iterations_per_step"] == 19 and d["value"] > 0  # 256^2 settings B: 19 Newton steps
     assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("R,nx,ny,levels,scheme", [(2, 32, 64, 1, "constant"), (3, 48, 96, 0, "constant"),
+                                                   (4, 32, 128, 2, "double_exponential")])
+def test_sharded_p2_solve_equals_single_handle(require_gpu, R, nx, ny, levels, scheme):
+    """P2 (`obstacle_pg.py -p 2`, BASELINE config 3) on R strips (round 3): vertex dofs by rows, the edge dofs of a vertex row as one
+    contiguous block owned with it; halo exchange of vertex rows AND edge blocks; two-level cycle with the vertex-star patch
+    smoother on the strip, the sharded P1 hierarchy below.  Same Newton / proximal counts and the same primal field as the
+    single-handle solve on the whole mesh; observables through ONE packed all-reduce."""
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    a_max, tol = (1e5, 1e-6) if scheme == "constant" else (1e2, 1e-4)
+    opts = dict(OPTS, pc_type="pgx_mg")  # the single handle takes the same preconditioner family (no LU fallback on either side)
+    msh = fem.create_rectangle(DOMAIN, (nx, ny))
+    problem, sol, sol_k, alpha = setup_problem(msh, 2, petsc_options=opts)
+    hg = run_outer_loop(problem, sol, sol_k, alpha, 100, scheme, a_max, tol)
+    xg = sol.x.array.copy()
+    ndg = sol.function_space.block_size
+    problem.close()
+    sx, eb = nx + 1, 3 * nx + 1
+    nvg = sx * (ny + 1)
+
+    def rank_main(c):
+        m = fem.create_rectangle(DOMAIN, (nx, ny), comm=c, dist_levels=levels)
+        pr, s, sk, al = setup_problem(m, 2, petsc_options=opts)
+        hist = run_outer_loop(pr, s, sk, al, 100, scheme, a_max, tol)
+        x = s.x.array.copy()
+        out = (x, hist, m.partition, pr.owned_range(), pr.owned_edge_range(), s.function_space.block_size, m.num_vertices)
+        pr.close()
+        return out
+
+    res = _run_ranks(pcomm.local_group(R), rank_main)
+    u = np.full(ndg, np.nan)
+    for x, hist, part, (voff, vcnt), (eoff, ecnt), nd, nv in res:
+        assert hist["Newton steps"] == hg["Newton steps"]
+        for col in ("Energy", "Primal increments", "Latent increments"):
+            assert np.allclose(hist[col], hg[col], rtol=1e-7, atol=1e-12), col
+        assert voff == (part.own0 - part.row0) * sx and vcnt == part.nown * sx
+        assert eoff == nv + (part.own0 - part.row0) * eb
+        u[part.own0 * sx: part.own0 * sx + vcnt] = x[voff: voff + vcnt]
+        ge = nvg + part.own0 * eb  # global edge block of the first owned row
+        u[ge: ge + ecnt] = x[eoff: eoff + ecnt]
+    assert not np.isnan(u).any()  # the owned ranges of the ranks tile the global dof set
+    assert np.linalg.norm(u - xg[:ndg]) <= 1e-10 * np.linalg.norm(xg[:ndg])
