@@ -411,7 +411,12 @@ def main():
                          "snes_max_it": 100}  # obstacle_pg.py:128-139
         for kv in args.opts.split(","):
             k, v = kv.split("=")
-            petsc_options[k] = float(v) if any(c in v for c in ".e") else int(v)
+            for cast in (int, float, str):
+                try:
+                    petsc_options[k] = cast(v)
+                    break
+                except ValueError:
+                    pass
     problem, sol, sol_k, alpha = setup_problem(msh, args.degree, petsc_options=petsc_options, device=local_rank)
     t_setup = time.perf_counter() - t_setup
     if os.environ.get("BENCH_TEST_DIE_RANK") == str(rank):  # test hook: a rank that vanishes before the first collective solve

@@ -94,3 +94,17 @@ def test_bench_launches_itself_when_asked_for_more_than_one_gpu(require_gpu):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+
+
+def test_sharded_p2_obstacle_solve_across_processes(require_gpu):
+    """BASELINE config 3's shape - P2, the mesh cut into strips, one process per strip - launched exactly as the driver launches it
+    (settings A; two ranks on one GPU through the shm transport): same counts as the single-process run."""
+    args = ["--degree", "2", "--cells", "128", "--settings", "A", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--watchdog", "500",
+            "--opts", "pc_type=pgx_mg"]
+    d = _launch(2, args)
+    d1 = _single(args)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"].startswith("sharded: ONE 128x128 solve on 2 strips")
+    assert d["config"]["newton_iterations_per_step"] == d1["config"]["newton_iterations_per_step"]
+    assert d["config"]["proximal_iterations_per_step"] == d1["config"]["proximal_iterations_per_step"]
+    assert d["value"] > 0
