@@ -136,3 +136,51 @@ def test_config5_signorini_70_cubed(require_gpu):
     right, left = mid[np.argmax(c[mid, 0])], mid[np.argmin(c[mid, 0])]
     print(f"config 5: min u_z on the contact face {uz[bottom].min():.3e}, lateral bulge {ux[right]:.4e} / {ux[left]:.4e}")
     assert ux[right] > 1e-3 and abs(ux[right] + ux[left]) < 0.05 * abs(ux[right])  # the 6-tet split is not mirror-symmetric
+
+
+def test_config3_p2_obstacle_1024_on_4_strips(require_gpu):
+    """Config 3 in its partitioned form (round 3): the 1024^2 P2 problem (8.4 M unknowns) cut into four strips, each with its own
+    handle, halo exchange of vertex rows and edge blocks through the in-process transport (a one-GPU box cannot host four RCCL
+    ranks; everything but the byte transport is the code of the multi-GPU launch).  Settings A: 27 Newton steps like the single
+    handle, every strip's owned part of a feasible solution with exact Dirichlet data."""
+    import threading
+
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import phi_set, run_outer_loop, setup_problem
+
+    N, R = 1024, 4
+    out, err = [None] * R, [None] * R
+
+    def work(c):
+        try:
+            msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (N, N), comm=c)
+            problem, sol, sol_k, alpha = setup_problem(msh, 2)
+            hist = run_outer_loop(problem, sol, sol_k, alpha, 500, "constant", 1e5, 1e-6)
+            V = sol.function_space
+            nd = V.block_size
+            u = sol.x.array[:nd].copy()
+            (vo, vc), (eo, ec) = problem.owned_range(), problem.owned_edge_range()
+            own = np.concatenate([np.arange(vo, vo + vc), np.arange(eo, eo + ec)])
+            xy = V.dof_coordinates()[own]
+            bc = np.intersect1d(msh.exterior_dofs(2), own)
+            out[c.rank] = (hist["Newton steps"], hist["Primal increments"][-1], float((u[own] - phi_set(xy.T.copy())).min()),
+                           float(u[own].max()), bool(np.all(u[bc] == 0.0)), problem.comm_counts())
+            problem.close()
+        except BaseException as e:  # noqa: BLE001
+            err[c.rank] = e
+
+    th = [threading.Thread(target=work, args=(c,)) for c in pcomm.local_group(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(o[0] == out[0][0] for o in out) and sum(out[0][0]) == 27, out[0][0]
+    assert all(o[1] < 1e-6 and o[2] > -1e-5 and o[4] for o in out)
+    assert abs(max(o[3] for o in out) - 0.5) < 1e-5
+    cc = out[0][5]
+    print(f"config 3 on 4 strips, 1024^2 P2: newton {out[0][0]}, halo exchanges per Krylov iteration "
+          f"{cc['halo_exchanges'] / max(cc['krylov_iterations'], 1):.1f}, all-reduces {cc['allreduces'] / max(cc['krylov_iterations'], 1):.1f}")
