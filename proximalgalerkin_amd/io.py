@@ -2,13 +2,13 @@
 
 The reference reads its meshes from XDMF/HDF5 written by gmsh scripts (examples/01_obstacle_problem/generate_mesh_gmsh.py:12-43,
 obstacle_pg.py:64-65) and writes results with VTXWriter / XDMFFile (obstacle_pg.py:239-243,
-gradient_constraint_dolfinx.py:145-158, signorini_dolfinx.py:293-299).  HDF5 and ADIOS2 are not available offline; the
-formats offered here are the ones every gmsh / ParaView installation handles directly:
+gradient_constraint_dolfinx.py:145-158, signorini_dolfinx.py:293-299).  No HDF5 binding and no ADIOS2 exist offline: HDF5 files of
+the kind DOLFINx writes are read and written by proximalgalerkin_amd/h5.py, results go to VTU:
 
     read_msh(path)                      gmsh MSH 2.2 / 4.1 ASCII  -> (points, cells_by_type, cell_tags_by_type)
-    read_xdmf(path, name)               XDMF with INLINE (XML / ASCII-encoded) heavy data - what
-                                        dolfinx.io.XDMFFile(..., encoding=XDMFFile.Encoding.ASCII) writes; HDF5-backed files are
-                                        refused with a message that says how to re-export
+    read_xdmf(path, name)               XDMF with the heavy data in HDF5 (DOLFINx's default: read through the pure-Python reader
+                                        proximalgalerkin_amd/h5.py - contiguous, unfiltered datasets, default format bounds) or
+                                        INLINE (dolfinx.io.XDMFFile(..., encoding=XDMFFile.Encoding.ASCII))
     read_mesh(path) / read_tet_mesh     -> fem.Mesh / (TetMesh, MeshTags) from either format; ORDER-2 geometry (6-node triangles,
                                         10-node tetrahedra: generate_mesh_gmsh.py:31, mesh_generation.py:88,158) is reduced to
                                         its vertices - the solvers use affine cells
@@ -125,14 +125,21 @@ def read_xdmf(path, name: str = "mesh"):
 
     root = ET.parse(str(path)).getroot()
 
+    h5files = {}
+
     def numbers(item, dtype):
         fmt = (item.get("Format") or "XML").upper()
-        if fmt != "XML":
-            raise NotImplementedError(
-                f"{path}: DataItem Format=\"{item.get('Format')}\" ({(item.text or '').strip()}): HDF5 is not available here. Re-export "
-                "with inline data - dolfinx.io.XDMFFile(comm, file, 'w', encoding=dolfinx.io.XDMFFile.Encoding.ASCII) - or pass the "
-                "gmsh .msh file")
         dims = [int(v) for v in item.get("Dimensions").split()]
+        if fmt in ("HDF", "HDF5"):  # "file.h5:/Mesh/mesh/geometry" - what XDMFFile writes by default (obstacle_pg.py:64-65)
+            from . import h5
+
+            fname, _, dset = (item.text or "").strip().partition(":")
+            hp = Path(path).parent / fname
+            if hp not in h5files:
+                h5files[hp] = h5.H5File(hp)
+            return np.asarray(h5files[hp][dset], dtype=dtype).reshape(dims)
+        if fmt != "XML":
+            raise NotImplementedError(f"{path}: DataItem Format=\"{item.get('Format')}\"")
         return np.array((item.text or "").split(), dtype=dtype).reshape(dims)
 
     grids = {g.get("Name"): g for g in root.iter("Grid") if g.find("Topology") is not None}
@@ -222,12 +229,26 @@ def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     return mesh, MeshTags(tagged_facets)
 
 
-def write_xdmf_mesh(path, mesh, name: str = "mesh"):
-    """XDMFFile.write_mesh (generate_mesh_gmsh.py:41-43) for a triangular fem.Mesh, inline (Format="XML") data items - the encoding
-    `read_xdmf` / `read_mesh` accept."""
+def write_xdmf_mesh(path, mesh, name: str = "mesh", encoding: str = "ASCII"):
+    """XDMFFile.write_mesh (generate_mesh_gmsh.py:41-43) for a triangular fem.Mesh.  encoding "ASCII": inline (Format="XML") data
+    items; "HDF5" (DOLFINx's default): the heavy data in `<stem>.h5` as /Mesh/<name>/geometry (float64) and /Mesh/<name>/topology
+    (int64), written by proximalgalerkin_amd/h5.py.  `read_xdmf` / `read_mesh` accept both."""
     path = Path(path)
     p, t = np.asarray(mesh.geometry), np.asarray(mesh.cells)
     path.parent.mkdir(parents=True, exist_ok=True)
+    if encoding.upper() in ("HDF5", "HDF"):
+        from . import h5
+
+        h5name = path.with_suffix(".h5")
+        h5.write(h5name, {f"/Mesh/{name}/geometry": np.asarray(p, dtype=np.float64), f"/Mesh/{name}/topology": np.asarray(t, dtype=np.int64)})
+        with open(path, "w") as f:
+            f.write('<?xml version="1.0"?>\n<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">'
+                    '<Domain>\n<Grid Name="%s" GridType="Uniform">\n' % name)
+            f.write('<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n<DataItem Dimensions="%d 3" '
+                    'NumberType="Int" Format="HDF">%s:/Mesh/%s/topology</DataItem></Topology>\n' % (len(t), len(t), h5name.name, name))
+            f.write('<Geometry GeometryType="XY"><DataItem Dimensions="%d 2" Format="HDF">%s:/Mesh/%s/geometry</DataItem></Geometry>\n'
+                    '</Grid>\n</Domain></Xdmf>\n' % (len(p), h5name.name, name))
+        return
     with open(path, "w") as f:
         f.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n<Grid Name="%s" GridType="Uniform">\n' % name)
         f.write('<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n<DataItem Dimensions="%d 3" NumberType="Int" '

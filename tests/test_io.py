@@ -2,6 +2,7 @@
 import xml.etree.ElementTree as ET
 
 import numpy as np
+import pytest
 
 from proximalgalerkin_amd import io
 
@@ -133,17 +134,54 @@ def test_tet_mesh_with_facet_tags_from_order2_msh_and_xdmf():
         assert (vol > 0).all() and np.isclose(vol.sum() / 6.0, 1.0)
 
 
-def test_hdf5_backed_xdmf_is_refused_with_instructions(tmp_path):
-    f = tmp_path / "m.xdmf"
-    f.write_text('<Xdmf><Domain><Grid Name="mesh"><Topology TopologyType="Triangle"><DataItem Dimensions="1 3" Format="HDF">m.h5:/Mesh/mesh/'
-                 'topology</DataItem></Topology><Geometry><DataItem Dimensions="3 2" Format="HDF">m.h5:/Mesh/mesh/geometry</DataItem>'
-                 '</Geometry></Grid></Domain></Xdmf>')
-    try:
-        io.read_mesh(f)
-    except NotImplementedError as e:
-        assert "Encoding.ASCII" in str(e)
-    else:
-        raise AssertionError("an HDF5-backed file must not be read silently")
+def test_hdf5_backed_xdmf_written_by_the_real_libhdf5_is_read():
+    """tests/golden/dolfinx_like_square.{xdmf,h5}: the .h5 was written by libhdf5 itself (tools/make_h5_fixtures.c: DOLFINx's dataset
+    names, contiguous, default format bounds), the .xdmf is what XDMFFile.write_mesh + write_meshtags put next to it.  The
+    pure-Python reader (proximalgalerkin_amd/h5.py) must return exactly the arrays the C program wrote - `obstacle_pg.py -f
+    mesh.xdmf` (obstacle_pg.py:64-65) on a file of the reference's own pipeline."""
+    from proximalgalerkin_amd import h5
+
+    f = h5.H5File(GOLD / "dolfinx_like_square.h5")
+    assert f.keys("/") == ["Mesh", "MeshTags"] and f.keys("/Mesh/mesh") == ["geometry", "topology"]
+    g, t = f["/Mesh/mesh/geometry"], f["/Mesh/mesh/topology"]
+    nx, ny = 5, 4
+    i, j = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    assert g.dtype == np.float64 and np.array_equal(g, np.stack([i.ravel() / nx, j.ravel() / ny], axis=1))
+    assert t.dtype == np.int64 and t.shape == (40, 3) and t[3].tolist() == [1, 7, 8] and t.max() == 29
+    assert f["/MeshTags/facet_tags/Values"].tolist() == [7] * 4 + [9] * 5
+    pts, cells, tags = io.read_xdmf(GOLD / "dolfinx_like_square.xdmf")
+    assert np.array_equal(pts, g) and np.array_equal(cells["triangle"], t)
+    assert tags["facet_tags"][0] == "line" and tags["facet_tags"][2].tolist() == [7] * 4 + [9] * 5
+    mesh = io.read_mesh(GOLD / "dolfinx_like_square.xdmf")
+    x = mesh.geometry[mesh.cells]
+    area = 0.5 * ((x[:, 1, 0] - x[:, 0, 0]) * (x[:, 2, 1] - x[:, 0, 1]) - (x[:, 1, 1] - x[:, 0, 1]) * (x[:, 2, 0] - x[:, 0, 0]))
+    assert (area > 0).all() and np.isclose(area.sum(), 1.0)
+
+
+def test_hdf5_xdmf_round_trip_and_unsupported_features(tmp_path):
+    from proximalgalerkin_amd import fem, h5
+
+    msh = fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (7, 5))
+    io.write_xdmf_mesh(tmp_path / "m.xdmf", msh, encoding="HDF5")
+    assert (tmp_path / "m.h5").exists() and 'Format="HDF">m.h5:/Mesh/mesh/geometry' in (tmp_path / "m.xdmf").read_text()
+    back = io.read_mesh(tmp_path / "m.xdmf")
+    # read_mesh orients every triangle counter-clockwise: compare the vertex sets of the cells
+    assert np.array_equal(back.geometry, msh.geometry) and np.array_equal(np.sort(back.cells, axis=1), np.sort(msh.cells, axis=1))
+    # dtypes and shapes the writer covers, an empty dataset, nested groups
+    data = {"/a/b/c": np.arange(12, dtype=np.int32).reshape(3, 4), "/a/x": np.linspace(0, 1, 5, dtype=np.float32), "/y": np.zeros((0, 3)),
+            "/a/b/d": np.array([2**40, -3], dtype=np.int64)}
+    h5.write(tmp_path / "t.h5", data)
+    f = h5.H5File(tmp_path / "t.h5")
+    assert f.keys("/a") == ["b", "x"]
+    for k, v in data.items():
+        assert f[k].dtype == v.dtype and np.array_equal(f[k], v)
+    with pytest.raises(KeyError):
+        f["/a/nothing"]
+    bad = bytearray((tmp_path / "t.h5").read_bytes())
+    bad[8] = 2  # superblock version 2 (libver='latest'): refused by name, never misread
+    (tmp_path / "v2.h5").write_bytes(bytes(bad))
+    with pytest.raises(NotImplementedError, match="superblock version 2"):
+        h5.H5File(tmp_path / "v2.h5")
 
 
 def test_generate_disk_writes_the_reference_named_xdmf_files(tmp_path):
