@@ -187,7 +187,7 @@ def test_hdf5_xdmf_round_trip_and_unsupported_features(tmp_path):
 def test_generate_disk_writes_the_reference_named_xdmf_files(tmp_path):
     """examples/01_obstacle_problem/generate_mesh_gmsh.py: `generate_disk(filename, res, order, refinement_level)` writes
     `<stem>_<level>.xdmf` (the reference's naming, generate_mesh_gmsh.py:40), every refinement level halves the mesh size, and the
-    file reads back as the mesh `fem.create_disk` makes (inline-data XDMF through io.write_xdmf_mesh / io.read_mesh)."""
+    file reads back as the mesh `fem.create_disk` makes (HDF5-backed XDMF through io.write_xdmf_mesh / io.read_mesh)."""
     import importlib.util
     import pathlib
 
@@ -200,7 +200,7 @@ def test_generate_disk_writes_the_reference_named_xdmf_files(tmp_path):
     sizes = []
     for level in (0, 1):
         out = mod.generate_disk(tmp_path / "meshes" / "disk.xdmf", res=0.4, order=2, refinement_level=level)
-        assert out.name == f"disk_{level}.xdmf" and out.exists()
+        assert out.name == f"disk_{level}.xdmf" and out.exists() and out.with_suffix(".h5").exists()  # HDF5-backed, as upstream
         m = io.read_mesh(out)
         ref = fem.create_disk(0.4 / 2**level)
         assert np.array_equal(m.cells, ref.cells) and np.abs(m.geometry - ref.geometry).max() == 0.0
