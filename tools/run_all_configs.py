@@ -47,7 +47,7 @@ print(f"config 2  ex01 2048^2 P1 (settings B): {sum(h['Newton steps'])} Newton i
 sizes = [(512, B, "B"), (1024, A, "A: constant alpha")] + ([(2048, A, "A: constant alpha")] if "--full" in sys.argv else [])
 for N, S, tag in sizes:
     h, dt, reason, _ = obstacle(N, 2, S)
-    print(f"config 3' ex01 {N}^2 P2 (settings {tag}; single GPU, sparse-LU preconditioner; the 2048^2 8-GPU case is pgx_create_lu_dist): "
+    print(f"config 3' ex01 {N}^2 P2 (settings {tag}; single GPU, patch-smoother multigrid with sparse-LU fallback; the 8-GPU case is the sharded path, bench.py --degree 2 --gpus 8): "
           f"{sum(h['Newton steps'])} Newton its in {dt:.2f} s, last SNES reason {reason}", flush=True)
 t = time.perf_counter()
 its, diffs = gc_solve(1024, 1024, verbose=False)
