@@ -403,7 +403,7 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
   std::vector<int32_t> blk{0};
   for (int r = 0; r < n;) {  // greedy: as many rows as fit PGX_BAL_CAP entries (a P2 row has at most 23), at most PGX_BLOCK rows
     int e = r;
-    while (e < n && e - r < PGX_BLOCK && rowptr[e + 1] - rowptr[r] <= PGX_BAL_CAP_HOST) ++e;
+    while (e < n && e - r < PGX_BLOCK && rowptr[e + 1] - rowptr[r] <= PGX_BAL_CAP) ++e;
     if (e == r) {
       blk.clear();  // a single row beyond the capacity: keep the unbalanced kernel
       break;

@@ -146,7 +146,9 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp);
 // nnz-balanced CSR-stream kernel (blocks blk[b] .. blk[b+1] of <= PGX_BAL_CAP entries and <= 256 rows); bu != nullptr: b - J x
-#define PGX_BAL_CAP_HOST 2048
+#ifndef PGX_BAL_CAP
+#define PGX_BAL_CAP 1536  // entries per block of k_bspmv_bal; measured at 2048^2 P2, ms per apply on two boxes: 1024 1.46, 1280 1.37, 1536 1.31 / 1.13, 1792 - / 1.12, 2048 1.50, 3072 1.61, 4096 2.20
+#endif
 void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
                     const double* K, const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu,
                     const double* xp, const double* bu, const double* bp, int remap, double* yu, double* yp);

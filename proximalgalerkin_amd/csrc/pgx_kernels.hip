@@ -623,9 +623,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
 // k_bspmv_bal (round 3): the CSR-stream kernel with NNZ-balanced blocks.  k_bspmv_stream gives every block 256 rows and the LDS of
 // the densest block: on P2 (19 nnz per vertex row, 9 per edge row) that is 78 KB per block = 2 blocks = 8 waves per CU, and the
 // kernel sat at 0.33 of the HBM peak.  Here the host cuts the rows into blocks of at most CAP entries
-// (blk[b] .. blk[b+1], never more than 256 rows), so every block parks <= CAP products per field: 32 KB of LDS, 5 blocks per CU,
+// (blk[b] .. blk[b+1], never more than 256 rows), so every block parks <= CAP = 1536 products per field: 24 KB of LDS, 6 blocks per CU,
 // equal work per block.  bu != nullptr: the residual b - J x instead of J x (the patch smoother's sweeps, pgx_patch.hip).
-#define PGX_BAL_CAP 2048
 __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* __restrict__ blk, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colm, const double* __restrict__ K,
                                                          const double* __restrict__ M, const double* __restrict__ D, double alpha,
