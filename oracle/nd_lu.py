@@ -418,7 +418,12 @@ class NDLinearSolve:
 
 
 def nodes_of_problem(prob):
-    """Node grouping of the oracle's obstacle problems: dof i of u and dof i of psi share node i (vertex or edge midpoint)."""
+    """Node grouping of the oracle's problems.  Obstacle (pg_oracle): dof i of u and dof i of psi share node i (vertex or edge
+    midpoint).  Gradient constraint (gc_oracle.GradientConstraintP2, layout u[n2] | psi_x[nv] | psi_y[nv]): a vertex node holds
+    (u_v, psi_x_v, psi_y_v), an edge node its P2 midpoint value."""
+    if hasattr(prob, "n2") and hasattr(prob, "ntot"):
+        nv, n2 = prob.nv, prob.n2
+        return np.concatenate([np.arange(n2), np.arange(nv), np.arange(nv)]), np.asarray(prob.dof_coords)[:n2]
     n = prob.n
     coords = getattr(prob, "dof_coords", prob.coords)
     return np.concatenate([np.arange(n), np.arange(n)]), np.asarray(coords)[:n]

@@ -92,3 +92,18 @@ def test_ordering_statistics_follow_nested_dissection():
         nd = ND.NDLU(J, *ND.nodes_of_problem(prob))
         st.append((nd.flops, nd.factor_entries))
     assert 5.0 < st[2][0] / st[1][0] < 9.5 and 3.5 < st[2][1] / st[1][1] < 5.5
+
+
+def test_nd_lu_runs_example_06_like_superlu():
+    """The nested-dissection LU as the linear solver of the example-06 oracle (node = vertex with (u, psi_x, psi_y) or edge midpoint
+    with u): same Newton counts and solution as the SuperLU default - it is what bench.py --workload ex06 times as cpu_baseline."""
+    from oracle import gc_oracle as G
+
+    c, e = O.create_rectangle(12, 12, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(c, e)
+    x0, its0, _ = G.solve_problem(prob)
+    ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    x1, its1, _ = G.solve_problem(prob, linear_solve=ls)
+    assert list(its0) == list(its1)
+    assert np.linalg.norm(x0 - x1) <= 1e-9 * np.linalg.norm(x0)
+    assert ls.last_relres < 1e-12

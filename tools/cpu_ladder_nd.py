@@ -3,7 +3,9 @@
 cpu_baseline leg measures live on the GPU box: seconds per Newton step (numpy assembly + numeric factorisation + solves with
 refinement; symbolic analysis and mesh setup untimed) for the first Newton steps of settings B at a series of mesh sizes, and the
 exponent of t = c N^p.  bench.py carries its live 1024^2 measurement to the benchmarked 2048^2 mesh with that exponent (2-D nested
-dissection: about N^3 in flops, N^2 log N in storage), and says so.   python tools/cpu_ladder_nd.py 256 512 1024  (build container)"""
+dissection: about N^3 in flops, N^2 log N in storage), and says so.   python tools/cpu_ladder_nd.py 256 512 1024  (build container)
+`--ex06 N...` does the same for example 06 (oracle/gc_oracle.py: P2 / vector-P1, alpha = 1 first proximal step; bench.py
+--workload ex06 measures the 256^2 point live) -> profiles/r03_cpu_ladder_ex06_nd.json."""
 import json
 import pathlib
 import platform
@@ -19,7 +21,7 @@ from oracle import nd_lu as ND  # noqa: E402
 from oracle import pg_oracle as O  # noqa: E402
 
 OUT = ROOT / "profiles" / "r03_cpu_ladder_nd.json"
-STEPS = 2
+STEPS = 3
 
 
 def one(N):
@@ -47,13 +49,59 @@ def one(N):
     return rec
 
 
+def one_ex06(N):
+    from oracle import gc_oracle as G
+
+    c, e = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    prob = G.GradientConstraintP2(c, e)
+    ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    ND.MAX_THREADS = 1
+    st = {"n": 0, "t0": None}
+
+    class Done(Exception):
+        pass
+
+    def solve(J, rhs):
+        dx = ls(J, rhs)
+        if st["t0"] is None:  # first call: symbolic analysis + first touch of the arena, untimed
+            st["t0"] = time.perf_counter()
+            ls.t_factor = ls.t_solve = 0.0
+            return dx
+        st["n"] += 1
+        st["dt"] = time.perf_counter() - st["t0"]
+        if st["n"] >= STEPS + 1:
+            raise Done
+        return dx
+
+    with threadpool_limits(1):
+        try:
+            G.solve_problem(prob, linear_solve=solve)
+        except Done:
+            pass
+    ND.MAX_THREADS = 0
+    n = st["n"]
+    rec = {"N": N, "unknowns": prob.ntot, "newton_steps": n, "s_per_newton_step": st["dt"] / n, "factor_s_per_step": ls.t_factor / n,
+           "solve_refine_s_per_step": ls.t_solve / n, "factor_gflop": ls.nd.flops / 1e9, "symbolic_s_untimed": ls.nd.symbolic_s,
+           "factor_storage_GB": 8e-9 * ls.nd.factor_entries}
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
 def main():
+    global OUT
+    argv = sys.argv[1:]
+    ex06 = "--ex06" in argv
+    if ex06:
+        argv.remove("--ex06")
+        OUT = ROOT / "profiles" / "r03_cpu_ladder_ex06_nd.json"
     doc = json.loads(OUT.read_text()) if OUT.exists() else {}
     pts = doc.get("points", [])
-    for a in sys.argv[1:]:
-        r = one(int(a))
+    for a in argv:
+        r = one_ex06(int(a)) if ex06 else one(int(a))
         pts = sorted([p for p in pts if p["N"] != r["N"]] + [r], key=lambda p: p["N"])
-    doc["what"] = ("CPU oracle with the nested-dissection multifrontal LU (oracle/nd_lu.py), 1 BLAS thread, P1 settings B on [-1,1]^2: "
+    doc["what"] = ("CPU oracle of example 06 (oracle/gc_oracle.py, P2 / vector-P1 on the unit square) with the nested-dissection multifrontal LU "
+                   "(oracle/nd_lu.py), 1 BLAS thread: seconds per Newton step over the first Newton steps after the first (assembly + numeric "
+                   "factorisation + solves with refinement; symbolic analysis untimed)") if ex06 else ("CPU oracle with the nested-dissection multifrontal LU (oracle/nd_lu.py), 1 BLAS thread, P1 settings B on [-1,1]^2: "
                    "seconds per Newton step over the first Newton steps (assembly + numeric factorisation + solves; symbolic analysis untimed)")
     doc["host"] = platform.processor() or platform.machine()
     doc["points"] = pts
