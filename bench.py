@@ -553,6 +553,9 @@ def main():
                 1: "k_st_spmv_r (matrix-free apply of the Newton matrix [[aK,M],[M,-D]] on the structured mesh: constant K/M "
                    "stencils, half-stored D(psi) stencil; the outer-Krylov SpMV of this workload)",
                 2: "k_st_apply<0> (generic matrix-free stencil apply)"}[kind]
+        if kind == 0 and args.degree == 2:
+            name = ("k_bspmv_bal (P2 operator apply: nnz-balanced CSR-stream SpMV of [[aK,M],[M,-D]]; on this uniform mesh K and M are "
+                    "read through a one-byte (K,M)-pair dictionary: 13 B per entry instead of 28)")
         traffic, src = pmc_traffic({0: "r03_spmv_pmc_traffic.json", 1: "r03_stspmv_pmc_traffic.json"}.get(kind, "none"))
         gbs = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
@@ -569,7 +572,7 @@ def main():
             # the 273 MB operator straddles the 256 MB Infinity Cache); `cold_frac` after a 512 MB sweep of unrelated storage
             r["cold_avg_launch_ms"] = cold_ms[kind]
             r["cold_frac"] = nbytes / (cold_ms[kind] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if kind == 0:
+        if kind == 0 and args.degree == 1:
             r["mixed_csr_equivalent_GBs"] = (12.0 * 4 * (nbytes - 4.0 * (n + 1) - 32.0 * n) / 28.0 + 20.0 * 2 * n) / (ms * 1e-3) / 1e9
         elif csr_bytes:
             # SURVEY.md section 8(d) prices the operator as the mixed CSR the reference assembles (12 B per nnz of the 2n x 2n matrix +

@@ -71,6 +71,9 @@ struct pgx_handle {
   size_t s_fill_lds = 0;
   int32_t* s_blk = nullptr;  // P2: row blocks of the nnz-balanced stream kernel (k_bspmv_bal), s_nblk + 1 entries
   int s_nblk = 0, spmv_bal = 1;
+  uint8_t* s_code = nullptr;  // P2 on a uniform mesh: per entry the index of its (K, M) pair in s_tab (k_bspmv_bal<true>)
+  double* s_tab = nullptr;    // 256 (K, M) pairs
+  int s_ntab = 0, spmv_dict = 1;
   std::vector<int32_t> s_h_rowptr, s_h_col;
   // P2 extras: cell dofs, inverted lists of the P2 plan, P1<->P2 transfers, two-level cycle scratch
   QuadTab2 q2{};
@@ -86,7 +89,10 @@ struct pgx_handle {
   bool patch_fresh = false;  // pinv holds the inverses of the current Jacobian
   std::vector<int32_t> patch_dof_host;
   int32_t *pdof = nullptr, *ppos = nullptr;
-  double *pinv = nullptr, *p2_su = nullptr, *p2_sp = nullptr;
+  void* pinv = nullptr;  // patch inverses: float by default (a smoother inside FGMRES: same Krylov counts as double at 512^2 ... 2048^2,
+                         // half the bytes of the stream that bounds the sweep), double with the tuning key PGX_P2_PATCH_F32=0
+  int patch_f32 = 1;
+  double *p2_su = nullptr, *p2_sp = nullptr;
   // state
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
   // Krylov workspace
@@ -503,6 +509,75 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
 
 // Is the stencil the same at every interior vertex (uniform grid)?  Then interior rows take their K and M
 // coefficients from kernel arguments.  Setup-time host check on a downloaded copy.
+// (K, M) dictionary of the P2 level for k_bspmv_bal<true>: distinct pairs up to 1e-11 of the largest entry (the tolerance of
+// detect_uniform below).  Seeded with nothing; every round lists up to 4096 unmatched entries, the host adds their distinct values.
+// More than 256 pairs (a non-uniform mesh) => no dictionary, the kernel streams K and M as before.
+static int build_km_dictionary(pgx_handle* h) {
+  const int64_t nnz = h->s_nnz;
+  const int cap = 4096;
+  uint8_t* code = nullptr;
+  double* tab = nullptr;
+  int* fail = nullptr;
+  int64_t* fail_k = nullptr;
+  DALLOC(code, (size_t)nnz);
+  DALLOC(tab, 512);
+  DALLOC(fail, 2);
+  DALLOC(fail_k, cap);
+  // scale: the largest |K|, |M| among the first rows (uniform mesh: every row kind occurs there; otherwise the dictionary fails anyway)
+  const size_t ns = (size_t)std::min<int64_t>(nnz, 1 << 16);
+  std::vector<double> ks(ns), ms(ns);
+  HIPCHK(hipMemcpyAsync(ks.data(), h->s_K, ns * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipMemcpyAsync(ms.data(), h->s_M, ns * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(hipStreamSynchronize(h->st));
+  double kmax = 0.0, mmax = 0.0;
+  for (size_t i = 0; i < ns; ++i) {
+    kmax = std::max(kmax, std::fabs(ks[i]));
+    mmax = std::max(mmax, std::fabs(ms[i]));
+  }
+  const double tk = 1e-11 * kmax, tm = 1e-11 * mmax;
+  std::vector<double> table(512, 0.0);
+  int ntab = 0;
+  std::vector<int64_t> fk(cap);
+  bool ok = false;
+  for (int round = 0; round < 64; ++round) {
+    HIPCHK(hipMemcpyAsync(tab, table.data(), 512 * sizeof(double), hipMemcpyHostToDevice, h->st));
+    HIPCHK(hipMemsetAsync(fail, 0, 2 * sizeof(int), h->st));
+    pgxk_dict_assign(h->st, nnz, h->s_K, h->s_M, ntab, tab, tk, tm, code, fail, cap, fail_k);
+    int f[2];
+    HIPCHK(hipMemcpyAsync(f, fail, sizeof(f), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    const int nf = std::min(f[0], cap);
+    if (nf == 0) {
+      ok = true;
+      break;
+    }
+    HIPCHK(hipMemcpy(fk.data(), fail_k, nf * sizeof(int64_t), hipMemcpyDeviceToHost));
+    bool full = false;
+    for (int i = 0; i < nf && !full; ++i) {
+      double kv, mv;
+      HIPCHK(hipMemcpy(&kv, h->s_K + fk[i], sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&mv, h->s_M + fk[i], sizeof(double), hipMemcpyDeviceToHost));
+      bool have = false;
+      for (int t = 0; t < ntab && !have; ++t) have = std::fabs(kv - table[2 * t]) <= tk && std::fabs(mv - table[2 * t + 1]) <= tm;
+      if (have) continue;
+      if (ntab == 256) {
+        full = true;
+        break;
+      }
+      table[2 * ntab] = kv;
+      table[2 * ntab + 1] = mv;
+      ++ntab;
+    }
+    if (full) break;
+  }
+  if (ok) {
+    h->s_code = code;
+    h->s_tab = tab;
+    h->s_ntab = ntab;
+  }  // else: the arrays stay allocated (freed with the handle) and unused
+  return PGX_OK;
+}
+
 static int detect_uniform(pgx_handle* h, GridLevel& L) {
   L.uniform = 0;
   L.interior_free = 0;
@@ -895,6 +970,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH")) h->p2_patch = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_NU")) h->patch_nu = std::max(1, atoi(e));
   if (const char* e = pgx_tune("PGX_P2_PATCH_OMEGA")) h->patch_omega = atof(e);
+  if (const char* e = pgx_tune("PGX_P2_PATCH_F32")) h->patch_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
     const char* e = pgx_tune("PGX_TAIL2");  // 0: the round-2 tail kernels (A/B)
@@ -905,6 +981,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_NU_COARSE")) h->nu_coarse = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_STREAM")) h->spmv_stream = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_BAL")) h->spmv_bal = atoi(e);
+  if (const char* e = pgx_tune("PGX_SPMV_DICT")) h->spmv_dict = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
   if (const char* e = pgx_tune("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
@@ -1114,6 +1191,10 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
                         h->coords, nullptr, h->q2, h->s_K);
       pgxk_fill_rows_p2(h->st, 1, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
                         h->coords, nullptr, h->q2, h->s_M);
+      if (h->spmv_dict && h->spmv_bal && h->s_blk) {
+        const int rc = build_km_dictionary(h);
+        if (rc) return rc;
+      }
       DALLOC(h->p2_stash, (size_t)16 * nc);
       DALLOC(h->p2_xu, nd);
       DALLOC(h->p2_xp, nd);
@@ -1418,7 +1499,7 @@ static void spmv_dev(pgx_handle* h, const double* x, double* y) {
     return;
   }
   if (h->spmv_stream && h->spmv_bal && h->s_blk)
-    pgxk_bspmv_bal(h->st, h->nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, x,
+    pgxk_bspmv_bal(h->st, h->nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, x,
                    x + h->nd, nullptr, nullptr, h->xcd_remap ? 1 : 0, y, y + h->nd);
   else if (h->spmv_stream && 2 * h->s_fill_lds <= 100 * 1024)
     pgxk_bspmv_stream(h->st, h->nd, h->s_fill_lds, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, x,
@@ -1628,7 +1709,11 @@ static int ensure_patches(pgx_handle* h) {
   if (!h->pdof) {
     DALLOC(h->pdof, (size_t)nv * NN);
     DALLOC(h->ppos, (size_t)nv * NN * NN);
-    DALLOC(h->pinv, (size_t)nv * P * P);
+    {
+      uint8_t* q = nullptr;
+      DALLOC(q, (size_t)nv * P * P * (h->patch_f32 ? sizeof(float) : sizeof(double)));
+      h->pinv = q;
+    }
     DALLOC(h->p2_su, (size_t)2 * (nd - nv));
     DALLOC(h->p2_sp, (size_t)2 * (nd - nv));
     HIPCHK(hipMemcpy(h->pdof, h->patch_dof_host.data(), sizeof(int32_t) * h->patch_dof_host.size(), hipMemcpyHostToDevice));
@@ -1636,7 +1721,7 @@ static int ensure_patches(pgx_handle* h) {
     pgxk_patch_positions(h->st, nv, NN, h->pdof, h->s_rowptr, h->s_colm, h->ppos);
   }
   if (!h->patch_fresh) {
-    pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv);
+    pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv, h->patch_f32);
     h->patch_fresh = true;
   }
   return PGX_OK;
@@ -1648,14 +1733,14 @@ static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, d
   const int nd = h->nd, nv = h->n, NN = h->patch_nn;
   auto resid = [&]() {
     if (h->spmv_bal && h->s_blk)
-      pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, xu, xp, bu,
+      pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu,
                      bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
     else
       pgxk_bspmv(h->st, 1, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, 0.0, h->xcd_remap,
                  h->p2_ru, h->p2_rp);
   };
   auto patch = [&](const double* ru, const double* rp) {
-    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
   };
   hipMemsetAsync(xu, 0, sizeof(double) * nd, h->st);
   hipMemsetAsync(xp, 0, sizeof(double) * nd, h->st);
@@ -1692,12 +1777,12 @@ static int pcycle_p2_patch_dist(pgx_handle* h, double* bu, double* bp, double* x
     return r;
   };
   auto resid = [&]() {
-    pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, xu, xp, bu, bp,
+    pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu, bp,
                    h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
     xv -= 1;
   };
   auto patch = [&](const double* ru, const double* rp) {
-    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
     xv -= 1;
   };
   if (!h->s_blk) {
@@ -2309,6 +2394,9 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
       // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
       // K and M are seven constants each
       *bytes = (16.0 + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
+    else if (h->s_code && h->spmv_bal && h->s_blk && h->spmv_stream)
+      // (K, M) dictionary: column (4 B) + code (1 B) + D (8 B) per scalar nnz; rowptr; x read once; y written
+      *bytes = 13.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
     else  // one pattern (4 B) + three value streams (24 B) per scalar nnz; rowptr; x read once; y written
       *bytes = 28.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
   }

@@ -150,8 +150,11 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
 #define PGX_BAL_CAP 1536  // entries per block of k_bspmv_bal; measured at 2048^2 P2, ms per apply on two boxes: 1024 1.46, 1280 1.37, 1536 1.31 / 1.13, 1792 - / 1.12, 2048 1.50, 3072 1.61, 4096 2.20
 #endif
 void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
-                    const double* K, const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu,
-                    const double* xp, const double* bu, const double* bp, int remap, double* yu, double* yp);
+                    const double* K, const double* M, const uint8_t* code, const double* table, const double* D, double alpha,
+                    const uint8_t* mask, const double* xu, const double* xp, const double* bu, const double* bp, int remap,
+                    double* yu, double* yp);
+void pgxk_dict_assign(hipStream_t st, int64_t nnz, const double* K, const double* M, int ntab, const double* table, double tk,
+                      double tm, uint8_t* code, int* fail, int cap, int64_t* fail_k);
 // CSR-stream form of y = Jx (256 rows per block through LDS); mask = Dirichlet flags of the u block
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,
@@ -193,9 +196,9 @@ void pgxk_observables_final_raw(hipStream_t st, int nblocks, const double* parti
 void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* rowptr, const int32_t* colm,
                           int32_t* ppos);
 void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
-                       const double* D, const uint8_t* mask, double alpha, double* pinv);
+                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32);
 void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
-                      const double* pinv, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
+                      const void* pinv, int f32, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
                       double* sp);
 // fused, atomic-free residual (+ optional D(psi) fill) for P1: see k_resid_fill_p1
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,

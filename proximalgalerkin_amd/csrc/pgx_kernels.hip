@@ -625,9 +625,16 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
 // kernel sat at 0.33 of the HBM peak.  Here the host cuts the rows into blocks of at most CAP entries
 // (blk[b] .. blk[b+1], never more than 256 rows), so every block parks <= CAP = 1536 products per field: 24 KB of LDS, 6 blocks per CU,
 // equal work per block.  bu != nullptr: the residual b - J x instead of J x (the patch smoother's sweeps, pgx_patch.hip).
+//
+// DICT (round 3): on a uniform mesh the constant matrices K and M hold a few dozen distinct (K_ij, M_ij) pairs (one per kind of row
+// and link, up to rounding).  The host finds them (pgxk_dict_assign; equal = within 1e-11 of the largest entry, the tolerance of the
+// P1 levels' uniform stencils) and the kernel reads ONE BYTE per entry - an index into a 256-entry table in LDS - instead of two
+// doubles: 13 B per entry (column, code, D) instead of 28.
+template <bool DICT>
 __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* __restrict__ blk, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colm, const double* __restrict__ K,
-                                                         const double* __restrict__ M, const double* __restrict__ D, double alpha,
+                                                         const double* __restrict__ M, const uint8_t* __restrict__ code,
+                                                         const double2* __restrict__ table, const double* __restrict__ D, double alpha,
                                                          const uint8_t* __restrict__ mask, const double* __restrict__ xu,
                                                          const double* __restrict__ xp, const double* __restrict__ bu,
                                                          const double* __restrict__ bp, int remap, double* __restrict__ yu,
@@ -637,19 +644,33 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
   const int b = xcd_block(blockIdx.x, gridDim.x, remap);
   const int r0 = blk[b], nr = blk[b + 1] - r0;
   const int tid = threadIdx.x;
+  __shared__ double2 stab[DICT ? 256 : 1];
   if (tid < nr) srp[tid] = rowptr[r0 + tid];
   if (tid == 0) srp[nr] = rowptr[r0 + nr];  // nr can be PGX_BLOCK: one entry more than there are threads
+  if (DICT) {
+    static_assert(PGX_BLOCK >= 256, "one table entry per thread");
+    if (tid < 256) stab[tid] = table[tid];
+  }
   __syncthreads();
   const int base = srp[0];
   const int len = srp[nr] - base;
   const int32_t* cb = colm + base;
   const double *Kb = K + base, *Mb = M + base, *Db = D + base;
+  const uint8_t* qb = code + base;
 #pragma unroll 4
   for (int k = tid; k < len; k += PGX_BLOCK) {
     const int cm = __builtin_nontemporal_load(cb + k);
     const int c = cm & 0x7fffffff;
-    const double kv = __builtin_nontemporal_load(Kb + k), mv = __builtin_nontemporal_load(Mb + k),
-                 dv = __builtin_nontemporal_load(Db + k);
+    double kv, mv;
+    if (DICT) {
+      const double2 km = stab[__builtin_nontemporal_load(qb + k)];
+      kv = km.x;
+      mv = km.y;
+    } else {
+      kv = __builtin_nontemporal_load(Kb + k);
+      mv = __builtin_nontemporal_load(Mb + k);
+    }
+    const double dv = __builtin_nontemporal_load(Db + k);
     const double xuv = (cm < 0) ? 0.0 : xu[c];
     const double xpv = xp[c];
     su[k] = alpha * kv * xuv + mv * xpv;
@@ -673,10 +694,51 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
 }
 
 void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
-                    const double* K, const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu,
-                    const double* xp, const double* bu, const double* bp, int remap, double* yu, double* yp) {
-  hipLaunchKernelGGL(k_bspmv_bal, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, D, alpha, mask, xu, xp, bu, bp,
-                     remap, yu, yp);
+                    const double* K, const double* M, const uint8_t* code, const double* table, const double* D, double alpha,
+                    const uint8_t* mask, const double* xu, const double* xp, const double* bu, const double* bp, int remap,
+                    double* yu, double* yp) {
+  if (code && table)
+    hipLaunchKernelGGL(k_bspmv_bal<true>, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, code,
+                       (const double2*)table, D, alpha, mask, xu, xp, bu, bp, remap, yu, yp);
+  else
+    hipLaunchKernelGGL(k_bspmv_bal<false>, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, code,
+                       (const double2*)table, D, alpha, mask, xu, xp, bu, bp, remap, yu, yp);
+}
+
+// code[k] = index of the table entry that equals (K[k], M[k]) within (tk, tm); entries without one are counted in fail[0] and the
+// first `cap` of them listed in fail_k (the host adds their values to the table and calls again)
+__global__ void __launch_bounds__(256) k_dict_assign(int64_t nnz, const double* __restrict__ K, const double* __restrict__ M, int ntab,
+                                                     const double2* __restrict__ table, double tk, double tm,
+                                                     uint8_t* __restrict__ code, int* __restrict__ fail, int cap,
+                                                     int64_t* __restrict__ fail_k) {
+  __shared__ double2 st[256];
+  if ((int)threadIdx.x < ntab) st[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const double kv = K[k], mv = M[k];
+  int found = -1;
+  for (int t = 0; t < ntab; ++t)
+    if (fabs(kv - st[t].x) <= tk && fabs(mv - st[t].y) <= tm) {
+      found = t;
+      break;
+    }
+  if (found >= 0) {
+    code[k] = (uint8_t)found;
+    return;
+  }
+  if (*(volatile int*)fail < cap) {  // racy on purpose: it only bounds the number of atomics
+    const int q = atomicAdd(fail, 1);
+    if (q < cap) fail_k[q] = k;
+  } else {
+    *(volatile int*)(fail + 1) = 1;  // "more than cap"
+  }
+}
+
+void pgxk_dict_assign(hipStream_t st, int64_t nnz, const double* K, const double* M, int ntab, const double* table, double tk,
+                      double tm, uint8_t* code, int* fail, int cap, int64_t* fail_k) {
+  hipLaunchKernelGGL(k_dict_assign, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, K, M, ntab, (const double2*)table, tk,
+                     tm, code, fail, cap, fail_k);
 }
 
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,

@@ -11,10 +11,11 @@
 //
 // Data (per handle, HBM): pdof [np][NN] patch dofs (-1 = unused slot), ppos [np][NN][NN] positions of the patch's scalar-block
 // entries in the P2 block-CSR (-1 = structurally zero), pinv [np][P][P] (P = 2 NN) the inverses of the patch matrices, row-major,
-// rebuilt once per Newton step (only D(psi) and alpha change).  At 2048^2 P2: 4.2 M patches, 6.6 GB of inverses.
+// rebuilt once per Newton step (only D(psi) and alpha change); computed in double, STORED in float by default (the sweep is a
+// smoother inside FGMRES: identical Krylov counts, half the stream).  At 2048^2 P2: 4.2 M patches, 3.3 GB of inverses.
 //
 // Mapping: a group of 16 lanes owns one patch, lane l its row l (four patches per 64-wide wavefront); rows meet through
-// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 1568 B per patch and sweep.
+// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 784 B per patch and sweep (1568 B in double).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,11 +48,11 @@ __global__ void __launch_bounds__(256) k_patch_positions(int np, int NN, const i
 // (the contract of src/lvpp/problem.py:69-77) and unused slots as identity, inverted in place by Gauss-Jordan WITHOUT pivoting:
 // u rows first (aK_pp is SPD), then the psi rows whose Schur complement -D_pp - M_pp (aK_pp)^-1 M_pp is negative definite - the
 // quasi-definite ordering that pgx_nd relies on as well.
-template <int NN>
+template <int NN, typename PT>
 __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __restrict__ pdof, const int32_t* __restrict__ ppos,
                                                       const double* __restrict__ K, const double* __restrict__ M,
                                                       const double* __restrict__ D, const uint8_t* __restrict__ mask, double alpha,
-                                                      double* __restrict__ pinv) {
+                                                      PT* __restrict__ pinv) {
   constexpr int P = 2 * NN;
   const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
   const int l = threadIdx.x & (GRP - 1);
@@ -108,18 +109,18 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
     }
   }
   if (live && l < P) {
-    double* out = pinv + ((size_t)p * P + l) * P;
+    PT* out = pinv + ((size_t)p * P + l) * P;
 #pragma unroll
-    for (int j = 0; j < P; ++j) out[j] = a[j];
+    for (int j = 0; j < P; ++j) out[j] = (PT)a[j];
   }
 }
 
 // One additive sweep: y_p = A_p^-1 r_p for every patch; the vertex dof of a patch belongs to it alone (x += omega y), an edge dof
 // to the patches of its two end vertices: their contributions are parked in stash[2 e + side] and averaged by k_patch_edges
 // (no atomics: bitwise reproducible).
-template <int NN>
+template <int NN, typename PT>
 __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, const int32_t* __restrict__ pdof,
-                                                     const int32_t* __restrict__ edge_ends, const double* __restrict__ pinv,
+                                                     const int32_t* __restrict__ edge_ends, const PT* __restrict__ pinv,
                                                      const double* __restrict__ ru, const double* __restrict__ rp, double omega,
                                                      double* __restrict__ xu, double* __restrict__ xp, double* __restrict__ su,
                                                      double* __restrict__ sp) {
@@ -138,9 +139,9 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
     // The patch matrix is symmetric (K, M, D blocks are; the Dirichlet rows / columns are replaced symmetrically), so row l of the
     // inverse is read as COLUMN l: for every j the lanes of a group touch P consecutive doubles - coalesced - where the row-wise
     // read made each of the P load instructions of a wave touch 56 different cache lines (2.9 -> 1.6 ms per sweep at 2048^2 P2).
-    const double* in = pinv + (size_t)pp * P * P + l;
+    const PT* in = pinv + (size_t)pp * P * P + l;
 #pragma unroll
-    for (int j = 0; j < P; ++j) row[j] = __builtin_nontemporal_load(in + j * P);  // streamed once per sweep
+    for (int j = 0; j < P; ++j) row[j] = (double)__builtin_nontemporal_load(in + j * P);  // streamed once per sweep
   } else {
 #pragma unroll
     for (int j = 0; j < P; ++j) row[j] = 0.0;
@@ -187,24 +188,31 @@ void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, c
 }
 
 void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
-                       const double* D, const uint8_t* mask, double alpha, double* pinv) {
+                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32) {
   const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
-  if (NN <= 7)
-    hipLaunchKernelGGL((k_patch_invert<7>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, pinv);
-  else
-    hipLaunchKernelGGL((k_patch_invert<8>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, pinv);
+#define PGX_INV(N, T) \
+  hipLaunchKernelGGL((k_patch_invert<N, T>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, (T*)pinv)
+  if (NN <= 7) {
+    if (f32) PGX_INV(7, float); else PGX_INV(7, double);
+  } else {
+    if (f32) PGX_INV(8, float); else PGX_INV(8, double);
+  }
+#undef PGX_INV
 }
 
 void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
-                      const double* pinv, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
+                      const void* pinv, int f32, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
                       double* sp) {
   const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
-  if (NN <= 7)
-    hipLaunchKernelGGL((k_patch_apply<7>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, pinv, ru, rp, omega, xu, xp,
-                       su, sp);
-  else
-    hipLaunchKernelGGL((k_patch_apply<8>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, pinv, ru, rp, omega, xu, xp,
-                       su, sp);
+#define PGX_APP(N, T)                                                                                                              \
+  hipLaunchKernelGGL((k_patch_apply<N, T>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, (const T*)pinv, ru, rp, omega, \
+                     xu, xp, su, sp)
+  if (NN <= 7) {
+    if (f32) PGX_APP(7, float); else PGX_APP(7, double);
+  } else {
+    if (f32) PGX_APP(8, float); else PGX_APP(8, double);
+  }
+#undef PGX_APP
   const int ne = nd - nv;
   hipLaunchKernelGGL(k_patch_edges, dim3((ne + 255) / 256), dim3(256), 0, st, ne, nv, omega, su, sp, xu, xp);
 }
