@@ -123,3 +123,22 @@ def test_p2_nnz_balanced_spmv_matches_oracle_and_the_row_block_kernel(require_gp
             assert _rel(out[bal], prob.jacobian(x, 3.5) @ v) < 1e-12
         problem.close()
     assert _rel(out["1"], out["0"]) < 1e-14
+
+
+@pytest.mark.parametrize("N,M", [(40, 40), (96, 33)])
+def test_p2_spmv_km_dictionary_equals_the_streamed_values(require_gpu, monkeypatch, N, M):
+    """k_bspmv_bal<true> (K and M read through the one-byte dictionary of their distinct pairs on a uniform mesh) against the same
+    kernel streaming K and M, and against the oracle's J @ v."""
+    out = {}
+    for d in ("1", "0"):
+        monkeypatch.setenv("PGX_SPMV_DICT", d)
+        problem, sol, sol_k, alpha, prob = _setup(N, M)
+        x, xk = _iterates(2 * prob.n, 5)
+        alpha.value = 0.7
+        sol_k.x.array[:] = xk
+        problem.assemble_jacobian(x)
+        v = np.random.default_rng(3).standard_normal(2 * prob.n)
+        out[d] = problem.spmv(v)
+        problem.close()
+    assert _rel(out["1"], out["0"]) < 1e-11  # equal pairs = within 1e-11 of the largest entry (build_km_dictionary)
+    assert _rel(out["1"], prob.jacobian(x, 0.7) @ v) < 1e-11
