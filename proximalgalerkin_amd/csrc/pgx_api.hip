@@ -509,8 +509,8 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
 
 // Is the stencil the same at every interior vertex (uniform grid)?  Then interior rows take their K and M
 // coefficients from kernel arguments.  Setup-time host check on a downloaded copy.
-// (K, M) dictionary of the P2 level for k_bspmv_bal<true>: distinct pairs up to 1e-11 of the largest entry (the tolerance of
-// detect_uniform below).  Seeded with nothing; every round lists up to 4096 unmatched entries, the host adds their distinct values.
+// (K, M) dictionary of the P2 level for k_bspmv_bal<true>: distinct pairs after rounding to a grid of 2^-40 of the largest entry
+// (finer than the tolerance of detect_uniform below; a function of each entry alone: deterministic).  Seeded with nothing; every round lists up to 4096 unmatched entries, the host adds their distinct values.
 // More than 256 pairs (a non-uniform mesh) => no dictionary, the kernel streams K and M as before.
 static int build_km_dictionary(pgx_handle* h) {
   const int64_t nnz = h->s_nnz;
@@ -534,7 +534,8 @@ static int build_km_dictionary(pgx_handle* h) {
     kmax = std::max(kmax, std::fabs(ks[i]));
     mmax = std::max(mmax, std::fabs(ms[i]));
   }
-  const double tk = 1e-11 * kmax, tm = 1e-11 * mmax;
+  // grid = 2^-40 (9e-13) of the largest entry, a power of two: rounding to it is exact arithmetic, the same on host and device
+  const double tk = std::ldexp(1.0, std::ilogb(kmax > 0 ? kmax : 1.0) - 40), tm = std::ldexp(1.0, std::ilogb(mmax > 0 ? mmax : 1.0) - 40);
   std::vector<double> table(512, 0.0);
   int ntab = 0;
   std::vector<int64_t> fk(cap);
@@ -557,8 +558,10 @@ static int build_km_dictionary(pgx_handle* h) {
       double kv, mv;
       HIPCHK(hipMemcpy(&kv, h->s_K + fk[i], sizeof(double), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(&mv, h->s_M + fk[i], sizeof(double), hipMemcpyDeviceToHost));
+      kv = std::nearbyint(kv / tk) * tk;
+      mv = std::nearbyint(mv / tm) * tm;
       bool have = false;
-      for (int t = 0; t < ntab && !have; ++t) have = std::fabs(kv - table[2 * t]) <= tk && std::fabs(mv - table[2 * t + 1]) <= tm;
+      for (int t = 0; t < ntab && !have; ++t) have = kv == table[2 * t] && mv == table[2 * t + 1];
       if (have) continue;
       if (ntab == 256) {
         full = true;
@@ -570,6 +573,7 @@ static int build_km_dictionary(pgx_handle* h) {
     }
     if (full) break;
   }
+  if (pgx_tune("PGX_SPMV_DICT_VERBOSE")) fprintf(stderr, "pgx: (K,M) dictionary: %d pairs, %s\n", ntab, ok ? "in use" : "overflow - not used");
   if (ok) {
     h->s_code = code;
     h->s_tab = tab;

@@ -627,8 +627,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
 // equal work per block.  bu != nullptr: the residual b - J x instead of J x (the patch smoother's sweeps, pgx_patch.hip).
 //
 // DICT (round 3): on a uniform mesh the constant matrices K and M hold a few dozen distinct (K_ij, M_ij) pairs (one per kind of row
-// and link, up to rounding).  The host finds them (pgxk_dict_assign; equal = within 1e-11 of the largest entry, the tolerance of the
-// P1 levels' uniform stencils) and the kernel reads ONE BYTE per entry - an index into a 256-entry table in LDS - instead of two
+// and link, up to rounding).  The host finds them (pgxk_dict_assign; entries are rounded to a grid of 2^-40 of the largest entry -
+// finer than the 1e-11 tolerance of the P1 levels' uniform stencils) and the kernel reads ONE BYTE per entry - an index into a 256-entry table in LDS - instead of two
 // doubles: 13 B per entry (column, code, D) instead of 28.
 template <bool DICT>
 __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* __restrict__ blk, const int32_t* __restrict__ rowptr,
@@ -705,8 +705,8 @@ void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const i
                        (const double2*)table, D, alpha, mask, xu, xp, bu, bp, remap, yu, yp);
 }
 
-// code[k] = index of the table entry that equals (K[k], M[k]) within (tk, tm); entries without one are counted in fail[0] and the
-// first `cap` of them listed in fail_k (the host adds their values to the table and calls again)
+// code[k] = index of the table entry that equals (K[k], M[k]) rounded to the grid (tk, tm); entries without one are counted in
+// fail[0] and the first `cap` of them listed in fail_k (the host adds their rounded values to the table and calls again)
 __global__ void __launch_bounds__(256) k_dict_assign(int64_t nnz, const double* __restrict__ K, const double* __restrict__ M, int ntab,
                                                      const double2* __restrict__ table, double tk, double tm,
                                                      uint8_t* __restrict__ code, int* __restrict__ fail, int cap,
@@ -716,10 +716,12 @@ __global__ void __launch_bounds__(256) k_dict_assign(int64_t nnz, const double* 
   __syncthreads();
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
-  const double kv = K[k], mv = M[k];
+  // (tk, tm) are powers of two: the pair an entry is replaced by is ITS OWN value rounded to that grid - a function of the entry
+  // alone, so the operator is bitwise the same whichever order the table was filled in
+  const double kv = rint(K[k] / tk) * tk, mv = rint(M[k] / tm) * tm;
   int found = -1;
   for (int t = 0; t < ntab; ++t)
-    if (fabs(kv - st[t].x) <= tk && fabs(mv - st[t].y) <= tm) {
+    if (kv == st[t].x && mv == st[t].y) {
       found = t;
       break;
     }
