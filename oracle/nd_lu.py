@@ -292,6 +292,8 @@ class NDLU:
                 ca, cb, kk, lp = self.cpos[c]
                 U = upd[c]
                 upd[c] = None
+                if U is None:  # a child without border (a component the Dirichlet rows cut off): nothing to add
+                    continue
                 if _HELPER is not None:
                     _HELPER.nd_extend_add(F11.ctypes.data, F12.ctypes.data, F21.ctypes.data, F22.ctypes.data, p, b,
                                           U.ctypes.data, U.shape[0], lp.ctypes.data, kk)
@@ -421,6 +423,9 @@ def nodes_of_problem(prob):
     """Node grouping of the oracle's problems.  Obstacle (pg_oracle): dof i of u and dof i of psi share node i (vertex or edge
     midpoint).  Gradient constraint (gc_oracle.GradientConstraintP2, layout u[n2] | psi_x[nv] | psi_y[nv]): a vertex node holds
     (u_v, psi_x_v, psi_y_v), an edge node its P2 midpoint value."""
+    if hasattr(prob, "cverts") and hasattr(prob, "npsi"):  # sg_oracle.SignoriniP1: u_x | u_y | u_z per vertex, psi per contact vertex
+        nv = prob.nv
+        return np.concatenate([np.arange(nv), np.arange(nv), np.arange(nv), np.asarray(prob.cverts)]), np.asarray(prob.coords)
     if hasattr(prob, "n2") and hasattr(prob, "ntot"):
         nv, n2 = prob.nv, prob.n2
         return np.concatenate([np.arange(n2), np.arange(nv), np.arange(nv)]), np.asarray(prob.dof_coords)[:n2]

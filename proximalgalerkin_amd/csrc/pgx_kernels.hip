@@ -657,24 +657,50 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
   const int32_t* cb = colm + base;
   const double *Kb = K + base, *Mb = M + base, *Db = D + base;
   const uint8_t* qb = code + base;
-#pragma unroll 4
-  for (int k = tid; k < len; k += PGX_BLOCK) {
-    const int cm = __builtin_nontemporal_load(cb + k);
-    const int c = cm & 0x7fffffff;
-    double kv, mv;
-    if (DICT) {
-      const double2 km = stab[__builtin_nontemporal_load(qb + k)];
-      kv = km.x;
-      mv = km.y;
-    } else {
-      kv = __builtin_nontemporal_load(Kb + k);
-      mv = __builtin_nontemporal_load(Mb + k);
+  // A block holds at most PGX_BAL_CAP entries = IT per thread: all IT column / code / value loads are issued before the first
+  // gather of x and all gathers before the first product (the kernel is bound by the bytes it keeps in flight, not by bandwidth:
+  // with the loop unrolled by 4 a wave went through two dependent load -> gather -> LDS chains per block)
+  constexpr int IT = PGX_BAL_CAP / PGX_BLOCK;
+  static_assert(IT * PGX_BLOCK == PGX_BAL_CAP, "block capacity must be a multiple of the block size");
+  int cm[IT];
+  double kv[IT], mv[IT], dv[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int k = tid + i * PGX_BLOCK;
+    cm[i] = 0;
+    kv[i] = mv[i] = dv[i] = 0.0;
+    if (k < len) {
+      cm[i] = __builtin_nontemporal_load(cb + k);
+      dv[i] = __builtin_nontemporal_load(Db + k);
+      if (DICT) {
+        kv[i] = (double)__builtin_nontemporal_load(qb + k);  // the code, parked in kv until the table is read below
+      } else {
+        kv[i] = __builtin_nontemporal_load(Kb + k);
+        mv[i] = __builtin_nontemporal_load(Mb + k);
+      }
     }
-    const double dv = __builtin_nontemporal_load(Db + k);
-    const double xuv = (cm < 0) ? 0.0 : xu[c];
-    const double xpv = xp[c];
-    su[k] = alpha * kv * xuv + mv * xpv;
-    sp[k] = mv * xuv - dv * xpv;
+  }
+  double xuv[IT], xpv[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int k = tid + i * PGX_BLOCK;
+    const int c = cm[i] & 0x7fffffff;
+    xuv[i] = (k < len && cm[i] >= 0) ? xu[c] : 0.0;
+    xpv[i] = (k < len) ? xp[c] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int k = tid + i * PGX_BLOCK;
+    if (k < len) {
+      double kk = kv[i], mm = mv[i];
+      if (DICT) {
+        const double2 km = stab[(int)kv[i]];
+        kk = km.x;
+        mm = km.y;
+      }
+      su[k] = alpha * kk * xuv[i] + mm * xpv[i];
+      sp[k] = mm * xuv[i] - dv[i] * xpv[i];
+    }
   }
   __syncthreads();
   if (tid >= nr) return;

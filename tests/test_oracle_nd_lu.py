@@ -107,3 +107,20 @@ def test_nd_lu_runs_example_06_like_superlu():
     assert list(its0) == list(its1)
     assert np.linalg.norm(x0 - x1) <= 1e-9 * np.linalg.norm(x0)
     assert ls.last_relres < 1e-12
+
+
+def test_nd_lu_runs_example_02_like_superlu():
+    """3-D: the Signorini oracle (vertex node = three displacement components + psi on the contact boundary; the Dirichlet rows cut
+    components off, i.e. fronts without border) with the nested-dissection LU: same Newton counts as SuperLU, same solution to the
+    Newton tolerance - what bench.py --workload ex02 times as cpu_baseline."""
+    from oracle import sg_oracle as S
+
+    m = 5
+    c, t = S.create_unit_cube_tets(m, m, m)
+    prob = S.SignoriniP1(c, t, S.boundary_facets_where(c, t, lambda x: np.isclose(x[:, 2], 0.0)), np.flatnonzero(np.isclose(c[:, 2], 1.0)))
+    x0, _, its0 = S.solve_contact_problem(prob)
+    ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    x1, _, its1 = S.solve_contact_problem(prob, linear_solve=ls)
+    assert list(its0) == list(its1)
+    assert np.linalg.norm(x0 - x1) <= 1e-4 * np.linalg.norm(x0)  # both stop at the Newton tolerance 1e-6 (1e-5 on the first step)
+    assert ls.last_relres < 1e-12

@@ -87,19 +87,57 @@ def one_ex06(N):
     return rec
 
 
+def one_ex02(m):
+    """example 02 (oracle/sg_oracle.py, unit cube of m^3 x 6 P1 tetrahedra): the full LVPP run (6 Newton steps), first linear solve
+    (symbolic analysis) untimed."""
+    from oracle import sg_oracle as S
+
+    c, t = S.create_unit_cube_tets(m, m, m)
+    prob = S.SignoriniP1(c, t, S.boundary_facets_where(c, t, lambda x: np.isclose(x[:, 2], 0.0)), np.flatnonzero(np.isclose(c[:, 2], 1.0)))
+    ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    ND.MAX_THREADS = 1
+    st = {"n": 0, "t0": None, "dt": 0.0}
+
+    def solve(J, rhs):
+        dx = ls(J, rhs)
+        if st["t0"] is None:
+            st["t0"] = time.perf_counter()
+            ls.t_factor = ls.t_solve = 0.0
+            return dx
+        st["n"] += 1
+        st["dt"] = time.perf_counter() - st["t0"]
+        return dx
+
+    with threadpool_limits(1):
+        S.solve_contact_problem(prob, linear_solve=solve)
+    ND.MAX_THREADS = 0
+    n = st["n"]
+    rec = {"N": m, "unknowns": prob.ntot, "newton_steps": n, "s_per_newton_step": st["dt"] / n, "factor_s_per_step": ls.t_factor / n,
+           "solve_refine_s_per_step": ls.t_solve / n, "factor_gflop": ls.nd.flops / 1e9, "symbolic_s_untimed": ls.nd.symbolic_s,
+           "factor_storage_GB": 8e-9 * ls.nd.factor_entries}
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
 def main():
     global OUT
     argv = sys.argv[1:]
     ex06 = "--ex06" in argv
+    ex02 = "--ex02" in argv
     if ex06:
         argv.remove("--ex06")
         OUT = ROOT / "profiles" / "r03_cpu_ladder_ex06_nd.json"
+    if ex02:
+        argv.remove("--ex02")
+        OUT = ROOT / "profiles" / "r03_cpu_ladder_ex02_nd.json"
     doc = json.loads(OUT.read_text()) if OUT.exists() else {}
     pts = doc.get("points", [])
     for a in argv:
-        r = one_ex06(int(a)) if ex06 else one(int(a))
+        r = one_ex02(int(a)) if ex02 else one_ex06(int(a)) if ex06 else one(int(a))
         pts = sorted([p for p in pts if p["N"] != r["N"]] + [r], key=lambda p: p["N"])
-    doc["what"] = ("CPU oracle of example 06 (oracle/gc_oracle.py, P2 / vector-P1 on the unit square) with the nested-dissection multifrontal LU "
+    doc["what"] = ("CPU oracle of example 02 (oracle/sg_oracle.py, Signorini contact on N^3 x 6 P1 tetrahedra) with the nested-dissection multifrontal "
+                   "LU (oracle/nd_lu.py), 1 BLAS thread: seconds per Newton step of the full LVPP run after the first linear solve (assembly + "
+                   "numeric factorisation + solves with refinement; symbolic analysis untimed)") if ex02 else ("CPU oracle of example 06 (oracle/gc_oracle.py, P2 / vector-P1 on the unit square) with the nested-dissection multifrontal LU "
                    "(oracle/nd_lu.py), 1 BLAS thread: seconds per Newton step over the first Newton steps after the first (assembly + numeric "
                    "factorisation + solves with refinement; symbolic analysis untimed)") if ex06 else ("CPU oracle with the nested-dissection multifrontal LU (oracle/nd_lu.py), 1 BLAS thread, P1 settings B on [-1,1]^2: "
                    "seconds per Newton step over the first Newton steps (assembly + numeric factorisation + solves; symbolic analysis untimed)")
