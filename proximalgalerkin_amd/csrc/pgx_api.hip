@@ -69,7 +69,7 @@ struct pgx_handle {
   double *s_K = nullptr, *s_M = nullptr, *s_D = nullptr;
   int s_nnz = 0;
   size_t s_fill_lds = 0;
-  int32_t* s_blk = nullptr;  // P2: row blocks of the nnz-balanced stream kernel (k_bspmv_bal), s_nblk + 1 entries
+  int32_t* s_blk = nullptr;  // P2: row blocks of the nnz-balanced stream kernel (k_bspmv_bal): s_nblk + 1 pairs (first row, its rowptr)
   int s_nblk = 0, spmv_bal = 1;
   uint8_t* s_code = nullptr;  // P2 on a uniform mesh: per entry the index of its (K, M) pair in s_tab (k_bspmv_bal<true>)
   double* s_tab = nullptr;    // 256 (K, M) pairs
@@ -484,8 +484,13 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
   }
   if (blk.size() > 1) {
     h->s_nblk = (int)blk.size() - 1;
-    DALLOC(h->s_blk, blk.size());
-    HIPCHK(hipMemcpy(h->s_blk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    std::vector<int32_t> blk2(2 * blk.size());  // (first row, its rowptr) per block boundary: the kernel's one metadata load
+    for (size_t i = 0; i < blk.size(); ++i) {
+      blk2[2 * i] = blk[i];
+      blk2[2 * i + 1] = rowptr[blk[i]];
+    }
+    DALLOC(h->s_blk, blk2.size());
+    HIPCHK(hipMemcpy(h->s_blk, blk2.data(), sizeof(int32_t) * blk2.size(), hipMemcpyHostToDevice));
   }
   DALLOC(h->s_colm, colm.size());
   DALLOC(h->p2_v2c_ptr, n + 1);

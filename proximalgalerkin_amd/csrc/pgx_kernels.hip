@@ -640,28 +640,40 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
                                                          const double* __restrict__ bp, int remap, double* __restrict__ yu,
                                                          double* __restrict__ yp) {
   __shared__ double su[PGX_BAL_CAP], sp[PGX_BAL_CAP];
-  __shared__ int srp[PGX_BLOCK + 1];
-  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
-  const int r0 = blk[b], nr = blk[b + 1] - r0;
-  const int tid = threadIdx.x;
+  __shared__ int srp[PGX_BLOCK + 1];  // row ENDS relative to the block's first entry (srp[0] = 0)
   __shared__ double2 stab[DICT ? 256 : 1];
-  if (tid < nr) srp[tid] = rowptr[r0 + tid];
-  if (tid == 0) srp[nr] = rowptr[r0 + nr];  // nr can be PGX_BLOCK: one entry more than there are threads
-  if (DICT) {
-    static_assert(PGX_BLOCK >= 256, "one table entry per thread");
-    if (tid < 256) stab[tid] = table[tid];
+  const int b = xcd_block(blockIdx.x, gridDim.x, remap);
+  // blk[2 b] = first row, blk[2 b + 1] = its rowptr: ONE (scalar) load tells the block its rows and its entry range, so that the row
+  // pointers, the CSR streams and the per-row data of the last phase are all requested together (the version that read
+  // blk -> rowptr -> streams -> gathers -> [barrier] -> b, mask in sequence: 0.90 ms per apply at 2048^2 P2, this one 0.87 ms; the
+  // PMC profile - waves waiting 85 % of their 7.8 us life, about two memory instructions in flight per CU - points at the two
+  // 8-byte gathers of x per entry, 20-40 cache lines per wave instruction, as what the kernel waits for: DESIGN.md section 5).
+  const int r0 = blk[2 * b], base = blk[2 * b + 1], nr = blk[2 * b + 2] - r0, len = blk[2 * b + 3] - base;
+  const int tid = threadIdx.x;
+  double2 tv = make_double2(0.0, 0.0);
+  if (DICT) tv = table[tid];  // first in the load queue: its wait does not cover the streams below
+  const int row = r0 + tid;
+  const bool live = tid < nr;
+  int rend = 0;
+  uint8_t mk = 0;
+  double xur = 0.0, bur = 0.0, bpr = 0.0;
+  if (live) {
+    rend = rowptr[row + 1] - base;
+    mk = mask[row];
+    xur = xu[row];
+    if (bu) {
+      bur = bu[row];
+      bpr = bp[row];
+    }
   }
-  __syncthreads();
-  const int base = srp[0];
-  const int len = srp[nr] - base;
   const int32_t* cb = colm + base;
   const double *Kb = K + base, *Mb = M + base, *Db = D + base;
   const uint8_t* qb = code + base;
   // A block holds at most PGX_BAL_CAP entries = IT per thread: all IT column / code / value loads are issued before the first
-  // gather of x and all gathers before the first product (the kernel is bound by the bytes it keeps in flight, not by bandwidth:
-  // with the loop unrolled by 4 a wave went through two dependent load -> gather -> LDS chains per block)
+  // gather of x and all gathers before the first product
   constexpr int IT = PGX_BAL_CAP / PGX_BLOCK;
   static_assert(IT * PGX_BLOCK == PGX_BAL_CAP, "block capacity must be a multiple of the block size");
+  static_assert(PGX_BLOCK >= 256, "one table entry per thread");
   int cm[IT];
   double kv[IT], mv[IT], dv[IT];
 #pragma unroll
@@ -679,6 +691,10 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
         mv[i] = __builtin_nontemporal_load(Mb + k);
       }
     }
+  }
+  if (DICT) {
+    if (tid < 256) stab[tid] = tv;
+    __syncthreads();  // early: the streams are still in flight
   }
   double xuv[IT], xpv[IT];
 #pragma unroll
@@ -702,18 +718,19 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
       sp[k] = mm * xuv[i] - dv[i] * xpv[i];
     }
   }
+  if (tid == 0) srp[0] = 0;
+  if (live) srp[tid + 1] = rend;
   __syncthreads();
-  if (tid >= nr) return;
-  const int row = r0 + tid;
+  if (!live) return;
   double au = 0.0, ap = 0.0;
-  for (int k = srp[tid] - base, e = srp[tid + 1] - base; k < e; ++k) {
+  for (int k = srp[tid], e = rend; k < e; ++k) {
     au += su[k];
     ap += sp[k];
   }
-  if (mask[row]) au = xu[row];
+  if (mk) au = xur;
   if (bu) {
-    au = bu[row] - au;
-    ap = bp[row] - ap;
+    au = bur - au;
+    ap = bpr - ap;
   }
   __builtin_nontemporal_store(au, yu + row);
   __builtin_nontemporal_store(ap, yp + row);
