@@ -523,11 +523,11 @@ static int build_km_dictionary(pgx_handle* h) {
   uint8_t* code = nullptr;
   double* tab = nullptr;
   int* fail = nullptr;
-  int64_t* fail_k = nullptr;
+  double* fail_v = nullptr;
   DALLOC(code, (size_t)nnz);
   DALLOC(tab, 512);
   DALLOC(fail, 2);
-  DALLOC(fail_k, cap);
+  DALLOC(fail_v, 2 * cap);
   // scale: the largest |K|, |M| among the first rows (uniform mesh: every row kind occurs there; otherwise the dictionary fails anyway)
   const size_t ns = (size_t)std::min<int64_t>(nnz, 1 << 16);
   std::vector<double> ks(ns), ms(ns);
@@ -543,12 +543,12 @@ static int build_km_dictionary(pgx_handle* h) {
   const double tk = std::ldexp(1.0, std::ilogb(kmax > 0 ? kmax : 1.0) - 40), tm = std::ldexp(1.0, std::ilogb(mmax > 0 ? mmax : 1.0) - 40);
   std::vector<double> table(512, 0.0);
   int ntab = 0;
-  std::vector<int64_t> fk(cap);
+  std::vector<double> fv(2 * cap);
   bool ok = false;
   for (int round = 0; round < 64; ++round) {
     HIPCHK(hipMemcpyAsync(tab, table.data(), 512 * sizeof(double), hipMemcpyHostToDevice, h->st));
     HIPCHK(hipMemsetAsync(fail, 0, 2 * sizeof(int), h->st));
-    pgxk_dict_assign(h->st, nnz, h->s_K, h->s_M, ntab, tab, tk, tm, code, fail, cap, fail_k);
+    pgxk_dict_assign(h->st, nnz, h->s_K, h->s_M, ntab, tab, tk, tm, code, fail, cap, fail_v);
     int f[2];
     HIPCHK(hipMemcpyAsync(f, fail, sizeof(f), hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
@@ -557,14 +557,10 @@ static int build_km_dictionary(pgx_handle* h) {
       ok = true;
       break;
     }
-    HIPCHK(hipMemcpy(fk.data(), fail_k, nf * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fv.data(), fail_v, 2 * nf * sizeof(double), hipMemcpyDeviceToHost));
     bool full = false;
     for (int i = 0; i < nf && !full; ++i) {
-      double kv, mv;
-      HIPCHK(hipMemcpy(&kv, h->s_K + fk[i], sizeof(double), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&mv, h->s_M + fk[i], sizeof(double), hipMemcpyDeviceToHost));
-      kv = std::nearbyint(kv / tk) * tk;
-      mv = std::nearbyint(mv / tm) * tm;
+      const double kv = fv[2 * i], mv = fv[2 * i + 1];  // already rounded to the grid by the kernel
       bool have = false;
       for (int t = 0; t < ntab && !have; ++t) have = kv == table[2 * t] && mv == table[2 * t + 1];
       if (have) continue;
@@ -1720,7 +1716,7 @@ static int ensure_patches(pgx_handle* h) {
     DALLOC(h->ppos, (size_t)nv * NN * NN);
     {
       uint8_t* q = nullptr;
-      DALLOC(q, (size_t)nv * P * P * (h->patch_f32 ? sizeof(float) : sizeof(double)));
+      DALLOC(q, (size_t)nv * P * (4 * ((P + 3) / 4)) * (h->patch_f32 ? sizeof(float) : sizeof(double)));  // rows padded to 4-vectors
       h->pinv = q;
     }
     DALLOC(h->p2_su, (size_t)2 * (nd - nv));

@@ -154,7 +154,7 @@ void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const i
                     const uint8_t* mask, const double* xu, const double* xp, const double* bu, const double* bp, int remap,
                     double* yu, double* yp);
 void pgxk_dict_assign(hipStream_t st, int64_t nnz, const double* K, const double* M, int ntab, const double* table, double tk,
-                      double tm, uint8_t* code, int* fail, int cap, int64_t* fail_k);
+                      double tm, uint8_t* code, int* fail, int cap, double* fail_v);
 // CSR-stream form of y = Jx (256 rows per block through LDS); mask = Dirichlet flags of the u block
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,
                        const double* K, const double* M, const double* D, double alpha, const uint8_t* mask,

@@ -749,11 +749,11 @@ void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const i
 }
 
 // code[k] = index of the table entry that equals (K[k], M[k]) rounded to the grid (tk, tm); entries without one are counted in
-// fail[0] and the first `cap` of them listed in fail_k (the host adds their rounded values to the table and calls again)
+// fail[0] and the rounded values of the first `cap` of them listed in fail_v (the host adds them to the table and calls again)
 __global__ void __launch_bounds__(256) k_dict_assign(int64_t nnz, const double* __restrict__ K, const double* __restrict__ M, int ntab,
                                                      const double2* __restrict__ table, double tk, double tm,
                                                      uint8_t* __restrict__ code, int* __restrict__ fail, int cap,
-                                                     int64_t* __restrict__ fail_k) {
+                                                     double2* __restrict__ fail_v) {
   __shared__ double2 st[256];
   if ((int)threadIdx.x < ntab) st[threadIdx.x] = table[threadIdx.x];
   __syncthreads();
@@ -774,16 +774,16 @@ __global__ void __launch_bounds__(256) k_dict_assign(int64_t nnz, const double* 
   }
   if (*(volatile int*)fail < cap) {  // racy on purpose: it only bounds the number of atomics
     const int q = atomicAdd(fail, 1);
-    if (q < cap) fail_k[q] = k;
+    if (q < cap) fail_v[q] = make_double2(kv, mv);
   } else {
     *(volatile int*)(fail + 1) = 1;  // "more than cap"
   }
 }
 
 void pgxk_dict_assign(hipStream_t st, int64_t nnz, const double* K, const double* M, int ntab, const double* table, double tk,
-                      double tm, uint8_t* code, int* fail, int cap, int64_t* fail_k) {
+                      double tm, uint8_t* code, int* fail, int cap, double* fail_v) {
   hipLaunchKernelGGL(k_dict_assign, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, K, M, ntab, (const double2*)table, tk,
-                     tm, code, fail, cap, fail_k);
+                     tm, code, fail, cap, (double2*)fail_v);
 }
 
 void pgxk_bspmv_stream(hipStream_t st, int n, size_t fill_lds_bytes, const int32_t* rowptr, const int32_t* colm,

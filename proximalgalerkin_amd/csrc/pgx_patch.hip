@@ -10,12 +10,12 @@
 // (an edge dof belongs to the patches of its two end vertices).
 //
 // Data (per handle, HBM): pdof [np][NN] patch dofs (-1 = unused slot), ppos [np][NN][NN] positions of the patch's scalar-block
-// entries in the P2 block-CSR (-1 = structurally zero), pinv [np][P][P] (P = 2 NN) the inverses of the patch matrices, row-major,
+// entries in the P2 block-CSR (-1 = structurally zero), pinv [np][P/4][P][4] (P = 2 NN) the inverses of the patch matrices (rows in 4-vectors),
 // rebuilt once per Newton step (only D(psi) and alpha change); computed in double, STORED in float by default (the sweep is a
-// smoother inside FGMRES: identical Krylov counts, half the stream).  At 2048^2 P2: 4.2 M patches, 3.3 GB of inverses.
+// smoother inside FGMRES: identical Krylov counts, half the stream).  At 2048^2 P2: 4.2 M patches, 3.8 GB of inverses.
 //
 // Mapping: a group of 16 lanes owns one patch, lane l its row l (four patches per 64-wide wavefront); rows meet through
-// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 784 B per patch and sweep (1568 B in double).
+// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 896 B per patch and sweep (1792 B in double).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
                                                       const double* __restrict__ K, const double* __restrict__ M,
                                                       const double* __restrict__ D, const uint8_t* __restrict__ mask, double alpha,
                                                       PT* __restrict__ pinv) {
-  constexpr int P = 2 * NN;
+  constexpr int P = 2 * NN, PQ = (P + 3) / 4;
   const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
   const int l = threadIdx.x & (GRP - 1);
   const bool live = p < np;
@@ -109,9 +109,17 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
     }
   }
   if (live && l < P) {
-    PT* out = pinv + ((size_t)p * P + l) * P;
+    // layout [patch][chunk of 4 columns][row l][4]: a lane stores (and k_patch_apply loads) its row as PQ 4-vectors, and the lanes of
+    // a group touch 4 P consecutive values per instruction
+    PT* out = pinv + (size_t)p * PQ * P * 4 + (size_t)l * 4;
 #pragma unroll
-    for (int j = 0; j < P; ++j) out[j] = (PT)a[j];
+    for (int q = 0; q < PQ; ++q) {
+      PT v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (4 * q + t < P) ? (PT)a[4 * q + t] : (PT)0;
+      typedef PT v4 __attribute__((ext_vector_type(4)));
+      *(v4*)(out + (size_t)q * P * 4) = (v4){v[0], v[1], v[2], v[3]};
+    }
   }
 }
 
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
                                                      const double* __restrict__ ru, const double* __restrict__ rp, double omega,
                                                      double* __restrict__ xu, double* __restrict__ xp, double* __restrict__ su,
                                                      double* __restrict__ sp) {
-  constexpr int P = 2 * NN;
+  constexpr int P = 2 * NN, PQ = (P + 3) / 4;
   const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
   const int l = threadIdx.x & (GRP - 1);
   const bool live = p < np;
@@ -136,12 +144,18 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
   if (l < P) {
     dof = pdof[(size_t)pp * NN + i];
     if (dof >= 0) r = (l < NN) ? ru[dof] : rp[dof];
-    // The patch matrix is symmetric (K, M, D blocks are; the Dirichlet rows / columns are replaced symmetrically), so row l of the
-    // inverse is read as COLUMN l: for every j the lanes of a group touch P consecutive doubles - coalesced - where the row-wise
-    // read made each of the P load instructions of a wave touch 56 different cache lines (2.9 -> 1.6 ms per sweep at 2048^2 P2).
-    const PT* in = pinv + (size_t)pp * P * P + l;
+    // Row l of the inverse as PQ 4-vectors (layout of k_patch_invert): four 16-byte loads per lane, the lanes of a group side by side.
+    // (History: row-major rows read row-wise 2.9 ms per sweep at 2048^2 P2 in double; read column-wise through the symmetry of the
+    // patch matrix 1.6 ms; stored in float 1.07 ms; this layout 0.93 ms.)
+    typedef PT v4 __attribute__((ext_vector_type(4)));
+    const PT* in = pinv + (size_t)pp * PQ * P * 4 + (size_t)l * 4;
 #pragma unroll
-    for (int j = 0; j < P; ++j) row[j] = (double)__builtin_nontemporal_load(in + j * P);  // streamed once per sweep
+    for (int q = 0; q < PQ; ++q) {
+      const v4 v = __builtin_nontemporal_load((const v4*)(in + (size_t)q * P * 4));  // streamed once per sweep
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * q + t < P) row[4 * q + t] = (double)v[t];
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < P; ++j) row[j] = 0.0;
