@@ -629,7 +629,19 @@ extern "C" int pgx_comm_shm_init(const char* name, int rank, int size, uint64_t 
       fd = shm_open(name, O_RDWR, 0600);
       if (fd >= 0) {
         struct stat sb;
-        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) {
+          // A segment left behind by a crashed run under the same name (rank 0 unlinks the name only once every rank has attached)
+          // would be attached to by a rank that arrives before this launch's rank 0 has recreated it.  Such a segment shows its
+          // age: a complete or broken group, or a barrier generation beyond the first.  Keep polling until rank 0 replaces it.
+          void* pm = mmap(nullptr, sizeof(ShmHeader), PROT_READ, MAP_SHARED, fd, 0);
+          bool stale = false;
+          if (pm != MAP_FAILED) {
+            const ShmHeader* hh = (const ShmHeader*)pm;
+            stale = hh->magic.load() == kShmMagic && (hh->gen.load() != 0 || hh->broken.load() != 0 || hh->attached.load() >= (uint32_t)size);
+            munmap(pm, sizeof(ShmHeader));
+          }
+          if (!stale) break;
+        }
         close(fd);
         fd = -1;
       }

@@ -536,6 +536,11 @@ static int nd_symbolic(pgx_nd* s, const pgx_nd_matrix* A) {
     s->stats.flops_padded += Lv.count * (2.0 / 3 * P * P * P + 2 * P * P * B + 2 * P * B * B);
     if (Lv.count) s->stats.max_front = std::max<int64_t>(s->stats.max_front, M);
   }
+  // k_nd_extend_add, k_nd_gather and k_nd_leaf index a front with 32-bit arithmetic (row * M + column)
+  if (s->stats.max_front >= 65536) {
+    s->err = "pgx_nd: a front of " + std::to_string(s->stats.max_front) + " rows exceeds the 65535 the assembly kernels index (32-bit front offsets)";
+    return PGX_EINVAL;
+  }
   s->virt_len = off;
   s->vec_len = voff;
   s->nfronts = nloc;

@@ -6,7 +6,11 @@ What DOLFINx / Basix provide the reference with for `basix.ufl.element("Lagrange
 
 * local nodes of degree k: the 3 vertices; then k - 1 interior nodes per edge, edge i OPPOSITE vertex i (as for P2 in pgx_mesh.cell_dofs),
   running from the edge's lower local vertex to its higher one; then the (k-1)(k-2)/2 interior nodes, by rows of increasing second
-  barycentric coordinate.  Points are the equispaced lattice (i, j, l) / k.
+  barycentric coordinate.  Points are the equispaced lattice (i, j, l) / k.  DEVIATION from the reference for k >= 3: Basix's
+  default Lagrange variant places the nodes at GLL-warped positions.  The spanned space P_k is the same, so the discrete SOLUTION
+  of a problem whose data is in the space is the same function; what differs is where `interpolate` samples phi and f (the
+  interpolants differ at O(h^(k+1))) and the conditioning of the nodal basis at k = 7, 8.  The oracle uses the same lattice;
+  degrees 1 and 2 (BASELINE configs) have one variant only.
 * basis: the nodal (Lagrange) basis of P_k on that lattice in closed form (products of one-dimensional factors in the barycentric
   coordinates).
 * global dofs: vertices (mesh numbering), then the edge-interior nodes edge by edge (edges in the order of `Mesh.edges()`), stored in
