@@ -558,7 +558,7 @@ def main():
 
     def pmc_traffic(fname):  # HBM bytes per launch from a committed rocprofv3 --pmc profile of the same kernel and mesh
         tj = _ladder(fname)
-        if tj and tj.get("cells") == N and args.degree == 1 and not sharded:
+        if tj and tj.get("cells") == N and not sharded:
             return tj["hbm_traffic_bytes_per_launch"], {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date",
                                                                                "traffic_over_algorithmic")}
         return None, None
@@ -571,7 +571,8 @@ def main():
         if kind == 0 and args.degree == 2:
             name = ("k_bspmv_bal (P2 operator apply: nnz-balanced CSR-stream SpMV of [[aK,M],[M,-D]]; on this uniform mesh K and M are "
                     "read through a one-byte (K,M)-pair dictionary: 13 B per entry instead of 28)")
-        traffic, src = pmc_traffic({0: "r03_spmv_pmc_traffic.json", 1: "r03_stspmv_pmc_traffic.json"}.get(kind, "none"))
+        traffic, src = pmc_traffic("r03_p2spmv_pmc_traffic.json" if args.degree == 2 else
+                                   {0: "r03_spmv_pmc_traffic.json", 1: "r03_stspmv_pmc_traffic.json"}.get(kind, "none"))
         gbs = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
