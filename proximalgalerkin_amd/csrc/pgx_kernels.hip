@@ -1869,6 +1869,17 @@ static inline RowmapGrid rowmap_grid(int nx, int ny, int fast_ok) {
   return g;
 }
 
+// The mirrored D links come from the neighbours, not from memory (round 3): D1[v - 1], D2[v - sx] and D3[v - sx - 1] are the stored
+// values of the left / upper / upper-left neighbour - the first is the left lane's register (DPP wave shift), the other two sit in
+// another wave's registers and cross LDS - so a vertex pulls 48 instead of 72 bytes of coefficients through the vector L1.  What
+// the timing experiments behind this say: the launch is bound by the memory traffic of its coefficient
+// streams at an effective 3-4 TB/s, not by the number of its load instructions.
+__device__ __forceinline__ double lane_shr1(double x) {  // the value of lane - 1 (lane 0 keeps its own)
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 // interior tiles: no bounds / Dirichlet tests, scalar K and M stencils with symmetric link pairs pre-summed; the global loads
 // of the NEXT row are in flight while the current row is computed (register double buffer)
 template <int TY, int K, bool POST>
@@ -1878,7 +1889,7 @@ __device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, c
                                                           const double* __restrict__ cp, int nxc,
                                                           const double* __restrict__ bu, const double* __restrict__ bp,
                                                           double omega, double* __restrict__ yu, double* __restrict__ yp,
-                                                          double2* img_a, double2* img_b) {
+                                                          double2* img_a, double2* img_b, double2* exch) {
   // A wave owns the SAME image rows in every sweep: lj = wave + NW k.  Their iterate-independent data (7 D links, b_u, b_psi)
   // is loaded ONCE, all loads in flight together, and stays in registers for the K sweeps: a wave's chain of dependent
   // HBM round trips - which, not bandwidth or arithmetic, bounded the 4-wave version (6 + 14 sequential row iterations of
@@ -1902,17 +1913,16 @@ __device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, c
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int lj = wave + NW * k;
-    if (lj >= 1 && lj < H0 - 1) {  // rows 0 and H0-1 are halo only
+    if (lj < H0 - 1) {  // rows 1 .. H0-2 are updated; row 0 only hands its upward links to row 1
       const unsigned v = (unsigned)((j0 + lj) * sx + gi);
-      rd[k][0] = Dh[v];
-      rd[k][1] = D1[v];
-      rd[k][2] = D1[v - 1];
       rd[k][3] = D2[v];
-      rd[k][4] = D2[v - sx];
       rd[k][5] = D3[v];
-      rd[k][6] = D3[v - sx - 1];
-      rbu[k] = bu[v];
-      rbp[k] = bp[v];
+      if (lj >= 1) {
+        rd[k][0] = Dh[v];
+        rd[k][1] = D1[v];
+        rbu[k] = bu[v];
+        rbp[k] = bp[v];
+      }
     }
   }
   if (POST) {
@@ -1939,7 +1949,21 @@ __device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, c
       const int lj = wave + NW * k;
       if (lj < H0) img0[lj * W + lane] = make_double2(xa[k], xc[k]);
     }
-    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < H0 - 1) exch[lj * W + lane] = make_double2(rd[k][3], rd[k][5]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj >= 1 && lj < H0 - 1) {
+      rd[k][2] = lane_shr1(rd[k][1]);                // D1[v - 1]
+      rd[k][4] = exch[(lj - 1) * W + lane].x;        // D2[v - sx]
+      rd[k][6] = exch[(lj - 1) * W + lane - 1].y;    // D3[v - sx - 1]; lane 0 (halo column, never updated) reads the guard band
+    }
   }
 #pragma unroll
   for (int s = 1; s <= K; ++s) {
@@ -2100,14 +2124,15 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_smoothR(int nx, int ny,
                                                           const double* __restrict__ bp, double omega, int remap,
                                                           double* __restrict__ yu, double* __restrict__ yp) {
   constexpr int W = 64, H0 = TY + 2 * K, PAD = W + 1;
-  __shared__ double2 img_[2][H0 * W + 2 * PAD];  // guard band: inactive edge lanes read (and discard) one entry outside a row
+  __shared__ double2 img_[3][H0 * W + 2 * PAD];  // guard band: inactive edge lanes read (and discard) one entry outside a row;
+                                                  // [2]: the (D2, D3) links every image row hands to the row below it
   const int blk = blockIdx.x;
   if (blk < nbnd)
     st_smoothR_bnd<TY, 4, K, POST>(blk, nx, ny, n, g, Kc, M, Dh, sc, mask, alpha, xu, xp, cu, cp, nxc, bu, bp, omega, yu, yp,
                                 img_[0] + PAD, img_[1] + PAD);
   else
     st_smoothR_fast<TY, K, POST>(xcd_block(blk - nbnd, gridDim.x - nbnd, remap), nx, n, g.nfx, Dh, sc, alpha, xu, xp, cu, cp, nxc,
-                                 bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD);
+                                 bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
 }
 
 template <int TYR, int KS = 3>
