@@ -130,6 +130,7 @@ struct pgx_handle {
   bool dh_interior = false;
   int stag_its = 12;       // PGX_STAG_ITS / PGX_STAG_GAIN: stagnation test of the smoother damping (fgmres)
   double stag_gain = 1e-4;
+  int smooth_d32 = 1;      // finest-level smoother reads a single-precision copy of the D stencils (PGX_SMOOTH_D32=0: the double ones)
   int k6_max = 0;          // levels with at most this many vertices run 6 sweeps per smoother launch (PGX_K6_MAX)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
@@ -773,6 +774,7 @@ static int build_multigrid(pgx_handle* h) {
   DALLOC(h->lev[0].K, (size_t)7 * h->n);
   DALLOC(h->lev[0].M, (size_t)7 * h->n);
   DALLOC(h->lev[0].Dh, (size_t)4 * h->n);
+  if (h->smooth_d32 && sizeof(dsten_t) == 8) DALLOC(h->lev[0].Dh32, (size_t)4 * h->n);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Kv, h->lev[0].K);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Mv, h->lev[0].M);
   int rc = detect_uniform(h, h->lev[0]);
@@ -848,6 +850,7 @@ static int build_multigrid_dist(pgx_handle* h) {
   DALLOC(h->lev[0].K, (size_t)7 * h->n);
   DALLOC(h->lev[0].M, (size_t)7 * h->n);
   DALLOC(h->lev[0].Dh, (size_t)4 * h->n);
+  if (h->smooth_d32 && sizeof(dsten_t) == 8) DALLOC(h->lev[0].Dh32, (size_t)4 * h->n);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Kv, h->lev[0].K);
   pgxk_csr_to_stencil(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Mv, h->lev[0].M);
   int rc = detect_uniform(h, h->lev[0]);
@@ -990,6 +993,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_SPMV_STENCIL")) h->spmv_stencil = atoi(e);
   if (const char* e = pgx_tune("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
+  if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
   if (const char* e = pgx_tune("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
   if (const char* e = pgx_tune("PGX_STAG_GAIN")) h->stag_gain = atof(e);
   if (const char* e = pgx_tune("PGX_FUSED_MIN")) h->fused_min = atoi(e);
@@ -1468,6 +1472,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
     pgxk_csr_to_stencil_h(h->st, h->n, h->nx + 1, h->rowptr, h->colm, h->Dv, h->lev[0].Dh,
                           (have_d && h->degree == 1 && h->dh_interior) ? h->lev[0].ny : 0);
     h->dh_interior = false;
+    if (h->lev[0].Dh32) pgxk_to_float(h->st, (size_t)4 * h->n, h->lev[0].Dh, h->lev[0].Dh32);
     const int ld = h->dist.on ? h->dist.ldist : 0;
     for (size_t l = 1; l < h->lev.size(); ++l) {
       if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks

@@ -50,6 +50,8 @@ struct GridLevel {
   // D(psi), refreshed every Newton step, symmetric-half storage [4*n]: slots 0:(0,0) 1:(+1,0) 2:(0,+1) 3:(+1,+1);
   // the three negative-direction links are the neighbours' positive ones (D is symmetric).
   dsten_t* Dh;
+  float* Dh32;               // finest level only (else nullptr): single-precision copy of Dh for the interior tiles of the row-mapped
+                             // smoother - a preconditioner inside FGMRES; the operator apply and every other kernel read Dh
   // On a uniform grid every interior vertex has the same K and M stencil: passed in the kernarg segment
   // instead of streaming 14 coefficient arrays. Verified on the host at create; 0 -> explicit arrays.
   int uniform;
@@ -110,6 +112,7 @@ int pgxk_observables_blocks(int nc);
 void pgxk_axpy(hipStream_t st, size_t len, double a, const double* x, double* y);          // y += a x
 void pgxk_scale_copy(hipStream_t st, size_t len, double a, const double* x, double* y);    // y = a x
 void pgxk_set(hipStream_t st, size_t len, double a, double* y);
+void pgxk_to_float(hipStream_t st, size_t len, const double* x, float* y);
 // out[i] = V_i . w, i<nv (V_i = V + i*ldv).  partials: [PGX_RED_BLOCKS * nv] scratch
 #define PGX_RED_BLOCKS 1024
 void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* w, double* partials,

@@ -948,6 +948,13 @@ void pgxk_set(hipStream_t st, size_t len, double a, double* y) {
   hipLaunchKernelGGL(k_set, stream_grid(len), dim3(PGX_BLOCK), 0, st, len, a, y);
 }
 
+__global__ void __launch_bounds__(PGX_BLOCK) k_to_float(size_t len, const double* __restrict__ x, float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+void pgxk_to_float(hipStream_t st, size_t len, const double* x, float* y) {
+  hipLaunchKernelGGL(k_to_float, stream_grid(len), dim3(PGX_BLOCK), 0, st, len, x, y);
+}
+
 // out[i] = V_i . w : each block streams a slice of w ONCE for NV vectors (Gram-Schmidt is the
 // second-largest HBM consumer of the Newton solve; batching cuts its traffic from 2 to 1+1/NV
 // vector reads per dot product).  Two-stage, fixed grid -> bitwise reproducible.
@@ -1882,8 +1889,8 @@ __device__ __forceinline__ double lane_shr1(double x) {  // the value of lane - 
 }
 // interior tiles: no bounds / Dirichlet tests, scalar K and M stencils with symmetric link pairs pre-summed; the global loads
 // of the NEXT row are in flight while the current row is computed (register double buffer)
-template <int TY, int K, bool POST>
-__device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, const dsten_t* __restrict__ Dh,
+template <int TY, int K, bool POST, typename DT>
+__device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, const DT* __restrict__ Dh,
                                                           const StConst& sc, double alpha, const double* __restrict__ xu,
                                                           const double* __restrict__ xp, const double* __restrict__ cu,
                                                           const double* __restrict__ cp, int nxc,
@@ -1906,9 +1913,9 @@ __device__ __forceinline__ void st_smoothR_fast(int b, int nx, int n, int nfx, c
                k5 = alpha * 0.5 * (sc.K[5] + sc.K[6]);
   const double m0 = sc.M[0], m1 = 0.5 * (sc.M[1] + sc.M[2]), m3 = 0.5 * (sc.M[3] + sc.M[4]), m5 = 0.5 * (sc.M[5] + sc.M[6]);
   const double nb2 = -m0 * m0;
-  const dsten_t* const D1 = Dh + n;
-  const dsten_t* const D2 = Dh + 2 * (size_t)n;
-  const dsten_t* const D3 = Dh + 3 * (size_t)n;
+  const DT* const D1 = Dh + n;
+  const DT* const D2 = Dh + 2 * (size_t)n;
+  const DT* const D3 = Dh + 3 * (size_t)n;
   double rd[R][7], rbu[R], rbp[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
@@ -2113,10 +2120,10 @@ __device__ __forceinline__ void st_smoothR_bnd(int b, int nx, int ny, int n, con
 
 // ONE launch per smoother call: blocks [0, nbnd) are the boundary tiles - they start first, so their long dependent-load
 // chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
-template <int TY, int K, bool POST>
+template <int TY, int K, bool POST, bool D32 = false>
 __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_smoothR(int nx, int ny, int n, RowmapGrid g, int nbnd,
                                                           const double* __restrict__ Kc, const double* __restrict__ M,
-                                                          const dsten_t* __restrict__ Dh, StConst sc,
+                                                          const dsten_t* __restrict__ Dh, const float* __restrict__ Dh32, StConst sc,
                                                           const uint8_t* __restrict__ mask, double alpha,
                                                           const double* __restrict__ xu, const double* __restrict__ xp,
                                                           const double* __restrict__ cu, const double* __restrict__ cp,
@@ -2130,9 +2137,12 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_smoothR(int nx, int ny,
   if (blk < nbnd)
     st_smoothR_bnd<TY, 4, K, POST>(blk, nx, ny, n, g, Kc, M, Dh, sc, mask, alpha, xu, xp, cu, cp, nxc, bu, bp, omega, yu, yp,
                                 img_[0] + PAD, img_[1] + PAD);
+  else if (D32)  // interior tiles read the single-precision copy of D (finest level)
+    st_smoothR_fast<TY, K, POST, float>(xcd_block(blk - nbnd, gridDim.x - nbnd, remap), nx, n, g.nfx, Dh32, sc, alpha, xu, xp, cu, cp,
+                                        nxc, bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
   else
-    st_smoothR_fast<TY, K, POST>(xcd_block(blk - nbnd, gridDim.x - nbnd, remap), nx, n, g.nfx, Dh, sc, alpha, xu, xp, cu, cp, nxc,
-                                 bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+    st_smoothR_fast<TY, K, POST, dsten_t>(xcd_block(blk - nbnd, gridDim.x - nbnd, remap), nx, n, g.nfx, Dh, sc, alpha, xu, xp, cu, cp,
+                                          nxc, bu, bp, omega, yu, yp, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
 }
 
 template <int TYR, int KS = 3>
@@ -2142,11 +2152,20 @@ static void launch_rowmap(hipStream_t st, int post, const GridLevel& L, const St
   const RowmapGrid g = rowmap_grid<TYR, KS>(L.nx, L.ny, L.interior_free);
   const int nfast = g.nfx * g.nfy, nbnd = (g.ntx * g.nty - nfast) * (TYR / 4);  // boundary tiles: sub-tiles of 4 rows
   dim3 grid(nbnd + nfast), block(PGX_ROWMAP_BLOCK);
+  if (L.Dh32 && KS == 3) {
+    if (post)
+      hipLaunchKernelGGL((k_st_smoothR<TYR, 3, true, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dh32, sc,
+                         L.mask, alpha, xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
+    else
+      hipLaunchKernelGGL((k_st_smoothR<TYR, 3, false, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dh32, sc,
+                         L.mask, alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
+    return;
+  }
   if (post)
-    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask, alpha,
-                       xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
+    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, true>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, nullptr, sc, L.mask,
+                       alpha, xu, xp, cu, cp, C ? C->nx : 0, bu, bp, omega, remap, yu, yp);
   else
-    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, false>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, sc, L.mask,
+    hipLaunchKernelGGL((k_st_smoothR<TYR, KS, false>), grid, block, 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, nullptr, sc, L.mask,
                        alpha, nullptr, nullptr, nullptr, nullptr, 0, bu, bp, omega, remap, yu, yp);
 }
 
