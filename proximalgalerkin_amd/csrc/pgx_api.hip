@@ -130,7 +130,9 @@ struct pgx_handle {
   bool dh_interior = false;
   int stag_its = 12;       // PGX_STAG_ITS / PGX_STAG_GAIN: stagnation test of the smoother damping (fgmres)
   double stag_gain = 1e-4;
-  int smooth_d32 = 1;      // finest-level smoother reads a single-precision copy of the D stencils (PGX_SMOOTH_D32=0: the double ones)
+  int smooth_d32 = 0;      // PGX_SMOOTH_D32=1: the finest-level smoother reads a single-precision copy of the D stencils.  OFF by
+                           // default: its launches get 10 % shorter, but the operator apply that follows the V-cycle no longer finds
+                           // the double stencils in the Infinity Cache (k_st_spmv_r 0.74 -> 0.55 of the HBM peak) - net +0.9 %
   int k6_max = 0;          // levels with at most this many vertices run 6 sweeps per smoother launch (PGX_K6_MAX)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
