@@ -1,9 +1,11 @@
 // Host side of libpgx.so: plan building (CSR pattern, inverted vertex->cell lists), multigrid
 // hierarchy, FGMRES, SNES-mirroring Newton driver, and the extern "C" ABI of include/pgx.h.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -134,6 +136,9 @@ struct pgx_handle {
                            // default: its launches get 10 % shorter, but the operator apply that follows the V-cycle no longer finds
                            // the double stencils in the Infinity Cache (k_st_spmv_r 0.74 -> 0.55 of the HBM peak) - net +0.9 %
   int k6_max = 0;          // levels with at most this many vertices run 6 sweeps per smoother launch (PGX_K6_MAX)
+  int mg_f32 = 1;          // PGX_MG_F32=0: the round-3 fp64 V-cycle.  Default: single-precision V-cycle legs (pgx_mg32.hip) on every
+                           // uniform level with at least f32_min vertices above the fused tail - half the bytes per launch
+  int f32_min = 4000;      // PGX_F32_MIN
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
@@ -199,24 +204,40 @@ struct PhaseTimer {
 // ---- tuning table (pgx_scope.h: pgx_tune) ----
 namespace {
 std::mutex g_tune_mu;
-std::map<std::string, std::string>& tune_table() {
-  static std::map<std::string, std::string> t;
+std::atomic<int> g_tune_gen{0};
+// values are interned in a pool that is never freed: pgx_tune hands out pointers that outlive any later pgx_tuning_set
+std::map<std::string, const std::string*>& tune_table() {
+  static std::map<std::string, const std::string*> t;
   return t;
+}
+std::deque<std::string>& tune_pool() {
+  static std::deque<std::string> p;
+  return p;
 }
 }  // namespace
 const char* pgx_tune(const char* name) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
   auto& t = tune_table();
   auto it = t.find(name);
-  return it == t.end() ? nullptr : it->second.c_str();
+  return it == t.end() ? nullptr : it->second->c_str();
 }
+int pgx_tune_gen() { return g_tune_gen.load(std::memory_order_acquire); }
 extern "C" int pgx_tuning_set(const char* key, const char* value) {
   if (!key || strncmp(key, "PGX_", 4) != 0) return PGX_EINVAL;
   std::lock_guard<std::mutex> lk(g_tune_mu);
-  if (value)
-    tune_table()[key] = value;
-  else
+  if (value) {
+    const std::string* interned = nullptr;
+    for (const std::string& s : tune_pool())
+      if (s == value) interned = &s;
+    if (!interned) {
+      tune_pool().emplace_back(value);  // std::deque never moves its elements
+      interned = &tune_pool().back();
+    }
+    tune_table()[key] = interned;
+  } else {
     tune_table().erase(key);
+  }
+  g_tune_gen.fetch_add(1, std::memory_order_release);
   return PGX_OK;
 }
 
@@ -765,6 +786,27 @@ static void setup_tail(pgx_handle* h, int first) {
   }
 }
 
+// Which levels run the single-precision legs (pgx_mg32.hip): a contiguous range from the finest level down, uniform stencils
+// (the row-mapped kernels), above the fused tail, never the coarsest level; `last_dist` >= 0: strip levels of a sharded handle only.
+static int setup_f32(pgx_handle* h, int last_dist) {
+  if (!h->mg_f32 || !h->structured || sizeof(dsten_t) != 8) return PGX_OK;
+  const int nl = (int)h->lev.size();
+  for (int l = 0; l + 1 < nl; ++l) {
+    GridLevel& L = h->lev[l];
+    if (!L.uniform || L.n < std::max(h->f32_min, h->fused_min) || (h->tail_start > 0 && l >= h->tail_start) ||
+        (last_dist >= 0 && l > last_dist))
+      break;
+    DALLOC(L.Dq, L.n);
+    DALLOC(L.xf, L.n);
+    DALLOC(L.xf2, L.n);
+    DALLOC(L.bf, L.n);
+    for (float2* p : {L.xf, L.xf2, L.bf}) HIPCHK(hipMemsetAsync(p, 0, sizeof(float2) * L.n, h->st));
+    HIPCHK(hipMemsetAsync(L.Dq, 0, sizeof(float4) * L.n, h->st));
+    L.f32 = 1;
+  }
+  return PGX_OK;
+}
+
 static int build_multigrid(pgx_handle* h) {
   GridLevel L0{};
   L0.nx = h->nx;
@@ -810,6 +852,8 @@ static int build_multigrid(pgx_handle* h) {
     h->lev.push_back(L);
   }
   setup_tail(h, 1);
+  rc = setup_f32(h, -1);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
@@ -996,6 +1040,8 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_RESID_GRID")) h->resid_grid = atoi(e);
   if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
   if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
+  if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
+  if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
   if (const char* e = pgx_tune("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
   if (const char* e = pgx_tune("PGX_STAG_GAIN")) h->stag_gain = atof(e);
   if (const char* e = pgx_tune("PGX_FUSED_MIN")) h->fused_min = atoi(e);
@@ -1475,6 +1521,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
                           (have_d && h->degree == 1 && h->dh_interior) ? h->lev[0].ny : 0);
     h->dh_interior = false;
     if (h->lev[0].Dh32) pgxk_to_float(h->st, (size_t)4 * h->n, h->lev[0].Dh, h->lev[0].Dh32);
+    if (h->lev[0].f32) pgxk_f_pack_d(h->st, h->lev[0]);
     const int ld = h->dist.on ? h->dist.ldist : 0;
     for (size_t l = 1; l < h->lev.size(); ++l) {
       if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks
@@ -1492,6 +1539,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
       } else {
         pgxk_rap7h(h->st, h->lev[l - 1], h->lev[l - 1].Dh, h->lev[l], h->lev[l].Dh);
       }
+      if (h->lev[l].f32) pgxk_f_pack_d(h->st, h->lev[l]);
     }
   }
   h->jac_valid = true;
@@ -1530,10 +1578,57 @@ static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const 
     pgxk_st_apply(h->st, mode, h->lev[l], h->alpha, xu, xp, bu, bp, omega, first | h->xcd_remap, yu, yp);
 }
 
+static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu, double omega);
+
+// Single-precision legs of the V-cycle on level l (GridLevel::f32; kernels: pgx_mg32.hip).  Level 0 reads the right-hand side from
+// the fp64 pair (bu, bp) - its first launch leaves the float2 copy in L.bf - and writes the result to the fp64 pair (outu, outp);
+// a lower level finds its right-hand side in L.bf (written by the level above) and returns the buffer that holds its correction.
+// The first level without f32 gets its right-hand side, and hands back its correction, in fp64 (vcycle()).
+static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu,
+                              double omega) {
+  GridLevel& L = h->lev[l];
+  GridLevel& C = h->lev[l + 1];
+  const int K = (nu % 3 == 0 && h->fused_k3) ? 3 : 2;
+  const int nl = nu / K;
+  const int remap = h->xcd_remap ? 1 : 0;
+  float2 *cu = L.xf, *ou = L.xf2;
+  pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, l == 0 ? bu : nullptr, l == 0 ? bp : nullptr, nullptr, nullptr, nullptr, nullptr,
+                omega, remap, cu, nullptr, nullptr);
+  for (int s = 1; s < nl; ++s) {
+    pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, omega, remap, ou, nullptr, nullptr);
+    std::swap(cu, ou);
+  }
+  const float2* cf = nullptr;
+  const double *cdu = nullptr, *cdp = nullptr;
+  if (C.f32) {
+    pgxk_f_resid_restrict(h->st, L, h->alpha, cu, C, remap, C.bf, nullptr, nullptr);
+    cf = vcycle_f(h, l + 1, nullptr, nullptr, nullptr, nullptr, nu, omega);
+  } else {
+    pgxk_f_resid_restrict(h->st, L, h->alpha, cu, C, remap, nullptr, C.bu, C.bp);
+    vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
+    cdu = C.xu;
+    cdp = C.xp;
+  }
+  for (int s = 0; s < nl; ++s) {
+    const bool out64 = (s + 1 == nl) && l == 0;
+    pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, s == 0 ? &C : nullptr, s == 0 ? cf : nullptr, s == 0 ? cdu : nullptr,
+                  s == 0 ? cdp : nullptr, omega, remap, ou, out64 ? outu : nullptr, out64 ? outp : nullptr);
+    std::swap(cu, ou);
+  }
+  return cu;
+}
+static inline bool f32_cycle_ok(const pgx_handle* h, int l, int nu) {
+  return h->lev[l].f32 && h->fused_legs && l + 1 < (int)h->lev.size() && nu >= 2 && (nu % 2 == 0 || (nu % 3 == 0 && h->fused_k3));
+}
+
 // one V(nu,nu) cycle for J_l x = b, zero initial guess, result in (outu,outp)
 static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu,
                    double omega) {
   GridLevel& L = h->lev[l];
+  if (l == 0 && f32_cycle_ok(h, 0, nu)) {
+    vcycle_f(h, 0, bu, bp, outu, outp, nu, omega);
+    return;
+  }
   if (l > 0 && l == h->tail_start) {  // all remaining levels in ONE launch (k_mg_tail); result in L.xu/L.xp
     h->tail.nu = (h->nu_coarse > 0) ? std::min(nu, h->nu_coarse) : nu;
     h->tail.omega = omega;
@@ -2310,8 +2405,18 @@ extern "C" int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, doubl
   HIPCHK(hipMemsetAsync(C.xu, 0, sizeof(double) * C.n, h->st));
   HIPCHK(hipMemsetAsync(C.xp, 0, sizeof(double) * C.n, h->st));
   const int remap = h->xcd_remap ? 1 : 0;
+  const bool f32 = f32_cycle_ok(h, 0, 6);
+  if (f32) {  // the single-precision launch of the same role: 3 sweeps on x + P x_c, float2 in and out
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)L.bf, 0x3f800000, 2 * n, h->st));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)L.xf, 0x3f000000, 2 * n, h->st));
+    if (C.f32) HIPCHK(hipMemsetAsync(C.xf, 0, sizeof(float2) * C.n, h->st));
+  }
   auto run = [&]() {
-    pgxk_st_smoothK(h->st, 3, 1, L, h->alpha, h->w, h->w + n, &C, C.xu, C.xp, h->rhs, h->rhs + n, 0.8, remap, h->tmp_u, h->tmp_p);
+    if (f32)
+      pgxk_f_smooth(h->st, 3, 0, L, h->alpha, L.xf, nullptr, nullptr, &C, C.f32 ? C.xf : nullptr, C.f32 ? nullptr : C.xu,
+                    C.f32 ? nullptr : C.xp, 0.8, remap, L.xf2, nullptr, nullptr);
+    else
+      pgxk_st_smoothK(h->st, 3, 1, L, h->alpha, h->w, h->w + n, &C, C.xu, C.xp, h->rhs, h->rhs + n, 0.8, remap, h->tmp_u, h->tmp_p);
   };
   for (int k = 0; k < 3; ++k) run();
   HIPCHK(hipEventRecord(h->e0, h->st));
@@ -2321,7 +2426,8 @@ extern "C" int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, doubl
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, h->e0, h->e1));
   *avg_ms = (double)ms / reps;
-  if (bytes) *bytes = 8.0 * (4.0 * n + 2.0 * n + 2.0 * n + 2.0 * C.n + 2.0 * n);
+  if (bytes)  // D stencil + right-hand side + iterate + coarse correction + result
+    *bytes = f32 ? (16.0 * n + 8.0 * n + 8.0 * n + (C.f32 ? 8.0 : 16.0) * C.n + 8.0 * n) : 8.0 * (4.0 * n + 2.0 * n + 2.0 * n + 2.0 * C.n + 2.0 * n);
   return PGX_OK;
 }
 
@@ -2341,7 +2447,14 @@ extern "C" int pgx_vcycle_bench(pgx_handle* h, int level, int reps, double* avg_
   double *xu = level == 0 ? h->w : L.xu, *xp = level == 0 ? h->w + L.n : L.xp;
   pgxk_set(h->st, (size_t)L.n, 1.0, bu);
   pgxk_set(h->st, (size_t)L.n, 1.0, bp);
-  auto run = [&]() { vcycle(h, level, bu, bp, xu, xp, od.mg_nu, od.mg_omega); };
+  const bool f32 = level > 0 && f32_cycle_ok(h, level, od.mg_nu);  // a single-precision level below the finest: float2 right-hand side
+  if (f32) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)L.bf, 0x3f800000, 2 * (size_t)L.n, h->st));
+  auto run = [&]() {
+    if (f32)
+      vcycle_f(h, level, nullptr, nullptr, nullptr, nullptr, od.mg_nu, od.mg_omega);
+    else
+      vcycle(h, level, bu, bp, xu, xp, od.mg_nu, od.mg_omega);
+  };
   for (int k = 0; k < 3; ++k) run();
   HIPCHK(hipEventRecord(h->e0, h->st));
   for (int k = 0; k < reps; ++k) run();

@@ -62,6 +62,13 @@ struct GridLevel {
   double *xu, *xp, *xu2, *xp2;  // solution ping-pong
   double *bu, *bp;           // right-hand side
   double *ru, *rp;           // residual scratch
+  // Single-precision V-cycle (pgx_mg32.hip; round 4).  On a level with f32 != 0 the cycle reads the D(psi) stencil as ONE float4 per
+  // vertex - (D(0,0), D(+1,0), D(0,+1), D(+1,+1)), repacked from Dh with every Jacobian - and keeps its vectors as interleaved
+  // (u, psi) float2: 40 B per vertex and smoother launch instead of 84.  The cycle is a preconditioner inside FGMRES (flexible);
+  // the operator apply, the residuals and the Krylov space stay fp64.
+  int f32;
+  float4* Dq;
+  float2 *xf, *xf2, *bf;
 };
 
 struct StConst {
@@ -220,6 +227,21 @@ void pgxk_multiaxpy_scale(hipStream_t st, size_t len, int nv, const double* V, s
 // w -= V h and out[0] = |w'|^2 in one pass over the basis (selective CGS2: the lean second pass)
 void pgxk_multiaxpy_norm(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w,
                          double* partials, double* out);
+// ---- single-precision V-cycle legs (pgx_mg32.hip) ----
+// Dq <- Dh (values above 1e30 are clamped: an overshot Newton iterate must not put infinities into the preconditioner)
+void pgxk_f_pack_d(hipStream_t st, const GridLevel& L);
+// K (2 or 3) collective-Jacobi sweeps per launch on a single-precision level, out of place.
+//   first != 0: S^K(0), xf unused; else S^K(xf + P x_c) with the coarse correction x_c = cf (float2: the next level is single
+//   precision) or (cdu, cdp) (fp64 arrays), all three nullptr: none.  C = the coarse level (its nx), nullptr without correction.
+//   b64u / b64p != nullptr: the right-hand side is read from these fp64 arrays and its float2 copy written to L.bf for the
+//   launches that follow (finest level, first launch); else L.bf is read.
+//   y64u / y64p != nullptr: the result is written as fp64 arrays (finest level, last launch); else to yf.
+void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
+                   const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
+                   int remap, float2* yf, double* y64u, double* y64p);
+// b_c = P^T (L.bf - J xf): to cbf (float2) or, when cb64u != nullptr, to the fp64 arrays (cb64u, cb64p) of an fp64 coarse level
+void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const float2* xf, const GridLevel& C, int remap,
+                           float2* cbf, double* cb64u, double* cb64p);
 // K (2 or 3) collective-Jacobi sweeps per launch; see k_st_smoothK
 int pgxk_st_smooth6_ok(const GridLevel& L);
 void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double alpha, const double* xu,

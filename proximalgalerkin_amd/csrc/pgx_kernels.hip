@@ -13,6 +13,7 @@
 //   k_multidot<NV>, k_axpy_dot, k_multiaxpy_scale<NV>, ...                3-pass CGS2 and Krylov vector kernels
 //   k_observables (+ P2 twins in pgx_p2.hip)
 #include "pgx_internal.h"
+#include "pgx_stencil.h"
 #include <algorithm>
 
 #define WAVE 64
@@ -34,17 +35,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
-}
-
-// XCD-aware block remap (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin,
-// so blocks b and b+8 share an XCD).  Logical block = the b-th block of a CONTIGUOUS range owned by one
-// XCD: neighbouring rows (which re-read the same x / stencil lines) then hit the same L2 instead of
-// pulling every line into up to 8 L2s.  Bijective for any grid size; speed only, never correctness.
-__device__ __forceinline__ int xcd_block(int b, int nb, int enable) {
-  if (!enable) return b;
-  const int xcd = b & 7, k = b >> 3;
-  const int q = nb >> 3, r = nb & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
 // non-temporal 16-B load (streamed-once data: Krylov basis slices)
@@ -229,8 +219,6 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows(int n, const int32_t* _
 // pair come out of the same loop at no extra exp cost (b_exp,a = row sum of the D_e row because the hat
 // functions sum to 1).  One launch replaces memset + k_residual_p1 (6 fp64 atomics per cell, ~1 ms at
 // 2048^2) + k_residual_final + k_fill_rows<2>, and the result is bitwise reproducible (no atomics).
-static inline StConst make_stconst(const GridLevel& L);
-
 template <bool WRITE_D, bool FRAME>
 __global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1(int n, const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ v2c_ptr,
@@ -1732,16 +1720,6 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smooth2(int nx, int ny, int n,
   }
 }
 
-static inline StConst make_stconst(const GridLevel& L) {
-  StConst sc;
-  for (int s = 0; s < 7; ++s) {
-    sc.K[s] = L.Kc[s];
-    sc.M[s] = L.Mc[s];
-  }
-  sc.uniform = L.uniform;
-  return sc;
-}
-
 // post=0: (yu,yp) = S(S(0));  post=1: (yu,yp) = S(S((xu,xp) + P (cu,cp)))   -- out of place
 void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha, const double* xu, const double* xp,
                      const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,
@@ -1855,27 +1833,6 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_st_smoothK(int nx, int ny, int n,
 //  * boundary tiles (7 % at 2048^2) run the same general per-point code as k_st_smoothK.
 // Image: 64 x (TY + 2K) vertices, tile = the inner (64 - 2K) x TY.  Same algebra as k_st_smoothK (different summation order).
 // ------------------------------------------------------------------------------------------------
-// Tiles whose image is interior: tx in [1, nfx], ty in [1, nfy]; all others are "boundary tiles" (k_st_smoothRb).
-struct RowmapGrid {
-  int ntx, nty, nfx, nfy;
-};
-template <int TY, int K>
-static inline RowmapGrid rowmap_grid(int nx, int ny, int fast_ok) {
-  constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K;
-  // the tile enumeration takes tx, ty >= 1 as "the image starts inside the grid": tx TX - K >= 1 and ty TY - K >= 1 at tx = ty = 1
-  static_assert(TX - K >= 1 && TY - K >= 1, "first interior tile would read outside the grid");
-  RowmapGrid g;
-  g.ntx = (nx + TX) / TX;
-  g.nty = (ny + TY) / TY;
-  // fast <=> tx*TX - K >= 1, tx*TX - K + W - 1 <= nx - 1, ty*TY - K >= 1, ty*TY - K + H0 - 1 <= ny - 1
-  g.nfx = (nx - 1 - (W - 1 - K)) >= TX ? (nx - 1 - (W - 1 - K)) / TX : 0;
-  g.nfy = (ny - 1 - (H0 - 1 - K)) >= TY ? (ny - 1 - (H0 - 1 - K)) / TY : 0;
-  g.nfx = std::min(g.nfx, g.ntx - 1);
-  g.nfy = std::min(g.nfy, g.nty - 1);
-  if (!fast_ok || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
-  return g;
-}
-
 // The mirrored D links come from the neighbours, not from memory (round 3): D1[v - 1], D2[v - sx] and D3[v - sx - 1] are the stored
 // values of the left / upper / upper-left neighbour - the first is the left lane's register (DPP wave shift), the other two sit in
 // another wave's registers and cross LDS - so a vertex pulls 48 instead of 72 bytes of coefficients through the vector L1.  What
@@ -2171,10 +2128,8 @@ static void launch_rowmap(hipStream_t st, int post, const GridLevel& L, const St
 
 // K = 6 is available on levels with uniform interior stencils (row-mapped kernels only)
 int pgxk_st_smooth6_ok(const GridLevel& L) {
-  const int rowmap = [] {
-    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
-    return e ? atoi(e) : 1;
-  }();
+  static PgxTuneInt t_rowmap("PGX_SMOOTH_ROWMAP", 1);
+  const int rowmap = t_rowmap.get();
   return rowmap && L.uniform;
 }
 
@@ -2187,15 +2142,11 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
     return;
   }
   const StConst sc = make_stconst(L);
-  const int rowmap = [] {
-    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
-    return e ? atoi(e) : 1;
-  }();
+  static PgxTuneInt t_rowmap("PGX_SMOOTH_ROWMAP", 1);
+  const int rowmap = t_rowmap.get();
   if (K == 6) {  // small levels (pgxk_st_smooth6_ok): SIX sweeps per launch - one latency-bound launch instead of two
-    const int ty6 = [] {
-      const char* e = pgx_tune("PGX_K6_TY");
-      return e ? atoi(e) : 0;
-    }();
+    static PgxTuneInt t_ty6("PGX_K6_TY", 0);
+    const int ty6 = t_ty6.get();
     if (ty6 == 16)  // measured at 2049^2: 16-row tiles 323 ms per solve, 8-row tiles 298 ms, three-sweep launches (default) 304 ms
       launch_rowmap<16, 6>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
     else
@@ -2204,10 +2155,8 @@ void pgxk_st_smoothK(hipStream_t st, int K, int post, const GridLevel& L, double
   }
   if (rowmap && L.uniform) {  // row-mapped kernels: image 64 x (TY + 6), tile 58 x TY; interior tiles + boundary tiles
     // tile height by level size (measured, us per launch at 2049^2 / 1025^2 / 513^2 / 257^2 vertices; PGX_ROWMAP_TY forces one)
-    const int ty_env = [] {
-      const char* e = pgx_tune("PGX_ROWMAP_TY");
-      return e ? atoi(e) : 0;
-    }();
+    static PgxTuneInt t_ty("PGX_ROWMAP_TY", 0);
+    const int ty_env = t_ty.get();
     const int ty = ty_env ? ty_env : (L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4);
     if (ty == 4)
       launch_rowmap<4>(st, post, L, sc, alpha, xu, xp, C, cu, cp, bu, bp, omega, remap, yu, yp);
@@ -2401,10 +2350,6 @@ __device__ __forceinline__ void st_rr_tile(int tx, int ty, int nx, int ny, int n
   }
 }
 
-struct RrGrid {
-  int ntx, nty, nfx, nfy;  // coarse tiles; interior ("fast") tiles are tx in [1, nfx], ty in [1, nfy]
-};
-
 __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_resid_restrict_r(int nx, int ny, int n, RrGrid g, int nbnd,
                                                                           const double* __restrict__ K,
                                                                           const double* __restrict__ M,
@@ -2446,10 +2391,8 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_resid_restrict_r(int nx
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp) {
-  const int rowmap = [] {
-    const char* e = pgx_tune("PGX_SMOOTH_ROWMAP");
-    return e ? atoi(e) : 1;
-  }();
+  static PgxTuneInt t_rowmap("PGX_SMOOTH_ROWMAP", 1);
+  const int rowmap = t_rowmap.get();
   if (rowmap && L.uniform) {
     constexpr int CX = 30, CY = 8;
     RrGrid g;
@@ -3245,6 +3188,7 @@ __global__ void __launch_bounds__(512) k_mg_tail2(TailArgs A) {
     int buf = 0;
     sweeps(l, last ? A.coarse_sweeps : A.nu, true, buf);
     if (tid == 0) cur[l] = buf;  // read again on the way up, many barriers later
+    if (last) __syncthreads();   // the coarsest level has no barrier after this write: the up leg / the copy-out read cur[l] next
     if (!last) {
       const double2* X = T2X(l, buf);
       double2* R = T2X(l, buf ^ 1);  // the idle half of the ping-pong pair holds the residual until it is restricted

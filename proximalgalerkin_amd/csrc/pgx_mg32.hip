@@ -1,0 +1,608 @@
+// Single-precision V-cycle legs for gfx950 (round 4).  Same algebra and the same row mapping as the fp64 kernels k_st_smoothR /
+// k_st_resid_restrict_r of pgx_kernels.hip - a workgroup of 8 waves owns a 64-wide image, a wave owns image rows, interior tiles
+// run without tests on scalar K / M stencils, boundary tiles (scheduled first) through the general per-point code - but on HALF
+// the bytes: what the level-0 launches of the fp64 cycle wait for is the unique bytes of their coefficient and vector streams
+// (cycle stamps + timing experiments), not instructions, LDS or occupancy.  Here
+//   * D(psi) is ONE float4 per vertex (centre + the three forward links): one 16-byte load instead of four 8-byte loads from four
+//     arrays; the three mirrored links still come from the neighbours (DPP lane shift, LDS row hand-over);
+//   * the cycle's vectors are interleaved (u, psi) float2: one 8-byte load / store per vertex and vector;
+//   * arithmetic in float: 20 registers of coefficients per image row instead of 36, LDS images of 8 B per vertex.
+// 40 B per vertex and smoother launch instead of 84.  The V-cycle is a preconditioner inside FGMRES, which is flexible; the operator
+// apply, the true residual that decides convergence and the Krylov space stay fp64, so the accuracy of the Newton steps is
+// untouched (tools/mg32_study.py: identical Krylov counts with a float32 cycle on the numpy twin).
+// The fp64 ends of the cycle: the first launch on the finest level reads the Krylov vector (fp64) and leaves its float2 copy for
+// the launches that follow; the last launch writes the preconditioned vector as fp64; a level below the last single-precision
+// one receives its right-hand side, and returns its correction, in fp64.
+#include <algorithm>
+
+#include "pgx_internal.h"
+#include "pgx_stencil.h"
+
+#define F32_BLOCK 512
+
+__device__ __forceinline__ float lane_shr1f(float x) {  // the value of lane - 1 (lane 0 keeps its own)
+  int v = __float_as_int(x);
+  v = __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  return __int_as_float(v);
+}
+
+__global__ void __launch_bounds__(256) k_f_pack_d(int n, const dsten_t* __restrict__ Dh, float4* __restrict__ Dq) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const float big = 1e30f;
+  Dq[v] = make_float4(fminf((float)Dh[v], big), fminf((float)Dh[(size_t)n + v], big), fminf((float)Dh[2 * (size_t)n + v], big),
+                      fminf((float)Dh[3 * (size_t)n + v], big));
+}
+void pgxk_f_pack_d(hipStream_t st, const GridLevel& L) {
+  hipLaunchKernelGGL(k_f_pack_d, dim3((L.n + 255) / 256), dim3(256), 0, st, L.n, L.Dh, L.Dq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// general per-point pieces (boundary tiles)
+// ------------------------------------------------------------------------------------------------
+struct FCoef {
+  float kv[7], mv[7], dv[7];  // kv already holds alpha K
+  int rowbc;
+};
+// Stencil slots: 0:(0,0) 1:(+1,0) 2:(-1,0) 3:(0,+1) 4:(0,-1) 5:(+1,+1) 6:(-1,-1).  Links that leave the grid hold 0 in K, M and Dq.
+__device__ __forceinline__ void f_load_coef(int v, int i, int j, int nx, int ny, int n, const double* __restrict__ K,
+                                            const double* __restrict__ M, const float4* __restrict__ Dq, const StConst& sc,
+                                            const uint8_t* __restrict__ mask, float alpha, FCoef& c) {
+  const int sx = nx + 1;
+  if (sc.uniform && i > 0 && i < nx && j > 0 && j < ny) {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      c.kv[s] = alpha * (float)sc.K[s];
+      c.mv[s] = (float)sc.M[s];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      c.kv[s] = alpha * (float)K[(size_t)s * n + v];
+      c.mv[s] = (float)M[(size_t)s * n + v];
+    }
+  }
+  const float4 q = Dq[v];
+  c.dv[0] = q.x;
+  c.dv[1] = q.y;
+  c.dv[3] = q.z;
+  c.dv[5] = q.w;
+  c.dv[2] = (i > 0) ? Dq[v - 1].y : 0.f;
+  c.dv[4] = (j > 0) ? Dq[v - sx].z : 0.f;
+  c.dv[6] = (i > 0 && j > 0) ? Dq[v - sx - 1].w : 0.f;
+  c.rowbc = mask[v];
+}
+
+__device__ __forceinline__ void f_jacobi(const FCoef& c, float omega, float au, float ap, float xur, float xpr, float buv, float bpv,
+                                         float& yu, float& yp) {
+  if (c.rowbc) au = xur;
+  const float su = buv - au, sp = bpv - ap;
+  float a = c.kv[0], b = c.mv[0];
+  const float dd = c.dv[0];
+  float om_u = omega;
+  if (c.rowbc) {  // Dirichlet row of u: solved exactly
+    a = 1.f;
+    b = 0.f;
+    om_u = 1.f;
+  }
+  const float det = -a * dd - b * b;
+  float du = 0.f, dpsi = 0.f;
+  if (det != 0.f) {
+    const float r = __builtin_amdgcn_rcpf(det);
+    du = (-dd * su - b * sp) * r;
+    dpsi = (-b * su + a * sp) * r;
+  } else if (c.rowbc) {
+    du = su;
+  }
+  yu = xur + om_u * du;
+  yp = xpr + omega * dpsi;
+}
+
+// x + P x_c at fine vertex (gi, gj); the coarse correction is float2 (cf) or a pair of fp64 arrays (cdu, cdp)
+__device__ __forceinline__ float2 f_add_coarse(float2 x, int gi, int gj, int nxc, const float2* __restrict__ cf,
+                                               const double* __restrict__ cdu, const double* __restrict__ cdp) {
+  const int sxc = nxc + 1;
+  const int jc = gj >> 1, ic = gi >> 1;
+  const unsigned c0 = (unsigned)(jc * sxc + ic), c1 = (unsigned)((jc + (gj & 1)) * sxc + ic + (gi & 1));
+  if (cf) {
+    const float2 a = cf[c0], b = cf[c1];
+    x.x += 0.5f * (a.x + b.x);
+    x.y += 0.5f * (a.y + b.y);
+  } else if (cdu) {
+    x.x += 0.5f * (float)(cdu[c0] + cdu[c1]);
+    x.y += 0.5f * (float)(cdp[c0] + cdp[c1]);
+  }
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K sweeps per launch.  IO: 0 = float2 in and out; 1 = right-hand side from fp64 arrays, copied to bfo (FIRST launches only);
+// 2 = result to fp64 arrays (launches with an iterate only).
+// ------------------------------------------------------------------------------------------------
+struct FSmoothArgs {
+  int nx, ny, n, nbnd, nxc, remap;
+  RowmapGrid g;
+  const double *K, *M;  // boundary rows only
+  const float4* Dq;
+  const uint8_t* mask;
+  const float2 *xf, *cf, *bf;
+  const double *cdu, *cdp, *b64u, *b64p;
+  float2 *bfo, *yf;
+  double *y64u, *y64p;
+  float alpha, omega;
+  StConst sc;
+};
+
+template <int TY, int K, bool FIRST, int IO>
+__device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float2* img0, float2* img1, float2* exch) {
+  constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
+  const int sx = A.nx + 1;
+  const int i0 = (1 + b % A.g.nfx) * TX - K, j0 = (1 + b / A.g.nfx) * TY - K;  // origin of the image
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  const float k0 = A.alpha * (float)A.sc.K[0], k1 = A.alpha * (float)(0.5 * (A.sc.K[1] + A.sc.K[2])),
+              k3 = A.alpha * (float)(0.5 * (A.sc.K[3] + A.sc.K[4])), k5 = A.alpha * (float)(0.5 * (A.sc.K[5] + A.sc.K[6]));
+  const float m0 = (float)A.sc.M[0], m1 = (float)(0.5 * (A.sc.M[1] + A.sc.M[2])), m3 = (float)(0.5 * (A.sc.M[3] + A.sc.M[4])),
+              m5 = (float)(0.5 * (A.sc.M[5] + A.sc.M[6]));
+  // A wave owns the SAME image rows in every sweep (lj = wave + NW k): their D links and right-hand side are loaded once, all
+  // loads in flight together, and stay in registers for the K sweeps.
+  float4 dq[R];
+  float2 rb[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < H0 - 1) {  // rows 1 .. H0-2 are updated; row 0 only hands its upward links to row 1
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      dq[k] = A.Dq[v];
+      if (lj >= 1) rb[k] = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
+    }
+  }
+  if (!FIRST) {
+    float2 xa[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < H0) {
+        const int gj = j0 + lj;
+        xa[k] = f_add_coarse(A.xf[(unsigned)(gj * sx + gi)], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < H0) img0[lj * W + lane] = xa[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < H0 - 1) exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
+  }
+  __syncthreads();
+  float d2[R], d4[R], d6[R], g0[R], g1[R], g3[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj >= 1 && lj < H0 - 1) {
+      d2[k] = lane_shr1f(dq[k].y);                   // D(+1,0) of the left neighbour
+      d4[k] = exch[(lj - 1) * W + lane].x;           // D(0,+1) of the vertex below
+      d6[k] = exch[(lj - 1) * W + lane - 1].y;       // D(+1,+1) of the vertex below left; lane 0 (halo, never updated) reads the guard band
+      // omega * inverse of the vertex block [[aK0, M0], [M0, -D0]] (det < 0: k0 > 0, d0 >= 0, m0 > 0), once per launch
+      const float det = fmaf(-k0, dq[k].x, -m0 * m0);
+      const float rc = A.omega * __builtin_amdgcn_rcpf(det);
+      g0[k] = -dq[k].x * rc;
+      g1[k] = -m0 * rc;
+      g3[k] = k0 * rc;
+      if (IO == 1 && lj >= K && lj < H0 - K && lane >= K && lane < W - K) A.bfo[(unsigned)((j0 + lj) * sx + gi)] = rb[k];
+    }
+  }
+#pragma unroll
+  for (int s = 1; s <= K; ++s) {
+    const float2* const src = ((s - 1) & 1) ? img1 : img0;
+    float2* const dst = (s & 1) ? img1 : img0;
+    const bool act = lane >= s && lane < W - s;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < s || lj >= H0 - s) continue;  // wave-uniform
+      float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
+      if (!FIRST || s > 1) {
+        const int q = lj * W + lane;
+        const float2 x0 = src[q], x1 = src[q + 1], x2 = src[q - 1], x3 = src[q + W], x4 = src[q - W], x5 = src[q + W + 1],
+                     x6 = src[q - W - 1];
+        const float u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+        const float p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+        au = (k0 * x0.x + k1 * u12) + (k3 * u34 + k5 * u56) + ((m0 * x0.y + m1 * p12) + (m3 * p34 + m5 * p56));
+        ap = ((m0 * x0.x + m1 * u12) + (m3 * u34 + m5 * u56)) -
+             (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2[k] * x2.y + dq[k].z * x3.y)) + ((d4[k] * x4.y + dq[k].w * x5.y) + d6[k] * x6.y));
+        xur = x0.x;
+        xpr = x0.y;
+      }
+      const float su = rb[k].x - au, sp = rb[k].y - ap;
+      const float ou = xur + fmaf(g0[k], su, g1[k] * sp);
+      const float op = xpr + fmaf(g1[k], su, g3[k] * sp);
+      if (act) {
+        if (s == K) {
+          const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+          if (IO == 2) {
+            A.y64u[v] = (double)ou;
+            A.y64p[v] = (double)op;
+          } else {
+            A.yf[v] = make_float2(ou, op);
+          }
+        } else {
+          dst[lj * W + lane] = make_float2(ou, op);
+        }
+      }
+    }
+    if (s < K) __syncthreads();
+  }
+}
+
+// boundary tiles (tile index as in k_st_smoothR: row ty = 0 | rows 1..nfy: columns 0 and nfx+1.. | rows nfy+1..), cut into
+// sub-tiles of TB rows: a boundary workgroup is a chain of dependent loads, and that chain is the floor of every level's launch
+template <int TY, int TB, int K, bool FIRST, int IO>
+__device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2* img0, float2* img1) {
+  constexpr int W = 64, TX = W - 2 * K, H0 = TB + 2 * K, NSUB = TY / TB, NW = F32_BLOCK / 64;
+  static_assert(TY % TB == 0, "sub-tiles must cover a tile");
+  const int nx = A.nx, ny = A.ny, sx = nx + 1;
+  const RowmapGrid& g = A.g;
+  int tx, ty;
+  const int sub = b % NSUB;
+  b /= NSUB;
+  const int side = g.ntx - g.nfx;  // boundary tiles in a row that also holds fast tiles
+  if (b < g.ntx) {
+    tx = b;
+    ty = 0;
+  } else if ((b -= g.ntx) < g.nfy * side) {
+    ty = 1 + b / side;
+    const int r = b % side;
+    tx = r == 0 ? 0 : g.nfx + r;
+  } else {
+    b -= g.nfy * side;
+    ty = g.nfy + 1 + b / g.ntx;
+    tx = b % g.ntx;
+  }
+  const int i0 = tx * TX - K, j0 = ty * TY + sub * TB - K;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  if (!FIRST) {
+    for (int lj = wave; lj < H0; lj += NW) {
+      const int gj = j0 + lj;
+      float2 x = make_float2(0.f, 0.f);
+      if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        x = f_add_coarse(A.xf[v], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
+        if (A.mask[v]) x.x = 0.f;  // pre-masked image: Dirichlet entries of u read as 0 by neighbours
+      }
+      img0[lj * W + lane] = x;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 1; s <= K; ++s) {
+    const float2* const src = ((s - 1) & 1) ? img1 : img0;
+    float2* const dst = (s & 1) ? img1 : img0;
+    const bool act = lane >= s && lane < W - s;
+    for (int lj = s + wave; lj < H0 - s; lj += NW) {
+      const int gj = j0 + lj;
+      const int q = lj * W + lane;
+      float ou = 0.f, op = 0.f;
+      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        FCoef c;
+        f_load_coef(v, gi, gj, nx, ny, A.n, A.K, A.M, A.Dq, A.sc, A.mask, A.alpha, c);
+        float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
+        if (!FIRST || s > 1) {
+          const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+#pragma unroll
+          for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0, links leaving the grid have zero coefficients
+            const float2 xn = src[q + off[t]];
+            au += c.kv[t] * xn.x + c.mv[t] * xn.y;
+            ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
+          }
+          const float2 x0 = src[q];
+          xur = x0.x;
+          xpr = x0.y;
+        }
+        const float2 bq = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
+        f_jacobi(c, A.omega, au, ap, xur, xpr, bq.x, bq.y, ou, op);
+        if (s == K) {
+          if (IO == 1) A.bfo[v] = bq;
+          if (IO == 2) {
+            A.y64u[v] = (double)ou;
+            A.y64p[v] = (double)op;
+          } else {
+            A.yf[v] = make_float2(ou, op);
+          }
+        }
+        if (c.rowbc) ou = 0.f;  // pre-masked image
+      }
+      if (s < K && act) dst[q] = make_float2(ou, op);
+    }
+    if (s < K) __syncthreads();
+  }
+}
+
+// ONE launch per smoother call: blocks [0, nbnd) are the boundary sub-tiles - they start first, so their long dependent-load
+// chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
+template <int TY, int K, bool FIRST, int IO>
+__global__ void __launch_bounds__(F32_BLOCK) k_f_smooth(const FSmoothArgs A) {
+  constexpr int W = 64, H0 = TY + 2 * K, PAD = W + 1;
+  __shared__ float2 img_[3][H0 * W + 2 * PAD];  // guard bands: inactive edge lanes read (and discard) one entry outside a row;
+                                                 // [2]: the (D(0,+1), D(+1,+1)) links every image row hands to the row above it
+  const int blk = blockIdx.x;
+  if (blk < A.nbnd)
+    f_smooth_bnd<TY, 4, K, FIRST, IO>(blk, A, img_[0] + PAD, img_[1] + PAD);
+  else
+    f_smooth_fast<TY, K, FIRST, IO>(xcd_block(blk - A.nbnd, gridDim.x - A.nbnd, A.remap), A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+}
+
+template <int TY, int K>
+static void launch_f_smooth(hipStream_t st, int first, FSmoothArgs& A, int fast_ok) {
+  A.g = rowmap_grid<TY, K>(A.nx, A.ny, fast_ok);
+  const int nfast = A.g.nfx * A.g.nfy;
+  A.nbnd = (A.g.ntx * A.g.nty - nfast) * (TY / 4);  // boundary tiles: sub-tiles of 4 rows
+  const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
+  if (first) {
+    if (A.b64u)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1>), grid, block, 0, st, A);
+    else
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0>), grid, block, 0, st, A);
+  } else {
+    if (A.y64u)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2>), grid, block, 0, st, A);
+    else
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0>), grid, block, 0, st, A);
+  }
+}
+
+static int f32_tile_rows(const GridLevel& L) {
+  static PgxTuneInt t_ty("PGX_F32_TY", 0);
+  const int ty = t_ty.get();
+  if (ty == 4 || ty == 8 || ty == 16) return ty;
+  return L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4;  // as k_st_smoothR (measured there per level size)
+}
+
+void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
+                   const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
+                   int remap, float2* yf, double* y64u, double* y64p) {
+  FSmoothArgs A;
+  A.nx = L.nx;
+  A.ny = L.ny;
+  A.n = L.n;
+  A.nxc = C ? C->nx : 0;
+  A.remap = remap;
+  A.K = L.K;
+  A.M = L.M;
+  A.Dq = L.Dq;
+  A.mask = L.mask;
+  A.xf = first ? nullptr : xf;
+  A.cf = first ? nullptr : cf;
+  A.cdu = first ? nullptr : cdu;
+  A.cdp = first ? nullptr : cdp;
+  A.b64u = first ? b64u : nullptr;
+  A.b64p = first ? b64p : nullptr;
+  A.bf = A.b64u ? nullptr : L.bf;
+  A.bfo = A.b64u ? L.bf : nullptr;
+  A.yf = yf;
+  A.y64u = first ? nullptr : y64u;
+  A.y64p = first ? nullptr : y64p;
+  A.alpha = (float)alpha;
+  A.omega = (float)omega;
+  A.sc = make_stconst(L);
+  const int ty = f32_tile_rows(L);
+  if (K == 3) {
+    if (ty == 4)
+      launch_f_smooth<4, 3>(st, first, A, L.interior_free);
+    else if (ty == 8)
+      launch_f_smooth<8, 3>(st, first, A, L.interior_free);
+    else
+      launch_f_smooth<16, 3>(st, first, A, L.interior_free);
+  } else {
+    if (ty == 4)
+      launch_f_smooth<4, 2>(st, first, A, L.interior_free);
+    else if (ty == 8)
+      launch_f_smooth<8, 2>(st, first, A, L.interior_free);
+    else
+      launch_f_smooth<16, 2>(st, first, A, L.interior_free);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// b_c = P^T (b - J x): a workgroup of 8 waves owns CX x CY = 30 x 8 coarse vertices.  (1) the iterate on the 63 x 19 fine
+// footprint goes into an LDS image, a wave per row, together with the (D(0,+1), D(+1,+1)) links every row hands to the row above;
+// (2) a wave per fine row evaluates the residual on 61 x 17 vertices into a second image; (3) wave w restricts coarse row w.
+// ------------------------------------------------------------------------------------------------
+struct FRrArgs {
+  int nx, ny, n, nbnd, nxc, nyc, remap;
+  RrGrid g;
+  const double *K, *M;
+  const float4* Dq;
+  const uint8_t *mask, *mask_c;
+  const float2 *xf, *bf;
+  float2* cbf;
+  double *cb64u, *cb64p;
+  float alpha;
+  StConst sc;
+};
+
+template <bool FAST, bool CB64>
+__device__ __forceinline__ void f_rr_tile(int tx, int ty, const FRrArgs& A, float2* ximg, float2* rimg, float2* exch) {
+  constexpr int W = 64, CX = 30, CY = 8, HX = 2 * CY + 3, HR = 2 * CY + 1, NW = F32_BLOCK / 64, R = (HX + NW - 1) / NW;
+  const int nx = A.nx, ny = A.ny, sx = nx + 1, sxc = A.nxc + 1;
+  const int I0 = tx * CX, J0 = ty * CY;
+  const int i0 = 2 * I0 - 2, j0 = 2 * J0 - 2;  // origin of the x image; the residual image starts one row / column further in
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  const bool act = lane >= 1 && lane < W - 1;
+  if (FAST) {
+    // every global load of the wave's (up to three) rows in flight before the first LDS store
+    float2 xa[R], rb[R];
+    float4 dq[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < HX) {
+        const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+        xa[k] = A.xf[v];
+        if (lj <= HR) dq[k] = A.Dq[v];
+        if (lj >= 1 && lj <= HR) rb[k] = A.bf[v];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < HX) ximg[lj * W + lane] = xa[k];
+      if (lj <= HR) exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
+    }
+    __syncthreads();
+    const float k0 = A.alpha * (float)A.sc.K[0], k1 = A.alpha * (float)(0.5 * (A.sc.K[1] + A.sc.K[2])),
+                k3 = A.alpha * (float)(0.5 * (A.sc.K[3] + A.sc.K[4])), k5 = A.alpha * (float)(0.5 * (A.sc.K[5] + A.sc.K[6]));
+    const float m0 = (float)A.sc.M[0], m1 = (float)(0.5 * (A.sc.M[1] + A.sc.M[2])), m3 = (float)(0.5 * (A.sc.M[3] + A.sc.M[4])),
+                m5 = (float)(0.5 * (A.sc.M[5] + A.sc.M[6]));
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < 1 || lj > HR) continue;  // wave-uniform
+      const float d2 = lane_shr1f(dq[k].y), d4 = exch[(lj - 1) * W + lane].x, d6 = exch[(lj - 1) * W + lane - 1].y;
+      const int q = lj * W + lane;
+      const float2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                   x6 = ximg[q - W - 1];
+      const float u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+      const float p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+      const float au = (k0 * x0.x + k1 * u12) + (k3 * u34 + k5 * u56) + ((m0 * x0.y + m1 * p12) + (m3 * p34 + m5 * p56));
+      const float ap = ((m0 * x0.x + m1 * u12) + (m3 * u34 + m5 * u56)) -
+                       (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2 * x2.y + dq[k].z * x3.y)) + ((d4 * x4.y + dq[k].w * x5.y) + d6 * x6.y));
+      if (act) rimg[(lj - 1) * W + lane] = make_float2(rb[k].x - au, rb[k].y - ap);
+    }
+  } else {
+    for (int lj = wave; lj < HX; lj += NW) {
+      const int gj = j0 + lj;
+      float2 x = make_float2(0.f, 0.f);
+      if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        x = A.xf[v];
+        if (A.mask[v]) x.x = 0.f;  // pre-masked image
+      }
+      ximg[lj * W + lane] = x;
+    }
+    __syncthreads();
+    for (int lj = 1 + wave; lj <= HR; lj += NW) {
+      const int gj = j0 + lj;
+      float ru = 0.f, rp = 0.f;
+      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
+        const int v = gj * sx + gi;
+        FCoef c;
+        f_load_coef(v, gi, gj, nx, ny, A.n, A.K, A.M, A.Dq, A.sc, A.mask, A.alpha, c);
+        const int q = lj * W + lane;
+        const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
+        float au = 0.f, ap = 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0; links leaving the grid have zero coefficients
+          const float2 xn = ximg[q + off[t]];
+          au += c.kv[t] * xn.x + c.mv[t] * xn.y;
+          ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
+        }
+        if (c.rowbc) au = A.xf[v].x;
+        const float2 bq = A.bf[v];
+        ru = bq.x - au;
+        rp = bq.y - ap;
+      }
+      if (act) rimg[(lj - 1) * W + lane] = make_float2(ru, rp);  // out-of-grid fine vertices hold 0
+    }
+  }
+  __syncthreads();
+  // (3) restriction: wave w -> coarse row J0 + w, lane -> coarse column I0 + lane.  Fine vertex (2I, 2J) sits at residual-image
+  // row 2w + 1 (image rows start at fine row 2 J0 - 1) and column 2 lane + 2
+  if (wave < CY && lane < CX) {
+    const int I = I0 + lane, J = J0 + wave;
+    if (FAST || (I <= A.nxc && J <= A.nyc)) {
+      const int q = (2 * wave + 1) * W + 2 * lane + 2;
+      const float2 r0 = rimg[q], r1 = rimg[q + 1], r2 = rimg[q - 1], r3 = rimg[q + W], r4 = rimg[q - W], r5 = rimg[q + W + 1],
+                   r6 = rimg[q - W - 1];
+      float su = r0.x + 0.5f * (((r1.x + r2.x) + (r3.x + r4.x)) + (r5.x + r6.x));
+      const float sp = r0.y + 0.5f * (((r1.y + r2.y) + (r3.y + r4.y)) + (r5.y + r6.y));
+      const int C = J * sxc + I;
+      if (!FAST && A.mask_c[C]) su = 0.f;
+      if (CB64) {
+        A.cb64u[C] = (double)su;
+        A.cb64p[C] = (double)sp;
+      } else {
+        A.cbf[C] = make_float2(su, sp);
+      }
+    }
+  }
+}
+
+template <bool CB64>
+__global__ void __launch_bounds__(F32_BLOCK) k_f_resid_restrict(const FRrArgs A) {
+  constexpr int W = 64, CY = 8, HX = 2 * CY + 3, HR = 2 * CY + 1, PAD = W + 1;
+  __shared__ float2 ximg_[HX * W + 2 * PAD], rimg_[HR * W + 2 * PAD], exch_[HX * W + 2 * PAD];
+  int b = blockIdx.x;
+  if (b < A.nbnd) {
+    int tx, ty;
+    const RrGrid& g = A.g;
+    const int side = g.ntx - g.nfx;
+    if (b < g.ntx) {
+      tx = b;
+      ty = 0;
+    } else if ((b -= g.ntx) < g.nfy * side) {
+      ty = 1 + b / side;
+      const int r = b % side;
+      tx = r == 0 ? 0 : g.nfx + r;
+    } else {
+      b -= g.nfy * side;
+      ty = g.nfy + 1 + b / g.ntx;
+      tx = b % g.ntx;
+    }
+    f_rr_tile<false, CB64>(tx, ty, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
+  } else {
+    b = xcd_block(b - A.nbnd, gridDim.x - A.nbnd, A.remap);
+    f_rr_tile<true, CB64>(1 + b % A.g.nfx, 1 + b / A.g.nfx, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
+  }
+}
+
+void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const float2* xf, const GridLevel& C, int remap,
+                           float2* cbf, double* cb64u, double* cb64p) {
+  constexpr int CX = 30, CY = 8;
+  FRrArgs A;
+  A.nx = L.nx;
+  A.ny = L.ny;
+  A.n = L.n;
+  A.nxc = C.nx;
+  A.nyc = C.ny;
+  A.remap = remap;
+  A.K = L.K;
+  A.M = L.M;
+  A.Dq = L.Dq;
+  A.mask = L.mask;
+  A.mask_c = C.mask;
+  A.xf = xf;
+  A.bf = L.bf;
+  A.cbf = cbf;
+  A.cb64u = cb64u;
+  A.cb64p = cb64p;
+  A.alpha = (float)alpha;
+  A.sc = make_stconst(L);
+  RrGrid& g = A.g;
+  g.ntx = (C.nx + CX) / CX;
+  g.nty = (C.ny + CY) / CY;
+  // interior <=> every vertex of the x image is strictly inside the fine grid: 2 tx CX - 2 >= 1, 2 tx CX - 2 + 63 <= nx - 1,
+  // 2 ty CY - 2 >= 1, 2 ty CY - 2 + (2 CY + 2) <= ny - 1
+  g.nfx = (L.nx - 62) >= 2 * CX ? (L.nx - 62) / (2 * CX) : 0;
+  g.nfy = (L.ny - 1 - 2 * CY) >= 2 * CY ? (L.ny - 1 - 2 * CY) / (2 * CY) : 0;
+  g.nfx = std::min(g.nfx, g.ntx - 1);
+  g.nfy = std::min(g.nfy, g.nty - 1);
+  if (!L.interior_free || !C.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
+  const int nfast = g.nfx * g.nfy;
+  A.nbnd = g.ntx * g.nty - nfast;
+  const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
+  if (cb64u)
+    hipLaunchKernelGGL(k_f_resid_restrict<true>, grid, block, 0, st, A);
+  else
+    hipLaunchKernelGGL(k_f_resid_restrict<false>, grid, block, 0, st, A);
+}

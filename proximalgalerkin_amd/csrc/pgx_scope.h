@@ -3,13 +3,35 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 // Tuning / A-B / test switches (kernel variants, tile sizes, thresholds, consistency checks).  libpgx.so NEVER reads them from the
 // environment: the table is filled only through the C ABI (include/pgx.h: pgx_tuning_set), so a deployed library behaves the same
 // whatever PGX_* variables happen to be set.  nullptr = not set.  The environment variables the library does read are the three
 // documented run-time options PGX_COMM_TIMEOUT, PGX_ROCTX and PGX_ND_THREADS.
+// The returned pointer stays valid for the life of the process (values are interned, never freed), so a concurrent
+// pgx_tuning_set cannot pull it away from a caller.
 const char* pgx_tune(const char* name);
+// Number of pgx_tuning_set calls so far: lets the per-launch switches below cache their value without taking the table's lock.
+int pgx_tune_gen();
+// An integer switch read on a hot path (smoother / restriction launches): one relaxed load per call, the table lookup only
+// after the table changed.
+struct PgxTuneInt {
+  const char* key;
+  int def;
+  std::atomic<int> gen{-1}, val{0};
+  PgxTuneInt(const char* k, int d) : key(k), def(d) {}
+  int get() {
+    const int g = pgx_tune_gen();
+    if (gen.load(std::memory_order_acquire) != g) {
+      const char* e = pgx_tune(key);
+      val.store(e ? atoi(e) : def, std::memory_order_relaxed);
+      gen.store(g, std::memory_order_release);
+    }
+    return val.load(std::memory_order_relaxed);
+  }
+};
 
 // roctx ranges around the solver phases (readable rocprofv3 --marker-trace timelines).  Off unless
 // PGX_ROCTX=1; the marker library is opened with dlopen, so libpgx.so has no link-time dependency on the profiler.
