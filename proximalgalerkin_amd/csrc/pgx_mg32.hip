@@ -19,6 +19,8 @@
 #include "pgx_stencil.h"
 
 #define F32_BLOCK 512
+#define F32_RR_CYB 2  // coarse rows of a boundary sub-tile of the residual + restriction
+#define F32_TB 2  // rows of a boundary sub-tile of the smoother: image of 2 + 2K <= 8 rows, one per wave
 
 __device__ __forceinline__ float lane_shr1f(float x) {  // the value of lane - 1 (lane 0 keeps its own)
   int v = __float_as_int(x);
@@ -44,16 +46,41 @@ struct FCoef {
   float kv[7], mv[7], dv[7];  // kv already holds alpha K
   int rowbc;
 };
+// uniform interior stencils as the kernels use them, converted once on the host (scalar registers: 22 instead of the 30 + conversions
+// of the fp64 StConst): alpha K and M per slot (boundary tiles) and with the symmetric link pairs averaged (interior tiles)
+struct FConst {
+  float kc[7], mc[7];
+  float k0, k1, k3, k5, m0, m1, m3, m5;
+  int uniform;
+};
+static inline FConst make_fconst(const GridLevel& L, double alpha) {
+  FConst c;
+  for (int s = 0; s < 7; ++s) {
+    c.kc[s] = (float)alpha * (float)L.Kc[s];
+    c.mc[s] = (float)L.Mc[s];
+  }
+  const float a = (float)alpha;
+  c.k0 = a * (float)L.Kc[0];
+  c.k1 = a * (float)(0.5 * (L.Kc[1] + L.Kc[2]));
+  c.k3 = a * (float)(0.5 * (L.Kc[3] + L.Kc[4]));
+  c.k5 = a * (float)(0.5 * (L.Kc[5] + L.Kc[6]));
+  c.m0 = (float)L.Mc[0];
+  c.m1 = (float)(0.5 * (L.Mc[1] + L.Mc[2]));
+  c.m3 = (float)(0.5 * (L.Mc[3] + L.Mc[4]));
+  c.m5 = (float)(0.5 * (L.Mc[5] + L.Mc[6]));
+  c.uniform = L.uniform;
+  return c;
+}
 // Stencil slots: 0:(0,0) 1:(+1,0) 2:(-1,0) 3:(0,+1) 4:(0,-1) 5:(+1,+1) 6:(-1,-1).  Links that leave the grid hold 0 in K, M and Dq.
 __device__ __forceinline__ void f_load_coef(int v, int i, int j, int nx, int ny, int n, const double* __restrict__ K,
-                                            const double* __restrict__ M, const float4* __restrict__ Dq, const StConst& sc,
+                                            const double* __restrict__ M, const float4* __restrict__ Dq, const FConst& sc,
                                             const uint8_t* __restrict__ mask, float alpha, FCoef& c) {
   const int sx = nx + 1;
   if (sc.uniform && i > 0 && i < nx && j > 0 && j < ny) {
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
-      c.kv[s] = alpha * (float)sc.K[s];
-      c.mv[s] = (float)sc.M[s];
+      c.kv[s] = sc.kc[s];
+      c.mv[s] = sc.mc[s];
     }
   } else {
 #pragma unroll
@@ -98,17 +125,19 @@ __device__ __forceinline__ void f_jacobi(const FCoef& c, float omega, float au, 
   yp = xpr + omega * dpsi;
 }
 
-// x + P x_c at fine vertex (gi, gj); the coarse correction is float2 (cf) or a pair of fp64 arrays (cdu, cdp)
+// x + P x_c at fine vertex (gi, gj).  CADD: 0 = no correction, 1 = the coarse correction is float2 (cf), 2 = a pair of fp64 arrays
+template <int CADD>
 __device__ __forceinline__ float2 f_add_coarse(float2 x, int gi, int gj, int nxc, const float2* __restrict__ cf,
                                                const double* __restrict__ cdu, const double* __restrict__ cdp) {
+  if (CADD == 0) return x;
   const int sxc = nxc + 1;
   const int jc = gj >> 1, ic = gi >> 1;
   const unsigned c0 = (unsigned)(jc * sxc + ic), c1 = (unsigned)((jc + (gj & 1)) * sxc + ic + (gi & 1));
-  if (cf) {
+  if (CADD == 1) {
     const float2 a = cf[c0], b = cf[c1];
     x.x += 0.5f * (a.x + b.x);
     x.y += 0.5f * (a.y + b.y);
-  } else if (cdu) {
+  } else {
     x.x += 0.5f * (float)(cdu[c0] + cdu[c1]);
     x.y += 0.5f * (float)(cdp[c0] + cdp[c1]);
   }
@@ -117,7 +146,7 @@ __device__ __forceinline__ float2 f_add_coarse(float2 x, int gi, int gj, int nxc
 
 // ------------------------------------------------------------------------------------------------
 // K sweeps per launch.  IO: 0 = float2 in and out; 1 = right-hand side from fp64 arrays, copied to bfo (FIRST launches only);
-// 2 = result to fp64 arrays (launches with an iterate only).
+// 2 = result to fp64 arrays (launches with an iterate only).  CADD: the coarse correction added to the iterate (f_add_coarse).
 // ------------------------------------------------------------------------------------------------
 struct FSmoothArgs {
   int nx, ny, n, nbnd, nxc, remap;
@@ -130,10 +159,10 @@ struct FSmoothArgs {
   float2 *bfo, *yf;
   double *y64u, *y64p;
   float alpha, omega;
-  StConst sc;
+  FConst sc;
 };
 
-template <int TY, int K, bool FIRST, int IO>
+template <int TY, int K, bool FIRST, int IO, int CADD>
 __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float2* img0, float2* img1, float2* exch) {
   constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
   const int sx = A.nx + 1;
@@ -141,10 +170,7 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi = i0 + lane;
-  const float k0 = A.alpha * (float)A.sc.K[0], k1 = A.alpha * (float)(0.5 * (A.sc.K[1] + A.sc.K[2])),
-              k3 = A.alpha * (float)(0.5 * (A.sc.K[3] + A.sc.K[4])), k5 = A.alpha * (float)(0.5 * (A.sc.K[5] + A.sc.K[6]));
-  const float m0 = (float)A.sc.M[0], m1 = (float)(0.5 * (A.sc.M[1] + A.sc.M[2])), m3 = (float)(0.5 * (A.sc.M[3] + A.sc.M[4])),
-              m5 = (float)(0.5 * (A.sc.M[5] + A.sc.M[6]));
+  const float k0 = A.sc.k0, k1 = A.sc.k1, k3 = A.sc.k3, k5 = A.sc.k5, m0 = A.sc.m0, m1 = A.sc.m1, m3 = A.sc.m3, m5 = A.sc.m5;
   // A wave owns the SAME image rows in every sweep (lj = wave + NW k): their D links and right-hand side are loaded once, all
   // loads in flight together, and stay in registers for the K sweeps.
   float4 dq[R];
@@ -165,7 +191,7 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
       const int lj = wave + NW * k;
       if (lj < H0) {
         const int gj = j0 + lj;
-        xa[k] = f_add_coarse(A.xf[(unsigned)(gj * sx + gi)], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
+        xa[k] = f_add_coarse<CADD>(A.xf[(unsigned)(gj * sx + gi)], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
       }
     }
 #pragma unroll
@@ -240,11 +266,18 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
   }
 }
 
-// boundary tiles (tile index as in k_st_smoothR: row ty = 0 | rows 1..nfy: columns 0 and nfx+1.. | rows nfy+1..), cut into
-// sub-tiles of TB rows: a boundary workgroup is a chain of dependent loads, and that chain is the floor of every level's launch
-template <int TY, int TB, int K, bool FIRST, int IO>
-__device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2* img0, float2* img1) {
-  constexpr int W = 64, TX = W - 2 * K, H0 = TB + 2 * K, NSUB = TY / TB, NW = F32_BLOCK / 64;
+// Boundary tiles (tile index as in k_st_smoothR: row ty = 0 | rows 1..nfy: columns 0 and nfx+1.. | rows nfy+1..), cut into
+// sub-tiles of TB rows.  Round 3's boundary path evaluated every vertex from scratch in every sweep - coefficient loads behind
+// per-lane tests, a chain of dependent memory round trips of ~1 us per row iteration, and on the small levels that chain IS the
+// launch time.  Here the boundary tiles are built like the interior ones: a wave owns image rows, EVERYTHING a row needs - its D
+// links, right-hand side, iterate, Dirichlet flag and, for the vertices of the grid's frame only, the K / M rows from the arrays
+// (every other vertex takes the uniform constants) - is loaded once, all loads in flight together, and stays in registers for the
+// K sweeps; the mirrored D links come from the neighbours (out-of-grid entries are loaded as 0, and a link that leaves the grid is
+// stored as 0, so no per-link test is left); the 2x2 vertex block is inverted once per launch.  With TB = 2 an image has
+// 2 + 2K <= 8 rows: one row per wave.
+template <int TY, int TB, int K, bool FIRST, int IO, int CADD>
+__device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2* img0, float2* img1, float2* exch) {
+  constexpr int W = 64, TX = W - 2 * K, H0 = TB + 2 * K, NSUB = TY / TB, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
   static_assert(TY % TB == 0, "sub-tiles must cover a tile");
   const int nx = A.nx, ny = A.ny, sx = nx + 1;
   const RowmapGrid& g = A.g;
@@ -268,59 +301,118 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi = i0 + lane;
-  if (!FIRST) {
-    for (int lj = wave; lj < H0; lj += NW) {
-      const int gj = j0 + lj;
-      float2 x = make_float2(0.f, 0.f);
-      if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
-        const int v = gj * sx + gi;
-        x = f_add_coarse(A.xf[v], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
-        if (A.mask[v]) x.x = 0.f;  // pre-masked image: Dirichlet entries of u read as 0 by neighbours
-      }
-      img0[lj * W + lane] = x;
+  float4 dq[R];
+  float2 rb[R], xa[R];
+  float kv[R][7], mv[R][7];
+  bool in[R], bc[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k, gj = j0 + lj;
+    in[k] = lj < H0 && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+    bc[k] = false;
+    dq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb[k] = xa[k] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      kv[k][t] = A.sc.kc[t];
+      mv[k][t] = A.sc.mc[t];
     }
-    __syncthreads();
+    if (in[k]) {
+      const int v = gj * sx + gi;
+      dq[k] = A.Dq[v];
+      bc[k] = A.mask[v] != 0;
+      if (lj >= 1 && lj < H0 - 1) rb[k] = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
+      if (!FIRST) xa[k] = f_add_coarse<CADD>(A.xf[v], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
+      if (!(A.sc.uniform && gi > 0 && gi < nx && gj > 0 && gj < ny)) {  // the grid's frame (or a level without uniform stencils)
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+          kv[k][t] = A.alpha * (float)A.K[(size_t)t * A.n + v];
+          mv[k][t] = (float)A.M[(size_t)t * A.n + v];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < H0) {
+      if (!FIRST) img0[lj * W + lane] = make_float2(bc[k] ? 0.f : xa[k].x, xa[k].y);  // pre-masked: Dirichlet u reads as 0
+      exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
+    }
+  }
+  __syncthreads();
+  float d2[R], d4[R], d6[R], g0[R], g1[R], g2[R], g3[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    d2[k] = d4[k] = d6[k] = g0[k] = g1[k] = g2[k] = g3[k] = 0.f;
+    if (lj >= 1 && lj < H0 - 1) {
+      d2[k] = lane_shr1f(dq[k].y);
+      d4[k] = exch[(lj - 1) * W + lane].x;
+      d6[k] = exch[(lj - 1) * W + lane - 1].y;
+      // damped inverse of the vertex block, once per launch (f_jacobi: a Dirichlet row of u is solved exactly)
+      float a = kv[k][0], bm = mv[k][0], om_u = A.omega;
+      if (bc[k]) {
+        a = 1.f;
+        bm = 0.f;
+        om_u = 1.f;
+      }
+      const float det = -a * dq[k].x - bm * bm;
+      if (det != 0.f) {
+        const float r = __builtin_amdgcn_rcpf(det);
+        g0[k] = om_u * (-dq[k].x * r);
+        g1[k] = om_u * (-bm * r);
+        g2[k] = A.omega * (-bm * r);
+        g3[k] = A.omega * (a * r);
+      } else if (bc[k]) {
+        g0[k] = 1.f;
+      }
+    }
   }
 #pragma unroll
   for (int s = 1; s <= K; ++s) {
     const float2* const src = ((s - 1) & 1) ? img1 : img0;
     float2* const dst = (s & 1) ? img1 : img0;
     const bool act = lane >= s && lane < W - s;
-    for (int lj = s + wave; lj < H0 - s; lj += NW) {
-      const int gj = j0 + lj;
-      const int q = lj * W + lane;
-      float ou = 0.f, op = 0.f;
-      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
-        const int v = gj * sx + gi;
-        FCoef c;
-        f_load_coef(v, gi, gj, nx, ny, A.n, A.K, A.M, A.Dq, A.sc, A.mask, A.alpha, c);
-        float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
-        if (!FIRST || s > 1) {
-          const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
 #pragma unroll
-          for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0, links leaving the grid have zero coefficients
-            const float2 xn = src[q + off[t]];
-            au += c.kv[t] * xn.x + c.mv[t] * xn.y;
-            ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
-          }
-          const float2 x0 = src[q];
-          xur = x0.x;
-          xpr = x0.y;
-        }
-        const float2 bq = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
-        f_jacobi(c, A.omega, au, ap, xur, xpr, bq.x, bq.y, ou, op);
-        if (s == K) {
-          if (IO == 1) A.bfo[v] = bq;
-          if (IO == 2) {
-            A.y64u[v] = (double)ou;
-            A.y64p[v] = (double)op;
-          } else {
-            A.yf[v] = make_float2(ou, op);
-          }
-        }
-        if (c.rowbc) ou = 0.f;  // pre-masked image
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < s || lj >= H0 - s) continue;  // wave-uniform
+      float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
+      if (!FIRST || s > 1) {
+        const int q = lj * W + lane;
+        const float2 x0 = src[q], x1 = src[q + 1], x2 = src[q - 1], x3 = src[q + W], x4 = src[q - W], x5 = src[q + W + 1],
+                     x6 = src[q - W - 1];
+        au = ((kv[k][0] * x0.x + kv[k][1] * x1.x) + (kv[k][2] * x2.x + kv[k][3] * x3.x)) +
+             ((kv[k][4] * x4.x + kv[k][5] * x5.x) + kv[k][6] * x6.x) +
+             (((mv[k][0] * x0.y + mv[k][1] * x1.y) + (mv[k][2] * x2.y + mv[k][3] * x3.y)) +
+              ((mv[k][4] * x4.y + mv[k][5] * x5.y) + mv[k][6] * x6.y));
+        ap = (((mv[k][0] * x0.x + mv[k][1] * x1.x) + (mv[k][2] * x2.x + mv[k][3] * x3.x)) +
+              ((mv[k][4] * x4.x + mv[k][5] * x5.x) + mv[k][6] * x6.x)) -
+             (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2[k] * x2.y + dq[k].z * x3.y)) + ((d4[k] * x4.y + dq[k].w * x5.y) + d6[k] * x6.y));
+        xur = x0.x;
+        xpr = x0.y;
       }
-      if (s < K && act) dst[q] = make_float2(ou, op);
+      if (bc[k]) au = xur;  // (the image holds 0 there: the row reads u = b_u)
+      const float su = rb[k].x - au, sp = rb[k].y - ap;
+      const float ou = xur + fmaf(g0[k], su, g1[k] * sp);
+      const float op = xpr + fmaf(g2[k], su, g3[k] * sp);
+      if (act) {
+        if (s == K) {
+          if (in[k]) {
+            const int v = (j0 + lj) * sx + gi;
+            if (IO == 1) A.bfo[v] = rb[k];
+            if (IO == 2) {
+              A.y64u[v] = (double)ou;
+              A.y64p[v] = (double)op;
+            } else {
+              A.yf[v] = make_float2(ou, op);
+            }
+          }
+        } else {
+          dst[lj * W + lane] = in[k] ? make_float2(bc[k] ? 0.f : ou, op) : make_float2(0.f, 0.f);
+        }
+      }
     }
     if (s < K) __syncthreads();
   }
@@ -328,34 +420,46 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
 
 // ONE launch per smoother call: blocks [0, nbnd) are the boundary sub-tiles - they start first, so their long dependent-load
 // chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
-template <int TY, int K, bool FIRST, int IO>
+template <int TY, int K, bool FIRST, int IO, int CADD>
 __global__ void __launch_bounds__(F32_BLOCK) k_f_smooth(const FSmoothArgs A) {
   constexpr int W = 64, H0 = TY + 2 * K, PAD = W + 1;
   __shared__ float2 img_[3][H0 * W + 2 * PAD];  // guard bands: inactive edge lanes read (and discard) one entry outside a row;
                                                  // [2]: the (D(0,+1), D(+1,+1)) links every image row hands to the row above it
   const int blk = blockIdx.x;
   if (blk < A.nbnd)
-    f_smooth_bnd<TY, 4, K, FIRST, IO>(blk, A, img_[0] + PAD, img_[1] + PAD);
+    f_smooth_bnd<TY, F32_TB, K, FIRST, IO, CADD>(blk, A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
   else
-    f_smooth_fast<TY, K, FIRST, IO>(xcd_block(blk - A.nbnd, gridDim.x - A.nbnd, A.remap), A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+    f_smooth_fast<TY, K, FIRST, IO, CADD>(xcd_block(blk - A.nbnd, gridDim.x - A.nbnd, A.remap), A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
 }
 
 template <int TY, int K>
 static void launch_f_smooth(hipStream_t st, int first, FSmoothArgs& A, int fast_ok) {
   A.g = rowmap_grid<TY, K>(A.nx, A.ny, fast_ok);
   const int nfast = A.g.nfx * A.g.nfy;
-  A.nbnd = (A.g.ntx * A.g.nty - nfast) * (TY / 4);  // boundary tiles: sub-tiles of 4 rows
+  A.nbnd = (A.g.ntx * A.g.nty - nfast) * (TY / F32_TB);  // boundary tiles: sub-tiles of F32_TB rows
   const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
   if (first) {
     if (A.b64u)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1, 0>), grid, block, 0, st, A);
     else
-      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0, 0>), grid, block, 0, st, A);
+    return;
+  }
+  const int cadd = A.cf ? 1 : (A.cdu ? 2 : 0);
+  if (A.y64u) {
+    if (cadd == 0)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 0>), grid, block, 0, st, A);
+    else if (cadd == 1)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 1>), grid, block, 0, st, A);
+    else
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 2>), grid, block, 0, st, A);
   } else {
-    if (A.y64u)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2>), grid, block, 0, st, A);
+    if (cadd == 0)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 0>), grid, block, 0, st, A);
+    else if (cadd == 1)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 1>), grid, block, 0, st, A);
     else
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 2>), grid, block, 0, st, A);
   }
 }
 
@@ -392,7 +496,7 @@ void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double 
   A.y64p = first ? nullptr : y64p;
   A.alpha = (float)alpha;
   A.omega = (float)omega;
-  A.sc = make_stconst(L);
+  A.sc = make_fconst(L, alpha);
   const int ty = f32_tile_rows(L);
   if (K == 3) {
     if (ty == 4)
@@ -426,108 +530,141 @@ struct FRrArgs {
   float2* cbf;
   double *cb64u, *cb64p;
   float alpha;
-  StConst sc;
+  FConst sc;
 };
 
-template <bool FAST, bool CB64>
-__device__ __forceinline__ void f_rr_tile(int tx, int ty, const FRrArgs& A, float2* ximg, float2* rimg, float2* exch) {
+template <bool CB64>
+__device__ __forceinline__ void f_rr_fast(int tx, int ty, const FRrArgs& A, float2* ximg, float2* rimg, float2* exch) {
   constexpr int W = 64, CX = 30, CY = 8, HX = 2 * CY + 3, HR = 2 * CY + 1, NW = F32_BLOCK / 64, R = (HX + NW - 1) / NW;
-  const int nx = A.nx, ny = A.ny, sx = nx + 1, sxc = A.nxc + 1;
+  const int sx = A.nx + 1, sxc = A.nxc + 1;
   const int I0 = tx * CX, J0 = ty * CY;
   const int i0 = 2 * I0 - 2, j0 = 2 * J0 - 2;  // origin of the x image; the residual image starts one row / column further in
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi = i0 + lane;
   const bool act = lane >= 1 && lane < W - 1;
-  if (FAST) {
-    // every global load of the wave's (up to three) rows in flight before the first LDS store
-    float2 xa[R], rb[R];
-    float4 dq[R];
+  // every global load of the wave's (up to three) rows in flight before the first LDS store
+  float2 xa[R], rb[R];
+  float4 dq[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int lj = wave + NW * k;
-      if (lj < HX) {
-        const unsigned v = (unsigned)((j0 + lj) * sx + gi);
-        xa[k] = A.xf[v];
-        if (lj <= HR) dq[k] = A.Dq[v];
-        if (lj >= 1 && lj <= HR) rb[k] = A.bf[v];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int lj = wave + NW * k;
-      if (lj < HX) ximg[lj * W + lane] = xa[k];
-      if (lj <= HR) exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
-    }
-    __syncthreads();
-    const float k0 = A.alpha * (float)A.sc.K[0], k1 = A.alpha * (float)(0.5 * (A.sc.K[1] + A.sc.K[2])),
-                k3 = A.alpha * (float)(0.5 * (A.sc.K[3] + A.sc.K[4])), k5 = A.alpha * (float)(0.5 * (A.sc.K[5] + A.sc.K[6]));
-    const float m0 = (float)A.sc.M[0], m1 = (float)(0.5 * (A.sc.M[1] + A.sc.M[2])), m3 = (float)(0.5 * (A.sc.M[3] + A.sc.M[4])),
-                m5 = (float)(0.5 * (A.sc.M[5] + A.sc.M[6]));
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int lj = wave + NW * k;
-      if (lj < 1 || lj > HR) continue;  // wave-uniform
-      const float d2 = lane_shr1f(dq[k].y), d4 = exch[(lj - 1) * W + lane].x, d6 = exch[(lj - 1) * W + lane - 1].y;
-      const int q = lj * W + lane;
-      const float2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
-                   x6 = ximg[q - W - 1];
-      const float u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
-      const float p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
-      const float au = (k0 * x0.x + k1 * u12) + (k3 * u34 + k5 * u56) + ((m0 * x0.y + m1 * p12) + (m3 * p34 + m5 * p56));
-      const float ap = ((m0 * x0.x + m1 * u12) + (m3 * u34 + m5 * u56)) -
-                       (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2 * x2.y + dq[k].z * x3.y)) + ((d4 * x4.y + dq[k].w * x5.y) + d6 * x6.y));
-      if (act) rimg[(lj - 1) * W + lane] = make_float2(rb[k].x - au, rb[k].y - ap);
-    }
-  } else {
-    for (int lj = wave; lj < HX; lj += NW) {
-      const int gj = j0 + lj;
-      float2 x = make_float2(0.f, 0.f);
-      if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
-        const int v = gj * sx + gi;
-        x = A.xf[v];
-        if (A.mask[v]) x.x = 0.f;  // pre-masked image
-      }
-      ximg[lj * W + lane] = x;
-    }
-    __syncthreads();
-    for (int lj = 1 + wave; lj <= HR; lj += NW) {
-      const int gj = j0 + lj;
-      float ru = 0.f, rp = 0.f;
-      if (act && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
-        const int v = gj * sx + gi;
-        FCoef c;
-        f_load_coef(v, gi, gj, nx, ny, A.n, A.K, A.M, A.Dq, A.sc, A.mask, A.alpha, c);
-        const int q = lj * W + lane;
-        const int off[7] = {0, 1, -1, W, -W, W + 1, -W - 1};
-        float au = 0.f, ap = 0.f;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {  // out-of-grid / Dirichlet entries of the image are 0; links leaving the grid have zero coefficients
-          const float2 xn = ximg[q + off[t]];
-          au += c.kv[t] * xn.x + c.mv[t] * xn.y;
-          ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
-        }
-        if (c.rowbc) au = A.xf[v].x;
-        const float2 bq = A.bf[v];
-        ru = bq.x - au;
-        rp = bq.y - ap;
-      }
-      if (act) rimg[(lj - 1) * W + lane] = make_float2(ru, rp);  // out-of-grid fine vertices hold 0
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < HX) {
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      xa[k] = A.xf[v];
+      if (lj <= HR) dq[k] = A.Dq[v];
+      if (lj >= 1 && lj <= HR) rb[k] = A.bf[v];
     }
   }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < HX) ximg[lj * W + lane] = xa[k];
+    if (lj <= HR) exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
+  }
   __syncthreads();
-  // (3) restriction: wave w -> coarse row J0 + w, lane -> coarse column I0 + lane.  Fine vertex (2I, 2J) sits at residual-image
+  const float k0 = A.sc.k0, k1 = A.sc.k1, k3 = A.sc.k3, k5 = A.sc.k5, m0 = A.sc.m0, m1 = A.sc.m1, m3 = A.sc.m3, m5 = A.sc.m5;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < 1 || lj > HR) continue;  // wave-uniform
+    const float d2 = lane_shr1f(dq[k].y), d4 = exch[(lj - 1) * W + lane].x, d6 = exch[(lj - 1) * W + lane - 1].y;
+    const int q = lj * W + lane;
+    const float2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                 x6 = ximg[q - W - 1];
+    const float u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+    const float p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+    const float au = (k0 * x0.x + k1 * u12) + (k3 * u34 + k5 * u56) + ((m0 * x0.y + m1 * p12) + (m3 * p34 + m5 * p56));
+    const float ap = ((m0 * x0.x + m1 * u12) + (m3 * u34 + m5 * u56)) -
+                     (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2 * x2.y + dq[k].z * x3.y)) + ((d4 * x4.y + dq[k].w * x5.y) + d6 * x6.y));
+    if (act) rimg[(lj - 1) * W + lane] = make_float2(rb[k].x - au, rb[k].y - ap);
+  }
+  __syncthreads();
+  // restriction: wave w -> coarse row J0 + w, lane -> coarse column I0 + lane.  Fine vertex (2I, 2J) sits at residual-image
   // row 2w + 1 (image rows start at fine row 2 J0 - 1) and column 2 lane + 2
   if (wave < CY && lane < CX) {
+    const int q = (2 * wave + 1) * W + 2 * lane + 2;
+    const float2 r0 = rimg[q], r1 = rimg[q + 1], r2 = rimg[q - 1], r3 = rimg[q + W], r4 = rimg[q - W], r5 = rimg[q + W + 1],
+                 r6 = rimg[q - W - 1];
+    const float su = r0.x + 0.5f * (((r1.x + r2.x) + (r3.x + r4.x)) + (r5.x + r6.x));
+    const float sp = r0.y + 0.5f * (((r1.y + r2.y) + (r3.y + r4.y)) + (r5.y + r6.y));
+    const int C = (J0 + wave) * sxc + I0 + lane;
+    if (CB64) {
+      A.cb64u[C] = (double)su;
+      A.cb64p[C] = (double)sp;
+    } else {
+      A.cbf[C] = make_float2(su, sp);
+    }
+  }
+}
+
+// boundary tiles, cut into sub-tiles of CYB = 2 coarse rows (x image of 7 fine rows: one per wave), register-resident like the
+// boundary tiles of the smoother (f_smooth_bnd): one batch of loads, no dependent chains
+template <bool CB64>
+__device__ __forceinline__ void f_rr_bnd(int tx, int ty, int sub, const FRrArgs& A, float2* ximg, float2* rimg, float2* exch) {
+  constexpr int W = 64, CX = 30, CY = 8, CYB = F32_RR_CYB, HX = 2 * CYB + 3, HR = 2 * CYB + 1, NW = F32_BLOCK / 64;
+  static_assert(HX <= NW && CY % CYB == 0, "one image row per wave");
+  const int nx = A.nx, ny = A.ny, sx = nx + 1, sxc = A.nxc + 1;
+  const int I0 = tx * CX, J0 = ty * CY + sub * CYB;
+  const int i0 = 2 * I0 - 2, j0 = 2 * J0 - 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane, lj = wave, gj = j0 + lj;
+  const bool in = lj < HX && gi >= 0 && gi <= nx && gj >= 0 && gj <= ny;
+  const bool act = lane >= 1 && lane < W - 1;
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 rb = make_float2(0.f, 0.f), xa = make_float2(0.f, 0.f);
+  float kv[7], mv[7];
+  bool bc = false;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    kv[t] = A.sc.kc[t];
+    mv[t] = A.sc.mc[t];
+  }
+  if (in) {
+    const int v = gj * sx + gi;
+    xa = A.xf[v];
+    bc = A.mask[v] != 0;
+    if (lj <= HR) dq = A.Dq[v];
+    if (lj >= 1 && lj <= HR) {
+      rb = A.bf[v];
+      if (!(A.sc.uniform && gi > 0 && gi < nx && gj > 0 && gj < ny)) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+          kv[t] = A.alpha * (float)A.K[(size_t)t * A.n + v];
+          mv[t] = (float)A.M[(size_t)t * A.n + v];
+        }
+      }
+    }
+  }
+  if (lj < HX) {
+    ximg[lj * W + lane] = make_float2(bc ? 0.f : xa.x, xa.y);  // pre-masked image
+    exch[lj * W + lane] = make_float2(dq.z, dq.w);
+  }
+  __syncthreads();
+  if (lj >= 1 && lj <= HR) {
+    const float d2 = lane_shr1f(dq.y), d4 = exch[(lj - 1) * W + lane].x, d6 = exch[(lj - 1) * W + lane - 1].y;
+    const int q = lj * W + lane;
+    const float2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                 x6 = ximg[q - W - 1];
+    float au = ((kv[0] * x0.x + kv[1] * x1.x) + (kv[2] * x2.x + kv[3] * x3.x)) + ((kv[4] * x4.x + kv[5] * x5.x) + kv[6] * x6.x) +
+               (((mv[0] * x0.y + mv[1] * x1.y) + (mv[2] * x2.y + mv[3] * x3.y)) + ((mv[4] * x4.y + mv[5] * x5.y) + mv[6] * x6.y));
+    const float ap = (((mv[0] * x0.x + mv[1] * x1.x) + (mv[2] * x2.x + mv[3] * x3.x)) + ((mv[4] * x4.x + mv[5] * x5.x) + mv[6] * x6.x)) -
+                     (((dq.x * x0.y + dq.y * x1.y) + (d2 * x2.y + dq.z * x3.y)) + ((d4 * x4.y + dq.w * x5.y) + d6 * x6.y));
+    if (bc) au = xa.x;  // Dirichlet row of u: r_u = b_u - u (the unmasked iterate)
+    if (act) rimg[(lj - 1) * W + lane] = in ? make_float2(rb.x - au, rb.y - ap) : make_float2(0.f, 0.f);  // out-of-grid fine vertices hold 0
+  }
+  __syncthreads();
+  if (wave < CYB && lane < CX) {
     const int I = I0 + lane, J = J0 + wave;
-    if (FAST || (I <= A.nxc && J <= A.nyc)) {
+    if (I <= A.nxc && J <= A.nyc) {
       const int q = (2 * wave + 1) * W + 2 * lane + 2;
       const float2 r0 = rimg[q], r1 = rimg[q + 1], r2 = rimg[q - 1], r3 = rimg[q + W], r4 = rimg[q - W], r5 = rimg[q + W + 1],
                    r6 = rimg[q - W - 1];
       float su = r0.x + 0.5f * (((r1.x + r2.x) + (r3.x + r4.x)) + (r5.x + r6.x));
       const float sp = r0.y + 0.5f * (((r1.y + r2.y) + (r3.y + r4.y)) + (r5.y + r6.y));
       const int C = J * sxc + I;
-      if (!FAST && A.mask_c[C]) su = 0.f;
+      if (A.mask_c[C]) su = 0.f;
       if (CB64) {
         A.cb64u[C] = (double)su;
         A.cb64p[C] = (double)sp;
@@ -544,6 +681,9 @@ __global__ void __launch_bounds__(F32_BLOCK) k_f_resid_restrict(const FRrArgs A)
   __shared__ float2 ximg_[HX * W + 2 * PAD], rimg_[HR * W + 2 * PAD], exch_[HX * W + 2 * PAD];
   int b = blockIdx.x;
   if (b < A.nbnd) {
+    constexpr int NSUB = 8 / F32_RR_CYB;
+    const int sub = b % NSUB;
+    b /= NSUB;
     int tx, ty;
     const RrGrid& g = A.g;
     const int side = g.ntx - g.nfx;
@@ -559,10 +699,10 @@ __global__ void __launch_bounds__(F32_BLOCK) k_f_resid_restrict(const FRrArgs A)
       ty = g.nfy + 1 + b / g.ntx;
       tx = b % g.ntx;
     }
-    f_rr_tile<false, CB64>(tx, ty, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
+    f_rr_bnd<CB64>(tx, ty, sub, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
   } else {
     b = xcd_block(b - A.nbnd, gridDim.x - A.nbnd, A.remap);
-    f_rr_tile<true, CB64>(1 + b % A.g.nfx, 1 + b / A.g.nfx, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
+    f_rr_fast<CB64>(1 + b % A.g.nfx, 1 + b / A.g.nfx, A, ximg_ + PAD, rimg_ + PAD, exch_ + PAD);
   }
 }
 
@@ -587,7 +727,7 @@ void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, con
   A.cb64u = cb64u;
   A.cb64p = cb64p;
   A.alpha = (float)alpha;
-  A.sc = make_stconst(L);
+  A.sc = make_fconst(L, alpha);
   RrGrid& g = A.g;
   g.ntx = (C.nx + CX) / CX;
   g.nty = (C.ny + CY) / CY;
@@ -599,7 +739,7 @@ void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, con
   g.nfy = std::min(g.nfy, g.nty - 1);
   if (!L.interior_free || !C.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
   const int nfast = g.nfx * g.nfy;
-  A.nbnd = g.ntx * g.nty - nfast;
+  A.nbnd = (g.ntx * g.nty - nfast) * (CY / F32_RR_CYB);  // boundary tiles: sub-tiles of F32_RR_CYB coarse rows
   const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
   if (cb64u)
     hipLaunchKernelGGL(k_f_resid_restrict<true>, grid, block, 0, st, A);
