@@ -139,6 +139,8 @@ struct pgx_handle {
   int mg_f32 = 1;          // PGX_MG_F32=0: the round-3 fp64 V-cycle.  Default: single-precision V-cycle legs (pgx_mg32.hip) on every
                            // uniform level with at least f32_min vertices above the fused tail - half the bytes per launch
   int f32_min = 4000;      // PGX_F32_MIN
+  int f32_rr_max = 100000;   // PGX_F32_RR_MAX (measured, us per V-cycle from that level: 257^2 and below -2 each, 513^2 +3, 1025^2 +5, 2049^2 +12): levels with at most this many vertices fuse the residual + restriction into the last
+                             // pre-smoothing launch (pgx_mg32.hip, RR mode)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
   bool lu_active = false;  // the current Newton solve preconditions with the factorisation
@@ -824,7 +826,11 @@ static int build_multigrid(pgx_handle* h) {
   int rc = detect_uniform(h, h->lev[0]);
   if (rc) return rc;
   int nx = h->nx, ny = h->ny;
-  while (nx % 2 == 0 && ny % 2 == 0 && nx > 2 && ny > 2) {
+  const int min_nx = [] {
+    const char* e = pgx_tune("PGX_MG_MIN_NX");  // experiment: stop coarsening at this many cells per side
+    return e ? std::max(2, atoi(e)) : 2;
+  }();
+  while (nx % 2 == 0 && ny % 2 == 0 && nx > min_nx && ny > min_nx) {
     nx /= 2;
     ny /= 2;
     GridLevel L{};
@@ -1042,6 +1048,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
+  if (const char* e = pgx_tune("PGX_F32_RR_MAX")) h->f32_rr_max = atoi(e);
   if (const char* e = pgx_tune("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
   if (const char* e = pgx_tune("PGX_STAG_GAIN")) h->stag_gain = atof(e);
   if (const char* e = pgx_tune("PGX_FUSED_MIN")) h->fused_min = atoi(e);
@@ -1592,19 +1599,29 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
   const int nl = nu / K;
   const int remap = h->xcd_remap ? 1 : 0;
   float2 *cu = L.xf, *ou = L.xf2;
-  pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, l == 0 ? bu : nullptr, l == 0 ? bp : nullptr, nullptr, nullptr, nullptr, nullptr,
-                omega, remap, cu, nullptr, nullptr);
+  // levels up to f32_rr_max vertices: the last pre-smoothing launch also restricts the residual of its result (one launch and one
+  // pass over D, b, x less per level and cycle; the finest level keeps the separate launch: its halo overhead costs more there)
+  const bool fuse = L.n <= h->f32_rr_max;
+  float2* const cbf = C.f32 ? C.bf : nullptr;
+  double* const cb64u = C.f32 ? nullptr : C.bu;
+  double* const cb64p = C.f32 ? nullptr : C.bp;
+  {
+    const bool rr = fuse && nl == 1;
+    pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, l == 0 ? bu : nullptr, l == 0 ? bp : nullptr, rr ? &C : nullptr, nullptr, nullptr,
+                  nullptr, omega, remap, cu, nullptr, nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr);
+  }
   for (int s = 1; s < nl; ++s) {
-    pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, omega, remap, ou, nullptr, nullptr);
+    const bool rr = fuse && s + 1 == nl;
+    pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, rr ? &C : nullptr, nullptr, nullptr, nullptr, omega, remap, ou, nullptr,
+                  nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr);
     std::swap(cu, ou);
   }
+  if (!fuse) pgxk_f_resid_restrict(h->st, L, h->alpha, cu, C, remap, cbf, cb64u, cb64p);
   const float2* cf = nullptr;
   const double *cdu = nullptr, *cdp = nullptr;
   if (C.f32) {
-    pgxk_f_resid_restrict(h->st, L, h->alpha, cu, C, remap, C.bf, nullptr, nullptr);
     cf = vcycle_f(h, l + 1, nullptr, nullptr, nullptr, nullptr, nu, omega);
   } else {
-    pgxk_f_resid_restrict(h->st, L, h->alpha, cu, C, remap, nullptr, C.bu, C.bp);
     vcycle(h, l + 1, C.bu, C.bp, C.xu, C.xp, nu, omega);
     cdu = C.xu;
     cdp = C.xp;

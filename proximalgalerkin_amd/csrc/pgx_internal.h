@@ -236,9 +236,12 @@ void pgxk_f_pack_d(hipStream_t st, const GridLevel& L);
 //   b64u / b64p != nullptr: the right-hand side is read from these fp64 arrays and its float2 copy written to L.bf for the
 //   launches that follow (finest level, first launch); else L.bf is read.
 //   y64u / y64p != nullptr: the result is written as fp64 arrays (finest level, last launch); else to yf.
+//   cbf or (cb64u, cb64p) != nullptr: the launch also restricts the residual of its result to the coarse level C, like
+//   pgxk_f_resid_restrict (no coarse correction and a float2 result in that case).
 void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
                    const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
-                   int remap, float2* yf, double* y64u, double* y64p);
+                   int remap, float2* yf, double* y64u, double* y64p, float2* cbf = nullptr, double* cb64u = nullptr,
+                   double* cb64p = nullptr);
 // b_c = P^T (L.bf - J xf): to cbf (float2) or, when cb64u != nullptr, to the fp64 arrays (cb64u, cb64p) of an fp64 coarse level
 void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const float2* xf, const GridLevel& C, int remap,
                            float2* cbf, double* cb64u, double* cb64p);

@@ -147,29 +147,36 @@ __device__ __forceinline__ float2 f_add_coarse(float2 x, int gi, int gj, int nxc
 // ------------------------------------------------------------------------------------------------
 // K sweeps per launch.  IO: 0 = float2 in and out; 1 = right-hand side from fp64 arrays, copied to bfo (FIRST launches only);
 // 2 = result to fp64 arrays (launches with an iterate only).  CADD: the coarse correction added to the iterate (f_add_coarse).
+// RR != 0: the launch ALSO restricts the residual of its result, b_c = P^T (b - J S^K(x)), to the coarse level (1: float2 cbf,
+// 2: fp64 arrays) - the last pre-smoothing launch and the residual + restriction launch of a level in one: the image carries
+// K + 2 halo rows / columns instead of K (K sweeps, one residual, one restriction stencil), the result is kept in LDS, the rows'
+// coefficients are still in registers.  Saves a launch per level and cycle (what the small levels are made of) and one pass
+// over D, b and x; costs (64 - 2K)(TY) / ((60 - 2K)(TY)) ... more halo work, so the finest level keeps the separate launches.
 // ------------------------------------------------------------------------------------------------
 struct FSmoothArgs {
-  int nx, ny, n, nbnd, nxc, remap;
+  int nx, ny, n, nbnd, nxc, nyc, remap;
   RowmapGrid g;
   const double *K, *M;  // boundary rows only
   const float4* Dq;
-  const uint8_t* mask;
+  const uint8_t *mask, *mask_c;
   const float2 *xf, *cf, *bf;
   const double *cdu, *cdp, *b64u, *b64p;
-  float2 *bfo, *yf;
-  double *y64u, *y64p;
+  float2 *bfo, *yf, *cbf;
+  double *y64u, *y64p, *cb64u, *cb64p;
   float alpha, omega;
   FConst sc;
 };
 
-template <int TY, int K, bool FIRST, int IO, int CADD>
+template <int TY, int K, bool FIRST, int IO, int CADD, int RR>
 __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float2* img0, float2* img1, float2* exch) {
-  constexpr int W = 64, TX = W - 2 * K, H0 = TY + 2 * K, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
+  constexpr int W = 64, HALO = K + (RR ? 2 : 0), TX = W - 2 * HALO, H0 = TY + 2 * HALO, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
   const int sx = A.nx + 1;
-  const int i0 = (1 + b % A.g.nfx) * TX - K, j0 = (1 + b / A.g.nfx) * TY - K;  // origin of the image
+  const int tx = 1 + b % A.g.nfx, ty = 1 + b / A.g.nfx;
+  const int i0 = tx * TX - HALO, j0 = ty * TY - HALO;  // origin of the image
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi = i0 + lane;
+  const bool own_lane = lane >= HALO && lane < W - HALO;
   const float k0 = A.sc.k0, k1 = A.sc.k1, k3 = A.sc.k3, k5 = A.sc.k5, m0 = A.sc.m0, m1 = A.sc.m1, m3 = A.sc.m3, m5 = A.sc.m5;
   // A wave owns the SAME image rows in every sweep (lj = wave + NW k): their D links and right-hand side are loaded once, all
   // loads in flight together, and stay in registers for the K sweeps.
@@ -220,9 +227,18 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
       g0[k] = -dq[k].x * rc;
       g1[k] = -m0 * rc;
       g3[k] = k0 * rc;
-      if (IO == 1 && lj >= K && lj < H0 - K && lane >= K && lane < W - K) A.bfo[(unsigned)((j0 + lj) * sx + gi)] = rb[k];
+      if (IO == 1 && lj >= HALO && lj < H0 - HALO && own_lane) A.bfo[(unsigned)((j0 + lj) * sx + gi)] = rb[k];
     }
   }
+  // (au, ap) = the two rows of J at image vertex q of row slot k
+#define F_ROWS(src, q, k, au, ap, x0)                                                                                              \
+  const float2 x0 = src[q], x1_ = src[q + 1], x2_ = src[q - 1], x3_ = src[q + W], x4_ = src[q - W], x5_ = src[q + W + 1],          \
+               x6_ = src[q - W - 1];                                                                                               \
+  const float u12_ = x1_.x + x2_.x, u34_ = x3_.x + x4_.x, u56_ = x5_.x + x6_.x;                                                    \
+  const float p12_ = x1_.y + x2_.y, p34_ = x3_.y + x4_.y, p56_ = x5_.y + x6_.y;                                                    \
+  au = (k0 * x0.x + k1 * u12_) + (k3 * u34_ + k5 * u56_) + ((m0 * x0.y + m1 * p12_) + (m3 * p34_ + m5 * p56_));                    \
+  ap = ((m0 * x0.x + m1 * u12_) + (m3 * u34_ + m5 * u56_)) -                                                                       \
+       (((dq[k].x * x0.y + dq[k].y * x1_.y) + (d2[k] * x2_.y + dq[k].z * x3_.y)) + ((d4[k] * x4_.y + dq[k].w * x5_.y) + d6[k] * x6_.y));
 #pragma unroll
   for (int s = 1; s <= K; ++s) {
     const float2* const src = ((s - 1) & 1) ? img1 : img0;
@@ -234,14 +250,7 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
       if (lj < s || lj >= H0 - s) continue;  // wave-uniform
       float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
       if (!FIRST || s > 1) {
-        const int q = lj * W + lane;
-        const float2 x0 = src[q], x1 = src[q + 1], x2 = src[q - 1], x3 = src[q + W], x4 = src[q - W], x5 = src[q + W + 1],
-                     x6 = src[q - W - 1];
-        const float u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
-        const float p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
-        au = (k0 * x0.x + k1 * u12) + (k3 * u34 + k5 * u56) + ((m0 * x0.y + m1 * p12) + (m3 * p34 + m5 * p56));
-        ap = ((m0 * x0.x + m1 * u12) + (m3 * u34 + m5 * u56)) -
-             (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2[k] * x2.y + dq[k].z * x3.y)) + ((d4[k] * x4.y + dq[k].w * x5.y) + d6[k] * x6.y));
+        F_ROWS(src, lj * W + lane, k, au, ap, x0)
         xur = x0.x;
         xpr = x0.y;
       }
@@ -249,7 +258,7 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
       const float ou = xur + fmaf(g0[k], su, g1[k] * sp);
       const float op = xpr + fmaf(g1[k], su, g3[k] * sp);
       if (act) {
-        if (s == K) {
+        if (s == K && lj >= HALO && lj < H0 - HALO && own_lane) {
           const unsigned v = (unsigned)((j0 + lj) * sx + gi);
           if (IO == 2) {
             A.y64u[v] = (double)ou;
@@ -257,13 +266,43 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
           } else {
             A.yf[v] = make_float2(ou, op);
           }
-        } else {
-          dst[lj * W + lane] = make_float2(ou, op);
         }
+        if (s < K || RR) dst[lj * W + lane] = make_float2(ou, op);
       }
     }
-    if (s < K) __syncthreads();
+    if (s < K || RR) __syncthreads();
   }
+  if (RR) {
+    const float2* const xk = (K & 1) ? img1 : img0;  // S^K(x) on rows / lanes [K, . - K)
+    float2* const rim = (K & 1) ? img0 : img1;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < K + 1 || lj >= H0 - K - 1) continue;  // wave-uniform
+      float au, ap;
+      F_ROWS(xk, lj * W + lane, k, au, ap, x0)
+      if (lane >= K + 1 && lane < W - K - 1) rim[lj * W + lane] = make_float2(rb[k].x - au, rb[k].y - ap);
+    }
+    __syncthreads();
+    // coarse vertex (I0 + ci, J0 + cj) = fine vertex at image row HALO + 2 cj, lane HALO + 2 ci
+    const int sxc = A.nxc + 1, I0 = (tx * TX) >> 1, J0 = (ty * TY) >> 1;
+    for (int cj = wave; cj < TY / 2; cj += NW)
+      if (lane < TX / 2) {
+        const int q = (HALO + 2 * cj) * W + HALO + 2 * lane;
+        const float2 r0 = rim[q], r1 = rim[q + 1], r2 = rim[q - 1], r3 = rim[q + W], r4 = rim[q - W], r5 = rim[q + W + 1],
+                     r6 = rim[q - W - 1];
+        const float su = r0.x + 0.5f * (((r1.x + r2.x) + (r3.x + r4.x)) + (r5.x + r6.x));
+        const float sp = r0.y + 0.5f * (((r1.y + r2.y) + (r3.y + r4.y)) + (r5.y + r6.y));
+        const int C = (J0 + cj) * sxc + I0 + lane;
+        if (RR == 2) {
+          A.cb64u[C] = (double)su;
+          A.cb64p[C] = (double)sp;
+        } else {
+          A.cbf[C] = make_float2(su, sp);
+        }
+      }
+  }
+#undef F_ROWS
 }
 
 // Boundary tiles (tile index as in k_st_smoothR: row ty = 0 | rows 1..nfy: columns 0 and nfx+1.. | rows nfy+1..), cut into
@@ -275,10 +314,11 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
 // K sweeps; the mirrored D links come from the neighbours (out-of-grid entries are loaded as 0, and a link that leaves the grid is
 // stored as 0, so no per-link test is left); the 2x2 vertex block is inverted once per launch.  With TB = 2 an image has
 // 2 + 2K <= 8 rows: one row per wave.
-template <int TY, int TB, int K, bool FIRST, int IO, int CADD>
+template <int TY, int TB, int K, bool FIRST, int IO, int CADD, int RR>
 __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2* img0, float2* img1, float2* exch) {
-  constexpr int W = 64, TX = W - 2 * K, H0 = TB + 2 * K, NSUB = TY / TB, NW = F32_BLOCK / 64, R = (H0 + NW - 1) / NW;
-  static_assert(TY % TB == 0, "sub-tiles must cover a tile");
+  constexpr int W = 64, HALO = K + (RR ? 2 : 0), TX = W - 2 * HALO, H0 = TB + 2 * HALO, NSUB = TY / TB, NW = F32_BLOCK / 64,
+                R = (H0 + NW - 1) / NW;
+  static_assert(TY % TB == 0 && TB % 2 == 0, "sub-tiles must cover a tile and start on even rows");
   const int nx = A.nx, ny = A.ny, sx = nx + 1;
   const RowmapGrid& g = A.g;
   int tx, ty;
@@ -297,10 +337,11 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
     ty = g.nfy + 1 + b / g.ntx;
     tx = b % g.ntx;
   }
-  const int i0 = tx * TX - K, j0 = ty * TY + sub * TB - K;
+  const int i0 = tx * TX - HALO, j0 = ty * TY + sub * TB - HALO;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi = i0 + lane;
+  const bool own_lane = lane >= HALO && lane < W - HALO;
   float4 dq[R];
   float2 rb[R], xa[R];
   float kv[R][7], mv[R][7];
@@ -369,6 +410,17 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
       }
     }
   }
+  // (au, ap) = the two rows of J at image vertex q of row slot k, per-lane K / M coefficients
+#define F_ROWS_G(src, q, k, au, ap, x0)                                                                                            \
+  const float2 x0 = src[q], x1_ = src[q + 1], x2_ = src[q - 1], x3_ = src[q + W], x4_ = src[q - W], x5_ = src[q + W + 1],          \
+               x6_ = src[q - W - 1];                                                                                               \
+  au = ((kv[k][0] * x0.x + kv[k][1] * x1_.x) + (kv[k][2] * x2_.x + kv[k][3] * x3_.x)) +                                            \
+       ((kv[k][4] * x4_.x + kv[k][5] * x5_.x) + kv[k][6] * x6_.x) +                                                                \
+       (((mv[k][0] * x0.y + mv[k][1] * x1_.y) + (mv[k][2] * x2_.y + mv[k][3] * x3_.y)) +                                           \
+        ((mv[k][4] * x4_.y + mv[k][5] * x5_.y) + mv[k][6] * x6_.y));                                                               \
+  ap = (((mv[k][0] * x0.x + mv[k][1] * x1_.x) + (mv[k][2] * x2_.x + mv[k][3] * x3_.x)) +                                           \
+        ((mv[k][4] * x4_.x + mv[k][5] * x5_.x) + mv[k][6] * x6_.x)) -                                                              \
+       (((dq[k].x * x0.y + dq[k].y * x1_.y) + (d2[k] * x2_.y + dq[k].z * x3_.y)) + ((d4[k] * x4_.y + dq[k].w * x5_.y) + d6[k] * x6_.y));
 #pragma unroll
   for (int s = 1; s <= K; ++s) {
     const float2* const src = ((s - 1) & 1) ? img1 : img0;
@@ -380,16 +432,7 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
       if (lj < s || lj >= H0 - s) continue;  // wave-uniform
       float au = 0.f, ap = 0.f, xur = 0.f, xpr = 0.f;
       if (!FIRST || s > 1) {
-        const int q = lj * W + lane;
-        const float2 x0 = src[q], x1 = src[q + 1], x2 = src[q - 1], x3 = src[q + W], x4 = src[q - W], x5 = src[q + W + 1],
-                     x6 = src[q - W - 1];
-        au = ((kv[k][0] * x0.x + kv[k][1] * x1.x) + (kv[k][2] * x2.x + kv[k][3] * x3.x)) +
-             ((kv[k][4] * x4.x + kv[k][5] * x5.x) + kv[k][6] * x6.x) +
-             (((mv[k][0] * x0.y + mv[k][1] * x1.y) + (mv[k][2] * x2.y + mv[k][3] * x3.y)) +
-              ((mv[k][4] * x4.y + mv[k][5] * x5.y) + mv[k][6] * x6.y));
-        ap = (((mv[k][0] * x0.x + mv[k][1] * x1.x) + (mv[k][2] * x2.x + mv[k][3] * x3.x)) +
-              ((mv[k][4] * x4.x + mv[k][5] * x5.x) + mv[k][6] * x6.x)) -
-             (((dq[k].x * x0.y + dq[k].y * x1.y) + (d2[k] * x2.y + dq[k].z * x3.y)) + ((d4[k] * x4.y + dq[k].w * x5.y) + d6[k] * x6.y));
+        F_ROWS_G(src, lj * W + lane, k, au, ap, x0)
         xur = x0.x;
         xpr = x0.y;
       }
@@ -398,38 +441,97 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
       const float ou = xur + fmaf(g0[k], su, g1[k] * sp);
       const float op = xpr + fmaf(g2[k], su, g3[k] * sp);
       if (act) {
-        if (s == K) {
-          if (in[k]) {
-            const int v = (j0 + lj) * sx + gi;
-            if (IO == 1) A.bfo[v] = rb[k];
-            if (IO == 2) {
-              A.y64u[v] = (double)ou;
-              A.y64p[v] = (double)op;
-            } else {
-              A.yf[v] = make_float2(ou, op);
-            }
+        if (s == K && in[k] && lj >= HALO && lj < H0 - HALO && own_lane) {
+          const int v = (j0 + lj) * sx + gi;
+          if (IO == 1) A.bfo[v] = rb[k];
+          if (IO == 2) {
+            A.y64u[v] = (double)ou;
+            A.y64p[v] = (double)op;
+          } else {
+            A.yf[v] = make_float2(ou, op);
           }
-        } else {
-          dst[lj * W + lane] = in[k] ? make_float2(bc[k] ? 0.f : ou, op) : make_float2(0.f, 0.f);
         }
+        if (s < K || RR) dst[lj * W + lane] = in[k] ? make_float2(bc[k] ? 0.f : ou, op) : make_float2(0.f, 0.f);
       }
     }
-    if (s < K) __syncthreads();
+    if (s < K || RR) __syncthreads();
   }
+  if (RR) {
+    const float2* const xk = (K & 1) ? img1 : img0;
+    float2* const rim = (K & 1) ? img0 : img1;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int lj = wave + NW * k;
+      if (lj < K + 1 || lj >= H0 - K - 1) continue;  // wave-uniform
+      float au, ap;
+      F_ROWS_G(xk, lj * W + lane, k, au, ap, x0)
+      // a Dirichlet row of u holds u = b_u after any sweep: its residual is 0 (the image keeps 0 there for the neighbours)
+      if (lane >= K + 1 && lane < W - K - 1)
+        rim[lj * W + lane] = in[k] ? make_float2(bc[k] ? 0.f : rb[k].x - au, rb[k].y - ap) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const int sxc = A.nxc + 1, I0 = (tx * TX) >> 1, J0 = (ty * TY + sub * TB) >> 1;
+    for (int cj = wave; cj < TB / 2; cj += NW)
+      if (lane < TX / 2 && I0 + lane <= A.nxc && J0 + cj <= A.nyc) {
+        const int q = (HALO + 2 * cj) * W + HALO + 2 * lane;
+        const float2 r0 = rim[q], r1 = rim[q + 1], r2 = rim[q - 1], r3 = rim[q + W], r4 = rim[q - W], r5 = rim[q + W + 1],
+                     r6 = rim[q - W - 1];
+        float su = r0.x + 0.5f * (((r1.x + r2.x) + (r3.x + r4.x)) + (r5.x + r6.x));
+        const float sp = r0.y + 0.5f * (((r1.y + r2.y) + (r3.y + r4.y)) + (r5.y + r6.y));
+        const int C = (J0 + cj) * sxc + I0 + lane;
+        if (A.mask_c[C]) su = 0.f;
+        if (RR == 2) {
+          A.cb64u[C] = (double)su;
+          A.cb64p[C] = (double)sp;
+        } else {
+          A.cbf[C] = make_float2(su, sp);
+        }
+      }
+  }
+#undef F_ROWS_G
 }
 
 // ONE launch per smoother call: blocks [0, nbnd) are the boundary sub-tiles - they start first, so their long dependent-load
 // chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
-template <int TY, int K, bool FIRST, int IO, int CADD>
+template <int TY, int K, bool FIRST, int IO, int CADD, int RR>
 __global__ void __launch_bounds__(F32_BLOCK) k_f_smooth(const FSmoothArgs A) {
-  constexpr int W = 64, H0 = TY + 2 * K, PAD = W + 1;
+  constexpr int W = 64, H0 = TY + 2 * (K + (RR ? 2 : 0)), PAD = W + 1;
   __shared__ float2 img_[3][H0 * W + 2 * PAD];  // guard bands: inactive edge lanes read (and discard) one entry outside a row;
                                                  // [2]: the (D(0,+1), D(+1,+1)) links every image row hands to the row above it
   const int blk = blockIdx.x;
   if (blk < A.nbnd)
-    f_smooth_bnd<TY, F32_TB, K, FIRST, IO, CADD>(blk, A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+    f_smooth_bnd<TY, F32_TB, K, FIRST, IO, CADD, RR>(blk, A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
   else
-    f_smooth_fast<TY, K, FIRST, IO, CADD>(xcd_block(blk - A.nbnd, gridDim.x - A.nbnd, A.remap), A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+    f_smooth_fast<TY, K, FIRST, IO, CADD, RR>(xcd_block(blk - A.nbnd, gridDim.x - A.nbnd, A.remap), A, img_[0] + PAD, img_[1] + PAD, img_[2] + PAD);
+}
+
+// last pre-smoothing launch + residual + restriction (no coarse correction, float2 result); TY >= 8: the first interior tile's
+// image (K + 2 halo rows) must start inside the grid
+template <int TY, int K>
+static void launch_f_smooth_rr(hipStream_t st, int first, FSmoothArgs& A, int fast_ok) {
+  const int rr = A.cbf ? 1 : 2;
+  A.g = rowmap_grid<TY, K + 2>(A.nx, A.ny, fast_ok);
+  const int nfast = A.g.nfx * A.g.nfy;
+  A.nbnd = (A.g.ntx * A.g.nty - nfast) * (TY / F32_TB);
+  const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
+  if (first) {
+    if (A.b64u) {
+      if (rr == 1)
+        hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1, 0, 1>), grid, block, 0, st, A);
+      else
+        hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1, 0, 2>), grid, block, 0, st, A);
+    } else {
+      if (rr == 1)
+        hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0, 0, 1>), grid, block, 0, st, A);
+      else
+        hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0, 0, 2>), grid, block, 0, st, A);
+    }
+  } else {
+    if (rr == 1)
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 0, 1>), grid, block, 0, st, A);
+    else
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 0, 2>), grid, block, 0, st, A);
+  }
 }
 
 template <int TY, int K>
@@ -440,26 +542,26 @@ static void launch_f_smooth(hipStream_t st, int first, FSmoothArgs& A, int fast_
   const dim3 grid(A.nbnd + nfast), block(F32_BLOCK);
   if (first) {
     if (A.b64u)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 1, 0, 0>), grid, block, 0, st, A);
     else
-      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, true, 0, 0, 0>), grid, block, 0, st, A);
     return;
   }
   const int cadd = A.cf ? 1 : (A.cdu ? 2 : 0);
   if (A.y64u) {
     if (cadd == 0)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 0, 0>), grid, block, 0, st, A);
     else if (cadd == 1)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 1>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 1, 0>), grid, block, 0, st, A);
     else
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 2>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 2, 2, 0>), grid, block, 0, st, A);
   } else {
     if (cadd == 0)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 0>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 0, 0>), grid, block, 0, st, A);
     else if (cadd == 1)
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 1>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 1, 0>), grid, block, 0, st, A);
     else
-      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 2>), grid, block, 0, st, A);
+      hipLaunchKernelGGL((k_f_smooth<TY, K, false, 0, 2, 0>), grid, block, 0, st, A);
   }
 }
 
@@ -472,8 +574,13 @@ static int f32_tile_rows(const GridLevel& L) {
 
 void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
                    const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
-                   int remap, float2* yf, double* y64u, double* y64p) {
+                   int remap, float2* yf, double* y64u, double* y64p, float2* cbf, double* cb64u, double* cb64p) {
   FSmoothArgs A;
+  A.nyc = C ? C->ny : 0;
+  A.mask_c = C ? C->mask : nullptr;
+  A.cbf = cbf;
+  A.cb64u = cb64u;
+  A.cb64p = cb64p;
   A.nx = L.nx;
   A.ny = L.ny;
   A.n = L.n;
@@ -498,6 +605,20 @@ void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double 
   A.omega = (float)omega;
   A.sc = make_fconst(L, alpha);
   const int ty = f32_tile_rows(L);
+  if (cbf || cb64u) {
+    if (K == 3) {
+      if (ty <= 8)
+        launch_f_smooth_rr<8, 3>(st, first, A, L.interior_free && (!C || C->interior_free));
+      else
+        launch_f_smooth_rr<16, 3>(st, first, A, L.interior_free && (!C || C->interior_free));
+    } else {
+      if (ty <= 8)
+        launch_f_smooth_rr<8, 2>(st, first, A, L.interior_free && (!C || C->interior_free));
+      else
+        launch_f_smooth_rr<16, 2>(st, first, A, L.interior_free && (!C || C->interior_free));
+    }
+    return;
+  }
   if (K == 3) {
     if (ty == 4)
       launch_f_smooth<4, 3>(st, first, A, L.interior_free);
