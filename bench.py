@@ -63,13 +63,14 @@ def extrapolate(v_measured, n_measured, n_workload, ladder, size_key="N"):
                       f"measurement at {size_key} = {n_measured}"}
 
 
-def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads: int = 1):
+def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads=(1,), degree: int = 1, min_steps: int = 4):
     """Oracle (numpy assembly + exact Newton with the nested-dissection multifrontal LU of oracle/nd_lu.py - the ordering class and
-    the BLAS-3 structure a CPU user gets from `pc_type lu` / MUMPS, obstacle_pg.py:129-131) timed on this host with `threads` BLAS
-    threads (1 = the reference's OMP_NUM_THREADS=1): the SAME LVPP run on an n_sample^2 mesh, stopped after the first Newton step that
-    ends beyond budget_s.  Timed region = the loop of obstacle_pg.py:173-227 (residual + Jacobian assembly, numeric factorisation,
+    the BLAS-3 structure a CPU user gets from `pc_type lu` / MUMPS, obstacle_pg.py:129-131) timed on this host: the SAME LVPP run on
+    an n_sample^2 mesh of Lagrange degree `degree`, stopped after the first Newton step that ends beyond budget_s AND after at
+    least `min_steps` Newton steps.  One timed run per entry of `threads` (BLAS threads; 1 = the reference's OMP_NUM_THREADS=1) on
+    the same setup.  Timed region = the loop of obstacle_pg.py:173-227 (residual + Jacobian assembly, numeric factorisation,
     solves with iterative refinement, observables); untimed, like the GPU side's setup: mesh / pattern construction and the
-    symbolic analysis of the pattern (done once per mesh by any direct solver)."""
+    symbolic analysis of the pattern (done once per mesh by any direct solver).  Returns [(value, steps, seconds, detail), ...]."""
     from threadpoolctl import threadpool_limits
 
     from oracle import nd_lu as ND  # CPU baseline leg only
@@ -77,39 +78,50 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads:
 
     t_setup = time.perf_counter()
     coords, cells = O.create_rectangle(n_sample, n_sample)
-    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(n_sample, n_sample))
-    x = np.zeros(2 * prob.n)
-    xk = x.copy()
+    if degree == 1:
+        prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(n_sample, n_sample))
+    else:
+        prob = O.ObstacleLagrange(coords, cells, degree)
     ls = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
-    ls.nd = ND.NDLU(prob.jacobian(x, 1.0), ls.node_of_dof, ls.node_coords, ls.leaf_nodes)
+    ls.nd = ND.NDLU(prob.jacobian(np.zeros(2 * prob.n), 1.0), ls.node_of_dof, ls.node_coords, ls.leaf_nodes)
     ls.nd.aoff = np.concatenate(([0], np.cumsum(ls.nd.p * ls.nd.p + 2 * ls.nd.p * ls.nd.b)))
     ls.nd.arena = np.ones(int(ls.nd.aoff[-1]))  # factor storage allocated and touched before the clock starts
     t_setup = time.perf_counter() - t_setup
-    sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
-    ND.MAX_THREADS = threads
-    steps, t0 = 0, time.perf_counter()
-    over = lambda: time.perf_counter() - t0 > budget_s  # noqa: E731
-    with threadpool_limits(threads):
-        for k in range(settings["max_outer"]):
-            alpha = sched.update(k)
-            F = prob.residual(x, xk, alpha)
-            f0 = np.linalg.norm(F)
-            for _ in range(100):
-                x = x + ls(prob.jacobian(x, alpha), -F)
-                steps += 1
+    runs = []
+    for nthreads in threads:
+        x = np.zeros(2 * prob.n)
+        xk = x.copy()
+        sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
+        ND.MAX_THREADS = nthreads
+        ls.t_factor = ls.t_solve = 0.0
+        ls.n_factor = 0
+        steps, t0 = 0, time.perf_counter()
+
+        def over():
+            return time.perf_counter() - t0 > budget_s and steps >= min_steps
+
+        with threadpool_limits(nthreads):
+            for k in range(settings["max_outer"]):
+                alpha = sched.update(k)
                 F = prob.residual(x, xk, alpha)
-                if np.linalg.norm(F) <= 1e-6 * f0 or over():
+                f0 = np.linalg.norm(F)
+                for _ in range(100):
+                    x = x + ls(prob.jacobian(x, alpha), -F)
+                    steps += 1
+                    F = prob.residual(x, xk, alpha)
+                    if np.linalg.norm(F) <= 1e-6 * f0 or over():
+                        break
+                if over() or prob.observables(x, xk, alpha)[4] < settings["tol_exit"]:
                     break
-            if over() or prob.observables(x, xk, alpha)[4] < settings["tol_exit"]:
-                break
-            xk = x.copy()
-    dt = time.perf_counter() - t0
-    ND.MAX_THREADS = 0
-    detail = {"setup_s_untimed": t_setup, "symbolic_s": ls.nd.symbolic_s, "factor_s": ls.t_factor, "solve_refine_s": ls.t_solve,
-              "assembly_and_rest_s": dt - ls.t_factor - ls.t_solve, "factor_gflops": ls.nd.flops / 1e9,
-              "factor_gflops_per_s": ls.nd.flops * ls.n_factor / max(ls.t_factor, 1e-9) / 1e9,
-              "factor_storage_GB": 8e-9 * ls.nd.factor_entries}
-    return steps / dt, steps, dt, detail
+                xk = x.copy()
+        dt = time.perf_counter() - t0
+        ND.MAX_THREADS = 0
+        detail = {"setup_s_untimed": t_setup, "symbolic_s": ls.nd.symbolic_s, "factor_s": ls.t_factor, "solve_refine_s": ls.t_solve,
+                  "assembly_and_rest_s": dt - ls.t_factor - ls.t_solve, "factor_gflops": ls.nd.flops / 1e9,
+                  "factor_gflops_per_s": ls.nd.flops * ls.n_factor / max(ls.t_factor, 1e-9) / 1e9,
+                  "factor_storage_GB": 8e-9 * ls.nd.factor_entries}
+        runs.append((steps / dt, steps, dt, detail))
+    return runs
 
 
 def host_info():
@@ -284,7 +296,7 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
             "metric": f"proximal-Newton iterations/sec, {args.workload} (LVPP Newton inner loop, sparse-LU linear solves)",
             "value": newton_total / dt, "unit": "Newton iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if world > 1 else "none", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "step": "one full LVPP solve from the zero state",
                        "newton_iterations_per_step": newton_total / args.steps, "newton_per_lvpp_step": [int(i) for i in its],
                        "parallelism": "single" if world == 1 else f"replicated iterate, sparse LU distributed over {world} ranks "
@@ -377,6 +389,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=1024, help="mesh size of the bounded CPU-baseline sample (cells per side)")
     ap.add_argument("--cpu-threads", type=int, default=1, help="BLAS threads of the CPU baseline (1 = the reference's OMP_NUM_THREADS=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the threaded-BLAS repeat of the CPU baseline sample")
     ap.add_argument("--solves-only", action="store_true",
                     help="profiling aid: skip the roofline microbenchmarks after the timed solves (their V-cycle replays would "
                          "distort a per-kernel time breakdown); `roofline` is then null")
@@ -609,7 +622,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
+            # one GPU: neither weak nor strong; N > 1: the SAME problem on N strips, or N independent replicas
+            "scaling": "strong" if sharded else ("weak" if world > 1 else "none"),
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -634,7 +648,9 @@ def main():
             kit = max(comm_counts["krylov_iterations"], 1)
             out["config"]["collectives_per_krylov_iteration"] = {
                 "halo_exchanges": comm_counts["halo_exchanges"] / kit, "allreduces": comm_counts["allreduces"] / kit,
-                "ghost_depth_multiplier": int(os.environ.get("PGX_GHOST_MUL", "3")), "counted": comm_counts}
+                # what the LIBRARY used: it never reads the environment; the loader forwards PGX_* keys only under PGX_TUNING_FROM_ENV=1
+                "ghost_depth_multiplier": (int(os.environ.get("PGX_GHOST_MUL", "3"))
+                                           if os.environ.get("PGX_TUNING_FROM_ENV") == "1" else 3), "counted": comm_counts}
         if smoother:
             out["roofline_dominant"] = smoother
         if coarse:
@@ -642,8 +658,14 @@ def main():
         if prof:
             out["phase_ms"] = prof
         if not args.no_cpu_baseline and world == 1:
-            cpu_n = min(args.cpu_n, N)
-            v, steps, secs, detail = cpu_baseline(cpu_n, S, threads=args.cpu_threads)
+            # degree 2: the P2 problem on half the cells per side has the node count of the P1 sample (a `--degree 2`
+            # line must not carry a P1 baseline)
+            cpu_n = min(args.cpu_n, N) if args.degree == 1 else min(args.cpu_n // 2, N)
+            hi = host_info()
+            all_cores = min(hi["host_cores_usable"] or 1, 64)  # one socket's worth: beyond it the fronts of a 2-D dissection starve
+            threads = [args.cpu_threads] + ([all_cores] if all_cores > args.cpu_threads and not args.no_cpu_all_cores else [])
+            runs = cpu_baseline(cpu_n, S, threads=threads, degree=args.degree)
+            v, steps, secs, detail = runs[0]
             ladder = _ladder("r03_cpu_ladder_nd.json") if args.degree == 1 else None
             out["cpu_baseline"] = {
                 "value": v,
@@ -653,20 +675,34 @@ def main():
                 # `value` is MEASURED, here, now, on the mesh named in `mesh`.  When that is smaller than the benchmarked mesh,
                 # `at_workload` carries it there with the exponent of the committed ladder (2-D nested dissection: flops ~ N^3)
                 # and says so; `--cpu-n 2048` measures on the workload itself (about 25 GB of factors, minutes per Newton step).
-                "mesh": f"{cpu_n}x{cpu_n}",
-                "workload_mesh": f"{N}x{N}",
+                "mesh": f"{cpu_n}x{cpu_n} P{args.degree}",
+                "workload_mesh": f"{N}x{N} P{args.degree}",
                 "sample": f"{steps} Newton step(s) ({secs:.1f} s) of the same LVPP run (settings {args.settings}) on a "
-                          f"{cpu_n}x{cpu_n} mesh: numpy assembly + exact Newton with a nested-dissection multifrontal LU on "
-                          f"LAPACK/BLAS (oracle/nd_lu.py), {args.cpu_threads} thread(s); symbolic analysis and mesh setup untimed "
+                          f"{cpu_n}x{cpu_n} P{args.degree} mesh: numpy assembly + exact Newton with a nested-dissection multifrontal LU "
+                          f"on LAPACK/BLAS (oracle/nd_lu.py), {args.cpu_threads} thread(s); symbolic analysis and mesh setup untimed "
                           f"(as on the GPU side).  The oracle - a stand-in for, not a measurement of, FEniCSx+MUMPS",
                 "detail": detail,
-                **host_info(),
+                **hi,
             }
-            if cpu_n != N:
-                ex = extrapolate(v, cpu_n, N, ladder)
+            if len(runs) > 1:  # BASELINE.md section 3's secondary figure: the same sample with threaded BLAS
+                v2, steps2, secs2, detail2 = runs[1]
+                out["cpu_baseline"]["all_cores"] = {"value": v2, "unit": "Newton iterations/s", "cores": threads[1],
+                                                    "sample": f"{steps2} Newton step(s) ({secs2:.1f} s), same mesh and code, "
+                                                              f"{threads[1]} BLAS threads", "detail": detail2}
+            if cpu_n != N or args.degree != 1:
+                ex = extrapolate(v, cpu_n, N, ladder) if ladder else None
                 if ex:
                     ex["gpu_over_cpu"] = out["value"] / ex["value"]
                     out["cpu_baseline"]["at_workload"] = ex
+                    if len(runs) > 1:
+                        ex2 = extrapolate(runs[1][0], cpu_n, N, ladder)
+                        ex2["gpu_over_cpu"] = out["value"] / ex2["value"]
+                        ex2["method"] += f" ({threads[1]} threads; the ladder's exponent was measured with one thread)"
+                        out["cpu_baseline"]["all_cores"]["at_workload"] = ex2
+                else:
+                    out["cpu_baseline"]["at_workload"] = None
+                    out["cpu_baseline"]["at_workload_note"] = ("no committed CPU ladder for this degree: the sample is reported "
+                                                               "on its own mesh and not carried to the workload")
             else:
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / v
     problem.close()

@@ -19,6 +19,14 @@
 #include "pgx_stencil.h"
 
 #define F32_BLOCK 512
+// A/B switches of the interior tiles, both measured slower at 2049^2 and off: F32_WAVES_EU = 8 (a fourth workgroup per CU by a 64-VGPR
+// cap: 12-28 B of scratch per lane, level-0 launches +20 %) and F32_LEAN (the 2x2 block inverse recomputed per sweep: +1 %)
+#ifndef F32_LEAN
+#define F32_LEAN 0
+#endif
+#ifndef F32_WAVES_EU
+#define F32_WAVES_EU 2
+#endif
 #define F32_RR_CYB 2  // coarse rows of a boundary sub-tile of the residual + restriction
 #define F32_TB 2  // rows of a boundary sub-tile of the smoother: image of 2 + 2K <= 8 rows, one per wave
 
@@ -213,7 +221,12 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
     if (lj < H0 - 1) exch[lj * W + lane] = make_float2(dq[k].z, dq[k].w);
   }
   __syncthreads();
-  float d2[R], d4[R], d6[R], g0[R], g1[R], g3[R];
+  // omega * inverse of the vertex block [[aK0, M0], [M0, -D0]] (det < 0: k0 > 0, d0 >= 0, m0 > 0): kept per row for the K sweeps,
+  // or (LEAN: images of three rows per wave) recomputed in every sweep - nine registers less, which is what lets a fourth
+  // workgroup live on the CU (64 VGPRs)
+  constexpr bool LEAN = F32_LEAN && R >= 3 && !RR;
+  const float nm2 = -m0 * m0, mo = -m0 * A.omega, ko = k0 * A.omega;
+  float d2[R], d4[R], d6[R], g0[LEAN ? 1 : R], g1[LEAN ? 1 : R], g3[LEAN ? 1 : R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int lj = wave + NW * k;
@@ -221,12 +234,12 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
       d2[k] = lane_shr1f(dq[k].y);                   // D(+1,0) of the left neighbour
       d4[k] = exch[(lj - 1) * W + lane].x;           // D(0,+1) of the vertex below
       d6[k] = exch[(lj - 1) * W + lane - 1].y;       // D(+1,+1) of the vertex below left; lane 0 (halo, never updated) reads the guard band
-      // omega * inverse of the vertex block [[aK0, M0], [M0, -D0]] (det < 0: k0 > 0, d0 >= 0, m0 > 0), once per launch
-      const float det = fmaf(-k0, dq[k].x, -m0 * m0);
-      const float rc = A.omega * __builtin_amdgcn_rcpf(det);
-      g0[k] = -dq[k].x * rc;
-      g1[k] = -m0 * rc;
-      g3[k] = k0 * rc;
+      if (!LEAN) {
+        const float rc = __builtin_amdgcn_rcpf(fmaf(-k0, dq[k].x, nm2));
+        g0[k] = -dq[k].x * A.omega * rc;
+        g1[k] = mo * rc;
+        g3[k] = ko * rc;
+      }
       if (IO == 1 && lj >= HALO && lj < H0 - HALO && own_lane) A.bfo[(unsigned)((j0 + lj) * sx + gi)] = rb[k];
     }
   }
@@ -255,8 +268,15 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
         xpr = x0.y;
       }
       const float su = rb[k].x - au, sp = rb[k].y - ap;
-      const float ou = xur + fmaf(g0[k], su, g1[k] * sp);
-      const float op = xpr + fmaf(g1[k], su, g3[k] * sp);
+      float ou, op;
+      if (LEAN) {
+        const float rc = __builtin_amdgcn_rcpf(fmaf(-k0, dq[k].x, nm2));
+        ou = xur + fmaf(-dq[k].x * A.omega, su, mo * sp) * rc;
+        op = xpr + fmaf(mo, su, ko * sp) * rc;
+      } else {
+        ou = xur + fmaf(g0[k], su, g1[k] * sp);
+        op = xpr + fmaf(g1[k], su, g3[k] * sp);
+      }
       if (act) {
         if (s == K && lj >= HALO && lj < H0 - HALO && own_lane) {
           const unsigned v = (unsigned)((j0 + lj) * sx + gi);
@@ -494,7 +514,7 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
 // ONE launch per smoother call: blocks [0, nbnd) are the boundary sub-tiles - they start first, so their long dependent-load
 // chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
 template <int TY, int K, bool FIRST, int IO, int CADD, int RR>
-__global__ void __launch_bounds__(F32_BLOCK) k_f_smooth(const FSmoothArgs A) {
+__global__ void __launch_bounds__(F32_BLOCK, (RR || TY > 16) ? 2 : F32_WAVES_EU) k_f_smooth(const FSmoothArgs A) {
   constexpr int W = 64, H0 = TY + 2 * (K + (RR ? 2 : 0)), PAD = W + 1;
   __shared__ float2 img_[3][H0 * W + 2 * PAD];  // guard bands: inactive edge lanes read (and discard) one entry outside a row;
                                                  // [2]: the (D(0,+1), D(+1,+1)) links every image row hands to the row above it
@@ -568,7 +588,7 @@ static void launch_f_smooth(hipStream_t st, int first, FSmoothArgs& A, int fast_
 static int f32_tile_rows(const GridLevel& L) {
   static PgxTuneInt t_ty("PGX_F32_TY", 0);
   const int ty = t_ty.get();
-  if (ty == 4 || ty == 8 || ty == 16) return ty;
+  if (ty == 4 || ty == 8 || ty == 16 || ty == 32) return ty;
   return L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4;  // as k_st_smoothR (measured there per level size)
 }
 
@@ -624,6 +644,8 @@ void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double 
       launch_f_smooth<4, 3>(st, first, A, L.interior_free);
     else if (ty == 8)
       launch_f_smooth<8, 3>(st, first, A, L.interior_free);
+    else if (ty == 32)
+      launch_f_smooth<32, 3>(st, first, A, L.interior_free);
     else
       launch_f_smooth<16, 3>(st, first, A, L.interior_free);
   } else {
