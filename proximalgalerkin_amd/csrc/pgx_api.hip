@@ -723,6 +723,17 @@ static int halo_level(pgx_handle* h, int l, double* fu, double* fp) {
   if (rc) h->err = h->dist.comm->err;
   return rc;
 }
+// the same for ONE interleaved (u, psi) float2 field of the single-precision cycle (8 bytes per vertex: one "double" field)
+static int halo_level_f(pgx_handle* h, int l, float2* f2) {
+  const DistLevel& d = h->dist.L[l];
+  const size_t sx = (size_t)h->lev[l].nx + 1;
+  double* f[1] = {reinterpret_cast<double*>(f2)};
+  const int rc = h->dist.comm->halo(h->st, f, 1, d.glo * sx, (d.g + 1) * sx, 0, d.g * sx, (d.glo + d.H - d.g) * sx, d.g * sx,
+                                    (d.glo + d.H) * sx, (d.g + 1) * sx);
+  ++h->dist.n_halo;
+  if (rc) h->err = h->dist.comm->err;
+  return rc;
+}
 // ghost entries of a SOLUTION-SPACE pair (fu, fp) - each [vertex dofs | edge dofs] for P2 - from their owners
 static int halo_solution(pgx_handle* h, double* fu, double* fp) {
   int rc = halo_level(h, 0, fu, fp);
@@ -788,16 +799,15 @@ static void setup_tail(pgx_handle* h, int first) {
   }
 }
 
-// Which levels run the single-precision legs (pgx_mg32.hip): a contiguous range from the finest level down, uniform stencils
-// (the row-mapped kernels), above the fused tail, never the coarsest level; `last_dist` >= 0: strip levels of a sharded handle only.
-static int setup_f32(pgx_handle* h, int last_dist) {
+// Which levels run the single-precision legs (pgx_mg32.hip): every level with uniform stencils (the row-mapped kernels) and at
+// least f32_min vertices above the fused tail, never the coarsest.  fp64 and single-precision levels may alternate: each hands its
+// right-hand side down and its correction up in the format of the level that receives it (vcycle / vcycle_f / vcycle_dist_f).
+static int setup_f32(pgx_handle* h) {
   if (!h->mg_f32 || !h->structured || sizeof(dsten_t) != 8) return PGX_OK;
   const int nl = (int)h->lev.size();
   for (int l = 0; l + 1 < nl; ++l) {
     GridLevel& L = h->lev[l];
-    if (!L.uniform || L.n < std::max(h->f32_min, h->fused_min) || (h->tail_start > 0 && l >= h->tail_start) ||
-        (last_dist >= 0 && l > last_dist))
-      break;
+    if (!L.uniform || L.n < std::max(h->f32_min, h->fused_min) || (h->tail_start > 0 && l >= h->tail_start)) continue;
     DALLOC(L.Dq, L.n);
     DALLOC(L.xf, L.n);
     DALLOC(L.xf2, L.n);
@@ -858,7 +868,7 @@ static int build_multigrid(pgx_handle* h) {
     h->lev.push_back(L);
   }
   setup_tail(h, 1);
-  rc = setup_f32(h, -1);
+  rc = setup_f32(h);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
@@ -1003,6 +1013,8 @@ static int build_multigrid_dist(pgx_handle* h) {
     h->lev.push_back(L);
   }
   setup_tail(h, ld);
+  rc = setup_f32(h);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->st));
   return PGX_OK;
 }
@@ -1587,10 +1599,11 @@ static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const 
 
 static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu, double omega);
 
-// Single-precision legs of the V-cycle on level l (GridLevel::f32; kernels: pgx_mg32.hip).  Level 0 reads the right-hand side from
-// the fp64 pair (bu, bp) - its first launch leaves the float2 copy in L.bf - and writes the result to the fp64 pair (outu, outp);
-// a lower level finds its right-hand side in L.bf (written by the level above) and returns the buffer that holds its correction.
-// The first level without f32 gets its right-hand side, and hands back its correction, in fp64 (vcycle()).
+// Single-precision legs of the V-cycle on level l (GridLevel::f32; kernels: pgx_mg32.hip).  With (bu, bp) != nullptr the level
+// reads its right-hand side from that fp64 pair (its first launch leaves the float2 copy in L.bf) and writes the result to the
+// fp64 pair (outu, outp): the finest level, or a level entered from an fp64 one.  Otherwise it finds its right-hand side in L.bf
+// (written by the single-precision level above) and returns the buffer that holds its correction.  A level without f32 below gets
+// its right-hand side, and hands back its correction, in fp64 (vcycle()).
 static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu,
                               double omega) {
   GridLevel& L = h->lev[l];
@@ -1607,8 +1620,8 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
   double* const cb64p = C.f32 ? nullptr : C.bp;
   {
     const bool rr = fuse && nl == 1;
-    pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, l == 0 ? bu : nullptr, l == 0 ? bp : nullptr, rr ? &C : nullptr, nullptr, nullptr,
-                  nullptr, omega, remap, cu, nullptr, nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr);
+    pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, bu, bp, rr ? &C : nullptr, nullptr, nullptr, nullptr, omega, remap, cu, nullptr,
+                  nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr);
   }
   for (int s = 1; s < nl; ++s) {
     const bool rr = fuse && s + 1 == nl;
@@ -1627,7 +1640,7 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
     cdp = C.xp;
   }
   for (int s = 0; s < nl; ++s) {
-    const bool out64 = (s + 1 == nl) && l == 0;
+    const bool out64 = (s + 1 == nl) && outu;
     pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, s == 0 ? &C : nullptr, s == 0 ? cf : nullptr, s == 0 ? cdu : nullptr,
                   s == 0 ? cdp : nullptr, omega, remap, ou, out64 ? outu : nullptr, out64 ? outp : nullptr);
     std::swap(cu, ou);
@@ -1642,8 +1655,8 @@ static inline bool f32_cycle_ok(const pgx_handle* h, int l, int nu) {
 static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, double* outu, double* outp, int nu,
                    double omega) {
   GridLevel& L = h->lev[l];
-  if (l == 0 && f32_cycle_ok(h, 0, nu)) {
-    vcycle_f(h, 0, bu, bp, outu, outp, nu, omega);
+  if (f32_cycle_ok(h, l, nu)) {
+    vcycle_f(h, l, bu, bp, outu, outp, nu, omega);
     return;
   }
   if (l > 0 && l == h->tail_start) {  // all remaining levels in ONE launch (k_mg_tail); result in L.xu/L.xp
@@ -1727,10 +1740,13 @@ static void vcycle(pgx_handle* h, int l, const double* bu, const double* bp, dou
 // when the depth runs out: with ghost depth 8/4/2 on the three distributed levels and nu = 6 that is 2 + 5 + 7
 // exchanges and one all-reduce (coarse right-hand side) per cycle.
 // ------------------------------------------------------------------------------------------------
+static int vcycle_dist_f(pgx_handle* h, int l, double* bu, double* bp, double* outu, double* outp, int need_out, int nu, double omega,
+                         const float2** res);
 static int vcycle_dist(pgx_handle* h, int l, double* bu, double* bp, double* outu, double* outp, int need_out, int nu,
                        double omega) {
   Dist& D = h->dist;
   GridLevel& L = h->lev[l];
+  if (L.f32 && h->fused_legs) return vcycle_dist_f(h, l, bu, bp, outu, outp, need_out, nu, omega, nullptr);
   const int g = D.L[l].g;
   const int K = (nu % 3 == 0 && g >= 3 && h->fused_k3) ? 3 : 2;
   if (nu % K) {
@@ -1800,6 +1816,94 @@ static int vcycle_dist(pgx_handle* h, int l, double* bu, double* bp, double* out
     hipMemcpyAsync(outu, cu, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
     hipMemcpyAsync(outp, cp, sizeof(double) * L.n, hipMemcpyDeviceToDevice, h->st);
   }
+  return PGX_OK;
+}
+
+// The sharded cycle on a single-precision strip level (GridLevel::f32): vcycle_dist with the kernels of pgx_mg32.hip.  Same depth
+// bookkeeping; a halo exchange moves ONE float2 field (8 bytes per vertex) instead of two fp64 ones.  (bu, bp) != nullptr: fp64
+// right-hand side in (the Krylov vector), fp64 result out; else L.bf in, *res = the buffer that holds the correction.
+static int vcycle_dist_f(pgx_handle* h, int l, double* bu, double* bp, double* outu, double* outp, int need_out, int nu, double omega,
+                         const float2** res) {
+  Dist& D = h->dist;
+  GridLevel& L = h->lev[l];
+  const int g = D.L[l].g;
+  const int K = (nu % 3 == 0 && g >= 3 && h->fused_k3) ? 3 : 2;
+  if (nu % K) {
+    h->err = "sharded V-cycle: mg_nu must be even (or a multiple of 3 with deep enough ghost rows)";
+    return PGX_EINVAL;
+  }
+  const int remap = h->xcd_remap ? 1 : 0;
+  const int nl = nu / K;
+  int rc = bu ? halo_level(h, l, bu, bp) : halo_level_f(h, l, L.bf);  // the right-hand side is correct on owned rows only
+  if (rc) return rc;
+  float2 *cu = L.xf, *ou = L.xf2;
+  pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, bu, bp, nullptr, nullptr, nullptr, nullptr, omega, remap, cu, nullptr, nullptr);
+  int xv = g - K;  // validity depth of cu
+  bool in64 = false;  // the current iterate already sits in (outu, outp)
+  auto more = [&](const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, bool last) -> int {
+    if (xv < K) {
+      const int r = halo_level_f(h, l, cu);
+      if (r) return r;
+      xv = g;
+    }
+    const bool out64 = last && outu;
+    pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, C, cf, cdu, cdp, omega, remap, ou, out64 ? outu : nullptr,
+                  out64 ? outp : nullptr);
+    std::swap(cu, ou);
+    in64 = out64;
+    xv -= K;
+    return PGX_OK;
+  };
+  for (int s = 1; s < nl; ++s)
+    if ((rc = more(nullptr, nullptr, nullptr, nullptr, false))) return rc;
+  if (xv < 2) {  // P^T (b - J x) on the owned coarse rows reads the residual one row out, i.e. x two rows out
+    if ((rc = halo_level_f(h, l, cu))) return rc;
+    xv = g;
+  }
+  const GridLevel* C;
+  const float2* cf = nullptr;
+  const double *cdu = nullptr, *cdp = nullptr;
+  if (l + 1 < D.ldist) {
+    GridLevel& Cl = h->lev[l + 1];
+    if (Cl.f32) {
+      pgxk_f_resid_restrict(h->st, L, h->alpha, cu, Cl, remap, Cl.bf, nullptr, nullptr);
+      if ((rc = vcycle_dist_f(h, l + 1, nullptr, nullptr, nullptr, nullptr, D.L[l + 1].g, nu, omega, &cf))) return rc;
+    } else {
+      pgxk_f_resid_restrict(h->st, L, h->alpha, cu, Cl, remap, nullptr, Cl.bu, Cl.bp);
+      if ((rc = vcycle_dist(h, l + 1, Cl.bu, Cl.bp, Cl.xu, Cl.xp, D.L[l + 1].g, nu, omega))) return rc;
+      cdu = Cl.xu;
+      cdp = Cl.xp;
+    }
+    C = &Cl;
+  } else {
+    // onto the replicated level (fp64 right-hand side: it is summed over the ranks): every rank restricts into its view, clears the
+    // view's ghost rows, and the all-reduce assembles the global right-hand side (exactly one non-zero contribution per entry)
+    GridLevel& G = h->lev[l + 1];
+    const GridLevel& V = D.view;
+    const size_t sxc = (size_t)G.nx + 1;
+    if (hipMemsetAsync(G.bu, 0, sizeof(double) * 2 * (size_t)G.n, h->st) != hipSuccess) return PGX_EHIP;
+    pgxk_f_resid_restrict(h->st, L, h->alpha, cu, V, remap, nullptr, V.bu, V.bp);
+    const size_t lo = (size_t)D.view_glo * sxc, hi0 = (size_t)(D.view_glo + D.view_H) * sxc, hi = (size_t)V.n - hi0;
+    double* const halves[2] = {V.bu, V.bp};
+    for (double* b : halves) {
+      if (lo) hipMemsetAsync(b, 0, sizeof(double) * lo, h->st);
+      if (hi) hipMemsetAsync(b + hi0, 0, sizeof(double) * hi, h->st);
+    }
+    if ((rc = allreduce_dev(h, G.bu, 2 * (size_t)G.n))) return rc;
+    vcycle(h, l + 1, G.bu, G.bp, G.xu, G.xp, nu, omega);  // identical work on every rank
+    C = &V;
+    cdu = V.xu;
+    cdp = V.xp;
+  }
+  // x + P x_c is correct to depth min(xv, g): the coarse correction covers every local row
+  if ((rc = more(C, cf, cdu, cdp, nl == 1))) return rc;
+  for (int s = 1; s < nl; ++s)
+    if ((rc = more(nullptr, nullptr, nullptr, nullptr, s + 1 == nl))) return rc;
+  if (xv < need_out) {
+    if ((rc = in64 ? halo_level(h, l, outu, outp) : halo_level_f(h, l, cu))) return rc;
+    xv = g;
+  }
+  if (res) *res = cu;
   return PGX_OK;
 }
 
