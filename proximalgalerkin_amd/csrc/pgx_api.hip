@@ -105,6 +105,8 @@ struct pgx_handle {
   unsigned long long* h_seq = nullptr;        // sequence word behind the payload (host view / device view)
   unsigned long long* h_seq_dev = nullptr;
   unsigned long long seq = 0;
+  int lazy_norm = 1;        // PGX_LAZY_NORM=0: every new Krylov vector is normalised in place (one more pass over it per iteration)
+  double rhs_scale = 1.0;   // factor the next level-0 V-cycle applies to its fp64 right-hand side as it reads it (lazy normalisation)
   int host_poll = 1;  // PGX_HOST_POLL=0: hipMemcpyAsync + hipStreamSynchronize for every small read-back (round 3)
   // multigrid
   std::vector<GridLevel> lev;
@@ -1064,6 +1066,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_K6_MAX")) h->k6_max = atoi(e);
   if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
   if (const char* e = pgx_tune("PGX_HOST_POLL")) h->host_poll = atoi(e);
+  if (const char* e = pgx_tune("PGX_LAZY_NORM")) h->lazy_norm = atoi(e);
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_RR_MAX")) h->f32_rr_max = atoi(e);
@@ -1494,21 +1497,25 @@ static int replica_agree(pgx_handle* h, double* dev, size_t n) {
 // iterations").  A one-workgroup kernel at the end of the enqueued work stores the n doubles into pinned, mapped host memory with
 // system-scope stores, fences, and publishes a sequence number; the host polls that word.  What used to cost a D2H copy command, a
 // stream synchronisation and the driver's wake-up (15-25 us in which the GPU idles) costs the PCIe write and a cache miss.
-__global__ void __launch_bounds__(64) k_publish(int n, const double* __restrict__ src, double* dst, unsigned long long seq,
-                                                unsigned long long* seqp) {
+__global__ void __launch_bounds__(64) k_publish(int n, const double* __restrict__ src, double* dst, int n2, const double* __restrict__ src2,
+                                                double* dst2, unsigned long long seq, unsigned long long* seqp) {
   for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int i = threadIdx.x; i < n2; i += 64) __hip_atomic_store(dst2 + i, src2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();  // one wave: every lane's stores are ordered before lane 0's flag store below
   if (threadIdx.x == 0) __hip_atomic_store(seqp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// h_small[hoff .. hoff + n) <- dsrc[0 .. n), blocking until the values have arrived
-static int fetch_small(pgx_handle* h, const double* dsrc, size_t n, size_t hoff = 0) {
+// h_small[hoff .. hoff + n) <- dsrc[0 .. n) (and optionally a second range), blocking until the values have arrived
+static int fetch_small(pgx_handle* h, const double* dsrc, size_t n, size_t hoff = 0, const double* dsrc2 = nullptr, size_t n2 = 0,
+                       size_t hoff2 = 0) {
   if (!h->host_poll) {
     HIPCHK(hipMemcpyAsync(h->h_small + hoff, dsrc, sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
+    if (n2) HIPCHK(hipMemcpyAsync(h->h_small + hoff2, dsrc2, sizeof(double) * n2, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     return PGX_OK;
   }
   const unsigned long long seq = ++h->seq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->st, (int)n, dsrc, h->h_small_dev + hoff, seq, h->h_seq_dev);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->st, (int)n, dsrc, h->h_small_dev + hoff, (int)n2, dsrc2, h->h_small_dev + hoff2,
+                     seq, h->h_seq_dev);
   for (unsigned long spins = 1;; ++spins) {
     if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return PGX_OK;
     if ((spins & 0x3fff) == 0) {  // a failed launch or a faulted kernel must not leave the host spinning
@@ -1671,8 +1678,9 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
   double* const cb64p = C.f32 ? nullptr : C.bp;
   {
     const bool rr = fuse && nl == 1;
+    const double bscale = (l == 0 && bu) ? h->rhs_scale : 1.0;
     pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, bu, bp, rr ? &C : nullptr, nullptr, nullptr, nullptr, omega, remap, cu, nullptr,
-                  nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr);
+                  nullptr, rr ? cbf : nullptr, rr ? cb64u : nullptr, rr ? cb64p : nullptr, bscale);
   }
   for (int s = 1; s < nl; ++s) {
     const bool rr = fuse && s + 1 == nl;
@@ -1888,7 +1896,8 @@ static int vcycle_dist_f(pgx_handle* h, int l, double* bu, double* bp, double* o
   int rc = bu ? halo_level(h, l, bu, bp) : halo_level_f(h, l, L.bf);  // the right-hand side is correct on owned rows only
   if (rc) return rc;
   float2 *cu = L.xf, *ou = L.xf2;
-  pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, bu, bp, nullptr, nullptr, nullptr, nullptr, omega, remap, cu, nullptr, nullptr);
+  pgxk_f_smooth(h->st, K, 1, L, h->alpha, nullptr, bu, bp, nullptr, nullptr, nullptr, nullptr, omega, remap, cu, nullptr, nullptr, nullptr,
+                nullptr, nullptr, (l == 0 && bu) ? h->rhs_scale : 1.0);
   int xv = g - K;  // validity depth of cu
   bool in64 = false;  // the current iterate already sits in (outu, outp)
   auto more = [&](const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, bool last) -> int {
@@ -2345,13 +2354,25 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     first_cycle = false;
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
+    // Lazy normalisation (round 4): a new basis vector stays as the Gram-Schmidt pass left it, W_{j+1} = w', and only its scale
+    // s_{j+1} = 1 / |w'| is kept (v_i = s_i W_i): the V-cycle multiplies its right-hand side by s_j as its first launch reads it, the
+    // batched dot products come back as s_i^2 (W_i . w) - the coefficients the projection w' = w - sum_i (v_i . w) v_i applies to the
+    // stored W_i - and the pass over w that only divided it by its norm (67 MB read + written per iteration) is gone.  Only where
+    // the preconditioner is the single-precision cycle entered on level 0 (it is the one that takes the factor).
+    const bool lazy = h->lazy_norm && !h->lu_active && h->degree == 1 && m + 2 <= PGX_DOT_SCALE_MAX && !h->lev.empty() &&
+                      f32_cycle_ok(h, 0, o->mg_nu);
+    PgxDotScale sc2;  // s_i^2
+    std::vector<double> sv((size_t)m + 2, 1.0);  // s_i
+    for (int i = 0; i < PGX_DOT_SCALE_MAX; ++i) sc2.s[i] = 1.0;
     int j = 0;
     for (; j < m && its < o->ksp_max_it; ++j) {
       double* vj = h->V + (size_t)j * nk;
       double* zj = h->Z + (size_t)j * n2;
       {
         PhaseTimer t(h, 4);
+        h->rhs_scale = lazy ? sv[j] : 1.0;
         rc = precond(h, vj, zj, o->mg_nu, omega);
+        h->rhs_scale = 1.0;
         if (rc) return rc;
       }
       {
@@ -2374,9 +2395,10 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         PhaseTimer t(h, 5);
         double* d_h1 = h->d_small;
         double* d_h2 = h->d_small + (m + 2);
+        const PgxDotScale* const dsc = lazy ? &sc2 : nullptr;
         // pass 1: h1 = V^T w.  passes 2+3 fused: w' = w - V h1 and [h2; |w'|^2] in one sweep over the basis.
         // Sharded: each batch of partial dot products is completed by ONE packed all-reduce, enqueued on the stream.
-        pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h1);
+        pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h1, dsc);
         if (dist && (rc = allreduce_dev(h, d_h1, j + 1))) return rc;
         double wp2, h1h1 = 0.0, hh = 0.0;
         bool second;
@@ -2385,19 +2407,27 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
           pgxk_multiaxpy_norm(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials, d_h2 + j + 1);
           if (dist && (rc = allreduce_dev(h, d_h2 + j + 1, 1))) return rc;
           if ((rc = replica_agree(h, h->d_small, 2 * (size_t)(m + 2)))) return rc;
-          if ((rc = fetch_small(h, h->d_small, 2 * (size_t)(m + 2)))) return rc;
-          for (int i = 0; i <= j; ++i) h1h1 += h->h_small[i] * h->h_small[i];
+          if ((rc = fetch_small(h, d_h1, (size_t)(j + 1), 0, d_h2 + j + 1, 1, (size_t)(m + 2) + j + 1))) return rc;
+          for (int i = 0; i <= j; ++i) {
+            h->h_small[i] /= sv[i];  // lazy: the device holds s_i^2 (W_i . w); the Hessenberg entry is s_i (W_i . w)
+            h1h1 += h->h_small[i] * h->h_small[i];
+          }
           wp2 = h->h_small[(m + 2) + j + 1];
           // "twice is enough" (Kahan / Parlett; Daniel-Gragg-Kaufman-Stewart): the second projection is only needed when the
           // first one cancelled most of w, |w'| < eta |w| with |w|^2 = |w'|^2 + |h1|^2
           second = wp2 < h->cgs_eta2 * (wp2 + h1h1);
           if (second) {
-            pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h2);
+            pgxk_multidot(h->st, nk, j + 1, h->V, nk, wj, h->partials, d_h2, dsc);
             if (dist && (rc = allreduce_dev(h, d_h2, j + 1))) return rc;
             if ((rc = replica_agree(h, d_h2, (size_t)(j + 1)))) return rc;
             if ((rc = fetch_small(h, d_h2, (size_t)(j + 1), (size_t)(m + 2)))) return rc;
+            for (int i = 0; i <= j; ++i) h->h_small[(m + 2) + i] /= sv[i];
           }
         } else {
+          if (lazy) {
+            h->err = "PGX_CGS_SELECTIVE=0 needs PGX_LAZY_NORM=0";
+            return PGX_EINVAL;
+          }
           if (j + 1 <= 60) {
             pgxk_axpy_dot(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials2, d_h2);
           } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
@@ -2418,11 +2448,20 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         if (second) {
           hn = std::sqrt(std::max(wp2 - hh, 0.0));
           // last pass fused with the normalisation: v_{j+1} = (w' - V h2) / hn   (|w''|^2 = |w'|^2 - |h2|^2, Pythagoras)
-          if (hn > 0.0) pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
+          if (hn > 0.0) {
+            if (lazy)
+              pgxk_multiaxpy(h->st, nk, j + 1, h->V, nk, d_h2, wj);
+            else
+              pgxk_multiaxpy_scale(h->st, nk, j + 1, h->V, nk, d_h2, 1.0 / hn, wj);
+          }
         } else {
           hn = std::sqrt(std::max(wp2, 0.0));
-          if (hn > 0.0) pgxk_scale_copy(h->st, nk, 1.0 / hn, wj, wj);
+          if (hn > 0.0 && !lazy) pgxk_scale_copy(h->st, nk, 1.0 / hn, wj, wj);
           ++h->cgs_skipped;
+        }
+        if (lazy && hn > 0.0) {
+          sv[j + 1] = 1.0 / hn;
+          sc2.s[j + 1] = sv[j + 1] * sv[j + 1];
         }
         ++h->cgs_total;
       }

@@ -122,8 +122,13 @@ void pgxk_set(hipStream_t st, size_t len, double a, double* y);
 void pgxk_to_float(hipStream_t st, size_t len, const double* x, float* y);
 // out[i] = V_i . w, i<nv (V_i = V + i*ldv).  partials: [PGX_RED_BLOCKS * nv] scratch
 #define PGX_RED_BLOCKS 1024
+// scale != nullptr: out[i] = scale->s[i] * (V_i . w)  (nv <= PGX_DOT_SCALE_MAX)
+#define PGX_DOT_SCALE_MAX 64
+struct PgxDotScale {
+  double s[PGX_DOT_SCALE_MAX];
+};
 void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* w, double* partials,
-                   double* out);
+                   double* out, const PgxDotScale* scale = nullptr);
 // w -= sum_i h[i] V_i   (h is a DEVICE pointer to nv doubles)
 void pgxk_multiaxpy(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h, double* w);
 // x = sum_i y[i] Z_i  (y device pointer); accumulate!=0 -> x += ...
@@ -241,7 +246,7 @@ void pgxk_f_pack_d(hipStream_t st, const GridLevel& L);
 void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
                    const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
                    int remap, float2* yf, double* y64u, double* y64p, float2* cbf = nullptr, double* cb64u = nullptr,
-                   double* cb64p = nullptr);
+                   double* cb64p = nullptr, double bscale = 1.0);  // bscale: factor applied to the fp64 right-hand side as it is read
 // b_c = P^T (L.bf - J xf): to cbf (float2) or, when cb64u != nullptr, to the fp64 arrays (cb64u, cb64p) of an fp64 coarse level
 void pgxk_f_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const float2* xf, const GridLevel& C, int remap,
                            float2* cbf, double* cb64u, double* cb64p);

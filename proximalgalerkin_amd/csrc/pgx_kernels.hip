@@ -978,9 +978,19 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_reduce_partials(int nblocks, int 
   const double r = block_sum(s, sm);
   if (threadIdx.x == 0) out[v] = r;
 }
+// the same with a factor per dot product (lazy normalisation of the Krylov basis: pgx_api.hip, fgmres)
+__global__ void __launch_bounds__(PGX_BLOCK) k_reduce_partials_scaled(int nblocks, int nv, const double* __restrict__ p, PgxDotScale sc,
+                                                                      double* __restrict__ out) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  const int v = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += p[(size_t)b * nv + v];
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) out[v] = r * sc.s[v];
+}
 
 void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* w, double* partials,
-                   double* out) {
+                   double* out, const PgxDotScale* scale) {
   const size_t len2 = len / 2, ldv2 = ldv / 2;
   size_t nb = (len2 + PGX_BLOCK - 1) / PGX_BLOCK;
   if (nb > PGX_RED_BLOCKS) nb = PGX_RED_BLOCKS;
@@ -1004,7 +1014,10 @@ void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t l
       done += 1;
     }
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nv), block, 0, st, (int)nb, nv, partials, out);
+  if (scale)
+    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3(nv), block, 0, st, (int)nb, nv, partials, *scale, out);
+  else
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nv), block, 0, st, (int)nb, nv, partials, out);
 }
 
 template <int NV>

@@ -172,6 +172,7 @@ struct FSmoothArgs {
   float2 *bfo, *yf, *cbf;
   double *y64u, *y64p, *cb64u, *cb64p;
   float alpha, omega;
+  double bscale;  // IO == 1: the fp64 right-hand side is multiplied by this as it is read (lazily normalised Krylov vectors)
   FConst sc;
 };
 
@@ -196,7 +197,7 @@ __device__ __forceinline__ void f_smooth_fast(int b, const FSmoothArgs& A, float
     if (lj < H0 - 1) {  // rows 1 .. H0-2 are updated; row 0 only hands its upward links to row 1
       const unsigned v = (unsigned)((j0 + lj) * sx + gi);
       dq[k] = A.Dq[v];
-      if (lj >= 1) rb[k] = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
+      if (lj >= 1) rb[k] = (IO == 1) ? make_float2((float)(A.b64u[v] * A.bscale), (float)(A.b64p[v] * A.bscale)) : A.bf[v];
     }
   }
   if (!FIRST) {
@@ -382,7 +383,7 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
       const int v = gj * sx + gi;
       dq[k] = A.Dq[v];
       bc[k] = A.mask[v] != 0;
-      if (lj >= 1 && lj < H0 - 1) rb[k] = (IO == 1) ? make_float2((float)A.b64u[v], (float)A.b64p[v]) : A.bf[v];
+      if (lj >= 1 && lj < H0 - 1) rb[k] = (IO == 1) ? make_float2((float)(A.b64u[v] * A.bscale), (float)(A.b64p[v] * A.bscale)) : A.bf[v];
       if (!FIRST) xa[k] = f_add_coarse<CADD>(A.xf[v], gi, gj, A.nxc, A.cf, A.cdu, A.cdp);
       if (!(A.sc.uniform && gi > 0 && gi < nx && gj > 0 && gj < ny)) {  // the grid's frame (or a level without uniform stencils)
 #pragma unroll
@@ -594,8 +595,9 @@ static int f32_tile_rows(const GridLevel& L) {
 
 void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double alpha, const float2* xf, const double* b64u,
                    const double* b64p, const GridLevel* C, const float2* cf, const double* cdu, const double* cdp, double omega,
-                   int remap, float2* yf, double* y64u, double* y64p, float2* cbf, double* cb64u, double* cb64p) {
+                   int remap, float2* yf, double* y64u, double* y64p, float2* cbf, double* cb64u, double* cb64p, double bscale) {
   FSmoothArgs A;
+  A.bscale = bscale;
   A.nyc = C ? C->ny : 0;
   A.mask_c = C ? C->mask : nullptr;
   A.cbf = cbf;
