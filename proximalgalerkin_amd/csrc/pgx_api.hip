@@ -146,7 +146,9 @@ struct pgx_handle {
   int mg_f32 = 1;          // PGX_MG_F32=0: the round-3 fp64 V-cycle.  Default: single-precision V-cycle legs (pgx_mg32.hip) on every
                            // uniform level with at least f32_min vertices above the fused tail - half the bytes per launch
   int f32_min = 4000;      // PGX_F32_MIN
-  int f32_rr_max = 100000;   // PGX_F32_RR_MAX (measured, us per V-cycle from that level: 257^2 and below -2 each, 513^2 +3, 1025^2 +5, 2049^2 +12): levels with at most this many vertices fuse the residual + restriction into the last
+  int f32_k6_max = 300000;   // PGX_F32_K6_MAX: levels with at most this many vertices (513^2) run six sweeps per launch; us per V-cycle
+                             // at 2048^2: off 459.7, up to 129^2 453.5, up to 257^2 448.5, up to 513^2 444.3
+  int f32_rr_max = 300000;   // PGX_F32_RR_MAX (measured, us per V-cycle from that level: 257^2 and below -2 each, 513^2 +3, 1025^2 +5, 2049^2 +12): levels with at most this many vertices fuse the residual + restriction into the last
                              // pre-smoothing launch (pgx_mg32.hip, RR mode)
   int resid_grid = 1;      // uniform structured P1: residual + D(psi) through k_resid_fill_grid (PGX_RESID_GRID=0: general kernel)
   int spmv_stencil = 1;    // structured P1: the outer-Krylov operator apply through the level-0 stencil kernels (matrix-free)
@@ -1070,6 +1072,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_RR_MAX")) h->f32_rr_max = atoi(e);
+  if (const char* e = pgx_tune("PGX_F32_K6_MAX")) h->f32_k6_max = atoi(e);
   if (const char* e = pgx_tune("PGX_STAG_ITS")) h->stag_its = std::max(2, atoi(e));
   if (const char* e = pgx_tune("PGX_STAG_GAIN")) h->stag_gain = atof(e);
   if (const char* e = pgx_tune("PGX_FUSED_MIN")) h->fused_min = atoi(e);
@@ -1666,7 +1669,9 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
                               double omega) {
   GridLevel& L = h->lev[l];
   GridLevel& C = h->lev[l + 1];
-  const int K = (nu % 3 == 0 && h->fused_k3) ? 3 : 2;
+  // small levels are bound by the latency of a launch, not by its work: all six sweeps of a leg in ONE launch (the pre-smoothing
+  // one restricts the residual as well: two launches per level and cycle instead of five)
+  const int K = (nu == 6 && L.n <= h->f32_k6_max && L.n <= h->f32_rr_max) ? 6 : ((nu % 3 == 0 && h->fused_k3) ? 3 : 2);
   const int nl = nu / K;
   const int remap = h->xcd_remap ? 1 : 0;
   float2 *cu = L.xf, *ou = L.xf2;

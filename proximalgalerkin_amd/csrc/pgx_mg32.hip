@@ -627,6 +627,13 @@ void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double 
   A.omega = (float)omega;
   A.sc = make_fconst(L, alpha);
   const int ty = f32_tile_rows(L);
+  if (K == 6) {  // small levels (launch-latency bound): a whole leg of six sweeps in ONE launch
+    if (cbf || cb64u)
+      launch_f_smooth_rr<16, 6>(st, first, A, L.interior_free && (!C || C->interior_free));
+    else
+      launch_f_smooth<8, 6>(st, first, A, L.interior_free);
+    return;
+  }
   if (cbf || cb64u) {
     if (K == 3) {
       if (ty <= 8)
