@@ -2518,6 +2518,72 @@ __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int
   }
 }
 
+// Interior tiles, round 4: ONE batch of global loads per wave - the iterate on its image rows AND the four stored D links of the
+// same rows, all in flight before the first LDS store - instead of the iterate first and, behind the barrier, seven D loads per
+// vertex (three of them re-reads of the neighbours' links).  The mirrored links come from the neighbours as in the smoother: the
+// left lane's register (DPP) and the (D2, D3) pair every row hands to the row above it through LDS.
+__device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, const dsten_t* __restrict__ Dh, const StConst& sc,
+                                             double alpha, const double* __restrict__ xu, const double* __restrict__ xp,
+                                             double* __restrict__ yu, double* __restrict__ yp, double2* ximg, double2* exch) {
+  constexpr int W = 64, CXS = 62, RY = PGX_SPMV_RY, HX = RY + 2, NW = PGX_ROWMAP_BLOCK / 64, R = (HX + NW - 1) / NW;
+  const int sx = nx + 1;
+  const int i0 = tx * CXS - 1, j0 = ty * RY - 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi = i0 + lane;
+  const dsten_t* const D1 = Dh + n;
+  const dsten_t* const D2 = Dh + 2 * (size_t)n;
+  const dsten_t* const D3 = Dh + 3 * (size_t)n;
+  double2 xa[R];
+  double d0[R], d1[R], d3[R], d5[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < HX) {
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      xa[k] = make_double2(xu[v], xp[v]);
+      if (lj <= RY) {  // row 0 only hands its upward links to row 1
+        d3[k] = D2[v];
+        d5[k] = D3[v];
+        if (lj >= 1) {
+          d0[k] = Dh[v];
+          d1[k] = D1[v];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < HX) ximg[lj * W + lane] = xa[k];
+    if (lj <= RY) exch[lj * W + lane] = make_double2(d3[k], d5[k]);
+  }
+  __syncthreads();
+  const bool act = lane >= 1 && lane < W - 1;
+  const double k0 = alpha * sc.K[0], k1 = alpha * 0.5 * (sc.K[1] + sc.K[2]), k3 = alpha * 0.5 * (sc.K[3] + sc.K[4]),
+               k5 = alpha * 0.5 * (sc.K[5] + sc.K[6]);
+  const double m0 = sc.M[0], m1 = 0.5 * (sc.M[1] + sc.M[2]), m3 = 0.5 * (sc.M[3] + sc.M[4]), m5 = 0.5 * (sc.M[5] + sc.M[6]);
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int lj = wave + NW * k;
+    if (lj < 1 || lj > RY) continue;  // wave-uniform
+    const double d2 = lane_shr1(d1[k]), d4 = exch[(lj - 1) * W + lane].x, d6 = exch[(lj - 1) * W + lane - 1].y;
+    const int q = lj * W + lane;
+    const double2 x0 = ximg[q], x1 = ximg[q + 1], x2 = ximg[q - 1], x3 = ximg[q + W], x4 = ximg[q - W], x5 = ximg[q + W + 1],
+                  x6 = ximg[q - W - 1];
+    const double u12 = x1.x + x2.x, u34 = x3.x + x4.x, u56 = x5.x + x6.x;
+    const double p12 = x1.y + x2.y, p34 = x3.y + x4.y, p56 = x5.y + x6.y;
+    const double au = k0 * x0.x + k1 * u12 + k3 * u34 + k5 * u56 + m0 * x0.y + m1 * p12 + m3 * p34 + m5 * p56;
+    const double ap = m0 * x0.x + m1 * u12 + m3 * u34 + m5 * u56 -
+                      (d0[k] * x0.y + d1[k] * x1.y + d2 * x2.y + d3[k] * x3.y + d4 * x4.y + d5[k] * x5.y + d6 * x6.y);
+    if (act) {
+      const unsigned v = (unsigned)((j0 + lj) * sx + gi);
+      __builtin_nontemporal_store(au, yu + v);
+      __builtin_nontemporal_store(ap, yp + v);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, int n, RrGrid g, int nbnd,
                                                                 const double* __restrict__ K, const double* __restrict__ M,
                                                                 const dsten_t* __restrict__ Dh, StConst sc,
@@ -2525,7 +2591,7 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, 
                                                                 const double* __restrict__ xu, const double* __restrict__ xp,
                                                                 int remap, double* __restrict__ yu, double* __restrict__ yp) {
   constexpr int W = 64, HX = PGX_SPMV_RY + 2, PAD = W + 1;
-  __shared__ double2 ximg_[HX * W + 2 * PAD];
+  __shared__ double2 ximg_[HX * W + 2 * PAD], exch_[HX * W + 2 * PAD];
   int b = blockIdx.x;
   if (b < nbnd) {  // same enumeration of the boundary frame as k_st_resid_restrict_r
     int tx, ty;
@@ -2545,7 +2611,7 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, 
     st_spmv_tile<false>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
   } else {
     b = xcd_block(b - nbnd, gridDim.x - nbnd, remap);
-    st_spmv_tile<true>(1 + b % g.nfx, 1 + b / g.nfx, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
+    st_spmv_fast(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
   }
 }
 

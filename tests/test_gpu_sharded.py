@@ -277,3 +277,45 @@ def test_sharded_p2_solve_equals_single_handle(require_gpu, R, nx, ny, levels, s
         u[ge: ge + ecnt] = x[eoff: eoff + ecnt]
     assert not np.isnan(u).any()  # the owned ranges of the ranks tile the global dof set
     assert np.linalg.norm(u - xg[:ndg]) <= 1e-10 * np.linalg.norm(xg[:ndg])
+
+
+def test_sharded_p2_config3_ci_point_512_settings_b_on_4_strips(require_gpu):
+    """BASELINE config 3's CI-settings point (512^2 P2, settings B = compare_all.py:80-87) in its sharded form.
+    The single handle takes the sparse LU for the one Newton solve in which the patch cycle stagnates (proximal step 7: the iterate
+    undamped Newton overshot); a sharded handle has no LU, so its Krylov solver simply keeps going on the un-restarted basis
+    (obstacle_pg.py:128-139 asks for an exact solve, not for a particular solver).  Same Newton counts as the nested-dissection
+    oracle's golden of that run, and the golden's primal field."""
+    import pathlib
+
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    gold = np.load(pathlib.Path(__file__).parent / "golden" / "obstacle_p2_n512_settingsB_nd.npz")
+    counts = [int(c) for c in gold["hist_Newton_steps"]]
+    assert counts == [5, 4, 3, 2, 1, 1, 4, 1]
+    N, R = 512, 4
+    sx, eb = N + 1, 3 * N + 1
+
+    def rank_main(c):
+        m = fem.create_rectangle(DOMAIN, (N, N), comm=c, dist_levels=0)
+        pr, s, sk, al = setup_problem(m, 2, petsc_options=OPTS)
+        hist = run_outer_loop(pr, s, sk, al, 500, "double_exponential", 1e2, 1e-4)
+        out = (s.x.array.copy(), hist, m.partition, pr.owned_range(), m.num_vertices)
+        pr.close()
+        return out
+
+    res = _run_ranks(pcomm.local_group(R), rank_main)
+    nvg = sx * (N + 1)
+    uv = np.full(nvg, np.nan)
+    for x, hist, part, (voff, vcnt), nv in res:
+        assert hist["Newton steps"] == counts, hist["Newton steps"]
+        uv[part.own0 * sx: part.own0 * sx + vcnt] = x[voff: voff + vcnt]
+    assert not np.isnan(uv).any()
+    # the golden's fingerprint of the vertex values of u (tests/test_gpu_golden.py): sub-lattice + block sums of every vertex
+    stride = int(gold["stride"])
+    grid = uv.reshape(N + 1, N + 1)
+    nb = N // stride
+    sample, blocksum = grid[::stride, ::stride], grid[: nb * stride, : nb * stride].reshape(nb, stride, nb, stride).sum(axis=(1, 3))
+    for got, ref in ((sample, gold["u_sample"]), (blocksum, gold["u_blocksum"])):
+        assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
