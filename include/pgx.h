@@ -260,7 +260,10 @@ int pgx_create_sharded(const pgx_mesh* local_mesh, const pgx_problem* local_prob
  * so that the replicas stay bitwise identical.  All calls are collective; results are identical on every rank.  Replaces
  * `mpirun -n N python obstacle_pg.py` with MUMPS distributing the factorisation (obstacle_pg.py:129-131). */
 int pgx_create_lu_dist(const pgx_mesh* mesh, const pgx_problem* prob, pgx_comm* comm, int device, pgx_handle** out);
-/* owned entries of a local vector: fields [0,n) and [n,2n) each hold owned entries at [offset, offset+count) */
+/* Owned VERTEX dofs of a local vector: each field block holds them at [offset, offset+count) (everything - all n vertex dofs - on
+ * an unsharded handle).  P1: that is the whole field.  P2: the field block is [vertex dofs | edge dofs] and this call reports the
+ * vertex part ONLY, on sharded and unsharded handles alike: a caller that slices the owned dofs of a P2 field must combine it
+ * with pgx_owned_edge_range below (on an unsharded P2 handle: all vertices + all edges). */
 int pgx_owned_range(const pgx_handle* h, int64_t* offset, int64_t* count);
 /* P2 handles: the owned EDGE dofs of each field block as (offset within the field block, count); the vertex dofs are what
  * pgx_owned_range reports.  An edge belongs to the rank that owns its lower vertex; edge dofs are numbered by their lower vertex,

@@ -552,6 +552,15 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
 // (K, M) dictionary of the P2 level for k_bspmv_bal<true>: distinct pairs after rounding to a grid of 2^-40 of the largest entry
 // (finer than the tolerance of detect_uniform below; a function of each entry alone: deterministic).  Seeded with nothing; every round lists up to 4096 unmatched entries, the host adds their distinct values.
 // More than 256 pairs (a non-uniform mesh) => no dictionary, the kernel streams K and M as before.
+static int allreduce_dev(pgx_handle* h, double* dev, size_t n);
+// max |x_i| through atomicMax on the bit pattern (non-negative doubles order like their 64-bit patterns)
+__global__ void __launch_bounds__(256) k_maxabs(int64_t n, const double* __restrict__ x, unsigned long long* out) {
+  double m = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(x[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 static int build_km_dictionary(pgx_handle* h) {
   const int64_t nnz = h->s_nnz;
   const int cap = 4096;
@@ -563,16 +572,39 @@ static int build_km_dictionary(pgx_handle* h) {
   DALLOC(tab, 512);
   DALLOC(fail, 2);
   DALLOC(fail_v, 2 * cap);
-  // scale: the largest |K|, |M| among the first rows (uniform mesh: every row kind occurs there; otherwise the dictionary fails anyway)
-  const size_t ns = (size_t)std::min<int64_t>(nnz, 1 << 16);
-  std::vector<double> ks(ns), ms(ns);
-  HIPCHK(hipMemcpyAsync(ks.data(), h->s_K, ns * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  HIPCHK(hipMemcpyAsync(ms.data(), h->s_M, ns * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  HIPCHK(hipStreamSynchronize(h->st));
+  // scale: the largest |K| and |M| over ALL entries (round 3 looked at the first 65536 only - vertex rows - and missed the larger
+  // edge-edge entries of P2), and on a sharded handle the largest over all ranks, so that every rank rounds the same
+  // global operator to the same grid
   double kmax = 0.0, mmax = 0.0;
-  for (size_t i = 0; i < ns; ++i) {
-    kmax = std::max(kmax, std::fabs(ks[i]));
-    mmax = std::max(mmax, std::fabs(ms[i]));
+  {
+    unsigned long long* dmax = nullptr;
+    DALLOC(dmax, 2);
+    HIPCHK(hipMemsetAsync(dmax, 0, 2 * sizeof(unsigned long long), h->st));
+    const int nb = (int)std::min<int64_t>((nnz + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_maxabs, dim3(nb), dim3(256), 0, h->st, nnz, h->s_K, dmax);
+    hipLaunchKernelGGL(k_maxabs, dim3(nb), dim3(256), 0, h->st, nnz, h->s_M, dmax + 1);
+    unsigned long long hm[2];
+    HIPCHK(hipMemcpyAsync(hm, dmax, sizeof(hm), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    memcpy(&kmax, &hm[0], 8);
+    memcpy(&mmax, &hm[1], 8);
+    if (h->dist.on) {  // max over the ranks through the sum all-reduce: slot `rank` of a zeroed buffer
+      const int R = h->dist.size;
+      std::vector<double> slots(2 * (size_t)R, 0.0);
+      slots[2 * (size_t)h->dist.rank] = kmax;
+      slots[2 * (size_t)h->dist.rank + 1] = mmax;
+      double* ds = nullptr;
+      DALLOC(ds, 2 * (size_t)R);
+      HIPCHK(hipMemcpyAsync(ds, slots.data(), slots.size() * sizeof(double), hipMemcpyHostToDevice, h->st));
+      const int rc = allreduce_dev(h, ds, 2 * (size_t)R);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(slots.data(), ds, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+      HIPCHK(hipStreamSynchronize(h->st));
+      for (int r = 0; r < R; ++r) {
+        kmax = std::max(kmax, slots[2 * (size_t)r]);
+        mmax = std::max(mmax, slots[2 * (size_t)r + 1]);
+      }
+    }
   }
   // grid = 2^-40 (9e-13) of the largest entry, a power of two: rounding to it is exact arithmetic, the same on host and device
   const double tk = std::ldexp(1.0, std::ilogb(kmax > 0 ? kmax : 1.0) - 40), tm = std::ldexp(1.0, std::ilogb(mmax > 0 ? mmax : 1.0) - 40);

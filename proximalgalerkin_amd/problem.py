@@ -363,7 +363,8 @@ class NonlinearProblem:
         return off.value, cnt.value
 
     def owned_range(self):
-        """(offset, count): owned entries of each field block of a local vector (everything for an unsharded mesh)."""
+        """(offset, count): owned VERTEX dofs of each field block of a local vector (all vertices for an unsharded mesh).  Degree 2:
+        the field block is [vertex dofs | edge dofs] and this is the vertex part only - combine it with owned_edge_range()."""
         off, cnt = C.c_int64(0), C.c_int64(0)
         _lib.check(self._lib, self._h, self._lib.pgx_owned_range(self._h, C.byref(off), C.byref(cnt)),
                    "pgx_owned_range")
