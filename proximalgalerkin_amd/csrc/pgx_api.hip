@@ -105,6 +105,7 @@ struct pgx_handle {
   unsigned long long* h_seq = nullptr;        // sequence word behind the payload (host view / device view)
   unsigned long long* h_seq_dev = nullptr;
   unsigned long long seq = 0;
+  int spmv_d4 = 1;          // PGX_SPMV_D4=0: the matrix-free operator apply reads the four D arrays instead of its double4 copy
   int lazy_norm = 1;        // PGX_LAZY_NORM=0: every new Krylov vector is normalised in place (one more pass over it per iteration)
   double rhs_scale = 1.0;   // factor the next level-0 V-cycle applies to its fp64 right-hand side as it reads it (lazy normalisation)
   int host_poll = 1;  // PGX_HOST_POLL=0: hipMemcpyAsync + hipStreamSynchronize for every small read-back (round 3)
@@ -844,6 +845,8 @@ static void setup_tail(pgx_handle* h, int first) {
 // least f32_min vertices above the fused tail, never the coarsest.  fp64 and single-precision levels may alternate: each hands its
 // right-hand side down and its correction up in the format of the level that receives it (vcycle / vcycle_f / vcycle_dist_f).
 static int setup_f32(pgx_handle* h) {
+  if (h->structured && h->degree == 1 && h->spmv_stencil == 1 && h->spmv_d4 && !h->lev.empty() && h->lev[0].uniform && sizeof(dsten_t) == 8)
+    DALLOC(h->lev[0].Dd4, h->lev[0].n);  // the operator apply's own copy of D (k_st_spmv_r)
   if (!h->mg_f32 || !h->structured || sizeof(dsten_t) != 8) return PGX_OK;
   const int nl = (int)h->lev.size();
   for (int l = 0; l + 1 < nl; ++l) {
@@ -1101,6 +1104,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
   if (const char* e = pgx_tune("PGX_HOST_POLL")) h->host_poll = atoi(e);
   if (const char* e = pgx_tune("PGX_LAZY_NORM")) h->lazy_norm = atoi(e);
+  if (const char* e = pgx_tune("PGX_SPMV_D4")) h->spmv_d4 = atoi(e);
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_RR_MAX")) h->f32_rr_max = atoi(e);
@@ -1634,6 +1638,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
     h->dh_interior = false;
     if (h->lev[0].Dh32) pgxk_to_float(h->st, (size_t)4 * h->n, h->lev[0].Dh, h->lev[0].Dh32);
     if (h->lev[0].f32) pgxk_f_pack_d(h->st, h->lev[0]);
+    if (h->lev[0].Dd4) pgxk_pack_d4(h->st, h->lev[0]);
     const int ld = h->dist.on ? h->dist.ldist : 0;
     for (size_t l = 1; l < h->lev.size(); ++l) {
       if (h->dist.on && (int)l == ld) {  // strip -> replicated level: owned rows + zeros, summed over the ranks

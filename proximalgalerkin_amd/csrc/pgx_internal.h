@@ -67,6 +67,8 @@ struct GridLevel {
   // (u, psi) float2: 40 B per vertex and smoother launch instead of 84.  The cycle is a preconditioner inside FGMRES (flexible);
   // the operator apply, the residuals and the Krylov space stay fp64.
   int f32;
+  double4* Dd4;  // finest level only (else nullptr): the fp64 D stencil as ONE double4 per vertex for the matrix-free operator apply
+                 // (two 16-byte loads per vertex instead of four 8-byte ones from four arrays); repacked with every Jacobian
   float4* Dq;
   float2 *xf, *xf2, *bf;
 };
@@ -157,6 +159,7 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
                      double omega, int remap, double* yu, double* yp);
 void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp, int remap, double* yu,
                   double* yp);
+void pgxk_pack_d4(hipStream_t st, const GridLevel& L);  // Dd4 <- Dh
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,
                             double* cbp);

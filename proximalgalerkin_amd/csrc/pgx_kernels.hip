@@ -2522,9 +2522,11 @@ __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int
 // same rows, all in flight before the first LDS store - instead of the iterate first and, behind the barrier, seven D loads per
 // vertex (three of them re-reads of the neighbours' links).  The mirrored links come from the neighbours as in the smoother: the
 // left lane's register (DPP) and the (D2, D3) pair every row hands to the row above it through LDS.
-__device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, const dsten_t* __restrict__ Dh, const StConst& sc,
-                                             double alpha, const double* __restrict__ xu, const double* __restrict__ xp,
-                                             double* __restrict__ yu, double* __restrict__ yp, double2* ximg, double2* exch) {
+template <bool D4>
+__device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, const dsten_t* __restrict__ Dh, const double4* __restrict__ Dd4,
+                                             const StConst& sc, double alpha, const double* __restrict__ xu,
+                                             const double* __restrict__ xp, double* __restrict__ yu, double* __restrict__ yp,
+                                             double2* ximg, double2* exch) {
   constexpr int W = 64, CXS = 62, RY = PGX_SPMV_RY, HX = RY + 2, NW = PGX_ROWMAP_BLOCK / 64, R = (HX + NW - 1) / NW;
   const int sx = nx + 1;
   const int i0 = tx * CXS - 1, j0 = ty * RY - 1;
@@ -2543,11 +2545,19 @@ __device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, cons
       const unsigned v = (unsigned)((j0 + lj) * sx + gi);
       xa[k] = make_double2(xu[v], xp[v]);
       if (lj <= RY) {  // row 0 only hands its upward links to row 1
-        d3[k] = D2[v];
-        d5[k] = D3[v];
-        if (lj >= 1) {
-          d0[k] = Dh[v];
-          d1[k] = D1[v];
+        if (D4) {
+          const double4 q = Dd4[v];
+          d0[k] = q.x;
+          d1[k] = q.y;
+          d3[k] = q.z;
+          d5[k] = q.w;
+        } else {
+          d3[k] = D2[v];
+          d5[k] = D3[v];
+          if (lj >= 1) {
+            d0[k] = Dh[v];
+            d1[k] = D1[v];
+          }
         }
       }
     }
@@ -2586,8 +2596,8 @@ __device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, cons
 
 __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, int n, RrGrid g, int nbnd,
                                                                 const double* __restrict__ K, const double* __restrict__ M,
-                                                                const dsten_t* __restrict__ Dh, StConst sc,
-                                                                const uint8_t* __restrict__ mask, double alpha,
+                                                                const dsten_t* __restrict__ Dh, const double4* __restrict__ Dd4,
+                                                                StConst sc, const uint8_t* __restrict__ mask, double alpha,
                                                                 const double* __restrict__ xu, const double* __restrict__ xp,
                                                                 int remap, double* __restrict__ yu, double* __restrict__ yp) {
   constexpr int W = 64, HX = PGX_SPMV_RY + 2, PAD = W + 1;
@@ -2611,7 +2621,10 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, 
     st_spmv_tile<false>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
   } else {
     b = xcd_block(b - nbnd, gridDim.x - nbnd, remap);
-    st_spmv_fast(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
+    if (Dd4)
+      st_spmv_fast<true>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
+    else
+      st_spmv_fast<false>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
   }
 }
 
@@ -2634,8 +2647,17 @@ void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double
   g.nfy = std::min(g.nfy, g.nty - 1);
   if (!L.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
   const int nfast = g.nfx * g.nfy, nbnd = g.ntx * g.nty - nfast;
-  hipLaunchKernelGGL(k_st_spmv_r, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh,
+  hipLaunchKernelGGL(k_st_spmv_r, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dd4,
                      make_stconst(L), L.mask, alpha, xu, xp, remap, yu, yp);
+}
+
+__global__ void __launch_bounds__(256) k_pack_d4(int n, const dsten_t* __restrict__ Dh, double4* __restrict__ Dd4) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  Dd4[v] = make_double4(Dh[v], Dh[(size_t)n + v], Dh[2 * (size_t)n + v], Dh[3 * (size_t)n + v]);
+}
+void pgxk_pack_d4(hipStream_t st, const GridLevel& L) {
+  hipLaunchKernelGGL(k_pack_d4, dim3((L.n + 255) / 256), dim3(256), 0, st, L.n, L.Dh, L.Dd4);
 }
 
 void pgxk_st_apply(hipStream_t st, int mode, const GridLevel& L, double alpha, const double* xu, const double* xp,
