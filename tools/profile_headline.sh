@@ -27,12 +27,17 @@ for what in "$@"; do
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_swrite -o w -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_swrite.log 2>&1 || exit 1
       python3 tools/pmc_summary.py --kernel k_st_spmv_r --traffic --cells 2048 --algorithmic-bytes 272896065 \
         --out $OUT/stspmv_pmc_traffic.json $OUT/pmc_sfetch $OUT/pmc_swrite > /dev/null || exit 1 ;;
+    fsmooth)  # the time-dominant kernel: the finest level's single-precision smoother launch, 40 B x 2049^2 vertices (+ coarse correction)
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_ffetch -o f -- python3 tools/smoother_bench.py 2048 > $OUT/pmc_ffetch.log 2>&1 || exit 1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fwrite -o w -- python3 tools/smoother_bench.py 2048 > $OUT/pmc_fwrite.log 2>&1 || exit 1
+      python3 tools/pmc_summary.py --kernel "k_f_smooth<16, 3, false, 0, 1, 0>" --traffic --cells 2048 --algorithmic-bytes 176341040 \
+        --out $OUT/fsmooth_pmc_traffic.json $OUT/pmc_ffetch $OUT/pmc_fwrite > /dev/null || exit 1 ;;
     smoother)
       rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d $OUT/pmc_sqA -o a -- $BENCH > $OUT/pmc_sqA.log 2>&1 || exit 1
       rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM \
         --kernel-trace --output-format csv -d $OUT/pmc_sqB -o b -- $BENCH > $OUT/pmc_sqB.log 2>&1 || exit 1
-      for k in k_st_smoothR k_st_resid_restrict_r k_bspmv_stream k_resid_fill_p1 k_multiaxpy_norm; do
+      for k in k_f_smooth k_f_resid_restrict k_st_spmv_r k_mg_tail2 k_multiaxpy_norm; do
         python3 tools/pmc_summary.py --kernel $k --out $OUT/pmc_sq_$k.json $OUT/pmc_sqA $OUT/pmc_sqB > /dev/null || true
       done ;;
   esac
