@@ -22,17 +22,23 @@ import numpy as np
 _TABLES = pathlib.Path(__file__).resolve().parent / "tables" / "quadrature.json"
 
 
-def quadrature_rule(cell: str, degree: int):
+def quadrature_rule(cell: str, degree: int, scheme: str | None = None):
     """(points (nq,2), weights (nq,)) on the reference triangle. Tables live in ONE file shared with
-    the oracle (tools/make_quadrature_tables.py)."""
+    the oracle (tools/make_quadrature_tables.py).  `scheme` names a table of that file explicitly (basix.ufl.quadrature_element's
+    `scheme` argument): "tri_deg6_12_b" is the second fully symmetric 12-point degree-6 rule (tools/quadrature_uniqueness.py)."""
     if cell == "quadrilateral":  # tensor Gauss-Legendre rule on the unit square, exact to `degree` in each variable
         g, w = np.polynomial.legendre.leggauss(degree // 2 + 1)
         g, w = 0.5 * (g + 1.0), 0.5 * w
         n = len(g)
         return (np.ascontiguousarray(np.stack([np.tile(g, n), np.repeat(g, n)], axis=1)), np.ascontiguousarray(np.repeat(w, n) * np.tile(w, n)))
     tabs = json.loads(_TABLES.read_text())
+    if scheme not in (None, "default"):
+        t = tabs.get(scheme)
+        if t is None or t["cell"] != cell or t["degree"] != degree:
+            raise NotImplementedError(f"no quadrature table {scheme!r} for {cell} degree {degree}")
+        return (np.ascontiguousarray(t["points"], dtype=np.float64), np.ascontiguousarray(t["weights"], dtype=np.float64))
     for t in tabs.values():
-        if t["cell"] == cell and t["degree"] == degree:
+        if t["cell"] == cell and t["degree"] == degree and not t.get("scheme_only"):
             return (np.ascontiguousarray(t["points"], dtype=np.float64),
                     np.ascontiguousarray(t["weights"], dtype=np.float64))
     raise NotImplementedError(f"no quadrature table for {cell} degree {degree} (available: "
@@ -555,9 +561,9 @@ class QuadratureFunction(_FormOperand):
     """Function in a quadrature space of the given degree: one value per (cell, point), dof =
     cell*nq + q (basix.ufl.quadrature_element + fem.functionspace, obstacle_pg.py:107-110)."""
 
-    def __init__(self, mesh: Mesh, degree: int, name="phi"):
+    def __init__(self, mesh: Mesh, degree: int, name="phi", scheme: str | None = None):
         self.mesh, self.degree, self.name = mesh, degree, name
-        self.points, self.weights = quadrature_rule(mesh.cell_name(), degree)
+        self.points, self.weights = quadrature_rule(mesh.cell_name(), degree, scheme)
         self.values = np.zeros((mesh.num_cells, len(self.weights)))
 
     def physical_points(self):

@@ -37,17 +37,18 @@ COLUMNS = ["Energy", "Complementarity", "Feasibility", "Dual Feasibility", "Newt
 
 
 def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict | None = None, device: int = 0,
-                  phi=phi_set, lu_comm=None, quadrature_degree: int = 6):
+                  phi=phi_set, lu_comm=None, quadrature_degree: int = 6, quadrature_scheme: str | None = None):
     """Everything obstacle_pg.py does before the loop (:66-152). Returns (problem, sol, sol_k, alpha).
     quadrature_degree: 6 is the reference's (:106); 1 selects the vertex rule (mass lumping), with which the system is the
-    finite-difference one of obstacle_finite_difference.jl (tests/test_gpu_fd_pin.py)."""
+    finite-difference one of obstacle_finite_difference.jl (tests/test_gpu_fd_pin.py).  quadrature_scheme names a table of
+    tables/quadrature.json explicitly ("tri_deg6_12_b": the second admissible 12-point degree-6 rule)."""
     V = fem.functionspace(msh, ("Lagrange", polynomial_order), ncomp=2)  # :68-70
     alpha = fem.Constant(msh, 1.0)  # :73
     f = fem.Constant(msh, 0.0)  # :74
     dofs = msh.exterior_dofs(polynomial_order)  # :76-79
     bcs = fem.dirichletbc(0.0, dofs, V.sub(0))  # :81-83
     sol, sol_k = fem.Function(V), fem.Function(V)  # :86-87
-    phi_fn = fem.QuadratureFunction(msh, quadrature_degree, name="phi")
+    phi_fn = fem.QuadratureFunction(msh, quadrature_degree, name="phi", scheme=quadrature_scheme)
     phi_fn.interpolate(phi)  # :110-111
     # the residual as the reference states it (:88-89,114-125), through the UFL-subset front end (ufl.py), which selects the
     # HIP kernel family for it

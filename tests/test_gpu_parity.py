@@ -118,6 +118,30 @@ def test_full_lvpp_run_matches_oracle(require_gpu, scheme, alpha_max, tol, N):
         assert np.allclose(hist[c], h_ref[c], rtol=1e-7, atol=1e-11), c
 
 
+def test_full_lvpp_run_with_the_second_degree6_rule_matches_oracle(require_gpu):
+    """The other admissible 12-point degree-6 rule (tables/quadrature.json "tri_deg6_12_b"; tools/quadrature_uniqueness.py finds
+    exactly two): HIP path and oracle on the same table agree like on the default one, and the two tables move the final u by
+    ~1e-7 at 64^2 - the size of what "parity unpinned" leaves open if the reference's table is the other root."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    N = 64
+    coords, cells = O.create_rectangle(N, N)
+    bc = O.boundary_vertices_rectangle(N, N)
+    u = {}
+    for scheme in (None, "tri_deg6_12_b"):
+        msh = fem.create_rectangle(DOMAIN, (N, N))
+        problem, sol, sol_k, alpha = setup_problem(msh, 1, quadrature_scheme=scheme)
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4, verbose=False)
+        prob = O.ObstacleP1(coords, cells, bc, quadrature=scheme or "tri_deg6_12")
+        x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
+        assert hist["Newton steps"] == h_ref["Newton steps"]
+        u[scheme] = sol.x.array[:prob.n].copy()
+        assert _rel(u[scheme], x_ref[:prob.n]) < 1e-10
+        problem.close()
+    assert 1e-9 < _rel(u["tri_deg6_12_b"], u[None]) < 1e-6
+
+
 def test_host_and_device_resident_loops_agree(require_gpu):
     from proximalgalerkin_amd import fem
     from proximalgalerkin_amd.obstacle import solve_problem

@@ -221,3 +221,35 @@ def test_galerkin_coarse_operators_stay_seven_point():
     # nested P1 spaces + exact integration: Galerkin coarse K and M ARE the coarse-mesh K and M
     assert abs(Kc - pc.K).max() < 1e-13
     assert abs((P.T @ p.M @ P) - pc.M).max() < 1e-13
+
+
+def test_both_admissible_degree6_rules_are_exact_and_are_the_only_ones_the_search_found():
+    """SURVEY.md H3 / VERDICT r03 item 8a: the moment system of a fully symmetric 12-point degree-6 rule with orbit structure
+    [3, 3, 6], interior points and positive weights has exactly TWO admissible roots in a global search of 30 000 starts
+    (tools/quadrature_uniqueness.py -> profiles/r04_quadrature_uniqueness.json): Dunavant's - the default table - and a second
+    one, shipped as "tri_deg6_12_b".  Both integrate every monomial of degree <= 6 exactly."""
+    import json
+    import math
+    import pathlib
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    rep = json.loads((root / "profiles" / "r04_quadrature_uniqueness.json").read_text())
+    assert rep["n_starts"] >= 30000 and rep["distinct_admissible_rules"] == 2
+    found = [np.array(r) for r in rep["rules"]]
+    for name in ("tri_deg6_12", "tri_deg6_12_b"):
+        pts, w = O.load_quadrature(name)
+        assert len(w) == 12 and w.min() > 0 and pts.min() > 0 and (pts.sum(axis=1) < 1).all()
+        for p in range(7):
+            for q in range(7 - p):
+                exact = math.factorial(p) * math.factorial(q) / math.factorial(p + q + 2)
+                assert abs(np.sum(w * pts[:, 0] ** p * pts[:, 1] ** q) - exact) < 1e-15
+        # canonical form of tools/quadrature_uniqueness.py: the two 3-orbits (a, w) sorted by a, the sorted 6-orbit point, its weight
+        bary = np.sort(np.column_stack([pts, 1 - pts.sum(axis=1)]), axis=1)
+        groups = {}
+        for b, wi in zip(bary, w):
+            groups.setdefault(round(float(wi), 13), []).append(b)
+        o3 = sorted((float(g[0][0]) if abs(g[0][0] - g[0][1]) < 1e-12 else float(g[0][2]), wi) for wi, g in groups.items() if len(g) == 3)
+        # a 3-orbit point sorted is (a, a, 1-2a) or (1-2a, a, a): its repeated coordinate is a
+        (w6, g6), = [(wi, g) for wi, g in groups.items() if len(g) == 6]
+        canon = np.array([o3[0][0], o3[0][1], o3[1][0], o3[1][1], *g6[0], w6])
+        assert min(np.max(np.abs(canon - f)) for f in found) < 1e-9, name

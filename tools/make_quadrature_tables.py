@@ -150,6 +150,24 @@ def main():
             "weights": [float(w) for w in wts],
         }
     }
+    # The OTHER fully symmetric 12-point degree-6 rule with orbit structure [3, 3, 6], interior points and positive weights: the
+    # global search of tools/quadrature_uniqueness.py (30 000 starts) finds exactly two admissible roots of the moment system,
+    # Dunavant's and this one.  Selected with scheme="tri_deg6_12_b" (fem.QuadratureFunction, setup_problem); never the default.
+    guess_b = [mp.mpf("0.08566656207648825"), mp.mpf("0.21942998254978308"), mp.mpf("0.04036554479651741"),
+               mp.mpf("0.4801379641122133"), mp.mpf("0.02031727989683051"), mp.mpf("0.14161901592396486"),
+               mp.mpf("0.8390092597147903")]
+    sol_b = mp.findroot(residual, guess_b, tol=1e-40, maxsteps=50)
+    params_b = [sol_b[i] for i in range(7)]
+    pts_b, wts_b = rule(params_b)
+    worst_b = mp.mpf(0)
+    for p in range(7):
+        for q in range(7 - p):
+            s = sum(w * x**p * y**q for (x, y), w in zip(pts_b, wts_b))
+            worst_b = max(worst_b, abs(s - moments_exact(p, q)))
+    assert worst_b < mp.mpf(10) ** (-35), worst_b
+    for g, sv in zip(guess_b, params_b):
+        assert abs(g - sv) < 1e-10, (g, sv)
+    assert min(wts_b) > 0 and all(x > 0 and y > 0 and x + y < 1 for x, y in pts_b)
     pts10, wts10 = collapsed_rule(6)
     worst10 = mp.mpf(0)
     for p in range(12):
@@ -188,6 +206,15 @@ def main():
         "source": "vertex rule: the three vertices, weights 1/6 (exact to degree 1; mass lumping); tools/make_quadrature_tables.py",
         "points": [[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]],
         "weights": [1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0],
+    }
+    table["tri_deg6_12_b"] = {
+        "cell": "triangle",
+        "degree": 6,
+        "scheme_only": True,  # never picked by (cell, degree): by name only
+        "source": "the second admissible root of the [3,3,6] degree-6 moment system (tools/quadrature_uniqueness.py), solved to "
+                  "40 digits by tools/make_quadrature_tables.py",
+        "points": [[float(x), float(y)] for (x, y) in pts_b],
+        "weights": [float(w) for w in wts_b],
     }
     out = pathlib.Path(__file__).resolve().parents[1] / "proximalgalerkin_amd" / "tables" / "quadrature.json"
     out.write_text(json.dumps(table, indent=1) + "\n")
