@@ -537,10 +537,21 @@ def main():
     smoother = None
     if not sharded and args.degree == 1 and not args.solves_only:
         sm_ms, sm_bytes = problem.smoother_bench(reps=50)
-        smoother = {"kernel": "k_st_smoothR<16,3,POST> on the finest level (three collective-Jacobi sweeps + x + P x_c per launch; the "
-                              "time-dominant kernel of the solve: profiles/r03_bench_2048_trace_by_level.txt)",
+        # the finest level's smoother launch of the single-precision V-cycle (pgx_mg32.hip): D as one float4, vectors as float2 -
+        # 40 B per vertex + the coarse correction; with PGX_MG_F32=0 the fp64 kernel k_st_smoothR (84 B per vertex) is timed instead
+        f32 = sm_bytes < 60.0 * n
+        sm_traffic, sm_src = (None, None)
+        if f32 and N == 2048:
+            tj = _ladder("r04_fsmooth_pmc_traffic.json")
+            if tj and tj.get("cells") == N:
+                sm_traffic = tj["hbm_traffic_bytes_per_launch"]
+                sm_src = {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date", "traffic_over_algorithmic")}
+        smoother = {"kernel": ("k_f_smooth<16,3,...> on the finest level (three collective-Jacobi sweeps on x + P x_c per launch, single "
+                               "precision inside the multigrid preconditioner; the time-dominant kernel of the solve: "
+                               "profiles/r04_bench_2048_trace_by_level.txt)") if f32 else
+                              "k_st_smoothR<16,3,POST> on the finest level (fp64 V-cycle, PGX_MG_F32=0)",
                     "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": sm_traffic, "traffic_source": sm_src,
                     "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
     coarse = None
     if not sharded and args.degree == 1 and not args.solves_only:
@@ -585,7 +596,7 @@ def main():
             name = ("k_bspmv_bal (P2 operator apply: nnz-balanced CSR-stream SpMV of [[aK,M],[M,-D]]; on this uniform mesh K and M are "
                     "read through a one-byte (K,M)-pair dictionary: 13 B per entry instead of 28)")
         traffic, src = pmc_traffic("r03_p2spmv_pmc_traffic.json" if args.degree == 2 else
-                                   {0: "r03_spmv_pmc_traffic.json", 1: "r03_stspmv_pmc_traffic.json"}.get(kind, "none"))
+                                   {0: "r04_spmv_pmc_traffic.json", 1: "r04_stspmv_pmc_traffic.json"}.get(kind, "none"))
         gbs = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -688,7 +699,11 @@ def main():
                 v2, steps2, secs2, detail2 = runs[1]
                 out["cpu_baseline"]["all_cores"] = {"value": v2, "unit": "Newton iterations/s", "cores": threads[1],
                                                     "sample": f"{steps2} Newton step(s) ({secs2:.1f} s), same mesh and code, "
-                                                              f"{threads[1]} BLAS threads", "detail": detail2}
+                                                              f"{threads[1]} BLAS threads", "detail": detail2,
+                                                    "note": "threaded LAPACK/BLAS inside the same multifrontal code (no parallel "
+                                                            "assembly, no tree parallelism beyond BLAS): where it is SLOWER than "
+                                                            "`value` the fronts of this 2-D dissection are too small to feed the "
+                                                            "threads, and the one-thread figure is the stronger CPU baseline"}
             if cpu_n != N or args.degree != 1:
                 ex = extrapolate(v, cpu_n, N, ladder) if ladder else None
                 if ex:
