@@ -1,0 +1,66 @@
+"""The single-precision V-cycle (csrc/pgx_mg32.hip, round 4) in every configuration of its template space that the default path does
+not reach: two sweeps per launch (mg_nu = 4), one launch per leg (mg_nu = 3 / 2: the first launch also restricts), six-sweep
+launches off, the residual + restriction as a launch of its own, single precision on the top levels only (fp64 right-hand side
+down, fp64 correction up in mid-hierarchy), the un-normalised Krylov basis off, stream-synchronising read-backs - each against the
+fp64 cycle of round 3 (PGX_MG_F32=0) AND against the CPU oracle: identical Newton counts, primal field within 1e-10.  The cycle is a
+preconditioner inside FGMRES, so none of these may change what a Newton step computes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DOMAIN = ((-1.0, -1.0), (1.0, 1.0))
+BASE = {"snes_linesearch_type": "none", "snes_rtol": 1e-6, "snes_max_it": 100, "snes_error_if_not_converged": True}
+
+
+def _solve(N, tuning, opts):
+    from proximalgalerkin_amd import _lib, fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    for k, v in tuning.items():
+        _lib.tuning_set(k, v)
+    try:
+        msh = fem.create_rectangle(DOMAIN, (N, N))
+        problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options=dict(BASE, **opts))
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4, verbose=False)
+        x = sol.x.array.copy()
+        problem.close()
+    finally:
+        for k in tuning:
+            _lib.tuning_set(k, None)
+    return x, hist
+
+
+@pytest.fixture(scope="module")
+def reference(require_gpu):
+    """The exact-Newton SuperLU oracle's run at 256^2 (tests/golden/, tools/make_golden_large.py): five single-precision levels above
+    the fused tail, tiles of every kind (interior, frame) on the top ones.  The fp64 cycle of round 3 must reproduce it too."""
+    import pathlib
+
+    g = np.load(pathlib.Path(__file__).parent / "golden" / "obstacle_p1_n256_settingsB_large.npz")
+    N, u_ref, counts = int(g["N"]), g["u_final"], [int(c) for c in g["hist_Newton_steps"]]
+    x64, h64 = _solve(N, {"PGX_MG_F32": 0}, {})
+    assert h64["Newton steps"] == counts
+    assert np.linalg.norm(x64[: len(u_ref)] - u_ref) <= 1e-10 * np.linalg.norm(u_ref)
+    return N, len(u_ref), u_ref, {"Newton steps": counts}
+
+
+@pytest.mark.parametrize("tuning,opts", [
+    ({}, {}),                                                    # default: K = 3 on the big levels, six-sweep launches below 513^2
+    ({}, {"mg_nu": 4}),                                          # two sweeps per launch, two launches per leg
+    ({}, {"mg_nu": 3}),                                          # one launch per leg: the FIRST launch restricts (levels <= 513^2)
+    ({"PGX_F32_RR_MAX": 0}, {"mg_nu": 2}),                       # one two-sweep launch per leg, restriction as its own launch
+    ({"PGX_F32_K6_MAX": 0}, {}),                                 # three sweeps per launch everywhere, fused restriction
+    ({"PGX_F32_K6_MAX": 0, "PGX_F32_RR_MAX": 0}, {}),            # ... and the restriction as its own launch
+    ({"PGX_F32_MIN": 20000}, {}),                                # single precision on 257^2 and 129^2... only: fp64 levels in between
+    ({"PGX_F32_TY": 16}, {}),                                    # 16-row tiles on every level
+    ({"PGX_F32_TY": 8, "PGX_F32_K6_MAX": 0}, {}),                # 8-row tiles
+    ({"PGX_LAZY_NORM": 0}, {}),                                  # Krylov vectors normalised in place
+    ({"PGX_HOST_POLL": 0}, {}),                                  # read-backs through hipMemcpyAsync + hipStreamSynchronize
+    ({"PGX_SPMV_D4": 0}, {}),                                    # operator apply from the four D arrays
+    ({"PGX_MG_MIN_NX": 2}, {}),                                  # 3 x 3 coarsest grid (round 3)
+])
+def test_single_precision_cycle_variants_match_the_oracle(reference, tuning, opts):
+    N, n, x_ref, h_ref = reference
+    x, h = _solve(N, tuning, opts)
+    assert h["Newton steps"] == h_ref["Newton steps"], (tuning, opts)
+    assert np.linalg.norm(x[:n] - x_ref[:n]) <= 1e-10 * np.linalg.norm(x_ref[:n]), (tuning, opts)
