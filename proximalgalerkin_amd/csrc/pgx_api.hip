@@ -66,6 +66,7 @@ struct pgx_handle {
   size_t fill_lds = 0;
   double *Kv = nullptr, *Mv = nullptr, *Dv = nullptr;
   bool jac_valid = false;
+  bool dv_lean = false;  // the interior rows of the CSR D values are stale (residual_dev(with_d = 2)); a full fill clears it
   // operator of the solution space (aliases the P1 arrays above for degree 1)
   int32_t *s_rowptr = nullptr, *s_colm = nullptr;
   double *s_K = nullptr, *s_M = nullptr, *s_D = nullptr;
@@ -105,6 +106,7 @@ struct pgx_handle {
   unsigned long long* h_seq = nullptr;        // sequence word behind the payload (host view / device view)
   unsigned long long* h_seq_dev = nullptr;
   unsigned long long seq = 0;
+  int lean_d = 1;           // PGX_LEAN_D=0: the Newton loop always writes the CSR form of D(psi) as well
   int spmv_d4 = 1;          // PGX_SPMV_D4=0: the matrix-free operator apply reads the four D arrays instead of its double4 copy
   int lazy_norm = 1;        // PGX_LAZY_NORM=0: every new Krylov vector is normalised in place (one more pass over it per iteration)
   double rhs_scale = 1.0;   // factor the next level-0 V-cycle applies to its fp64 right-hand side as it reads it (lazy normalisation)
@@ -1111,6 +1113,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_HOST_POLL")) h->host_poll = atoi(e);
   if (const char* e = pgx_tune("PGX_LAZY_NORM")) h->lazy_norm = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_D4")) h->spmv_d4 = atoi(e);
+  if (const char* e = pgx_tune("PGX_LEAN_D")) h->lean_d = atoi(e);
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_MIN")) h->f32_min = atoi(e);
   if (const char* e = pgx_tune("PGX_F32_RR_MAX")) h->f32_rr_max = atoi(e);
@@ -1606,9 +1609,13 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
   }
   // row-parallel, atomic-free, bitwise reproducible; with_d: also fills D(psi) at the same x (Newton driver)
   if (h->resid_grid && h->structured && !h->lev.empty() && h->lev[0].uniform) {  // uniform structured mesh: LDS-staged element blocks
-    pgxk_resid_fill_grid(h->st, with_d, h->lev[0], h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
-                         h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv, with_d);
+    // with_d == 2 (the Newton loop of a handle whose operator apply is matrix-free and whose preconditioner is the multigrid
+    // cycle): the interior rows of D go to the stencil only - their CSR form (56 B per vertex, 235 MB at 2048^2) has no reader
+    // until the next pgx_jacobian_fill / pgx_csr_export, which refill it (jac_valid is dropped at the end of the solve)
+    pgxk_resid_fill_grid(h->st, with_d ? 1 : 0, h->lev[0], h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
+                         h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv, with_d);
     h->dh_interior = with_d != 0;  // the interior rows of the finest D stencil are in place (consumed by jacobian_dev(have_d))
+    if (with_d == 2) h->dv_lean = true;
     return;
   }
   pgxk_resid_fill_p1(h->st, with_d, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
@@ -1631,6 +1638,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
       pgxk_resid_fill_grid(h->st, 1, h->lev[0], h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
                            h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, h->w, h->Dv, 1);
       h->dh_interior = true;
+      h->dv_lean = false;  // a full fill: CSR rows and stencil
       have_d = true;
     } else {
       pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
@@ -2341,7 +2349,9 @@ static int precond(pgx_handle* h, const double* b, double* z, int nu, double ome
 
 // FGMRES(restart) on J dx = b, right-preconditioned by one V-cycle; CGS2 orthogonalisation with
 // batched device dot products; Givens rotations on the host (one small D2H copy + sync per iteration).
-static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts* o, int* its_out, double* relres) {
+// bnorm_known >= 0: the 2-norm of b, already on the host (the Newton driver's |F|: b = -F) - saves a reduction and its read-back
+static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts* o, int* its_out, double* relres,
+                  double bnorm_known = -1.0) {
   const size_t n2 = 2 * (size_t)h->nd;
   // Sharded: the Krylov space lives on OWNED dofs (basis vectors V_j, b, residuals are owned-compact, length nk, so the
   // tuned vector kernels run unchanged and every dot product is "local partial + one all-reduce"); the operators work
@@ -2352,9 +2362,9 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
   // P2: the two-level preconditioner is weaker on the late large-alpha systems (30-60 its): use the full basis
   const int m = (h->degree == 2) ? h->restart : std::min(std::max(o->ksp_restart, 1), h->restart);
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m);
-  double bnorm;
-  int rc = dev_norm(h, b, &bnorm, nk);
-  if (rc) return rc;
+  double bnorm = bnorm_known;
+  int rc = PGX_OK;
+  if (!(bnorm_known >= 0.0) && (rc = dev_norm(h, b, &bnorm, nk))) return rc;
   pgxk_set(h->st, n2, 0.0, x);
   *its_out = 0;
   *relres = 0.0;
@@ -2918,8 +2928,10 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     gather_owned(h, v, h->dist.wc);
     return dev_norm(h, h->dist.wc, out, nk);
   };
+  // matrix-free operator + multigrid preconditioner: nobody reads the CSR form of D inside this solve (see residual_dev)
+  const int with_d = (!use_lu && !mg_first && h->degree == 1 && h->structured && h->spmv_stencil == 1 && h->lean_d) ? 2 : 1;
   pgxk_scale_copy(h->st, n2, 1.0, h->x, h->xw);
-  residual_dev(h, h->xw, h->F, 1);
+  residual_dev(h, h->xw, h->F, with_d);
   if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
   if (dist) {
     gather_owned(h, h->F, h->rhs);
@@ -2952,7 +2964,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     if (mg_first && !use_lu) {
       pgx_snes_opts ol = optv;
       ol.ksp_max_it = std::min(optv.ksp_max_it, h->p2_fallback_its);
-      rc = fgmres(h, h->rhs, h->dx, &ol, &kits, &relres);
+      rc = fgmres(h, h->rhs, h->dx, &ol, &kits, &relres, fnorm);
       if (rc) return rc;
       // stagnation = the iteration cap was reached without convergence (an early exit at the attainable accuracy, a few 1e-10
       // after 10-15 iterations on the late systems, is not): factorise, and keep the factorisation for this solve
@@ -2964,11 +2976,11 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
         h->lu_active = true;
         use_lu = true;
         ++h->p2_fallbacks;
-        rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
+        rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres, fnorm);
         if (rc) return rc;
       }
     } else {
-      rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres);
+      rc = fgmres(h, h->rhs, h->dx, opts, &kits, &relres, fnorm);
       if (rc) return rc;
     }
     lin += kits;
@@ -2980,7 +2992,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
     }
     pgxk_axpy(h->st, n2, 1.0, h->dx, h->xw);
     if (dist && (rc = halo_solution(h, h->xw, h->xw + h->nd))) return rc;
-    residual_dev(h, h->xw, h->F, 1);
+    residual_dev(h, h->xw, h->F, with_d);
     if ((rc = replica_check(h, h->F, n2, "the residual"))) return rc;
     if (dist) {
       gather_owned(h, h->F, h->rhs);
@@ -3012,7 +3024,7 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   if (rsn > 0) pgxk_scale_copy(h->st, n2, 1.0, h->xw, h->x);
   // the last residual evaluation refreshed D(psi) at the final iterate on the finest level only (k_resid_fill_grid writes
   // the interior rows of its stencil in passing): the hierarchy no longer describes ONE matrix until the next fill
-  if (h->dh_interior) h->jac_valid = false;
+  if (h->dh_interior || h->dv_lean) h->jac_valid = false;
   HIPCHK(hipStreamSynchronize(h->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the solve must not pass silently
   if (h->prof) h->ms[7] += scope.stop();

@@ -227,6 +227,7 @@ void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_
                           const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                           const double* coords, const uint8_t* mask, const double* gbc, const double* bphi, const double* x,
                           const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout, int write_sh);
+// write_sh: 0 = CSR rows only; 1 = CSR rows + the half-stencil L.Dh of the interior; 2 = half-stencil only (interior CSR rows NOT written)
 // CGS2 with fused passes: (w' = w - V h1; [h2; |w'|^2] = [V,w']^T w') in one pass, then v = (w' - V h2)*scale
 void pgxk_axpy_dot(hipStream_t st, size_t len, int nv, const double* V, size_t ldv, const double* h1, double* w,
                    double* partials, double* out);

@@ -383,14 +383,16 @@ __global__ void __launch_bounds__(PGX_RF_TX * PGX_RF_TY) k_resid_fill_grid(
   const double dN = adet * (nwl[5] + neu[4]);   // NW-LR (1,2), NE-UL (0,2)
   const double dNE = adet * (nel[4] + neu[3]);  // NE-LR (0,2), NE-UL (0,1)
   if (WRITE_D) {
-    double* d = Dout + rowptr[v];
-    d[0] = dSW;
-    d[1] = dS;
-    d[2] = dW;
-    d[3] = dC;
-    d[4] = dE;
-    d[5] = dN;
-    d[6] = dNE;
+    if (Dout) {  // nullptr: the Newton loop of a matrix-free handle - nobody reads the CSR form of the interior rows (56 B per vertex)
+      double* d = Dout + rowptr[v];
+      d[0] = dSW;
+      d[1] = dS;
+      d[2] = dW;
+      d[3] = dC;
+      d[4] = dE;
+      d[5] = dN;
+      d[6] = dNE;
+    }
     if (Sh) {  // the multigrid's half-stored stencil of the same row: centre + the three forward links
       Sh[v] = (dsten_t)dC;
       Sh[(size_t)n + v] = (dsten_t)dE;
@@ -444,7 +446,7 @@ void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_
   const StConst sc = make_stconst(L);
   if (write_d)
     hipLaunchKernelGGL(k_resid_fill_grid<true>, dim3(ntx * nty), dim3(PGX_RF_TX * PGX_RF_TY), 0, st, L.nx, L.ny, n, rowptr, coords,
-                       mask, gbc, bphi, x, xk, alpha, f, q, sc, F, Dout, write_sh ? L.Dh : nullptr);
+                       mask, gbc, bphi, x, xk, alpha, f, q, sc, F, write_sh == 2 ? nullptr : Dout, write_sh ? L.Dh : nullptr);
   else
     hipLaunchKernelGGL(k_resid_fill_grid<false>, dim3(ntx * nty), dim3(PGX_RF_TX * PGX_RF_TY), 0, st, L.nx, L.ny, n, rowptr, coords,
                        mask, gbc, bphi, x, xk, alpha, f, q, sc, F, Dout, nullptr);
