@@ -20,7 +20,8 @@
 
 #define F32_BLOCK 512
 // A/B switches of the interior tiles, both measured slower at 2049^2 and off: F32_WAVES_EU = 8 (a fourth workgroup per CU by a 64-VGPR
-// cap: 12-28 B of scratch per lane, level-0 launches +20 %) and F32_LEAN (the 2x2 block inverse recomputed per sweep: +1 %)
+// cap: 12-28 B of scratch per lane, level-0 launches +20 %) and F32_LEAN (the 2x2 block inverse recomputed per sweep: +1 %).
+// 32-row tiles (halo 1.31 instead of 1.52, but 94 VGPRs = two workgroups per CU) were +15 % and are not instantiated.
 #ifndef F32_LEAN
 #define F32_LEAN 0
 #endif
@@ -515,7 +516,7 @@ __device__ __forceinline__ void f_smooth_bnd(int b, const FSmoothArgs& A, float2
 // ONE launch per smoother call: blocks [0, nbnd) are the boundary sub-tiles - they start first, so their long dependent-load
 // chains overlap with the interior tiles that follow - blocks [nbnd, nbnd + nfast) the interior tiles.
 template <int TY, int K, bool FIRST, int IO, int CADD, int RR>
-__global__ void __launch_bounds__(F32_BLOCK, (RR || TY > 16) ? 2 : F32_WAVES_EU) k_f_smooth(const FSmoothArgs A) {
+__global__ void __launch_bounds__(F32_BLOCK, RR ? 2 : F32_WAVES_EU) k_f_smooth(const FSmoothArgs A) {
   constexpr int W = 64, H0 = TY + 2 * (K + (RR ? 2 : 0)), PAD = W + 1;
   __shared__ float2 img_[3][H0 * W + 2 * PAD];  // guard bands: inactive edge lanes read (and discard) one entry outside a row;
                                                  // [2]: the (D(0,+1), D(+1,+1)) links every image row hands to the row above it
@@ -589,7 +590,7 @@ static void launch_f_smooth(hipStream_t st, int first, FSmoothArgs& A, int fast_
 static int f32_tile_rows(const GridLevel& L) {
   static PgxTuneInt t_ty("PGX_F32_TY", 0);
   const int ty = t_ty.get();
-  if (ty == 4 || ty == 8 || ty == 16 || ty == 32) return ty;
+  if (ty == 4 || ty == 8 || ty == 16) return ty;
   return L.n >= 2000000 ? 16 : L.n >= 500000 ? 8 : 4;  // as k_st_smoothR (measured there per level size)
 }
 
@@ -653,8 +654,6 @@ void pgxk_f_smooth(hipStream_t st, int K, int first, const GridLevel& L, double 
       launch_f_smooth<4, 3>(st, first, A, L.interior_free);
     else if (ty == 8)
       launch_f_smooth<8, 3>(st, first, A, L.interior_free);
-    else if (ty == 32)
-      launch_f_smooth<32, 3>(st, first, A, L.interior_free);
     else
       launch_f_smooth<16, 3>(st, first, A, L.interior_free);
   } else {
