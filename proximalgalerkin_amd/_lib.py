@@ -169,6 +169,21 @@ class pgx_qvi_problem(C.Structure):  # include/pgx_qvi.h
     ]
 
 
+class pgx_ic_problem(C.Structure):  # include/pgx_ic.h
+    _fields_ = [
+        ("n_vertices", C.c_int32),
+        ("x", c_double_p),
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("phi0_q", c_double_p),
+        ("phi_q", c_double_p),
+        ("c", C.c_double),
+        ("n_bc", C.c_int32),
+        ("bc_dofs", c_int32_p),
+    ]
+
+
 class pgx_partition(C.Structure):
     _fields_ = [
         ("rank", C.c_int32),
@@ -308,6 +323,26 @@ SYMBOLS = [
      [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pgx_qvi_h1_increment", C.c_int, [_H, c_double_p]),
     ("pgx_qvi_profile", C.c_int, [_H, C.c_int, c_double_p]),
+    # example 08: intersecting constraints (include/pgx_ic.h)
+    ("pgx_ic_create", C.c_int, [C.POINTER(pgx_ic_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_ic_destroy", None, [_H]),
+    ("pgx_ic_last_error", C.c_char_p, [_H]),
+    ("pgx_ic_num_dofs", C.c_int, [_H, c_int64_p]),
+    ("pgx_ic_set_state", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_get_state", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_set_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_get_prev", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_advance_prev", C.c_int, [_H]),
+    ("pgx_ic_set_alpha", C.c_int, [_H, C.c_double]),
+    ("pgx_ic_set_phi", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_residual", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("pgx_ic_jacobian_fill", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_csr_export", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_double_p]),
+    ("pgx_ic_spmv", C.c_int, [_H, c_double_p, c_double_p]),
+    ("pgx_ic_newton_solve", C.c_int,
+     [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pgx_ic_l2_increment", C.c_int, [_H, c_double_p]),
+    ("pgx_ic_profile", C.c_int, [_H, C.c_int, c_double_p]),
 ]
 
 _lib = None

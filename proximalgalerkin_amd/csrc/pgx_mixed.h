@@ -155,7 +155,7 @@ static __global__ void k_mx_axpby(int64_t len, double a, const double* __restric
   if (i < len) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
 
-static void mx_par_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+[[maybe_unused]] static void mx_par_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
   unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (n < 20000) T = 1;
   std::vector<std::thread> th;
@@ -707,6 +707,134 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
       double xnorm;
       if ((rc = mx_norm(h, h->xw, &xnorm))) return rc;
       if (lam * ynorm < opts->snes_stol * xnorm)
+        rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
+      else if (fnorm > opts->snes_divtol * fnorm0)
+        rsn = PGX_SNES_DIVERGED_DTOL;
+    }
+  }
+  if (rsn > 0) MXHIP(hipMemcpyAsync(h->x, h->xw, bytes, hipMemcpyDeviceToDevice, h->st));
+  MXHIP(hipStreamSynchronize(h->st));
+  MXHIP(hipGetLastError());
+  if (h->prof) h->ms[5] += scope.stop();
+  *reason = rsn;
+  if (its_out) *its_out = its;
+  if (lin_out) *lin_out = lin;
+  return PGX_OK;
+}
+
+// SNES newtonls with the `l2` line search (examples/08_intersecting_constraints/intersecting_constraints_dolfinx.py:66-79:
+// snes_linesearch_type l2, maxlambda 1): restates PETSc's SNESLineSearchApply_L2 [upstream, recalled; the same restatement as
+// oracle/ic_oracle.py::newton_l2] - |F|^2 sampled at lambda_old = 0, the midpoint and lambda = 1, ONE secant step on its
+// derivative (PETSc's default max_it of this search), the update kept only inside [steptol, maxlambda] = [1e-12, 1]; a non-finite
+// end-point residual halves lambda.  The update is x - lambda y with y = J^{-1} F.
+static int mx_newton_solve_l2(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
+  if (!opts || !reason) return PGX_EINVAL;
+  PgxSolveScope scope(h->st, h->prof, nullptr);
+  PgxRange range("pgx:newton_solve");
+  const size_t bytes = sizeof(double) * h->ntot;
+  const double steptol = 1e-12, maxlambda0 = 1.0;
+  int its = 0, lin = 0, rsn = 0, rc = PGX_OK;
+  double fnorm = 0, fnorm0 = 0;
+  h->stale_failed = false;
+  MXHIP(hipMemcpyAsync(h->xw, h->x, bytes, hipMemcpyDeviceToDevice, h->st));
+  h->residual_dev(h->xw, h->F);
+  if ((rc = mx_norm(h, h->F, &fnorm))) return rc;
+  fnorm0 = fnorm;
+  if (opts->monitor) printf("  0 SNES Function norm %.12e\n", fnorm);
+  if (!std::isfinite(fnorm))
+    rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+  else if (fnorm < opts->snes_atol)
+    rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+  const double ttol = fnorm * opts->snes_rtol;
+  auto trial = [&](double l, double* g) -> int {  // z = xw - l y ; r = F(z) ; g = |r|^2
+    mx_axpby(h, 1.0, h->xw, 0.0, h->z);
+    mx_axpby(h, -l, h->dx, 1.0, h->z);
+    h->residual_dev(h->z, h->r);
+    double gn = 0;
+    const int r2 = mx_norm(h, h->r, &gn);
+    *g = gn * gn;
+    return r2;
+  };
+  while (rsn == 0) {
+    if (its >= opts->snes_max_it) {
+      rsn = PGX_SNES_DIVERGED_MAX_IT;
+      break;
+    }
+    h->jacobian_dev(h->xw);
+    {
+      MxTimer t(h, 2);
+      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+    }
+    if (rc) {
+      h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
+      return rc;
+    }
+    int ns = 0;
+    double relres = 0;
+    if ((rc = mx_linear_solve(h, h->F, h->dx, opts, &ns, &relres))) return rc;
+    lin += ns;
+    ++its;
+    if (opts->monitor) printf("    KSP (LU + %d refinement solves)  true rel residual %.3e\n", ns - 1, relres);
+    bool lin_ok = false;
+    if ((rc = mx_linear_solve_ok(h, h->F, h->dx, relres, &lin_ok))) return rc;
+    if (!lin_ok) {
+      rsn = PGX_SNES_DIVERGED_LINEAR_SOLVE;
+      break;
+    }
+    double lam = 1.0, lam_old = 0.0, maxl = maxlambda0, fn_old = fnorm * fnorm, fm = 0, fe = 0;
+    double lam_mid = 0.5 * (lam + lam_old);
+    bool failed = false;
+    for (int i = 0; i < 1; ++i) {  // -snes_linesearch_max_it of l2: 1
+      while (true) {
+        if ((rc = trial(lam_mid, &fm))) return rc;
+        if ((rc = trial(lam, &fe))) return rc;
+        if (std::isfinite(fe)) break;
+        if (lam <= steptol) {
+          failed = true;
+          break;
+        }
+        maxl = 0.95 * lam;
+        lam = 0.5 * (lam + lam_old);
+        lam_mid = 0.5 * (lam + lam_old);
+      }
+      if (failed) break;
+      const double dl = lam - lam_old;
+      const double d1 = (3.0 * fe - 4.0 * fm + fn_old) / dl, d1_old = (-3.0 * fn_old + 4.0 * fm - fe) / dl;
+      const double d2 = (d1 - d1_old) / dl;
+      double upd;
+      if (d2 > 0.0)
+        upd = lam - d1 / d2;
+      else if (d2 < 0.0)
+        upd = lam + d1 / d2;
+      else
+        break;
+      if (upd < steptol) upd = 0.5 * (lam + lam_old);
+      if (!std::isfinite(upd) || upd > maxl) break;
+      lam_old = lam, lam = upd, fn_old = fe;
+      lam_mid = 0.5 * (lam + lam_old);
+    }
+    if (failed) {
+      rsn = PGX_SNES_DIVERGED_LINE_SEARCH;
+      break;
+    }
+    double g = 0;
+    if ((rc = trial(lam, &g))) return rc;
+    MXHIP(hipMemcpyAsync(h->xw, h->z, bytes, hipMemcpyDeviceToDevice, h->st));
+    MXHIP(hipMemcpyAsync(h->F, h->r, bytes, hipMemcpyDeviceToDevice, h->st));
+    fnorm = std::sqrt(g);
+    if (opts->monitor > 1) printf("      line search: lambda %.6e\n", lam);
+    if (opts->monitor) printf("  %d SNES Function norm %.12e\n", its, fnorm);
+    if (!std::isfinite(fnorm)) {
+      rsn = PGX_SNES_DIVERGED_FNORM_NAN;
+    } else if (fnorm < opts->snes_atol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_ABS;
+    } else if (fnorm <= ttol) {
+      rsn = PGX_SNES_CONVERGED_FNORM_RELATIVE;
+    } else {
+      double xnorm, ynorm;
+      if ((rc = mx_norm(h, h->dx, &ynorm))) return rc;
+      if ((rc = mx_norm(h, h->xw, &xnorm))) return rc;
+      if (ynorm < opts->snes_stol * xnorm)
         rsn = PGX_SNES_CONVERGED_SNORM_RELATIVE;
       else if (fnorm > opts->snes_divtol * fnorm0)
         rsn = PGX_SNES_DIVERGED_DTOL;

@@ -249,6 +249,55 @@ def create_unit_square(nx, ny, cell_type="triangle"):
     return create_rectangle(((0.0, 0.0), (1.0, 1.0)), (nx, ny))
 
 
+class IntervalMesh:
+    """dolfinx.mesh.create_unit_interval / create_interval (intersecting_constraints_dolfinx.py:13): vertices in increasing order,
+    cell e joins vertices e and e + 1 - the topology include/pgx_ic.h takes.  `geometry` is (nv, 1) like DOLFINx's for gdim 1."""
+
+    def __init__(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        if len(x) < 2 or not np.all(np.diff(x) > 0):
+            raise ValueError("an interval mesh needs at least two strictly increasing vertex coordinates")
+        self.geometry = x.reshape(-1, 1)
+        self.cells = np.stack([np.arange(len(x) - 1), np.arange(1, len(x))], axis=1).astype(np.int32)
+        self.structured = None
+        self.partition = None
+
+    @property
+    def num_vertices(self):
+        return self.geometry.shape[0]
+
+    @property
+    def num_cells(self):
+        return self.cells.shape[0]
+
+    def cell_name(self):
+        return "interval"
+
+    def exterior_vertices(self):
+        return np.array([0, self.num_vertices - 1], dtype=np.int32)
+
+    def exterior_dofs(self, degree):
+        if degree != 1:
+            raise NotImplementedError("P1 on the interval")
+        return self.exterior_vertices()
+
+
+def create_interval(n, points=(0.0, 1.0)):
+    return IntervalMesh(np.linspace(float(points[0]), float(points[1]), int(n) + 1))
+
+
+def create_unit_interval(n):
+    return create_interval(n, (0.0, 1.0))
+
+
+def interval_quadrature(degree):
+    """Basix's default rule for `degree` on the interval - Gauss-Jacobi with (degree + 2) // 2 points, i.e. Gauss-Legendre - on
+    (0, 1) with weights summing to 1."""
+    m = (int(degree) + 2) // 2
+    t, w = np.polynomial.legendre.leggauss(m)
+    return np.ascontiguousarray(0.5 * (t + 1.0)), np.ascontiguousarray(0.5 * w)
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass(frozen=True)
 class FunctionSpace:

@@ -592,6 +592,19 @@ def _gradient_constraint_template(degree, roles_present):
     return F
 
 
+def _intersecting_template(degree, roles_present):
+    """The residual of intersecting_constraints_dolfinx.py:47-58 in terms of roles: alpha dE/dz + example 01's latent rows for psi0
+    + example 06's for psi (compose(), below); phi0 and phi are DATA - expressions of the coordinates, lifted by lift_data()."""
+    u, psi0, v, w0, psi0_iter = (_role(n) for n in ("u", "psi0", "v", "w0", "psi0_iter"))
+    psi, w, psi_iter = _role("psi", 1), _role("w", 1), _role("psi_iter", 1)
+    alpha, c, phi0, phi = (_role(n) for n in ("alpha", "c", "phi0", "phi"))
+    dx = Measure("dx", metadata={"quadrature_degree": degree} if degree is not None else None)
+    primal = alpha * inner(grad(u), grad(v)) * dx
+    if "c" in roles_present:
+        primal = primal + alpha * c * v * dx
+    return compose(primal, [("exp", u, psi0, psi0_iter, v, w0, phi0, dx), ("hellinger", u, psi, psi_iter, v, w, phi, dx)])
+
+
 @dataclass
 class GradientConstraintSpec:
     """Example 06 (gradient_constraint_dolfinx.py:38-107): sol = (u, psi) in [P_k, (P_{k-1})^2], previous iterate w0, bound phi and
@@ -617,6 +630,127 @@ class ThermoformingSpec:
     bound1: fem.Constant
     eps: fem.Constant | None
     quadrature_degree: int | None
+
+
+@dataclass
+class IntersectingSpec:
+    """Example 08 (intersecting_constraints_dolfinx.py:13-58): z = (u, psi0, psi) in [P1, P1, (P1)^gdim], previous proximal iterate
+    z_iter, the Constant c of the energy (None: absent), obstacle phi0 and gradient bound phi as DataExpressions (sampled at the
+    quadrature points at every solve: their Constants - `phic` - stay live)."""
+    z: fem.Function
+    z_iter: fem.Function
+    alpha: fem.Constant
+    c: fem.Constant | None
+    phi0: "DataExpression"
+    phi: "DataExpression"
+    quadrature_degree: int | None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data expressions: sub-expressions of the coordinates and Constants only (phi0, phi of example 08)
+# ---------------------------------------------------------------------------------------------------------------------
+class DataExpression:
+    """A maximal sub-expression of a form that depends on the spatial coordinates (and Constants) only.  The families treat it as a
+    coefficient; the host evaluates it where the kernels need it (FFCx would inline it into the generated element kernel)."""
+
+    def __init__(self, expr: Expr, mesh):
+        self.expr, self.mesh = expr, mesh
+
+    def __call__(self, x):
+        """x: (gdim, npts) like a dolfinx interpolation callable -> (npts,)"""
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(all="ignore"):  # both branches of a conditional are evaluated
+            v = _evaluate(self.expr, x)
+        return np.broadcast_to(np.asarray(v, dtype=np.float64), x.shape[1:]).copy()
+
+
+def _evaluate(e, x):
+    if isinstance(e, Number):
+        return e.v
+    if isinstance(e, Terminal):
+        if e.kind == "coordinate":
+            return x[e.index]
+        if e.kind == "constant" and e.rank == 0:
+            return float(e.obj.value)
+        raise NotImplementedError(f"a {e.kind} terminal inside a data expression")
+    if isinstance(e, Sum):
+        return _evaluate(e.a, x) + _evaluate(e.b, x)
+    if isinstance(e, Scaled):
+        return e.c * _evaluate(e.a, x)
+    if isinstance(e, Product):
+        return _evaluate(e.a, x) * _evaluate(e.b, x)
+    if isinstance(e, Division):
+        return _evaluate(e.a, x) / _evaluate(e.b, x)
+    if isinstance(e, Func):
+        a = [_evaluate(q, x) for q in e.args]
+        if e.name == "conditional":
+            return np.where(a[0], a[1], a[2])
+        fn = {"exp": np.exp, "sqrt": np.sqrt, "sin": np.sin, "abs": np.abs, "max_value": np.maximum, "lt": np.less,
+              "le": np.less_equal, "gt": np.greater, "ge": np.greater_equal}.get(e.name)
+        if fn is None:
+            raise NotImplementedError(f"{e.name} in a data expression")
+        return fn(*a)
+    raise NotImplementedError(f"{type(e).__name__} in a data expression")
+
+
+def lift_data(F: Form):
+    """-> (form with every maximal coordinate-dependent data sub-expression replaced by a 'coefficient' Terminal whose object is a
+    DataExpression, list of those DataExpressions).  Identical sub-expression OBJECTS share one placeholder."""
+    kinds = {}
+
+    def data_kind(e):  # 0: not data; 1: data without a coordinate (numbers, Constants); 2: data that varies in space
+        k = kinds.get(id(e))
+        if k is not None:
+            return k
+        if isinstance(e, Number):
+            k = 1
+        elif isinstance(e, Terminal):
+            k = 2 if e.kind == "coordinate" else 1 if (e.kind == "constant" and e.rank == 0) else 0
+        elif isinstance(e, (Sum, Product, Division)):
+            ka, kb = data_kind(e.a), data_kind(e.b)
+            k = 0 if 0 in (ka, kb) else max(ka, kb)
+        elif isinstance(e, Scaled):
+            k = data_kind(e.a)
+        elif isinstance(e, Func):
+            ks = [data_kind(a) for a in e.args]
+            k = 0 if 0 in ks else max(ks)
+        else:
+            k = 0
+        kinds[id(e)] = k
+        return k
+
+    lifted, by_id = [], {}
+
+    def walk(e):
+        if data_kind(e) == 2:
+            t = by_id.get(id(e))
+            if t is None:
+                mesh = next(q.obj for q in _walk_terminals(e) if q.kind == "coordinate")
+                d = DataExpression(e, mesh)
+                lifted.append(d)
+                t = by_id[id(e)] = Terminal("coefficient", d)
+            return t
+        if isinstance(e, (Sum, Product, Division, Inner)):
+            return type(e)(walk(e.a), walk(e.b))
+        if isinstance(e, Scaled):
+            return Scaled(e.c, walk(e.a))
+        if isinstance(e, (Grad, Sym, Tr)):
+            return type(e)(walk(e.a))
+        if isinstance(e, Func):
+            return Func(e.name, *[walk(a) for a in e.args])
+        return e
+
+    return Form([Integral(walk(it.integrand), it.measure, it.scale) for it in F.integrals]), lifted
+
+
+def _walk_terminals(e):
+    if isinstance(e, Terminal):
+        yield e
+    for a in ("a", "b"):
+        if isinstance(getattr(e, a, None), Expr):
+            yield from _walk_terminals(getattr(e, a))
+    for a in getattr(e, "args", ()):
+        yield from _walk_terminals(a)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -686,6 +820,11 @@ _FAMILIES = [
          required=("alpha",), optional=(), coefs=("phi", "f"), quads=0, needs_degree=True, template=_gradient_constraint_template,
          text="alpha*inner(grad(u),grad(v)) + inner(psi,grad(v)) - alpha*f*v - inner(psi0,grad(v)) + inner(grad(u),w) "
               "- phi*dot(psi,w)/sqrt(1+dot(psi,psi))"),
+    # two latent variables on one primal field; phi0 and phi are data expressions lifted to coefficients (compile_form)
+    dict(name="intersecting constraints (example 08)", comps=("u", "psi0", "psi"), prev=("u_iter", "psi0_iter", "psi_iter"),
+         args=("v", "w0", "w"), ranks=(0, 0, 1), required=("alpha",), optional=("c",), coefs=("phi0", "phi"), quads=0,
+         needs_degree=False, template=_intersecting_template,
+         text="alpha*(inner(grad(u),grad(v)) + c*v) + exp_latent_rows(u, psi0; phi0) + hellinger_latent_rows(u, psi; phi)"),
 ]
 
 
@@ -770,7 +909,22 @@ def compile_form(F: Form, u: fem.Function, J=None):
     derivative) or ThermoformingSpec (example 05, G may carry the -eps/alpha (grad psi, grad w) modification)."""
     from .problem import ObstacleResidual
 
-    fam, r, degree = _match(F, u)
+    try:
+        fam, r, degree = _match(F, u)
+    except NotImplementedError as first:
+        # expressions of the coordinates that no family spells out (example 08's phi0, phi): lift them to coefficients, match again
+        Fl, lifted = lift_data(F) if isinstance(F, Form) else (F, [])
+        if not lifted:
+            raise
+        try:
+            fam, r, degree = _match(Fl, u)
+        except NotImplementedError:
+            raise first from None
+    if fam["name"].startswith("intersecting"):
+        if J is not None and getattr(J, "form", None) is not F:
+            raise NotImplementedError("example 08 passes no Jacobian form: NonlinearProblem differentiates F "
+                                      "(intersecting_constraints_dolfinx.py:75-77)")
+        return IntersectingSpec(u, r["previous"], r["alpha"], r.get("c"), r["phi0"], r["phi"], degree)
     G = None
     if J is not None:
         if not (hasattr(J, "form") and hasattr(J, "u")) or J.u is not u:
