@@ -95,6 +95,7 @@ struct pgx_handle {
   void* pinv = nullptr;  // patch inverses: float by default (a smoother inside FGMRES: same Krylov counts as double at 512^2 ... 2048^2,
                          // half the bytes of the stream that bounds the sweep), double with the tuning key PGX_P2_PATCH_F32=0
   int patch_f32 = 1;
+  int patch_sym = 1;     // float inverses in symmetric packing (pgx_patch.hip: 512 instead of 896 B per patch); PGX_P2_PATCH_SYM=0: full rows
   double *p2_su = nullptr, *p2_sp = nullptr;
   // state
   double *x = nullptr, *xk = nullptr, *F = nullptr, *dx = nullptr, *xw = nullptr, *rhs = nullptr;
@@ -1095,6 +1096,8 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH_NU")) h->patch_nu = std::max(1, atoi(e));
   if (const char* e = pgx_tune("PGX_P2_PATCH_OMEGA")) h->patch_omega = atof(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_F32")) h->patch_f32 = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_PATCH_SYM")) h->patch_sym = atoi(e);
+  if (!h->patch_f32) h->patch_sym = 0;
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
     const char* e = pgx_tune("PGX_TAIL2");  // 0: the round-2 tail kernels (A/B)
@@ -2049,13 +2052,13 @@ static void scatter_owned(pgx_handle* h, const double* cmp, double* loc) {
 // the P1 subspace with its full multigrid hierarchy (one V-cycle); T = P1->P2 interpolation.
 // Patch data of the P2 level: tables on first use, inverses once per Jacobian (alpha and D(psi) change every Newton step)
 static int ensure_patches(pgx_handle* h) {
-  const int NN = h->patch_nn, nv = h->n, nd = h->nd, P = 2 * NN;
+  const int NN = h->patch_nn, nv = h->n, nd = h->nd;
   if (!h->pdof) {
     DALLOC(h->pdof, (size_t)nv * NN);
     DALLOC(h->ppos, (size_t)nv * NN * NN);
     {
       uint8_t* q = nullptr;
-      DALLOC(q, (size_t)nv * P * (4 * ((P + 3) / 4)) * (h->patch_f32 ? sizeof(float) : sizeof(double)));  // rows padded to 4-vectors
+      DALLOC(q, pgxk_patch_inverse_bytes(nv, NN, h->patch_f32, h->patch_sym));
       h->pinv = q;
     }
     DALLOC(h->p2_su, (size_t)2 * (nd - nv));
@@ -2065,7 +2068,7 @@ static int ensure_patches(pgx_handle* h) {
     pgxk_patch_positions(h->st, nv, NN, h->pdof, h->s_rowptr, h->s_colm, h->ppos);
   }
   if (!h->patch_fresh) {
-    pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv, h->patch_f32);
+    pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv, h->patch_f32, h->patch_sym);
     h->patch_fresh = true;
   }
   return PGX_OK;
@@ -2084,7 +2087,7 @@ static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, d
                  h->p2_ru, h->p2_rp);
   };
   auto patch = [&](const double* ru, const double* rp) {
-    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, h->patch_sym, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
   };
   hipMemsetAsync(xu, 0, sizeof(double) * nd, h->st);
   hipMemsetAsync(xp, 0, sizeof(double) * nd, h->st);
@@ -2126,7 +2129,7 @@ static int pcycle_p2_patch_dist(pgx_handle* h, double* bu, double* bp, double* x
     xv -= 1;
   };
   auto patch = [&](const double* ru, const double* rp) {
-    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
+    pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, h->patch_sym, ru, rp, h->patch_omega, xu, xp, h->p2_su, h->p2_sp);
     xv -= 1;
   };
   if (!h->s_blk) {

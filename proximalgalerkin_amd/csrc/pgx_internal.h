@@ -214,10 +214,11 @@ void pgxk_observables_final_raw(hipStream_t st, int nblocks, const double* parti
 void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* rowptr, const int32_t* colm,
                           int32_t* ppos);
 void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
-                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32);
+                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32, int sym);
 void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
-                      const void* pinv, int f32, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
-                      double* sp);
+                      const void* pinv, int f32, int sym, const double* ru, const double* rp, double omega, double* xu, double* xp,
+                      double* su, double* sp);
+size_t pgxk_patch_inverse_bytes(int np, int NN, int f32, int sym);  // sym: symmetric packing (float form only)
 // fused, atomic-free residual (+ optional D(psi) fill) for P1: see k_resid_fill_p1
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,

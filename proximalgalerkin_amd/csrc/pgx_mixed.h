@@ -727,7 +727,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
 // oracle/ic_oracle.py::newton_l2] - |F|^2 sampled at lambda_old = 0, the midpoint and lambda = 1, ONE secant step on its
 // derivative (PETSc's default max_it of this search), the update kept only inside [steptol, maxlambda] = [1e-12, 1]; a non-finite
 // end-point residual halves lambda.  The update is x - lambda y with y = J^{-1} F.
-static int mx_newton_solve_l2(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
+[[maybe_unused]] static int mx_newton_solve_l2(MixedBase* h, const pgx_snes_opts* opts, int* reason, int* its_out, int* lin_out) {
   if (!opts || !reason) return PGX_EINVAL;
   PgxSolveScope scope(h->st, h->prof, nullptr);
   PgxRange range("pgx:newton_solve");

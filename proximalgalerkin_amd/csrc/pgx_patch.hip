@@ -10,12 +10,14 @@
 // (an edge dof belongs to the patches of its two end vertices).
 //
 // Data (per handle, HBM): pdof [np][NN] patch dofs (-1 = unused slot), ppos [np][NN][NN] positions of the patch's scalar-block
-// entries in the P2 block-CSR (-1 = structurally zero), pinv [np][P/4][P][4] (P = 2 NN) the inverses of the patch matrices (rows in 4-vectors),
+// entries in the P2 block-CSR (-1 = structurally zero), pinv (P = 2 NN) the inverses of the patch matrices in 4-vectors - symmetric packing
+// [np][chunk q][rows 4q..P-1][4] by default, the full [np][P/4][P][4] behind PGX_P2_PATCH_SYM=0 and for the double form -,
 // rebuilt once per Newton step (only D(psi) and alpha change); computed in double, STORED in float by default (the sweep is a
 // smoother inside FGMRES: identical Krylov counts, half the stream).  At 2048^2 P2: 4.2 M patches, 3.8 GB of inverses.
 //
 // Mapping: a group of 16 lanes owns one patch, lane l its row l (four patches per 64-wide wavefront); rows meet through
-// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 896 B per patch and sweep (1792 B in double).
+// width-16 shuffles.  The kernels are streaming kernels over pinv (HBM-bound): 512 B per patch and sweep (packed float; 896 B full
+// float, 1792 B in double).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,7 +50,13 @@ __global__ void __launch_bounds__(256) k_patch_positions(int np, int NN, const i
 // (the contract of src/lvpp/problem.py:69-77) and unused slots as identity, inverted in place by Gauss-Jordan WITHOUT pivoting:
 // u rows first (aK_pp is SPD), then the psi rows whose Schur complement -D_pp - M_pp (aK_pp)^-1 M_pp is negative definite - the
 // quasi-definite ordering that pgx_nd relies on as well.
-template <int NN, typename PT>
+// Symmetric packing (round 4): the patch matrix and hence its inverse are symmetric, so only the 4-column chunks at or left of a
+// row's diagonal block are kept - chunk q holds rows 4q .. P-1: [patch][q][row - 4q][4], 32 instead of 56 4-vectors at P = 14
+// (512 instead of 896 B per patch and sweep in float), 40 instead of 64 at P = 16.
+__host__ __device__ constexpr int patch_sym_off(int P, int q) { return q * P - 2 * q * (q - 1); }  // in 4-vectors
+__host__ __device__ constexpr int patch_sym_vecs(int P) { return patch_sym_off(P, (P + 3) / 4); }
+
+template <int NN, typename PT, bool SYM>
 __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __restrict__ pdof, const int32_t* __restrict__ ppos,
                                                       const double* __restrict__ K, const double* __restrict__ M,
                                                       const double* __restrict__ D, const uint8_t* __restrict__ mask, double alpha,
@@ -111,14 +119,17 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
   if (live && l < P) {
     // layout [patch][chunk of 4 columns][row l][4]: a lane stores (and k_patch_apply loads) its row as PQ 4-vectors, and the lanes of
     // a group touch 4 P consecutive values per instruction
-    PT* out = pinv + (size_t)p * PQ * P * 4 + (size_t)l * 4;
+    typedef PT v4 __attribute__((ext_vector_type(4)));
+    PT* out = pinv + (SYM ? (size_t)p * patch_sym_vecs(P) * 4 : (size_t)p * PQ * P * 4 + (size_t)l * 4);
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
       PT v[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[t] = (4 * q + t < P) ? (PT)a[4 * q + t] : (PT)0;
-      typedef PT v4 __attribute__((ext_vector_type(4)));
-      *(v4*)(out + (size_t)q * P * 4) = (v4){v[0], v[1], v[2], v[3]};
+      if (!SYM)
+        *(v4*)(out + (size_t)q * P * 4) = (v4){v[0], v[1], v[2], v[3]};
+      else if (4 * q <= l)
+        *(v4*)(out + (size_t)(patch_sym_off(P, q) + l - 4 * q) * 4) = (v4){v[0], v[1], v[2], v[3]};
     }
   }
 }
@@ -126,7 +137,7 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
 // One additive sweep: y_p = A_p^-1 r_p for every patch; the vertex dof of a patch belongs to it alone (x += omega y), an edge dof
 // to the patches of its two end vertices: their contributions are parked in stash[2 e + side] and averaged by k_patch_edges
 // (no atomics: bitwise reproducible).
-template <int NN, typename PT>
+template <int NN, typename PT, bool SYM>
 __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, const int32_t* __restrict__ pdof,
                                                      const int32_t* __restrict__ edge_ends, const PT* __restrict__ pinv,
                                                      const double* __restrict__ ru, const double* __restrict__ rp, double omega,
@@ -141,7 +152,47 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
   int dof = -1;
   double r = 0.0;
   double row[P];
-  if (l < P) {
+  if (SYM) {
+    // packed inverse: a lane loads the chunks at or left of its diagonal block (1 .. 4 16-byte loads), the group rebuilds the full
+    // matrix in LDS - every loaded entry lands at (l, j), those left of the diagonal block at (j, l) as well - and each lane reads
+    // its row back as four 16-byte LDS loads.  (The float form only: the LDS image is float.)
+    constexpr int LD = 4 * PQ + 4;  // 80-byte rows: 16-byte aligned, the 16 rows of a patch on distinct bank groups
+    __shared__ float sA[256 / GRP][P][LD];
+    const int g = threadIdx.x / GRP;
+    typedef PT v4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (l < P) {
+      dof = pdof[(size_t)pp * NN + i];
+      if (dof >= 0) r = (l < NN) ? ru[dof] : rp[dof];
+      const PT* in = pinv + (size_t)pp * patch_sym_vecs(P) * 4;
+      v4 v[PQ];
+#pragma unroll
+      for (int q = 0; q < PQ; ++q)
+        if (4 * q <= l) v[q] = __builtin_nontemporal_load((const v4*)(in + (size_t)(patch_sym_off(P, q) + l - 4 * q) * 4));
+#pragma unroll
+      for (int q = 0; q < PQ; ++q)
+        if (4 * q <= l) {
+          *(f4*)&sA[g][l][4 * q] = (f4){(float)v[q][0], (float)v[q][1], (float)v[q][2], (float)v[q][3]};
+          if (4 * q + 4 <= (l & ~3)) {  // strictly left of the diagonal block: the mirrored entries
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sA[g][4 * q + t][l] = (float)v[q][t];
+          }
+        }
+    }
+    __syncthreads();
+    if (l < P) {
+#pragma unroll
+      for (int q = 0; q < PQ; ++q) {
+        const f4 w = *(const f4*)&sA[g][l][4 * q];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (4 * q + t < P) row[4 * q + t] = (double)w[t];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < P; ++j) row[j] = 0.0;
+    }
+  } else if (l < P) {
     dof = pdof[(size_t)pp * NN + i];
     if (dof >= 0) r = (l < NN) ? ru[dof] : rp[dof];
     // Row l of the inverse as PQ 4-vectors (layout of k_patch_invert): four 16-byte loads per lane, the lanes of a group side by side.
@@ -201,30 +252,36 @@ void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, c
   hipLaunchKernelGGL(k_patch_positions, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, np, NN, pdof, rowptr, colm, ppos);
 }
 
+size_t pgxk_patch_inverse_bytes(int np, int NN, int f32, int sym) {
+  const int P = 2 * NN <= 14 ? 14 : 16;
+  const size_t vecs = sym ? (size_t)patch_sym_vecs(P) : (size_t)P * ((P + 3) / 4);
+  return (size_t)np * vecs * 4 * (f32 ? sizeof(float) : sizeof(double));
+}
+
 void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
-                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32) {
+                       const double* D, const uint8_t* mask, double alpha, void* pinv, int f32, int sym) {
   const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
-#define PGX_INV(N, T) \
-  hipLaunchKernelGGL((k_patch_invert<N, T>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, (T*)pinv)
+#define PGX_INV(N, T, S) \
+  hipLaunchKernelGGL((k_patch_invert<N, T, S>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, (T*)pinv)
   if (NN <= 7) {
-    if (f32) PGX_INV(7, float); else PGX_INV(7, double);
+    if (f32 && sym) PGX_INV(7, float, true); else if (f32) PGX_INV(7, float, false); else PGX_INV(7, double, false);
   } else {
-    if (f32) PGX_INV(8, float); else PGX_INV(8, double);
+    if (f32 && sym) PGX_INV(8, float, true); else if (f32) PGX_INV(8, float, false); else PGX_INV(8, double, false);
   }
 #undef PGX_INV
 }
 
 void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int32_t* pdof, const int32_t* edge_ends,
-                      const void* pinv, int f32, const double* ru, const double* rp, double omega, double* xu, double* xp, double* su,
-                      double* sp) {
+                      const void* pinv, int f32, int sym, const double* ru, const double* rp, double omega, double* xu, double* xp,
+                      double* su, double* sp) {
   const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
-#define PGX_APP(N, T)                                                                                                              \
-  hipLaunchKernelGGL((k_patch_apply<N, T>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, (const T*)pinv, ru, rp, omega, \
-                     xu, xp, su, sp)
+#define PGX_APP(N, T, S)                                                                                                          \
+  hipLaunchKernelGGL((k_patch_apply<N, T, S>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, (const T*)pinv, ru, rp, \
+                     omega, xu, xp, su, sp)
   if (NN <= 7) {
-    if (f32) PGX_APP(7, float); else PGX_APP(7, double);
+    if (f32 && sym) PGX_APP(7, float, true); else if (f32) PGX_APP(7, float, false); else PGX_APP(7, double, false);
   } else {
-    if (f32) PGX_APP(8, float); else PGX_APP(8, double);
+    if (f32 && sym) PGX_APP(8, float, true); else if (f32) PGX_APP(8, float, false); else PGX_APP(8, double, false);
   }
 #undef PGX_APP
   const int ne = nd - nv;

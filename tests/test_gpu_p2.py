@@ -142,3 +142,25 @@ def test_p2_spmv_km_dictionary_equals_the_streamed_values(require_gpu, monkeypat
         problem.close()
     assert _rel(out["1"], out["0"]) < 1e-11  # entries rounded to 2^-40 of the largest one (build_km_dictionary)
     assert _rel(out["1"], prob.jacobian(x, 0.7) @ v) < 1e-11
+
+
+@pytest.mark.parametrize("N,M", [(48, 48), (96, 20)])
+def test_p2_patch_inverses_in_symmetric_packing_equal_the_full_rows(require_gpu, monkeypatch, N, M):
+    """The patch smoother streams its float inverses in symmetric packing (chunks at or left of a row's diagonal block, the group
+    rebuilds the matrix in LDS): the same run with the full rows (PGX_P2_PATCH_SYM=0) and with double inverses takes the same Newton
+    steps and ends in the same primal field (the two float forms differ by the asymmetry of a float-rounded inverse)."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.obstacle import solve_problem
+
+    out = {}
+    for name, env in (("sym", {}), ("full", {"PGX_P2_PATCH_SYM": "0"}), ("double", {"PGX_P2_PATCH_F32": "0"})):
+        for k in ("PGX_P2_PATCH_SYM", "PGX_P2_PATCH_F32"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        msh = fem.create_rectangle(DOMAIN, (N, M))
+        sol, newton, hist = solve_problem(msh, 2, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+        out[name] = (hist["Newton steps"], sol.x.array[: sol.function_space.block_size].copy())
+    for other in ("full", "double"):
+        assert out["sym"][0] == out[other][0]
+        assert _rel(out["sym"][1], out[other][1]) < 1e-10
