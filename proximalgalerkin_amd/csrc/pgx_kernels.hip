@@ -1002,19 +1002,25 @@ void pgxk_multidot(hipStream_t st, size_t len, int nv, const double* V, size_t l
   while (done < nv) {
     const int rem = nv - done;
     const double2* Vp = (const double2*)(V + (size_t)done * ldv);
-    if (rem >= 8) {
-      hipLaunchKernelGGL(k_multidot<8>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
-      done += 8;
-    } else if (rem >= 4) {
-      hipLaunchKernelGGL(k_multidot<4>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
-      done += 4;
-    } else if (rem >= 2) {
-      hipLaunchKernelGGL(k_multidot<2>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
-      done += 2;
-    } else {
-      hipLaunchKernelGGL(k_multidot<1>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);
-      done += 1;
+    // one launch per chunk of at most 8 vectors, the last chunk of EXACTLY the remaining size: w is read once per chunk (the
+    // 8/4/2/1 split of rounds 1-3 read it up to three times); the per-vector partials do not depend on the grouping
+#define PGX_MD(N)                                                                                                          \
+  case N:                                                                                                                  \
+    hipLaunchKernelGGL(k_multidot<N>, grid, block, 0, st, len2, Vp, ldv2, (const double2*)w, partials, nv, done);          \
+    break
+    const int take = rem >= 8 ? 8 : rem;
+    switch (take) {
+      PGX_MD(1);
+      PGX_MD(2);
+      PGX_MD(3);
+      PGX_MD(4);
+      PGX_MD(5);
+      PGX_MD(6);
+      PGX_MD(7);
+      PGX_MD(8);
     }
+#undef PGX_MD
+    done += take;
   }
   if (scale)
     hipLaunchKernelGGL(k_reduce_partials_scaled, dim3(nv), block, 0, st, (int)nb, nv, partials, *scale, out);
