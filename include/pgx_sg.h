@@ -64,11 +64,16 @@ typedef struct {
 } pgx_sg_problem;
 
 int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int device, pgx_sg_handle** out);
-/* One handle per GPU over a pgx_comm (BASELINE.json config 5: 4 GPUs): every rank holds the whole (small) mesh and the
- * replicated iterate and assembles redundantly - assembly is < 1 % of a Newton step here - while the sparse LU, 94 % of it,
- * is distributed (pgx_nd_create_dist).  Replaces `mpirun -n N python signorini_dolfinx.py`; all calls are collective and
- * return identical results on every rank. */
+/* One handle per GPU over a pgx_comm (BASELINE.json config 5: 4 GPUs).  The ELEMENTS are partitioned (round 4): the cells are cut
+ * into comm->size slabs of equal count along the longest axis of the mesh, every rank assembles the elasticity blocks of its own
+ * slab only and one all-reduce sums the constant matrix - the owned-cell assembly of a distributed DOLFINx mesh
+ * (signorini_dolfinx.py:283-291, `kind="mpi"`); the sparse LU, 94 % of a Newton step, is distributed (pgx_nd_create_dist).  Still
+ * replicated: the mesh arrays handed in, the iterate, and what a Newton step assembles on top of the constant matrix (a product
+ * with it and the contact facets: < 1 % of a step).  Replaces `mpirun -n N python signorini_dolfinx.py`; all calls are collective
+ * and return identical results on every rank.  Tuning key PGX_SG_PARTITION=0: every rank assembles every cell (rounds 2-3). */
 int pgx_sg_create_dist(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, pgx_comm* comm, int device, pgx_sg_handle** out);
+/* cells whose element matrices THIS rank assembled / cells of the mesh (equal on a single handle) */
+int pgx_sg_partition_info(const pgx_sg_handle* h, int64_t* owned_cells, int64_t* total_cells);
 /* symbolic statistics of the handle's sparse LU (flop counts, arena size: include/pgx_nd.h) */
 int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st);
 void pgx_sg_destroy(pgx_sg_handle* h);

@@ -285,6 +285,7 @@ SYMBOLS = [
     # example 02: Signorini contact (include/pgx_sg.h)
     ("pgx_sg_create", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.c_int, C.POINTER(_H)]),
     ("pgx_sg_create_dist", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_sg_partition_info", C.c_int, [_H, c_int64_p, c_int64_p]),
     ("pgx_sg_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
     ("pgx_sg_destroy", None, [_H]),
     ("pgx_sg_last_error", C.c_char_p, [_H]),

@@ -36,6 +36,8 @@ struct pgx_sg_handle : MixedBase {
   uint8_t *mask = nullptr, *kind = nullptr;
   double* Jc = nullptr;
   std::vector<int32_t> cverts;
+  bool partitioned = false;  // distributed handle: this rank assembled the elasticity blocks of its slab of cells only
+  int nc_owned = 0;
   void residual_dev(const double* xin, double* Fout) override;
   void jacobian_dev(const double* xin) override;
 };
@@ -554,14 +556,53 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
         kind[k] = t;
       }
   });
+  // Element partition of a distributed handle (round 4): the cells are cut into `size` slabs of equal count along the longest axis
+  // of the mesh and every rank assembles the elasticity blocks of ITS slab only - what DOLFINx does with the owned cells of a
+  // distributed mesh (signorini_dolfinx.py:283-291, `kind="mpi"`); ONE all-reduce sums the constant matrix at create time.  What a
+  // Newton step assembles afterwards - a product with that matrix and the few thousand contact facets - stays replicated: it is
+  // < 1 % of a step, and an all-reduce of the matrix values per step would cost more than it saves.
+  std::vector<int32_t> own;
+  {
+    const char* e = pgx_tune("PGX_SG_PARTITION");
+    const bool part = comm && comm->size > 1 && !(e && atoi(e) == 0);
+    if (part) {
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (int v = 0; v < nv; ++v)
+        for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], m->coords[3 * (size_t)v + d]), hi[d] = std::max(hi[d], m->coords[3 * (size_t)v + d]);
+      int ax = 0;
+      for (int d = 1; d < 3; ++d)
+        if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+      std::vector<double> key(nc);
+      for (int c = 0; c < nc; ++c) {
+        double z = 0.0;
+        for (int a = 0; a < NPC; ++a) z += m->coords[3 * (size_t)m->cells[NPC * (size_t)c + a] + ax];
+        key[c] = z;
+      }
+      std::vector<int32_t> order(nc);
+      for (int c = 0; c < nc; ++c) order[c] = c;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+      const int64_t c0 = (int64_t)nc * comm->rank / comm->size, c1 = (int64_t)nc * (comm->rank + 1) / comm->size;
+      own.assign(order.begin() + c0, order.begin() + c1);
+      std::sort(own.begin(), own.end());
+      h->partitioned = true;
+    } else {
+      own.resize(nc);
+      for (int c = 0; c < nc; ++c) own[c] = c;
+    }
+  }
+  const int nco = (int)own.size();
+  h->nc_owned = nco;
   // destination tables, slot-major like the stashes the kernels write: table[slot * n_entities + entity]
-  std::vector<int32_t> d144((size_t)nc * NE), d18((size_t)nf * 2 * NF2), dD((size_t)nf * NF2), dbg((size_t)nf * NPF), dbe((size_t)nf * NPF);
-  mx_par_for(nc, [&](int64_t a0, int64_t b0) {
-    for (int64_t c = a0; c < b0; ++c) {
+  std::vector<int32_t> d144((size_t)nco * NE), d18((size_t)nf * 2 * NF2), dD((size_t)nf * NF2), dbg((size_t)nf * NPF), dbe((size_t)nf * NPF);
+  std::vector<int32_t> cown((size_t)nco * NPC);
+  mx_par_for(nco, [&](int64_t a0, int64_t b0) {
+    for (int64_t k = a0; k < b0; ++k) {
+      const int c = own[k];
       int32_t md[ND];
-      cell_dofs((int)c, md);
+      cell_dofs(c, md);
+      for (int a = 0; a < NPC; ++a) cown[NPC * (size_t)k + a] = m->cells[NPC * (size_t)c + a];
       for (int a = 0; a < ND; ++a)
-        for (int b = 0; b < ND; ++b) d144[(size_t)(a * ND + b) * nc + (size_t)c] = find(md[a], md[b]);
+        for (int b = 0; b < ND; ++b) d144[(size_t)(a * ND + b) * nco + (size_t)k] = find(md[a], md[b]);
     }
   });
   for (int f = 0; f < nf; ++f) {
@@ -633,19 +674,21 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   // constant blocks, once, deterministic: park per entity, sum per destination; tables and stashes are temporary
   std::vector<void*> tmp;
   PgxScatter sc_c, sc_f, sc_g;
-  std::string e1 = pgx_scatter_build(d144.data(), (int64_t)NE * nc, tot, tmp, &sc_c);
+  std::string e1 = pgx_scatter_build(d144.data(), (int64_t)NE * nco, tot, tmp, &sc_c);
   if (e1.empty()) e1 = pgx_scatter_build(d18.data(), (int64_t)2 * NF2 * nf, tot, tmp, &sc_f);
   if (e1.empty()) e1 = pgx_scatter_build(dbg.data(), (int64_t)NPF * nf, npsi, tmp, &sc_g);
   double *st_c = nullptr, *st_f = nullptr;
-  hipError_t e = e1.empty() ? hipMalloc((void**)&d_cells, sizeof(int32_t) * NPC * (size_t)nc) : hipErrorOutOfMemory;
-  if (e == hipSuccess) e = hipMalloc((void**)&st_c, sizeof(double) * NE * (size_t)nc);
+  hipError_t e = e1.empty() ? hipMalloc((void**)&d_cells, sizeof(int32_t) * NPC * (size_t)std::max(nco, 1)) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipMalloc((void**)&st_c, sizeof(double) * NE * (size_t)std::max(nco, 1));
   if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * NFS * (size_t)std::max(nf, 1));
-  if (e == hipSuccess) e = hipMemcpy(d_cells, m->cells, sizeof(int32_t) * NPC * (size_t)nc, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_cells, cown.data(), sizeof(int32_t) * NPC * (size_t)nco, hipMemcpyHostToDevice);
+  int rc_comm = PGX_OK;
   if (e == hipSuccess) {
+    // (the cell kernels below see the OWNED cells only: nco of them, compact)
     if (NPC == 4) {
-      hipLaunchKernelGGL(k_sg_const_cells, dim3((nc + 127) / 128), dim3(128), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+      hipLaunchKernelGGL(k_sg_const_cells, dim3((nco + 127) / 128), dim3(128), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
     } else if (NPC == 10) {
-      hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nc + 63) / 64), dim3(64), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda, st_c);
+      hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
     } else {  // hexahedra: Gauss-Legendre (d + 1)^3 on [0,1]^3, tensor Lagrange reference gradients
       const int d = NPC == 8 ? 1 : 2, n1 = d + 1, nq3 = n1 * n1 * n1;
       const double gp2[2] = {0.5 - 0.5 / sqrt(3.0), 0.5 + 0.5 / sqrt(3.0)}, gw2[2] = {0.5, 0.5};
@@ -674,11 +717,12 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
       if (e == hipSuccess) e = hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
       if (e == hipSuccess) {
         tmp.push_back(d_tab);
-        hipLaunchKernelGGL(k_sg_const_cells_tab<NPC>, dim3((nc + 63) / 64), dim3(64), 0, h->st, nc, d_cells, h->coords, h->mu, h->lmbda,
+        hipLaunchKernelGGL(k_sg_const_cells_tab<NPC>, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda,
                            nq3, d_tab, 0, d, d * n1, d * n1 * n1, st_c);
       }
     }
     pgx_scatter_run(h->st, sc_c, st_c, 1.0, 0, h->Jc);
+    if (h->partitioned) rc_comm = comm->allreduce(h->st, h->Jc, (size_t)tot);  // sum of the slabs (fixed rank order: identical on every rank)
     if (nf > 0) {
       hipLaunchKernelGGL(k_sg_const_facets<NPF>, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
                          h->Q, st_f);
@@ -694,6 +738,10 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   if (e != hipSuccess) {
     h->err = std::string("constant Jacobian blocks: ") + (e1.empty() ? hipGetErrorString(e) : e1.c_str());
     return PGX_EHIP;
+  }
+  if (rc_comm) {
+    h->err = "sum of the partitioned elasticity blocks: " + comm->err;
+    return rc_comm;
   }
   return PGX_OK;
 }
@@ -732,6 +780,12 @@ static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* co
 
 extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
   return sg_create(m, p, nullptr, device, out);
+}
+extern "C" int pgx_sg_partition_info(const pgx_sg_handle* h, int64_t* owned_cells, int64_t* total_cells) {
+  if (!h) return PGX_EINVAL;
+  if (owned_cells) *owned_cells = h->nc_owned;
+  if (total_cells) *total_cells = h->nc;
+  return PGX_OK;
 }
 extern "C" int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st) { return h ? pgx_nd_get_stats(h->lu, st) : PGX_EINVAL; }
 extern "C" int pgx_sg_create_dist(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device,

@@ -302,6 +302,13 @@ class SignoriniProblem:
         self._check(self._lib.pgx_sg_spmv(self._h, _lib.dptr(x), _lib.dptr(y)), "pgx_sg_spmv")
         return y
 
+    def partition_info(self):
+        """(cells whose element matrices this rank assembled, cells of the mesh): equal on a single handle; a distributed handle
+        assembles its slab only (include/pgx_sg.h: pgx_sg_create_dist)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.pgx_sg_partition_info(self._h, C.byref(a), C.byref(b)), "pgx_sg_partition_info")
+        return a.value, b.value
+
     def lu_stats(self) -> dict:
         st = _lib.pgx_nd_stats()
         self._check(self._lib.pgx_sg_lu_stats(self._h, C.byref(st)), "pgx_sg_lu_stats")

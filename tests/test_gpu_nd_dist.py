@@ -120,6 +120,46 @@ def test_example02_distributed_run_matches_single_gpu(require_gpu, R):
     assert list(its1) == list(its_ref)
 
 
+@pytest.mark.parametrize("kind,degree", [("tet", 1), ("tet", 2), ("hex", 1)])
+def test_example02_elements_are_partitioned_over_the_ranks(require_gpu, monkeypatch, kind, degree):
+    """pgx_sg_create_dist: every rank assembles the elasticity blocks of ITS slab of cells (equal counts, together all cells), one
+    all-reduce sums the constant matrix: the Jacobian and residual of every rank equal the single handle's to rounding (the slabs
+    are summed in another order), and bitwise each other's.  PGX_SG_PARTITION=0 restores the replicated assembly of rounds 2-3."""
+    from proximalgalerkin_amd import comm as pcomm
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube(5, 4, 7) if kind == "tet" else G.create_unit_cube_hex(4, 3, 6)
+    mt, bcs = G.native_tags(mesh)
+    contact = np.concatenate([mt.find(t) for t in bcs["contact"]])
+    bcf = np.concatenate([mt.find(t) for t in bcs["displacement"]])
+
+    def make(c):
+        bv = np.unique(bcf.ravel()) if (degree == 1 and kind == "tet") else None
+        p = G.SignoriniProblem(mesh, contact, bv, 2.0e4, 0.3, 0.0, -0.25, comm=c, degree=degree, bc_facets=bcf)
+        rng = np.random.default_rng(1)
+        x = 0.01 * rng.standard_normal(p.ndofs)
+        p.set_alpha(0.7)
+        p.set_prev(0.5 * x)
+        F, _ = p.residual(x)
+        J = p.jacobian(x)
+        info = p.partition_info()
+        p.close()
+        return F, J, info
+
+    F1, J1, info1 = make(None)
+    assert info1[0] == info1[1]
+    R = 4
+    res = _run_ranks(pcomm.local_group(R), make)
+    assert sum(r[2][0] for r in res) == info1[1] and all(0 < r[2][0] < info1[1] for r in res)
+    for F, J, _ in res:
+        assert np.array_equal(F, res[0][0]) and np.array_equal(J.data, res[0][1].data)
+        assert np.linalg.norm(F - F1) <= 1e-13 * np.linalg.norm(F1)
+        assert abs(J - J1).max() <= 1e-13 * abs(J1).max()
+    monkeypatch.setenv("PGX_SG_PARTITION", "0")
+    for F, J, info in _run_ranks(pcomm.local_group(2), make):
+        assert info[0] == info[1] and np.array_equal(F, F1) and np.array_equal(J.data, J1.data)
+
+
 def test_example06_distributed_run_matches_single_gpu(require_gpu):
     from proximalgalerkin_amd import comm as pcomm
     from proximalgalerkin_amd.gradient_constraint import solve_problem
