@@ -115,3 +115,18 @@ def test_problem_stated_as_forms_runs_the_same_solve(require_gpu):
     lb, nb, zb = I.solve_problem_forms(300)
     assert list(la) == list(lb) and list(na) == list(nb)
     assert np.linalg.norm(za - zb) <= 1e-10 * np.linalg.norm(za)
+
+
+def test_references_configuration_matches_the_committed_golden(require_gpu):
+    """1001 cells, phic = 3, 2, 1, 0.5, 0.1, 0.01 (intersecting_constraints_dolfinx.py:13,114) against tests/golden/intersecting_n1001.npz
+    (the oracle's run, committed): every attempt's (phic, k, alpha, Newton steps, reason), the counts per phic, u to 1e-8."""
+    import pathlib
+
+    from proximalgalerkin_amd.intersecting import solve_problem
+
+    g = np.load(pathlib.Path(__file__).parent / "golden" / "intersecting_n1001.npz")
+    n = int(g["N"])
+    n_lvpp, n_newton, z, log = solve_problem(n, verbose=False)
+    assert list(n_lvpp) == list(g["lvpp"]) and list(n_newton) == list(g["newton"])
+    assert np.array_equal(np.asarray([[r[0], r[1], r[2], r[3], r[4]] for r in log], dtype=np.float64), g["attempts"])
+    assert _rel(z[: n + 1], g["z_final"][: n + 1]) < 1e-8

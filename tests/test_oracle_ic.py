@@ -56,3 +56,15 @@ def test_full_continuation_is_feasible_for_both_constraints():
     outer = (prob.x[1:] <= 0.2) | (prob.x[:-1] > 0.8)
     assert slope[outer].max() <= 0.01 * (1 + 1e-2) and slope.max() < 100.0
     assert abs(u.max() - 1.0) < 1e-2  # the membrane touches the bump's top, phi0(0.5) = 1
+
+
+def test_oracle_reproduces_the_committed_golden_of_the_references_configuration():
+    """tests/golden/intersecting_n1001.npz (tools/make_golden_families.py ic 1001): 1001 cells, phic = 3 ... 0.01."""
+    import pathlib
+
+    g = np.load(pathlib.Path(__file__).parent / "golden" / "intersecting_n1001.npz")
+    prob = IO.Intersecting(int(g["N"]))
+    z, n_lvpp, n_newton, log = IO.solve_problem(prob)
+    assert list(n_lvpp) == list(g["lvpp"]) and list(n_newton) == list(g["newton"])
+    assert np.array_equal(np.asarray([[r[0], r[1], r[2], r[3], r[4]] for r in log], dtype=np.float64), g["attempts"])
+    assert np.linalg.norm(z - g["z_final"]) <= 1e-12 * np.linalg.norm(g["z_final"])

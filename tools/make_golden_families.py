@@ -3,7 +3,9 @@
 final primal field + per-step Newton counts, at sizes where the GPU path's sparse LU works on a deep dissection tree with several
 size classes per depth (the oracle-compared full runs in tests/test_gpu_*.py stop at N = 20 / 8x6x5 / 32 because the oracle runs
 inside the GPU test).  Generated from the ORACLE (parity unpinned, see the oracle headers).
-    python tools/make_golden_families.py [gc N] [sg n] [sg2 n] [p2 N] [hexdefault D] ...      default: gc 64  sg 14  sg2 8  p2 96"""
+    python tools/make_golden_families.py [gc N] [sg n] [sg2 n] [p2 N] [hexdefault D] [ic N] ...      default: gc 64  sg 14  sg2 8  p2 96
+`ic N`: example 08 (oracle/ic_oracle.py) at the reference's size N = 1001 - the whole continuation in phic: final state, LVPP and
+Newton counts per phic and the log of every attempt (phic, k, alpha, Newton steps, SNES reason)."""
 import pathlib
 import sys
 import time
@@ -48,6 +50,16 @@ def sghex(nx, ny, nz, degree):
     return its
 
 
+def ic(N):
+    from oracle import ic_oracle as I8
+
+    p = I8.Intersecting(N)
+    z, n_lvpp, n_newton, log = I8.solve_problem(p)
+    np.savez_compressed(GOLD / f"intersecting_n{N}.npz", N=N, z_final=z, lvpp=np.asarray(n_lvpp), newton=np.asarray(n_newton),
+                        attempts=np.asarray([[r[0], r[1], r[2], r[3], r[4]] for r in log], dtype=np.float64))
+    return n_newton
+
+
 def p2(N):
     coords, cells = O.create_rectangle(N, N)
     p = O.ObstacleLagrange(coords, cells, degree=2)
@@ -61,5 +73,5 @@ if __name__ == "__main__":
     for kind, size in zip(a[::2], a[1::2]):
         t = time.perf_counter()
         its = {"gc": gc, "sg": lambda n: sg(n, 1), "sg2": lambda n: sg(n, 2), "p2": p2,
-               "hexdefault": lambda d: sghex(16, 7, 5, d)}[kind](int(size))  # hexdefault D: the reference's native mesh, degree D
+               "hexdefault": lambda d: sghex(16, 7, 5, d), "ic": ic}[kind](int(size))  # hexdefault D: the reference's native mesh, degree D
         print(f"{kind} {size}: Newton {list(its)}  ({time.perf_counter() - t:.1f} s)", flush=True)
