@@ -64,3 +64,37 @@ def test_single_precision_cycle_variants_match_the_oracle(reference, tuning, opt
     x, h = _solve(N, tuning, opts)
     assert h["Newton steps"] == h_ref["Newton steps"], (tuning, opts)
     assert np.linalg.norm(x[:n] - x_ref[:n]) <= 1e-10 * np.linalg.norm(x_ref[:n]), (tuning, opts)
+
+
+def _solve_rect(cells, tuning, opts, domain):
+    from proximalgalerkin_amd import _lib, fem
+    from proximalgalerkin_amd.obstacle import run_outer_loop, setup_problem
+
+    for k, v in tuning.items():
+        _lib.tuning_set(k, v)
+    try:
+        msh = fem.create_rectangle(domain, cells)
+        problem, sol, sol_k, alpha = setup_problem(msh, 1, petsc_options=dict(BASE, **opts))
+        hist = run_outer_loop(problem, sol, sol_k, alpha, 100, "double_exponential", 1e2, 1e-4, verbose=False)
+        x = sol.x.array.copy()
+        problem.close()
+    finally:
+        for k in tuning:
+            _lib.tuning_set(k, None)
+    return x, hist
+
+
+@pytest.mark.parametrize("cells", [(200, 72), (130, 260), (96, 48), (330, 118), (90, 270), (258, 130), (124, 124)])
+def test_single_precision_cycle_on_rectangular_grids_that_cut_every_tile(require_gpu, cells):
+    """Grids whose sides are no multiples of the tile sizes (58 / 52 / 48 columns, 8 / 16 rows), long and thin in either direction,
+    with odd coarse levels: the boundary sub-tiles, the last partial tiles and the coarse-correction reads of every launch flavour
+    on shapes the square goldens do not have.  Single precision is forced down to levels of 500 vertices (PGX_F32_MIN) so that two
+    to four levels run it.  Against the fp64 cycle on the same mesh: identical Newton counts, primal field within 1e-10; and the
+    default path (single precision above 4 000 vertices) as well."""
+    domain = ((-1.0, -1.0), (1.0, 1.0))  # cells up to 3 : 1 (a point smoother is not made for the 16 : 1 cells of, say, 640 x 40)
+    x64, h64 = _solve_rect(cells, {"PGX_MG_F32": 0}, {}, domain)
+    n = (cells[0] + 1) * (cells[1] + 1)
+    for tuning in ({"PGX_F32_MIN": 500}, {}, {"PGX_F32_MIN": 500, "PGX_F32_K6_MAX": 0, "PGX_F32_RR_MAX": 0}):
+        x, h = _solve_rect(cells, tuning, {}, domain)
+        assert h["Newton steps"] == h64["Newton steps"], (cells, tuning)
+        assert np.linalg.norm(x[:n] - x64[:n]) <= 1e-10 * np.linalg.norm(x64[:n]), (cells, tuning)
