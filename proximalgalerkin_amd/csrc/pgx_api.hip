@@ -95,6 +95,8 @@ struct pgx_handle {
   void* pinv = nullptr;  // patch inverses: float by default (a smoother inside FGMRES: same Krylov counts as double at 512^2 ... 2048^2,
                          // half the bytes of the stream that bounds the sweep), double with the tuning key PGX_P2_PATCH_F32=0
   int patch_f32 = 1;
+  float* s_Df = nullptr;  // float copy of D(psi) for the residuals inside the P2 cycle (k_bspmv_bal<., true>); PGX_P2_RESID_F32=0: fp64
+  int p2_resid_f32 = 1;
   int patch_sym = 1;     // float inverses in symmetric packing (pgx_patch.hip: 512 instead of 896 B per patch); PGX_P2_PATCH_SYM=0: full rows
   double *p2_su = nullptr, *p2_sp = nullptr;
   // state
@@ -1097,6 +1099,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH_OMEGA")) h->patch_omega = atof(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_F32")) h->patch_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_SYM")) h->patch_sym = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_RESID_F32")) h->p2_resid_f32 = atoi(e);
   if (!h->patch_f32) h->patch_sym = 0;
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
@@ -2061,6 +2064,7 @@ static int ensure_patches(pgx_handle* h) {
       DALLOC(q, pgxk_patch_inverse_bytes(nv, NN, h->patch_f32, h->patch_sym));
       h->pinv = q;
     }
+    if (h->p2_resid_f32) DALLOC(h->s_Df, (size_t)h->s_nnz);
     DALLOC(h->p2_su, (size_t)2 * (nd - nv));
     DALLOC(h->p2_sp, (size_t)2 * (nd - nv));
     HIPCHK(hipMemcpy(h->pdof, h->patch_dof_host.data(), sizeof(int32_t) * h->patch_dof_host.size(), hipMemcpyHostToDevice));
@@ -2069,6 +2073,7 @@ static int ensure_patches(pgx_handle* h) {
   }
   if (!h->patch_fresh) {
     pgxk_patch_invert(h->st, nv, NN, h->pdof, h->ppos, h->s_K, h->s_M, h->s_D, h->mask, h->alpha, h->pinv, h->patch_f32, h->patch_sym);
+    if (h->s_Df) pgxk_to_float(h->st, (size_t)h->s_nnz, h->s_D, h->s_Df);
     h->patch_fresh = true;
   }
   return PGX_OK;
@@ -2081,7 +2086,7 @@ static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, d
   auto resid = [&]() {
     if (h->spmv_bal && h->s_blk)
       pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu,
-                     bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
+                     bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp, h->s_Df);
     else
       pgxk_bspmv(h->st, 1, nd, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, xu, xp, bu, bp, 0.0, h->xcd_remap,
                  h->p2_ru, h->p2_rp);
@@ -2125,7 +2130,7 @@ static int pcycle_p2_patch_dist(pgx_handle* h, double* bu, double* bp, double* x
   };
   auto resid = [&]() {
     pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu, bp,
-                   h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp);
+                   h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp, h->s_Df);
     xv -= 1;
   };
   auto patch = [&](const double* ru, const double* rp) {

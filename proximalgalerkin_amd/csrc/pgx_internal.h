@@ -170,7 +170,7 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
 void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
                     const double* K, const double* M, const uint8_t* code, const double* table, const double* D, double alpha,
                     const uint8_t* mask, const double* xu, const double* xp, const double* bu, const double* bp, int remap,
-                    double* yu, double* yp);
+                    double* yu, double* yp, const float* Df = nullptr);
 void pgxk_dict_assign(hipStream_t st, int64_t nnz, const double* K, const double* M, int ntab, const double* table, double tk,
                       double tm, uint8_t* code, int* fail, int cap, double* fail_v);
 // CSR-stream form of y = Jx (256 rows per block through LDS); mask = Dirichlet flags of the u block

@@ -620,11 +620,14 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_stream(int n, int cap, cons
 // and link, up to rounding).  The host finds them (pgxk_dict_assign; entries are rounded to a grid of 2^-40 of the largest entry -
 // finer than the 1e-11 tolerance of the P1 levels' uniform stencils) and the kernel reads ONE BYTE per entry - an index into a 256-entry table in LDS - instead of two
 // doubles: 13 B per entry (column, code, D) instead of 28.
-template <bool DICT>
+// DF (round 4): D(psi) read from a FLOAT copy (9 instead of 13 B per entry) - for the residuals INSIDE the P2 two-level cycle, a
+// preconditioner within FGMRES; the Krylov solver's own operator apply and every true residual read the fp64 array.
+template <bool DICT, bool DF>
 __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* __restrict__ blk, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colm, const double* __restrict__ K,
                                                          const double* __restrict__ M, const uint8_t* __restrict__ code,
-                                                         const double2* __restrict__ table, const double* __restrict__ D, double alpha,
+                                                         const double2* __restrict__ table, const double* __restrict__ D,
+                                                         const float* __restrict__ Df, double alpha,
                                                          const uint8_t* __restrict__ mask, const double* __restrict__ xu,
                                                          const double* __restrict__ xp, const double* __restrict__ bu,
                                                          const double* __restrict__ bp, int remap, double* __restrict__ yu,
@@ -658,6 +661,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
   }
   const int32_t* cb = colm + base;
   const double *Kb = K + base, *Mb = M + base, *Db = D + base;
+  const float* Dfb = Df + base;
   const uint8_t* qb = code + base;
   // A block holds at most PGX_BAL_CAP entries = IT per thread: all IT column / code / value loads are issued before the first
   // gather of x and all gathers before the first product
@@ -673,7 +677,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
     kv[i] = mv[i] = dv[i] = 0.0;
     if (k < len) {
       cm[i] = __builtin_nontemporal_load(cb + k);
-      dv[i] = __builtin_nontemporal_load(Db + k);
+      dv[i] = DF ? (double)__builtin_nontemporal_load(Dfb + k) : __builtin_nontemporal_load(Db + k);
       if (DICT) {
         kv[i] = (double)__builtin_nontemporal_load(qb + k);  // the code, parked in kv until the table is read below
       } else {
@@ -729,13 +733,16 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bspmv_bal(int n, const int32_t* _
 void pgxk_bspmv_bal(hipStream_t st, int n, int nblk, const int32_t* blk, const int32_t* rowptr, const int32_t* colm,
                     const double* K, const double* M, const uint8_t* code, const double* table, const double* D, double alpha,
                     const uint8_t* mask, const double* xu, const double* xp, const double* bu, const double* bp, int remap,
-                    double* yu, double* yp) {
-  if (code && table)
-    hipLaunchKernelGGL(k_bspmv_bal<true>, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, code,
-                       (const double2*)table, D, alpha, mask, xu, xp, bu, bp, remap, yu, yp);
-  else
-    hipLaunchKernelGGL(k_bspmv_bal<false>, dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, code,
-                       (const double2*)table, D, alpha, mask, xu, xp, bu, bp, remap, yu, yp);
+                    double* yu, double* yp, const float* Df) {
+#define PGX_BAL(DI, FL)                                                                                                       \
+  hipLaunchKernelGGL((k_bspmv_bal<DI, FL>), dim3(nblk), dim3(PGX_BLOCK), 0, st, n, blk, rowptr, colm, K, M, code,            \
+                     (const double2*)table, D, Df, alpha, mask, xu, xp, bu, bp, remap, yu, yp)
+  if (code && table) {
+    if (Df) PGX_BAL(true, true); else PGX_BAL(true, false);
+  } else {
+    if (Df) PGX_BAL(false, true); else PGX_BAL(false, false);
+  }
+#undef PGX_BAL
 }
 
 // code[k] = index of the table entry that equals (K[k], M[k]) rounded to the grid (tk, tm); entries without one are counted in
