@@ -592,10 +592,14 @@ def main():
                 1: "k_st_spmv_r (matrix-free apply of the Newton matrix [[aK,M],[M,-D]] on the structured mesh: constant K/M "
                    "stencils, half-stored D(psi) stencil; the outer-Krylov SpMV of this workload)",
                 2: "k_st_apply<0> (generic matrix-free stencil apply)"}[kind]
+        if kind == 3:
+            name = ("k_p2st_apply_lds + k_p2_rows_csr (P2 operator apply on the structured mesh, csrc/pgx_p2st.hip: interior vertex/edge "
+                    "groups through a 46-entry table - no column indices, K and M as constants, D(psi) from its structure-of-arrays "
+                    "copy, the iterate staged in LDS: 496 B per group; the frame rows in CSR form)")
         if kind == 0 and args.degree == 2:
             name = ("k_bspmv_bal (P2 operator apply: nnz-balanced CSR-stream SpMV of [[aK,M],[M,-D]]; on this uniform mesh K and M are "
                     "read through a one-byte (K,M)-pair dictionary: 13 B per entry instead of 28)")
-        traffic, src = pmc_traffic("r03_p2spmv_pmc_traffic.json" if args.degree == 2 else
+        traffic, src = pmc_traffic(("r04_p2stspmv_pmc_traffic.json" if kind == 3 else "r03_p2spmv_pmc_traffic.json") if args.degree == 2 else
                                    {0: "r04_spmv_pmc_traffic.json", 1: "r04_stspmv_pmc_traffic.json"}.get(kind, "none"))
         gbs = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,

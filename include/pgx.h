@@ -162,8 +162,15 @@ int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset);
  * block-CSR stream kernel k_bspmv_stream (what general meshes and P2 always use, 232 B per P1 row); kind 2: generic
  * one-thread-per-vertex stencil kernel (A/B); kind -1: query only.  *active (may be NULL) receives the kind that will run on
  * this handle (0 when the mesh has no grid structure).  pgx_spmv / pgx_spmv_bench follow the selection; pgx_spmv_bench's
- * `bytes` are the algorithmic bytes of the selected kernel. */
+ * `bytes` are the algorithmic bytes of the selected kernel.  P2 handles (round 4): kind 3 (or 1; the default on the uniform
+ * structured mesh) = the structured apply of csrc/pgx_p2st.hip - interior vertex / edge groups through a 46-entry table, no column
+ * indices, D(psi) from a structure-of-arrays copy, 496 B per group; the frame rows in CSR form -, kind 0 = the block-CSR kernel
+ * k_bspmv_bal; *active is 3 or 0. */
 int pgx_spmv_select(pgx_handle* h, int kind, int* active);
+/* P2 handles: out = {state, i0, ni, j0, nj} of the structured apply - state 0: not available on this mesh (general meshes, strips,
+ * fewer than 8 cells per side, a pattern or K / M entries that are not those of the uniform right-diagonal mesh), 1: pattern verified,
+ * 2: in use; the interior groups are the vertices (i, j), i0 <= i < i0 + ni, j0 <= j < j0 + nj, with their three edges. */
+int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]);
 /* The same for the TIME-DOMINANT kernel of the multigrid-preconditioned solve: the fused three-sweep smoother of the finest
  * level (k_st_smoothR, post-smoothing variant: x + P x_c folded in), at the Jacobian of the last pgx_jacobian_fill.
  * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,

@@ -220,6 +220,7 @@ SYMBOLS = [
     ("pgx_smoother_bench", C.c_int, [_H, C.c_int, c_double_p, c_double_p]),
     ("pgx_vcycle_bench", C.c_int, [_H, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     ("pgx_spmv_select", C.c_int, [_H, C.c_int, C.POINTER(C.c_int)]),
+    ("pgx_p2_stencil_info", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("pgx_comm_counts", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int]),
     ("pgx_newton_solve", C.c_int,
      [_H, C.POINTER(pgx_snes_opts), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -95,6 +95,17 @@ struct pgx_handle {
   void* pinv = nullptr;  // patch inverses: float by default (a smoother inside FGMRES: same Krylov counts as double at 512^2 ... 2048^2,
                          // half the bytes of the stream that bounds the sweep), double with the tuning key PGX_P2_PATCH_F32=0
   int patch_f32 = 1;
+  // structured P2 operator apply (pgx_p2st.hip): interior groups [i0, i0 + ni) x [j0, j0 + nj) through the table-driven kernel,
+  // the frame rows through the CSR form.  state: 0 off, 1 pattern verified (K / M constants not yet fetched), 2 ready
+  struct P2St {
+    int state = 0, enable = 1, select = 1, i0 = 0, ni = 0, j0 = 0, nj = 0, nframe = 0, ref_rows[4] = {0, 0, 0, 0};
+    P2StTab tab;
+    double K[46];
+    double* Dst = nullptr;
+    float* Dstf = nullptr;
+    int32_t* frame = nullptr;
+    bool fresh = false;
+  } p2st;
   float* s_Df = nullptr;  // float copy of D(psi) for the residuals inside the P2 cycle (k_bspmv_bal<., true>); PGX_P2_RESID_F32=0: fp64
   int p2_resid_f32 = 1;
   int patch_sym = 1;     // float inverses in symmetric packing (pgx_patch.hip: 512 instead of 896 B per patch); PGX_P2_PATCH_SYM=0: full rows
@@ -508,6 +519,92 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
   }
   std::vector<int32_t> colm(col.size());
   for (size_t k = 0; k < col.size(); ++k) colm[k] = col[k] | (hmask[col[k]] ? (int32_t)0x80000000 : 0);
+  // structured operator apply (pgx_p2st.hip): derive the 46-entry table from one interior group, verify it on every group of the
+  // largest rectangle of groups that match, list the rows of the frame around it
+  if (h->structured && !h->dist.on && h->p2st.enable && h->nx >= 8 && h->ny >= 8) {
+    const int nx = h->nx, ny = h->ny, sx = nx + 1;
+    auto ebase = [&](int i, int j) { return nv + j * (3 * nx + 1) + 3 * i; };
+    bool ok = (nv == sx * (ny + 1)) && (ne == ny * (3 * nx + 1) + nx);
+    for (int j = 0; j < ny && ok; ++j)
+      for (int i = 0; i < nx && ok; ++i) {  // edges numbered by lower vertex: H, V, D of vertex (i, j)
+        const int v = j * sx + i, e = ebase(i, j) - nv;
+        ok = ends[2 * e] == v && ends[2 * e + 1] == v + 1 && ends[2 * e + 2] == v && ends[2 * e + 3] == v + sx &&
+             ends[2 * e + 4] == v && ends[2 * e + 5] == v + sx + 1;
+      }
+    pgx_handle::P2St& S = h->p2st;
+    const int ir = nx / 2, jr = ny / 2;  // reference group
+    int nt[4] = {19, 9, 9, 9}, off[4] = {0, 19, 28, 37};
+    if (ok) {
+      const int vr = jr * sx + ir, er = ebase(ir, jr);
+      for (int t = 0; t < 4 && ok; ++t) {
+        const int row = t == 0 ? vr : er + t - 1;
+        S.ref_rows[t] = row;
+        ok = rowptr[row + 1] - rowptr[row] == nt[t];
+        for (int k = 0; k < nt[t] && ok; ++k) {
+          const int c = col[rowptr[row] + k];
+          S.tab.isedge[off[t] + k] = c >= nv;
+          S.tab.delta[off[t] + k] = c >= nv ? c - er : c - vr;
+        }
+      }
+    }
+    auto group_ok = [&](int i, int j) -> bool {
+      if (i < 1 || j < 1 || i >= nx || j >= ny) return false;
+      const int v = j * sx + i, eb = ebase(i, j);
+      for (int t = 0; t < 4; ++t) {
+        const int row = t == 0 ? v : eb + t - 1;
+        if (hmask[row] || rowptr[row + 1] - rowptr[row] != nt[t]) return false;
+        for (int k = 0; k < nt[t]; ++k) {
+          const int c = col[rowptr[row] + k];
+          if (hmask[c] || c != (S.tab.isedge[off[t] + k] ? eb : v) + S.tab.delta[off[t] + k]) return false;
+        }
+      }
+      return true;
+    };
+    if (ok && group_ok(ir, jr)) {
+      int i0 = ir, i1 = ir, j0 = jr, j1 = jr;
+      while (group_ok(i0 - 1, jr)) --i0;
+      while (group_ok(i1 + 1, jr)) ++i1;
+      while (group_ok(ir, j0 - 1)) --j0;
+      while (group_ok(ir, j1 + 1)) ++j1;
+      for (int j = j0; j <= j1 && ok; ++j)
+        for (int i = i0; i <= i1 && ok; ++i) ok = group_ok(i, j);
+      if (ok) {
+        std::vector<int32_t> frame;
+        auto fast = [&](int v) {
+          const int i = v % sx, j = v / sx;
+          return i >= i0 && i <= i1 && j >= j0 && j <= j1;
+        };
+        for (int v = 0; v < nv; ++v)
+          if (!fast(v)) frame.push_back(v);
+        for (int e = 0; e < ne; ++e)
+          if (!fast(ends[2 * e])) frame.push_back(nv + e);
+        // LDS form: decode every entry into (dj, di[, kind]) and its offset in the block tiles of k_p2st_apply_lds
+        {
+          const int VW = PGX_P2ST_BW + 2, EW = 3 * VW, erow = 3 * nx + 1;
+          bool lds = true;
+          for (int e = 0; e < 46 && lds; ++e) {
+            const int d = S.tab.delta[e];
+            if (!S.tab.isedge[e]) {
+              const int dj = (int)std::lround((double)d / sx), di = d - dj * sx;
+              lds = std::abs(dj) <= 1 && std::abs(di) <= 1;
+              S.tab.lofs[e] = (dj + 1) * VW + di + 1;
+            } else {
+              const int dj = (int)std::lround((double)d / erow), rem = d - dj * erow;  // rem = 3 di + kind, di in {-1, 0, 1}
+              const int di = (rem + 3) / 3 - 1, kind = rem - 3 * di;
+              lds = std::abs(dj) <= 1 && std::abs(di) <= 1 && kind >= 0 && kind <= 2;
+              S.tab.lofs[e] = (dj + 1) * EW + 3 * (di + 1) + kind;
+            }
+          }
+          S.tab.lds = lds ? 1 : 0;
+          if (const char* e = pgx_tune("PGX_P2ST_LDS")) S.tab.lds = S.tab.lds && atoi(e);
+        }
+        S.i0 = i0, S.ni = i1 - i0 + 1, S.j0 = j0, S.nj = j1 - j0 + 1, S.nframe = (int)frame.size();
+        DALLOC(S.frame, std::max<size_t>(frame.size(), 1));
+        HIPCHK(hipMemcpy(S.frame, frame.data(), sizeof(int32_t) * frame.size(), hipMemcpyHostToDevice));
+        S.state = 1;
+      }
+    }
+  }
   DALLOC(h->s_rowptr, n + 1);
   {  // vertex-star patches: slot 0 = the vertex, then the edge dofs that meet in it (pgx_patch.hip)
     int maxdeg = 0;
@@ -1100,6 +1197,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH_F32")) h->patch_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_PATCH_SYM")) h->patch_sym = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_RESID_F32")) h->p2_resid_f32 = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_STENCIL")) h->p2st.enable = atoi(e);
   if (!h->patch_f32) h->patch_sym = 0;
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
@@ -1681,13 +1779,83 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
   }
   h->jac_valid = true;
   h->patch_fresh = false;
+  h->p2st.fresh = false;
   return PGX_OK;
+}
+
+// Structured P2 operator apply (pgx_p2st.hip).  First use: the K / M constants of the reference group, checked on every interior
+// group; once per Jacobian: the structure-of-arrays copies of D(psi).  Returns false when the CSR kernels have to do the work.
+static bool p2st_ready(pgx_handle* h) {
+  pgx_handle::P2St& S = h->p2st;
+  if (S.state == 0 || !S.select || !h->s_K || !h->s_D) return false;
+  static const int nt[4] = {19, 9, 9, 9}, off[4] = {0, 19, 28, 37};
+  const size_t G = (size_t)h->n;  // groups = vertices
+  if (S.state == 1) {
+    S.state = 0;  // until everything below has succeeded
+    const std::vector<int32_t>& rp = h->s_h_rowptr;
+    double kmax = 0.0, mmax = 0.0;
+    for (int t = 0; t < 4; ++t) {
+      const int p = rp[S.ref_rows[t]];
+      if (hipMemcpy(S.K + off[t], h->s_K + p, sizeof(double) * nt[t], hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(S.tab.M + off[t], h->s_M + p, sizeof(double) * nt[t], hipMemcpyDeviceToHost) != hipSuccess)
+        return false;
+    }
+    for (int e = 0; e < 46; ++e) kmax = std::max(kmax, std::fabs(S.K[e])), mmax = std::max(mmax, std::fabs(S.tab.M[e]));
+    S.tab.kmax = kmax, S.tab.mmax = mmax;
+    for (int e = 0; e < 46; ++e) S.tab.aK[e] = S.K[e];
+    int* d_fail = nullptr;
+    if (hipMalloc((void**)&d_fail, sizeof(int)) != hipSuccess) return false;
+    hipMemsetAsync(d_fail, 0, sizeof(int), h->st);
+    pgxk_p2st_check(h->st, S.tab, h->nx, h->n, S.i0, S.ni, S.j0, S.nj, 1.0, 1e-12, h->s_rowptr, h->s_K, h->s_M, d_fail);
+    int fail = 1;
+    const hipError_t e1 = hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, h->st);
+    const hipError_t e2 = hipStreamSynchronize(h->st);
+    hipFree(d_fail);
+    if (e1 != hipSuccess || e2 != hipSuccess || fail) return false;  // not the uniform mesh the table assumes: CSR kernels
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(double) * 46 * G) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    h->allocs.push_back(q);
+    S.Dst = (double*)q;
+    if (h->p2_resid_f32) {
+      if (hipMalloc(&q, sizeof(float) * 46 * G) == hipSuccess) {
+        h->allocs.push_back(q);
+        S.Dstf = (float*)q;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    S.state = 2;
+  }
+  if (!S.fresh) {
+    pgxk_p2st_pack(h->st, h->nx, h->n, S.i0, S.ni, S.j0, S.nj, G, h->s_rowptr, h->s_D, S.Dst, 0);
+    if (S.Dstf) pgxk_p2st_pack(h->st, h->nx, h->n, S.i0, S.ni, S.j0, S.nj, G, h->s_rowptr, h->s_D, S.Dstf, 1);
+    S.fresh = true;
+  }
+  for (int e = 0; e < 46; ++e) S.tab.aK[e] = h->alpha * S.K[e];
+  return true;
+}
+// y = J x (bu == nullptr) or y = b - J x; inner: a residual inside the preconditioner (may read the float copy of D)
+static void p2st_apply(pgx_handle* h, const double* xu, const double* xp, const double* bu, const double* bp, double* yu, double* yp,
+                       bool inner) {
+  pgx_handle::P2St& S = h->p2st;
+  const bool f32 = inner && S.Dstf;
+  pgxk_p2st_apply(h->st, S.tab, h->nx, h->n, S.i0, S.ni, S.j0, S.nj, (size_t)h->n, f32 ? (const void*)S.Dstf : (const void*)S.Dst, f32, xu,
+                  xp, bu, bp, yu, yp);
+  pgxk_p2_rows_csr(h->st, S.nframe, S.frame, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_D, h->alpha, h->mask, xu, xp, bu, bp, yu, yp);
 }
 
 // y = J x on device vectors of length 2*nd
 static void level_apply(pgx_handle* h, int l, int mode, const double* xu, const double* xp, const double* bu,
                         const double* bp, double omega, int first, double* yu, double* yp);
 static void spmv_dev(pgx_handle* h, const double* x, double* y) {
+  if (h->degree == 2 && h->spmv_stream && h->spmv_bal && p2st_ready(h)) {
+    static PgxTuneInt bench_inner("PGX_P2ST_BENCH_INNER", 0);  // measurement hook (tools/p2_spmv_bench.py): time the float-D form
+    p2st_apply(h, x, x + h->nd, nullptr, nullptr, y, y + h->nd, bench_inner.get() != 0);
+    return;
+  }
   if (h->spmv_stencil && h->structured && h->degree == 1) {
     if (h->spmv_stencil == 2)  // A/B: the generic one-thread-per-vertex stencil kernel
       level_apply(h, 0, 0, x, x + h->nd, nullptr, nullptr, 0.0, 0, y, y + h->nd);
@@ -2083,8 +2251,11 @@ static int ensure_patches(pgx_handle* h) {
 // patch_nu sweeps.  A sweep = residual (block-CSR SpMV) + one pass over the patch inverses.
 static void pcycle_p2_patch(pgx_handle* h, const double* bu, const double* bp, double* xu, double* xp, int nu, double omega) {
   const int nd = h->nd, nv = h->n, NN = h->patch_nn;
+  const bool st_apply = h->spmv_bal && p2st_ready(h);
   auto resid = [&]() {
-    if (h->spmv_bal && h->s_blk)
+    if (st_apply)
+      p2st_apply(h, xu, xp, bu, bp, h->p2_ru, h->p2_rp, true);
+    else if (h->spmv_bal && h->s_blk)
       pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu,
                      bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp, h->s_Df);
     else
@@ -2793,7 +2964,12 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
       // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
       // K and M are seven constants each
       *bytes = (16.0 + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
-    else if (h->s_code && h->spmv_bal && h->s_blk && h->spmv_stream)
+    else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && h->spmv_stream && h->spmv_bal) {
+      // structured P2 apply: 46 D values per interior group (SoA copy), nothing else of the matrix; the frame rows in CSR form
+      // (column + K + M + D = 28 B per entry, the row list); x read once; y written
+      const double nfast = (double)h->p2st.ni * h->p2st.nj;
+      *bytes = 368.0 * nfast + 28.0 * ((double)h->s_nnz - 46.0 * nfast) + 4.0 * h->p2st.nframe + 8.0 * n2 + 8.0 * n2;
+    } else if (h->s_code && h->spmv_bal && h->s_blk && h->spmv_stream)
       // (K, M) dictionary: column (4 B) + code (1 B) + D (8 B) per scalar nnz; rowptr; x read once; y written
       *bytes = 13.0 * h->s_nnz + 4.0 * (h->nd + 1) + 8.0 * n2 + 8.0 * n2;
     else  // one pattern (4 B) + three value streams (24 B) per scalar nnz; rowptr; x read once; y written
@@ -2819,8 +2995,23 @@ extern "C" int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset) {
   return PGX_OK;
 }
 
+extern "C" int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]) {
+  NEED(h);
+  if (!out) return PGX_EINVAL;
+  const pgx_handle::P2St& S = h->p2st;
+  out[0] = h->degree == 2 ? S.state : 0;
+  out[1] = S.i0, out[2] = S.ni, out[3] = S.j0, out[4] = S.nj;
+  return PGX_OK;
+}
 extern "C" int pgx_spmv_select(pgx_handle* h, int kind, int* active) {
   NEED(h);
+  if (h->degree == 2) {  // P2: 3 (or 1) = the structured apply of pgx_p2st.hip where the mesh allows it, 0 = the block-CSR kernel
+    if (kind == 0) h->p2st.select = 0;
+    else if (kind == 1 || kind == 3) h->p2st.select = 1;
+    else if (kind != -1) return PGX_EINVAL;
+    if (active) *active = (h->p2st.state && h->p2st.select && h->spmv_stream && h->spmv_bal) ? 3 : 0;
+    return PGX_OK;
+  }
   if (kind == 0 || kind == 1 || kind == 2) h->spmv_stencil = kind;
   else if (kind != -1) return PGX_EINVAL;
   if (active) *active = (h->spmv_stencil && h->structured && h->degree == 1) ? h->spmv_stencil : 0;

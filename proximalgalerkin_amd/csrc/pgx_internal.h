@@ -219,6 +219,25 @@ void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int3
                       const void* pinv, int f32, int sym, const double* ru, const double* rp, double omega, double* xu, double* xp,
                       double* su, double* sp);
 size_t pgxk_patch_inverse_bytes(int np, int NN, int f32, int sym);  // sym: symmetric packing (float form only)
+// structured P2 operator apply (pgx_p2st.hip): the 46 entries of an interior group's four rows (vertex: 19, three edges: 9 each)
+struct P2StTab {
+  int delta[46];             // neighbour dof = (isedge ? first edge dof of the group : vertex index of the group) + delta
+  unsigned char isedge[46];
+  int lofs[46];              // LDS form: offset of the neighbour in the block's vertex / edge tile relative to the thread's own slot
+  int lds;                   // 1: every entry reaches at most one group row / column away (the tiles of k_p2st_apply_lds hold it)
+  double aK[46], M[46];      // alpha K and M of the entry (uniform mesh: the same in every interior group)
+  double kmax, mmax;
+};
+#define PGX_P2ST_BW 128      // groups per block of k_p2st_apply_lds
+void pgxk_p2st_apply(hipStream_t st, const P2StTab& S, int nx, int nv, int i0, int ni, int j0, int nj, size_t G, const void* Dst, int f32,
+                     const double* xu, const double* xp, const double* bu, const double* bp, double* yu, double* yp);
+void pgxk_p2st_pack(hipStream_t st, int nx, int nv, int i0, int ni, int j0, int nj, size_t G, const int32_t* rowptr, const double* D,
+                    void* Dst, int f32);
+void pgxk_p2st_check(hipStream_t st, const P2StTab& S, int nx, int nv, int i0, int ni, int j0, int nj, double alpha_ref, double tol,
+                     const int32_t* rowptr, const double* K, const double* M, int* fail);
+void pgxk_p2_rows_csr(hipStream_t st, int nrows, const int32_t* rows, const int32_t* rowptr, const int32_t* colm, const double* K,
+                      const double* M, const double* D, double alpha, const uint8_t* mask, const double* xu, const double* xp,
+                      const double* bu, const double* bp, double* yu, double* yp);
 // fused, atomic-free residual (+ optional D(psi) fill) for P1: see k_resid_fill_p1
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,

@@ -326,6 +326,12 @@ class NonlinearProblem:
         _lib.check(self._lib, self._h, self._lib.pgx_spmv_select(self._h, int(kind), C.byref(act)), "pgx_spmv_select")
         return act.value
 
+    def p2_stencil_info(self):
+        """(state, i0, ni, j0, nj) of the structured P2 operator apply (include/pgx.h: pgx_p2_stencil_info)."""
+        out = (C.c_int32 * 5)()
+        _lib.check(self._lib, self._h, self._lib.pgx_p2_stencil_info(self._h, out), "pgx_p2_stencil_info")
+        return tuple(int(v) for v in out)
+
     def comm_counts(self, reset=False):
         """Collectives this rank issued since the last reset (include/pgx.h: pgx_comm_counts)."""
         out = (C.c_int64 * 4)()

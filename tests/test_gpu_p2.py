@@ -130,6 +130,7 @@ def test_p2_spmv_km_dictionary_equals_the_streamed_values(require_gpu, monkeypat
     """k_bspmv_bal<true> (K and M read through the one-byte dictionary of their distinct pairs on a uniform mesh) against the same
     kernel streaming K and M, and against the oracle's J @ v."""
     out = {}
+    monkeypatch.setenv("PGX_P2_STENCIL", "0")  # the CSR kernel itself (the structured apply of the interior reads no K / M stream)
     for d in ("1", "0"):
         monkeypatch.setenv("PGX_SPMV_DICT", d)
         problem, sol, sol_k, alpha, prob = _setup(N, M)
@@ -164,3 +165,34 @@ def test_p2_patch_inverses_in_symmetric_packing_equal_the_full_rows(require_gpu,
     for other in ("full", "double"):
         assert out["sym"][0] == out[other][0]
         assert _rel(out["sym"][1], out[other][1]) < 1e-10
+
+
+@pytest.mark.parametrize("N,M", [(8, 8), (9, 6), (40, 40), (96, 33), (257, 9), (64, 130)])
+def test_p2_structured_apply_equals_the_csr_kernel_and_the_oracle(require_gpu, monkeypatch, N, M):
+    """pgx_p2st.hip: interior groups through the table-driven kernel (no column indices, K / M as constants, D(psi) from its
+    structure-of-arrays copy), the frame through the CSR form - against k_bspmv_bal on the same Jacobian and vectors (1e-13: another
+    summation order) and against the oracle's J @ v; at two alpha (the table's alpha K is refreshed per call) and after a SECOND
+    Jacobian (the SoA copy is refreshed).  9 x 6 has no interior rectangle: the CSR kernel serves it alone."""
+    out = {}
+    for st in ("1", "0"):
+        monkeypatch.setenv("PGX_P2_STENCIL", st)
+        problem, sol, sol_k, alpha, prob = _setup(N, M)
+        res = []
+        for seed, a in ((11, 3.5), (12, 0.25)):
+            x, xk = _iterates(2 * prob.n, seed)
+            alpha.value = a
+            sol_k.x.array[:] = xk
+            problem.assemble_jacobian(x)
+            v = np.random.default_rng(seed).standard_normal(2 * prob.n)
+            y = problem.spmv(v)
+            if st == "1":
+                info = problem.p2_stencil_info()  # in use wherever the mesh has an interior: groups 2 ... n - 2 in both directions
+                assert info == ((2, 2, N - 3, 2, M - 3) if min(N, M) >= 8 else (0, 0, 0, 0, 0)), info
+                assert problem.spmv_select() == (3 if min(N, M) >= 8 else 0)
+                assert _rel(y, prob.jacobian(x, a) @ v) < 1e-12
+                assert np.array_equal(problem.spmv(v), y)  # bitwise reproducible
+            res.append(y)
+        out[st] = res
+        problem.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert _rel(a, b) < 1e-13

@@ -17,4 +17,5 @@ best = None
 for rep in range(3):
     ms, by = problem.spmv_bench(reps=10)
     best = ms if best is None else min(best, ms)
+print("structured apply (state, i0, ni, j0, nj):", problem.p2_stencil_info(), "kind", problem.spmv_select())
 print(f"N={N} P2 lib={os.environ.get('PGX_LIB', 'default')}: {best * 1e3:.1f} us  {by / best / 1e6:.0f} GB/s ({by / best / 1e6 / 8000 * 100:.1f} % of 8 TB/s)")
