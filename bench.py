@@ -591,7 +591,7 @@ def main():
         name = {0: "k_bspmv_stream (block-CSR SpMV of the Newton matrix [[aK,M],[M,-D]], one shared pattern)",
                 1: "k_st_spmv_r (matrix-free apply of the Newton matrix [[aK,M],[M,-D]] on the structured mesh: constant K/M "
                    "stencils, half-stored D(psi) stencil; the outer-Krylov SpMV of this workload)",
-                2: "k_st_apply<0> (generic matrix-free stencil apply)"}[kind]
+                2: "k_st_apply<0> (generic matrix-free stencil apply)"}.get(kind, "")
         if kind == 3:
             name = ("k_p2st_apply_lds + k_p2_rows_csr (P2 operator apply on the structured mesh, csrc/pgx_p2st.hip: interior vertex/edge "
                     "groups through a 46-entry table - no column indices, K and M as constants, D(psi) from its structure-of-arrays "

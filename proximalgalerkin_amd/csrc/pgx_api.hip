@@ -1787,7 +1787,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
 // group; once per Jacobian: the structure-of-arrays copies of D(psi).  Returns false when the CSR kernels have to do the work.
 static bool p2st_ready(pgx_handle* h) {
   pgx_handle::P2St& S = h->p2st;
-  if (S.state == 0 || !S.select || !h->s_K || !h->s_D) return false;
+  if (S.state == 0 || !S.select || h->dist.on || !h->s_K || !h->s_D) return false;  // strips keep the CSR kernel (ghost rows, halo depth)
   static const int nt[4] = {19, 9, 9, 9}, off[4] = {0, 19, 28, 37};
   const size_t G = (size_t)h->n;  // groups = vertices
   if (S.state == 1) {
@@ -2964,7 +2964,7 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
       // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
       // K and M are seven constants each
       *bytes = (16.0 + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
-    else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && h->spmv_stream && h->spmv_bal) {
+    else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && !h->dist.on && h->spmv_stream && h->spmv_bal) {
       // structured P2 apply: 46 D values per interior group (SoA copy), nothing else of the matrix; the frame rows in CSR form
       // (column + K + M + D = 28 B per entry, the row list); x read once; y written
       const double nfast = (double)h->p2st.ni * h->p2st.nj;
@@ -2999,7 +2999,7 @@ extern "C" int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]) {
   NEED(h);
   if (!out) return PGX_EINVAL;
   const pgx_handle::P2St& S = h->p2st;
-  out[0] = h->degree == 2 ? S.state : 0;
+  out[0] = (h->degree == 2 && !h->dist.on) ? S.state : 0;
   out[1] = S.i0, out[2] = S.ni, out[3] = S.j0, out[4] = S.nj;
   return PGX_OK;
 }
@@ -3009,7 +3009,7 @@ extern "C" int pgx_spmv_select(pgx_handle* h, int kind, int* active) {
     if (kind == 0) h->p2st.select = 0;
     else if (kind == 1 || kind == 3) h->p2st.select = 1;
     else if (kind != -1) return PGX_EINVAL;
-    if (active) *active = (h->p2st.state && h->p2st.select && h->spmv_stream && h->spmv_bal) ? 3 : 0;
+    if (active) *active = (h->p2st.state && h->p2st.select && !h->dist.on && h->spmv_stream && h->spmv_bal) ? 3 : 0;
     return PGX_OK;
   }
   if (kind == 0 || kind == 1 || kind == 2) h->spmv_stencil = kind;
