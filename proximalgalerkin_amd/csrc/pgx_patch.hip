@@ -141,8 +141,8 @@ template <int NN, typename PT, bool SYM>
 __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, const int32_t* __restrict__ pdof,
                                                      const int32_t* __restrict__ edge_ends, const PT* __restrict__ pinv,
                                                      const double* __restrict__ ru, const double* __restrict__ rp, double omega,
-                                                     double* __restrict__ xu, double* __restrict__ xp, double* __restrict__ su,
-                                                     double* __restrict__ sp) {
+                                                     double* __restrict__ xu, double* __restrict__ xp, float* __restrict__ su,
+                                                     float* __restrict__ sp) {
   constexpr int P = 2 * NN, PQ = (P + 3) / 4;
   const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GRP);
   const int l = threadIdx.x & (GRP - 1);
@@ -231,17 +231,17 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
   } else {
     const int e = dof - nv;
     const int side = (edge_ends[2 * e] == v) ? 0 : 1;
-    (l < NN ? su : sp)[2 * (size_t)e + side] = y;
+    (l < NN ? su : sp)[2 * (size_t)e + side] = (float)y;  // the stash is float (round 4): corrections of a float-accurate smoother
   }
 }
 
-__global__ void __launch_bounds__(256) k_patch_edges(int ne, int nv, double omega, const double* __restrict__ su,
-                                                     const double* __restrict__ sp, double* __restrict__ xu, double* __restrict__ xp) {
+__global__ void __launch_bounds__(256) k_patch_edges(int ne, int nv, double omega, const float* __restrict__ su,
+                                                     const float* __restrict__ sp, double* __restrict__ xu, double* __restrict__ xp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
-  const double2 a = ((const double2*)su)[e], b = ((const double2*)sp)[e];
-  xu[nv + e] += omega * 0.5 * (a.x + a.y);
-  xp[nv + e] += omega * 0.5 * (b.x + b.y);
+  const float2 a = ((const float2*)su)[e], b = ((const float2*)sp)[e];
+  xu[nv + e] += omega * 0.5 * ((double)a.x + (double)a.y);
+  xp[nv + e] += omega * 0.5 * ((double)b.x + (double)b.y);
 }
 
 }  // namespace
@@ -277,7 +277,7 @@ void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int3
   const unsigned blocks = (unsigned)(((int64_t)np * GRP + 255) / 256);
 #define PGX_APP(N, T, S)                                                                                                          \
   hipLaunchKernelGGL((k_patch_apply<N, T, S>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, (const T*)pinv, ru, rp, \
-                     omega, xu, xp, su, sp)
+                     omega, xu, xp, (float*)su, (float*)sp)
   if (NN <= 7) {
     if (f32 && sym) PGX_APP(7, float, true); else if (f32) PGX_APP(7, float, false); else PGX_APP(7, double, false);
   } else {
@@ -285,5 +285,5 @@ void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int3
   }
 #undef PGX_APP
   const int ne = nd - nv;
-  hipLaunchKernelGGL(k_patch_edges, dim3((ne + 255) / 256), dim3(256), 0, st, ne, nv, omega, su, sp, xu, xp);
+  hipLaunchKernelGGL(k_patch_edges, dim3((ne + 255) / 256), dim3(256), 0, st, ne, nv, omega, (const float*)su, (const float*)sp, xu, xp);
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of the headline workload (2048^2 P1, settings B) on the GPU box; run from the repo root through gpurun.
-#   bash tools/profile_headline.sh <outdir under gpurun_out> [stats|spmv|stspmv|smoother ...]
+#   bash tools/profile_headline.sh <outdir under gpurun_out> [stats|spmv|stspmv|p2stspmv|fsmooth|smoother ...]
 # stats    : rocprofv3 --kernel-trace --stats of `bench.py --steps 3`
 # spmv     : FETCH_SIZE and WRITE_SIZE of k_bspmv_stream in SEPARATE passes (TCC slots) -> profiles/ via tools/pmc_summary.py
 # smoother : two SQ passes over one solve (wait/issue counters; LDS conflict counters)
@@ -27,6 +27,11 @@ for what in "$@"; do
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_swrite -o w -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_swrite.log 2>&1 || exit 1
       python3 tools/pmc_summary.py --kernel k_st_spmv_r --traffic --cells 2048 --algorithmic-bytes 272896065 \
         --out $OUT/stspmv_pmc_traffic.json $OUT/pmc_sfetch $OUT/pmc_swrite > /dev/null || exit 1 ;;
+    p2stspmv)  # the structured P2 operator apply (pgx_p2st.hip): 496 B x 2045^2 interior groups at 2048^2
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfetch -o f -- python3 tools/p2_spmv_bench.py 2048 > $OUT/pmc_pfetch.log 2>&1 || exit 1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pwrite -o w -- python3 tools/p2_spmv_bench.py 2048 > $OUT/pmc_pwrite.log 2>&1 || exit 1
+      python3 tools/pmc_summary.py --kernel "k_p2st_apply_lds<double" --traffic --cells 2048 --algorithmic-bytes 2074284400 \
+        --out $OUT/p2stspmv_pmc_traffic.json $OUT/pmc_pfetch $OUT/pmc_pwrite > /dev/null || exit 1 ;;
     fsmooth)  # the time-dominant kernel: the finest level's single-precision smoother launch, 40 B x 2049^2 vertices (+ coarse correction)
       rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_ffetch -o f -- python3 tools/smoother_bench.py 2048 > $OUT/pmc_ffetch.log 2>&1 || exit 1
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fwrite -o w -- python3 tools/smoother_bench.py 2048 > $OUT/pmc_fwrite.log 2>&1 || exit 1
