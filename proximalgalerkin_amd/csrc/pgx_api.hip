@@ -1199,6 +1199,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_RESID_F32")) h->p2_resid_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_STENCIL")) h->p2st.enable = atoi(e);
   if (!h->patch_f32) h->patch_sym = 0;
+  if (h->patch_f32 == 2 && !h->patch_sym) h->patch_f32 = 1;  // bfloat16 storage exists in the symmetric packing only
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
   {
     const char* e = pgx_tune("PGX_TAIL2");  // 0: the round-2 tail kernels (A/B)

@@ -56,6 +56,28 @@ __global__ void __launch_bounds__(256) k_patch_positions(int np, int NN, const i
 __host__ __device__ constexpr int patch_sym_off(int P, int q) { return q * P - 2 * q * (q - 1); }  // in 4-vectors
 __host__ __device__ constexpr int patch_sym_vecs(int P) { return patch_sym_off(P, (P + 3) / 4); }
 
+// storage conversions of an inverse entry: double, float, or bfloat16 kept as its 16 bits (PT = unsigned short; round 4: the
+// sweep is a smoother inside FGMRES - entries of 8 significant bits give the same Krylov counts as float ones and halve the stream
+// that bounds k_patch_apply once more; the symmetric packing only)
+typedef unsigned short pgx_bf16;
+template <typename PT>
+__device__ __forceinline__ PT patch_to_store(double a) {
+  return (PT)a;
+}
+template <>
+__device__ __forceinline__ pgx_bf16 patch_to_store<pgx_bf16>(double a) {
+  const unsigned u = __float_as_uint((float)a);
+  return (pgx_bf16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // round to nearest even
+}
+template <typename PT>
+__device__ __forceinline__ float patch_from_store(PT v) {
+  return (float)v;
+}
+template <>
+__device__ __forceinline__ float patch_from_store<pgx_bf16>(pgx_bf16 v) {
+  return __uint_as_float((unsigned)v << 16);
+}
+
 template <int NN, typename PT, bool SYM>
 __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __restrict__ pdof, const int32_t* __restrict__ ppos,
                                                       const double* __restrict__ K, const double* __restrict__ M,
@@ -125,7 +147,7 @@ __global__ void __launch_bounds__(256) k_patch_invert(int np, const int32_t* __r
     for (int q = 0; q < PQ; ++q) {
       PT v[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = (4 * q + t < P) ? (PT)a[4 * q + t] : (PT)0;
+      for (int t = 0; t < 4; ++t) v[t] = patch_to_store<PT>((4 * q + t < P) ? a[4 * q + t] : 0.0);
       if (!SYM)
         *(v4*)(out + (size_t)q * P * 4) = (v4){v[0], v[1], v[2], v[3]};
       else if (4 * q <= l)
@@ -172,10 +194,11 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
 #pragma unroll
       for (int q = 0; q < PQ; ++q)
         if (4 * q <= l) {
-          *(f4*)&sA[g][l][4 * q] = (f4){(float)v[q][0], (float)v[q][1], (float)v[q][2], (float)v[q][3]};
+          *(f4*)&sA[g][l][4 * q] = (f4){patch_from_store<PT>(v[q][0]), patch_from_store<PT>(v[q][1]), patch_from_store<PT>(v[q][2]),
+                                        patch_from_store<PT>(v[q][3])};
           if (4 * q + 4 <= (l & ~3)) {  // strictly left of the diagonal block: the mirrored entries
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sA[g][4 * q + t][l] = (float)v[q][t];
+            for (int t = 0; t < 4; ++t) sA[g][4 * q + t][l] = patch_from_store<PT>(v[q][t]);
           }
         }
     }
@@ -205,7 +228,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(int np, int nv, int nd, con
       const v4 v = __builtin_nontemporal_load((const v4*)(in + (size_t)q * P * 4));  // streamed once per sweep
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (4 * q + t < P) row[4 * q + t] = (double)v[t];
+        if (4 * q + t < P) row[4 * q + t] = sizeof(PT) == 2 ? (double)patch_from_store<PT>(v[t]) : (double)v[t];
     }
   } else {
 #pragma unroll
@@ -255,7 +278,7 @@ void pgxk_patch_positions(hipStream_t st, int np, int NN, const int32_t* pdof, c
 size_t pgxk_patch_inverse_bytes(int np, int NN, int f32, int sym) {
   const int P = 2 * NN <= 14 ? 14 : 16;
   const size_t vecs = sym ? (size_t)patch_sym_vecs(P) : (size_t)P * ((P + 3) / 4);
-  return (size_t)np * vecs * 4 * (f32 ? sizeof(float) : sizeof(double));
+  return (size_t)np * vecs * 4 * (f32 == 2 ? sizeof(pgx_bf16) : f32 ? sizeof(float) : sizeof(double));
 }
 
 void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, const int32_t* ppos, const double* K, const double* M,
@@ -264,9 +287,11 @@ void pgxk_patch_invert(hipStream_t st, int np, int NN, const int32_t* pdof, cons
 #define PGX_INV(N, T, S) \
   hipLaunchKernelGGL((k_patch_invert<N, T, S>), dim3(blocks), dim3(256), 0, st, np, pdof, ppos, K, M, D, mask, alpha, (T*)pinv)
   if (NN <= 7) {
-    if (f32 && sym) PGX_INV(7, float, true); else if (f32) PGX_INV(7, float, false); else PGX_INV(7, double, false);
+    if (f32 == 2 && sym) PGX_INV(7, pgx_bf16, true);
+    else if (f32 && sym) PGX_INV(7, float, true); else if (f32) PGX_INV(7, float, false); else PGX_INV(7, double, false);
   } else {
-    if (f32 && sym) PGX_INV(8, float, true); else if (f32) PGX_INV(8, float, false); else PGX_INV(8, double, false);
+    if (f32 == 2 && sym) PGX_INV(8, pgx_bf16, true);
+    else if (f32 && sym) PGX_INV(8, float, true); else if (f32) PGX_INV(8, float, false); else PGX_INV(8, double, false);
   }
 #undef PGX_INV
 }
@@ -279,9 +304,11 @@ void pgxk_patch_sweep(hipStream_t st, int np, int NN, int nv, int nd, const int3
   hipLaunchKernelGGL((k_patch_apply<N, T, S>), dim3(blocks), dim3(256), 0, st, np, nv, nd, pdof, edge_ends, (const T*)pinv, ru, rp, \
                      omega, xu, xp, (float*)su, (float*)sp)
   if (NN <= 7) {
-    if (f32 && sym) PGX_APP(7, float, true); else if (f32) PGX_APP(7, float, false); else PGX_APP(7, double, false);
+    if (f32 == 2 && sym) PGX_APP(7, pgx_bf16, true);
+    else if (f32 && sym) PGX_APP(7, float, true); else if (f32) PGX_APP(7, float, false); else PGX_APP(7, double, false);
   } else {
-    if (f32 && sym) PGX_APP(8, float, true); else if (f32) PGX_APP(8, float, false); else PGX_APP(8, double, false);
+    if (f32 == 2 && sym) PGX_APP(8, pgx_bf16, true);
+    else if (f32 && sym) PGX_APP(8, float, true); else if (f32) PGX_APP(8, float, false); else PGX_APP(8, double, false);
   }
 #undef PGX_APP
   const int ne = nd - nv;
