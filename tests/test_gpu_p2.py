@@ -154,7 +154,8 @@ def test_p2_patch_inverses_in_symmetric_packing_equal_the_full_rows(require_gpu,
     from proximalgalerkin_amd.obstacle import solve_problem
 
     out = {}
-    for name, env in (("sym", {}), ("full", {"PGX_P2_PATCH_SYM": "0"}), ("double", {"PGX_P2_PATCH_F32": "0"})):
+    for name, env in (("sym", {}), ("full", {"PGX_P2_PATCH_SYM": "0"}), ("double", {"PGX_P2_PATCH_F32": "0"}),
+                      ("bf16", {"PGX_P2_PATCH_F32": "2"})):  # opt-in: bfloat16 entries in the symmetric packing
         for k in ("PGX_P2_PATCH_SYM", "PGX_P2_PATCH_F32"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -162,7 +163,7 @@ def test_p2_patch_inverses_in_symmetric_packing_equal_the_full_rows(require_gpu,
         msh = fem.create_rectangle(DOMAIN, (N, M))
         sol, newton, hist = solve_problem(msh, 2, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
         out[name] = (hist["Newton steps"], sol.x.array[: sol.function_space.block_size].copy())
-    for other in ("full", "double"):
+    for other in ("full", "double", "bf16"):
         assert out["sym"][0] == out[other][0]
         assert _rel(out["sym"][1], out[other][1]) < 1e-10
 
