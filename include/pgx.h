@@ -167,7 +167,7 @@ int pgx_comm_counts(pgx_handle* h, int64_t out[4], int reset);
  * indices, D(psi) from a structure-of-arrays copy, 496 B per group; the frame rows in CSR form -, kind 0 = the block-CSR kernel
  * k_bspmv_bal; *active is 3 or 0. */
 int pgx_spmv_select(pgx_handle* h, int kind, int* active);
-/* P2 handles: out = {state, i0, ni, j0, nj} of the structured apply - state 0: not available on this mesh (general meshes, strips,
+/* P2 handles: out = {state, i0, ni, j0, nj} of the structured apply - state 0: not available on this mesh (general meshes,
  * fewer than 8 cells per side, a pattern or K / M entries that are not those of the uniform right-diagonal mesh), 1: pattern verified,
  * 2: in use; the interior groups are the vertices (i, j), i0 <= i < i0 + ni, j0 <= j < j0 + nj, with their three edges. */
 int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]);

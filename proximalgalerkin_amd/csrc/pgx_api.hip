@@ -98,7 +98,7 @@ struct pgx_handle {
   // structured P2 operator apply (pgx_p2st.hip): interior groups [i0, i0 + ni) x [j0, j0 + nj) through the table-driven kernel,
   // the frame rows through the CSR form.  state: 0 off, 1 pattern verified (K / M constants not yet fetched), 2 ready
   struct P2St {
-    int state = 0, enable = 1, select = 1, i0 = 0, ni = 0, j0 = 0, nj = 0, nframe = 0, ref_rows[4] = {0, 0, 0, 0};
+    int state = 0, enable = 1, dist_enable = 1, select = 1, i0 = 0, ni = 0, j0 = 0, nj = 0, nframe = 0, ref_rows[4] = {0, 0, 0, 0};
     P2StTab tab;
     double K[46];
     double* Dst = nullptr;
@@ -521,7 +521,7 @@ static int build_plan_p2(pgx_handle* h, const pgx_mesh* m, const std::vector<uin
   for (size_t k = 0; k < col.size(); ++k) colm[k] = col[k] | (hmask[col[k]] ? (int32_t)0x80000000 : 0);
   // structured operator apply (pgx_p2st.hip): derive the 46-entry table from one interior group, verify it on every group of the
   // largest rectangle of groups that match, list the rows of the frame around it
-  if (h->structured && !h->dist.on && h->p2st.enable && h->nx >= 8 && h->ny >= 8) {
+  if (h->structured && (!h->dist.on || h->p2st.dist_enable) && h->p2st.enable && h->nx >= 8 && h->ny >= 8) {
     const int nx = h->nx, ny = h->ny, sx = nx + 1;
     auto ebase = [&](int i, int j) { return nv + j * (3 * nx + 1) + 3 * i; };
     bool ok = (nv == sx * (ny + 1)) && (ne == ny * (3 * nx + 1) + nx);
@@ -1198,6 +1198,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_P2_PATCH_SYM")) h->patch_sym = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_RESID_F32")) h->p2_resid_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_P2_STENCIL")) h->p2st.enable = atoi(e);
+  if (const char* e = pgx_tune("PGX_P2_STENCIL_DIST")) h->p2st.dist_enable = atoi(e);
   if (!h->patch_f32) h->patch_sym = 0;
   if (h->patch_f32 == 2 && !h->patch_sym) h->patch_f32 = 1;  // bfloat16 storage exists in the symmetric packing only
   if (const char* e = pgx_tune("PGX_P2_FALLBACK_ITS")) h->p2_fallback_its = std::max(1, atoi(e));
@@ -1788,7 +1789,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
 // group; once per Jacobian: the structure-of-arrays copies of D(psi).  Returns false when the CSR kernels have to do the work.
 static bool p2st_ready(pgx_handle* h) {
   pgx_handle::P2St& S = h->p2st;
-  if (S.state == 0 || !S.select || h->dist.on || !h->s_K || !h->s_D) return false;  // strips keep the CSR kernel (ghost rows, halo depth)
+  if (S.state == 0 || !S.select || (h->dist.on && !S.dist_enable) || !h->s_K || !h->s_D) return false;  // strips too (PGX_P2_STENCIL_DIST=0: CSR kernel there)
   static const int nt[4] = {19, 9, 9, 9}, off[4] = {0, 19, 28, 37};
   const size_t G = (size_t)h->n;  // groups = vertices
   if (S.state == 1) {
@@ -2300,9 +2301,13 @@ static int pcycle_p2_patch_dist(pgx_handle* h, double* bu, double* bp, double* x
     xv = g;
     return r;
   };
+  const bool st_apply = h->spmv_bal && p2st_ready(h);
   auto resid = [&]() {
-    pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu, bp,
-                   h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp, h->s_Df);
+    if (st_apply)
+      p2st_apply(h, xu, xp, bu, bp, h->p2_ru, h->p2_rp, true);
+    else
+      pgxk_bspmv_bal(h->st, nd, h->s_nblk, h->s_blk, h->s_rowptr, h->s_colm, h->s_K, h->s_M, h->s_code, h->s_tab, h->s_D, h->alpha, h->mask, xu, xp, bu,
+                     bp, h->xcd_remap ? 1 : 0, h->p2_ru, h->p2_rp, h->s_Df);
     xv -= 1;
   };
   auto patch = [&](const double* ru, const double* rp) {
@@ -2965,7 +2970,7 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
       // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
       // K and M are seven constants each
       *bytes = (16.0 + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
-    else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && !h->dist.on && h->spmv_stream && h->spmv_bal) {
+    else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && (!h->dist.on || h->p2st.dist_enable) && h->spmv_stream && h->spmv_bal) {
       // structured P2 apply: 46 D values per interior group (SoA copy), nothing else of the matrix; the frame rows in CSR form
       // (column + K + M + D = 28 B per entry, the row list); x read once; y written
       const double nfast = (double)h->p2st.ni * h->p2st.nj;
@@ -3000,7 +3005,7 @@ extern "C" int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]) {
   NEED(h);
   if (!out) return PGX_EINVAL;
   const pgx_handle::P2St& S = h->p2st;
-  out[0] = (h->degree == 2 && !h->dist.on) ? S.state : 0;
+  out[0] = (h->degree == 2 && (!h->dist.on || S.dist_enable)) ? S.state : 0;
   out[1] = S.i0, out[2] = S.ni, out[3] = S.j0, out[4] = S.nj;
   return PGX_OK;
 }
@@ -3010,7 +3015,7 @@ extern "C" int pgx_spmv_select(pgx_handle* h, int kind, int* active) {
     if (kind == 0) h->p2st.select = 0;
     else if (kind == 1 || kind == 3) h->p2st.select = 1;
     else if (kind != -1) return PGX_EINVAL;
-    if (active) *active = (h->p2st.state && h->p2st.select && !h->dist.on && h->spmv_stream && h->spmv_bal) ? 3 : 0;
+    if (active) *active = (h->p2st.state && h->p2st.select && (!h->dist.on || h->p2st.dist_enable) && h->spmv_stream && h->spmv_bal) ? 3 : 0;
     return PGX_OK;
   }
   if (kind == 0 || kind == 1 || kind == 2) h->spmv_stencil = kind;

@@ -14,7 +14,7 @@
 //   * D(psi) is read from a structure-of-arrays copy Dst[entry][group] (k_p2st_pack, once per Newton step): consecutive lanes are
 //     consecutive groups, every load is a full line;
 //   * a thread owns a group: 4 rows, both fields, every load of a row issued before its first use - no LDS staging, no row sums.
-// The frame (groups within two of the boundary, where columns are missing or Dirichlet) keeps the CSR form: k_p2_rows_csr on the
+// The frame (groups within two of the boundary - on a strip also of its cut lines -, where columns are missing or Dirichlet) keeps the CSR form: k_p2_rows_csr on the
 // list of its rows.  Algorithmic bytes per group: 46 D values + 4 (u, psi) pairs read + 4 written = 496 B (CSR: 726 B).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -260,6 +260,9 @@ def test_sharded_p2_solve_equals_single_handle(require_gpu, R, nx, ny, levels, s
         pr, s, sk, al = setup_problem(m, 2, petsc_options=opts)
         hist = run_outer_loop(pr, s, sk, al, 100, scheme, a_max, tol)
         x = s.x.array.copy()
+        # round 4: the strips apply the P2 operator through the structured kernel too (pgx_p2st.hip) wherever a strip has an interior
+        st = pr.p2_stencil_info()
+        assert (st[0] == 2 and pr.spmv_select() == 3) or min(nx, m.num_vertices // (nx + 1) - 1) < 8, st
         out = (x, hist, m.partition, pr.owned_range(), pr.owned_edge_range(), s.function_space.block_size, m.num_vertices)
         pr.close()
         return out
