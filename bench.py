@@ -553,6 +553,18 @@ def main():
                     "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": sm_traffic, "traffic_source": sm_src,
                     "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
+    if not sharded and args.degree == 2 and not args.solves_only:
+        try:  # P2: the patch sweep of the two-level cycle (k_patch_apply + k_patch_edges) on the inverses of the final Jacobian
+            sm_ms, sm_bytes = problem.smoother_bench(reps=20)
+            smoother = {"kernel": "k_patch_apply<7, float, SYM> + k_patch_edges (one additive vertex-star patch sweep of the P2 level: float "
+                                  "inverses in symmetric packing, 512 B per patch; the time-dominant kernel pair of the P2 solve: "
+                                  "profiles/r04_config3_p2_2048_kernel_stats.csv)",
+                        "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                        "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
+        except Exception as e:  # handles without the patch smoother (general meshes with vertex degree > 7)
+            smoother = None
+            sys.stderr.write(f"bench.py: no roofline_dominant for this P2 handle: {e}\n")
     coarse = None
     if not sharded and args.degree == 1 and not args.solves_only:
         # the part of one V-cycle on the levels of at most 513^2 vertices, launches back to back

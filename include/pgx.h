@@ -171,6 +171,8 @@ int pgx_spmv_select(pgx_handle* h, int kind, int* active);
  * fewer than 8 cells per side, a pattern or K / M entries that are not those of the uniform right-diagonal mesh), 1: pattern verified,
  * 2: in use; the interior groups are the vertices (i, j), i0 <= i < i0 + ni, j0 <= j < j0 + nj, with their three edges. */
 int pgx_p2_stencil_info(pgx_handle* h, int32_t out[5]);
+/* (P2 handles: pgx_smoother_bench times one additive patch sweep - k_patch_apply + k_patch_edges - on the inverses of the last
+ * Jacobian; `bytes` = inverses + dof table + residual and iterate of the patch dofs + the parked edge contributions.) */
 /* The same for the TIME-DOMINANT kernel of the multigrid-preconditioned solve: the fused three-sweep smoother of the finest
  * level (k_st_smoothR, post-smoothing variant: x + P x_c folded in), at the Jacobian of the last pgx_jacobian_fill.
  * algorithmic_bytes = one pass over the level: 4 D-stencil arrays + b (2) + x (2) + the coarse correction (2 arrays of n/4) read,

@@ -2847,6 +2847,40 @@ extern "C" int pgx_smoother_bench(pgx_handle* h, int reps, double* avg_ms, doubl
     h->err = "pgx_smoother_bench needs a structured single-GPU handle with a grid hierarchy and a filled Jacobian";
     return PGX_ESTATE;
   }
+  if (h->degree == 2) {
+    // P2: the time-dominant kernel is the patch sweep (k_patch_apply + k_patch_edges) on the current Jacobian's inverses
+    if (!h->patch_nn || !h->p2_patch) {
+      h->err = "pgx_smoother_bench (P2): no patch smoother on this handle";
+      return PGX_ESTATE;
+    }
+    const int rcp = ensure_patches(h);
+    if (rcp) return rcp;
+    const int nd = h->nd, nv = h->n, NN = h->patch_nn, P = 2 * NN;
+    pgxk_set(h->st, 2 * (size_t)nd, 1.0, h->rhs);
+    HIPCHK(hipMemsetAsync(h->w, 0, sizeof(double) * 2 * nd, h->st));
+    auto sweep = [&]() {
+      pgxk_patch_sweep(h->st, nv, NN, nv, nd, h->pdof, h->edge_ends, h->pinv, h->patch_f32, h->patch_sym, h->rhs, h->rhs + nd, h->patch_omega,
+                       h->w, h->w + nd, h->p2_su, h->p2_sp);
+    };
+    for (int k = 0; k < 3; ++k) sweep();
+    HIPCHK(hipEventRecord(h->e0, h->st));
+    for (int k = 0; k < reps; ++k) sweep();
+    HIPCHK(hipEventRecord(h->e1, h->st));
+    HIPCHK(hipEventSynchronize(h->e1));
+    float msp = 0;
+    HIPCHK(hipEventElapsedTime(&msp, h->e0, h->e1));
+    *avg_ms = (double)msp / reps;
+    if (bytes) {
+      // per patch: the inverse, the dof table, the residual at its 2 NN dofs (read once: every dof is gathered by its patches out
+      // of L2, HBM sees each value once -> 16 B per dof), the vertex iterate read + written, the parked edge contributions; per edge
+      // (k_patch_edges): the two parked pairs read, the edge iterate read + written
+      const double inv = (double)pgxk_patch_inverse_bytes(nv, NN, h->patch_f32, h->patch_sym);
+      const double ne = (double)(nd - nv);
+      *bytes = inv + 4.0 * NN * nv + 16.0 * nd + 32.0 * nv + 2.0 * 2.0 * 4.0 * ne + (16.0 + 32.0) * ne;
+    }
+    (void)P;
+    return PGX_OK;
+  }
   GridLevel& L = h->lev[0];
   GridLevel& C = h->lev[1];
   const size_t n = (size_t)L.n;

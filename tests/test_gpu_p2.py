@@ -197,3 +197,16 @@ def test_p2_structured_apply_equals_the_csr_kernel_and_the_oracle(require_gpu, m
         problem.close()
     for a, b in zip(out["1"], out["0"]):
         assert _rel(a, b) < 1e-13
+
+
+def test_p2_patch_sweep_microbenchmark(require_gpu):
+    """pgx_smoother_bench on a P2 handle times the patch sweep (bench.py's `roofline_dominant` of --degree 2): positive time, the
+    byte count of its streams (512 B of packed float inverses per patch dominate)."""
+    problem, sol, sol_k, alpha, prob = _setup(64, 64)
+    x, xk = _iterates(2 * prob.n, 4)
+    sol_k.x.array[:] = xk
+    problem.assemble_jacobian(x)
+    ms, by = problem.smoother_bench(reps=3)
+    nv = 65 * 65
+    assert ms > 0 and 512 * nv < by < 1100 * nv
+    problem.close()
