@@ -74,6 +74,14 @@ int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
 /* accumulated device time of the last factor / solve calls in ms (HIP events; 0 until pgx_nd_timing(s,1)) */
 int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
 
+/* Diagnostic: device time per TREE DEPTH (0 = root) of the factorisations, forward sweeps and backward sweeps since recording was
+ * switched on (HIP events on the solver's stream at the depth boundaries).  enable > 0: start recording and clear the sums,
+ * 0: stop and clear, < 0: leave the state alone (read only).  *n_depths: in = capacity of the arrays, out = number of tree
+ * depths; any array may be NULL; calls[3] = factorisations / forward / backward sweeps summed.  The arrays are filled BEFORE
+ * the state changes, so one call can read and stop. */
+int pgx_nd_depth_profile(pgx_nd* s, int enable, int32_t* n_depths, double* factor_ms, double* fwd_ms, double* bwd_ms,
+                         int32_t* calls);
+
 /* Symbolic structure, for tests (the numpy emulation in tests/test_nd_symbolic.py factorises with exactly these maps).
  * Call with NULL arrays to get sizes.  Layout: fronts are numbered batch by batch ("slots"); a batch = the fronts of one
  * tree depth and one size class, batches ordered by depth (root first);

@@ -143,9 +143,17 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  bool solve_small = true;  // PGX_ND_SOLVE_SMALL=0: the three-launch path for small fronts too (A/B)
   int panel_kind = 0;  // PGX_ND_PANEL: 0 MFMA (default), 1 LDS-blocked scalar, 2 register-column scalar panel kernel
   double factor_ms = 0, solve_ms = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  // per-depth device time (pgx_nd_depth_profile; diagnostic): events on the main stream at the depth boundaries of the
+  // factorisation and of both sweeps of the solve - [phase][depth], phase 0 factor, 1 forward, 2 backward
+  bool dprof = false;
+  std::vector<hipEvent_t> dp_ev;
+  std::vector<std::pair<int, int>> dp_tag;  // (phase, depth) of the interval that ENDS at event i + 1
+  std::vector<double> dp_ms[3];
+  int dp_calls[3] = {0, 0, 0};
   std::vector<void*> allocs;
 };
 
@@ -918,45 +926,7 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 
 
 // ---- dense kernels, batched over the fronts of one level (blockIdx.x = front within the level) ---------------------
-#define ND_NB 64   // widest pivot panel (diagonal block kept in LDS; one wavefront lane per row)
-#define ND_TS 64   // panel chunk
-#define ND_KC 16   // GEMM k-chunk staged in LDS
-#define ND_SLAB 256 // pivots per triangular-solve launch in the solve phase
-#define ND_OUTER 256 // pivots per outer block of the factorisation (rank of the big trailing updates)
-typedef double nd_v4d __attribute__((ext_vector_type(4)));
-
-// Parent-centric assembly fused into the Schur update (GATHER variants of the GEMM kernels): the border block of a front is never
-// written by k_nd_gather and read back - the update computes C = (children's Schur entries through the inverse maps) - A B.
-struct NdGatherCtx {
-  int64_t f0;  // first front of the batch
-  const int32_t *child0, *child1, *fM, *fP, *inv0, *inv1;
-  const int64_t *fbase, *vbase;
-};
-struct NdGatherSrc {
-  const double *S0, *S1;
-  const int32_t *I0, *I1;
-  int M0, M1;
-};
-__device__ __forceinline__ NdGatherSrc nd_gather_src(const NdGatherCtx& g, const double* arena, int64_t f) {
-  NdGatherSrc q;
-  const int c0 = g.child0[f], c1 = g.child1[f];
-  q.I0 = g.inv0 + g.vbase[f];
-  q.I1 = g.inv1 + g.vbase[f];
-  q.M0 = q.M1 = 0;
-  q.S0 = q.S1 = nullptr;
-  if (c0 >= 0) q.M0 = g.fM[c0], q.S0 = arena + g.fbase[c0] + (int64_t)g.fP[c0] * q.M0 + g.fP[c0];
-  if (c1 >= 0) q.M1 = g.fM[c1], q.S1 = arena + g.fbase[c1] + (int64_t)g.fP[c1] * q.M1 + g.fP[c1];
-  return q;
-}
-
-// broadcast of one lane's double to the wave when the lane index is wave-uniform: two v_readlane_b32 (scalar result) instead
-// of the two ds_bpermute_b32 round trips through the LDS crossbar that __shfl compiles to - these broadcasts sit on the
-// serial chains of the diagonal-block LU and of the triangular solves
-__device__ __forceinline__ double nd_bcast(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
+#include "pgx_nd_gemm.h"
 
 // LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level.  Blocked by 8 columns:
 // (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
@@ -1447,211 +1417,6 @@ static void nd_launch_panel(int kind, hipStream_t q, unsigned count, unsigned nc
     hipLaunchKernelGGL(k_nd_panel_r<64>, grid, dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
 }
 
-// C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
-// B = F[k0:k1, cols); (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of v_mfma_f64_16x16x4_f64, operands swapped
-// (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
-// into registers while the current one feeds the matrix cores.
-template <int WT, bool GATHER>
-__global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
-  constexpr int TS = 32 * WT;
-  constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
-  __shared__ double As[ND_KC][TS + 8];
-  __shared__ double Bs[TS][ND_KC + 1];
-  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
-  const int rmax = r1g, cmax = c1g;
-  if (r0 >= rmax || c0 >= cmax) return;
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
-  const int64_t MP = (int64_t)M * P;
-  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels (compact store)
-  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
-  const int wi = (wv >> 1) * 16 * WT, wj = (wv & 1) * 16 * WT;
-  nd_v4d acc[WT][WT];  // [tj][ti]
-#pragma unroll
-  for (int a = 0; a < WT; ++a)
-#pragma unroll
-    for (int b = 0; b < WT; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
-  double ra[NLD], rb[NLD];
-  auto fetch = [&](int kc) {
-    const int kn = min(ND_KC, k1 - kc);
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + 256 * q;
-      const int i = idx % TS, k = idx / TS;
-      ra[q] = (k < kn && r0 + i < rmax) ? S[(int64_t)(kc + k) * M + r0 + i] : 0.0;
-      const int k2 = idx % ND_KC, j2 = idx / ND_KC, cj = c0 + j2;
-      rb[q] = (k2 < kn && cj < cmax) ? S[cj < P ? (int64_t)cj * M + kc + k2 : MP + (int64_t)(cj - P) * P + kc + k2] : 0.0;
-    }
-  };
-  fetch(k0);
-  for (int kc = k0; kc < k1; kc += ND_KC) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + 256 * q;
-      As[idx / TS][idx % TS] = ra[q];
-      Bs[idx / ND_KC][idx % ND_KC] = rb[q];
-    }
-    __syncthreads();
-    if (kc + ND_KC < k1) fetch(kc + ND_KC);
-#pragma unroll
-    for (int kk = 0; kk < ND_KC; kk += 4) {
-      const int kq = kk + (l >> 4);
-      double uf[WT], lf[WT];
-#pragma unroll
-      for (int t = 0; t < WT; ++t) {
-        uf[t] = Bs[wj + 16 * t + (l & 15)][kq];
-        lf[t] = As[kq][wi + 16 * t + (l & 15)];
-      }
-#pragma unroll
-      for (int tj = 0; tj < WT; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < WT; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[tj], lf[ti], acc[tj][ti], 0, 0, 0);
-    }
-  }
-  // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
-  if (GATHER) {
-    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
-    int a0[WT], a1[WT];  // the lane's rows in the children's borders
-#pragma unroll
-    for (int ti = 0; ti < WT; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
-      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
-    }
-#pragma unroll
-    for (int tj = 0; tj < WT; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (j >= cmax) continue;
-        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
-#pragma unroll
-        for (int ti = 0; ti < WT; ++ti) {
-          const int i = r0 + wi + 16 * ti + (l & 15);
-          if (i >= rmax) continue;
-          double v = 0.0;
-          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
-          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
-          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int tj = 0; tj < WT; ++tj)
-#pragma unroll
-    for (int ti = 0; ti < WT; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (i < rmax && j < cmax) F[(int64_t)j * M + i] -= acc[tj][ti][reg];
-      }
-    }
-}
-
-// 128 x 128 tiles with EIGHT waves (wave tile 64 x 32 = 4 x 2 MFMA tiles): 64 accumulator VGPRs instead of 128, so that
-// two workgroups = 4 waves per SIMD are resident (launch bounds: 4 waves per SIMD -> <= 128 VGPRs) and one wave's LDS staging and
-// barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
-template <bool GATHER>
-__global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
-  constexpr int TS = 128, NT = 512;
-  constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
-  __shared__ double As[ND_KC][TS + 8];
-  __shared__ double Bs[TS][ND_KC + 1];
-  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
-  const int rmax = r1g, cmax = c1g;
-  if (r0 >= rmax || c0 >= cmax) return;
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
-  const int64_t MP = (int64_t)M * P;
-  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels
-  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
-  const int wi = (wv >> 2) * 64, wj = (wv & 3) * 32;
-  nd_v4d acc[2][4];  // [tj][ti]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (nd_v4d){0.0, 0.0, 0.0, 0.0};
-  double ra[NLD], rb[NLD];
-  auto fetch = [&](int kc) {
-    const int kn = min(ND_KC, k1 - kc);
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + NT * q;
-      const int i = idx % TS, k = idx / TS;
-      ra[q] = (k < kn && r0 + i < rmax) ? S[(int64_t)(kc + k) * M + r0 + i] : 0.0;
-      const int k2 = idx % ND_KC, j2 = idx / ND_KC, cj = c0 + j2;
-      rb[q] = (k2 < kn && cj < cmax) ? S[cj < P ? (int64_t)cj * M + kc + k2 : MP + (int64_t)(cj - P) * P + kc + k2] : 0.0;
-    }
-  };
-  fetch(k0);
-  for (int kc = k0; kc < k1; kc += ND_KC) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + NT * q;
-      As[idx / TS][idx % TS] = ra[q];
-      Bs[idx / ND_KC][idx % ND_KC] = rb[q];
-    }
-    __syncthreads();
-    if (kc + ND_KC < k1) fetch(kc + ND_KC);
-#pragma unroll
-    for (int kk = 0; kk < ND_KC; kk += 4) {
-      const int kq = kk + (l >> 4);
-      double uf[2], lf[4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) uf[t] = Bs[wj + 16 * t + (l & 15)][kq];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) lf[t] = As[kq][wi + 16 * t + (l & 15)];
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[tj], lf[ti], acc[tj][ti], 0, 0, 0);
-    }
-  }
-  if (GATHER) {
-    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
-    int a0[4], a1[4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
-      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
-    }
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (j >= cmax) continue;
-        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const int i = r0 + wi + 16 * ti + (l & 15);
-          if (i >= rmax) continue;
-          double v = 0.0;
-          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
-          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
-          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (i < rmax && j < cmax) F[(int64_t)j * M + i] -= acc[tj][ti][reg];
-      }
-    }
-}
-
 // in-place triangular solve of the diagonal range [k0,k1) of every front's pivot block on w: upper == 0: unit lower L11;
 // upper != 0: U11.  One workgroup per front, 64-wide blocks: the 64x64 triangle is solved by wave 0 with lane shuffles,
 // the remaining rows OF THE RANGE are updated by all threads; rows outside the range are left to k_nd_gemv (many
@@ -1771,6 +1536,136 @@ __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ aren
   red[g][lane] = a;
   __syncthreads();
   if (g == 0 && r < r1) w[r] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ---- solve phase of SMALL fronts (round 5): P <= 64, M <= 256 - ONE WAVE per front does what k_nd_fwd_assemble + k_nd_trsv + k_nd_gemv
+// (forward) resp. k_nd_bwd_gather + k_nd_gemv + k_nd_trsv (backward) did in three launches of 256-thread workgroups.  The deep levels
+// of a 2-D tree are hundreds of thousands of fronts of 50-150 rows: a launch per step and four waves per front left them at 0.7-2.5
+// TB/s (ex 06 at 1024^2: depth 17, 130 052 fronts of 5 + 48: 1.4 ms for 1 GB of factors).  Lane = row (rows lane + 64 i), the
+// column of L / U for the next 8 pivots is requested before the 8 dependent steps, pivot values travel by v_readlane.
+template <int NR>
+__global__ __launch_bounds__(64) void k_nd_fwd_small(const double* __restrict__ arena, int64_t lev_off, int64_t fs, int64_t f0, int P,
+                                                     int M, const int32_t* __restrict__ fp, const int32_t* __restrict__ fb,
+                                                     const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
+                                                     const int32_t* __restrict__ fP, const int64_t* __restrict__ vbase,
+                                                     const int64_t* __restrict__ dof_ptr, const int32_t* __restrict__ own_dofs,
+                                                     const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel,
+                                                     const double* __restrict__ b, double* __restrict__ vec) {
+  __shared__ double ws[64 * NR];
+  const int64_t f = f0 + blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* L = arena + lev_off + (int64_t)blockIdx.x * fs;
+  double* w = vec + vbase[f];
+  const int p = fp[f];
+  const int32_t* od = own_dofs + dof_ptr[f];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = lane + 64 * i;
+    ws[r] = r < p ? b[od[r]] : 0.0;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {  // the children's border contributions (a child's map is injective: no conflicts)
+    const int c = pass == 0 ? child0[f] : child1[f];
+    if (c < 0) continue;
+    const double* wc = vec + vbase[c] + fP[c];
+    const int32_t* R = rel + rel_ptr[c];
+    const int bc = fb[c];
+    for (int k = lane; k < bc; k += 64) ws[R[k]] += wc[k];
+    __syncthreads();
+  }
+  double wr[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) wr[i] = ws[lane + 64 * i];
+  for (int k0 = 0; k0 < p; k0 += 8) {
+    double col[8][NR];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + q;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int r = lane + 64 * i;
+        col[q][i] = (k < p && r > k && r < M) ? L[(int64_t)k * M + r] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + q;
+      if (k < p) {  // uniform
+        const double yk = nd_bcast(wr[0], k);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) wr[i] -= col[q][i] * yk;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = lane + 64 * i;
+    if (r < M) w[r] = wr[i];
+  }
+}
+
+// backward sweep of a small front: border values from the parent's vector, y <- y - U12 x_border (lanes = (pivot row, column group),
+// partial sums folded across the groups), then the U11 back substitution in registers.  gather == 0: the border values are already
+// in the front's vector (subtree roots of a distributed factorisation).
+template <int NR>
+__global__ __launch_bounds__(64) void k_nd_bwd_small(const double* __restrict__ arena, int64_t lev_off, int64_t fs, int64_t f0, int P,
+                                                     int M, int pplog, const int32_t* __restrict__ fp, const int32_t* __restrict__ fb,
+                                                     const int32_t* __restrict__ parent, const int64_t* __restrict__ vbase,
+                                                     const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel,
+                                                     double* __restrict__ vec, int gather) {
+  __shared__ double xb[64 * NR];
+  const int64_t f = f0 + blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* S = arena + lev_off + (int64_t)blockIdx.x * fs;
+  double* w = vec + vbase[f];
+  const int p = fp[f], b = fb[f], B = M - P;
+  const int pf = parent[f];
+  const bool take = gather && pf >= 0;
+  const double* wp = take ? vec + vbase[pf] : nullptr;
+  const int32_t* R = rel + rel_ptr[f];
+  for (int j = lane; j < B; j += 64) {
+    double v = 0.0;
+    if (j < b) v = take ? wp[R[j]] : w[P + j];
+    xb[j] = v;
+    if (take && j < b) w[P + j] = v;  // the children of this front read it from here
+  }
+  __syncthreads();
+  const int PP = 1 << pplog, G = 64 >> pplog;
+  const int k = lane & (PP - 1), g = lane >> pplog;
+  const double* U12 = S + (int64_t)M * P + k;
+  double acc = 0.0;
+  if (k < P) {
+    int j = g;
+    for (; j + 7 * G < b; j += 8 * G) {
+      double u[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = U12[(int64_t)(j + q * G) * P];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += u[q] * xb[j + q * G];
+    }
+    for (; j < b; j += G) acc += U12[(int64_t)j * P] * xb[j];
+  }
+  for (int off = PP; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+  double y = lane < P ? w[lane] - acc : 0.0;
+  const double rd = lane < p ? 1.0 / S[(int64_t)lane * M + lane] : 1.0;
+  for (int k0 = ((p - 1) / 8) * 8; k0 >= 0; k0 -= 8) {
+    double col[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int kk = k0 + q;
+      col[q] = (kk < p && lane < kk) ? S[(int64_t)kk * M + lane] : 0.0;
+    }
+#pragma unroll
+    for (int q = 7; q >= 0; --q) {
+      const int kk = k0 + q;
+      if (kk < p) {  // uniform
+        const double xk = nd_bcast(y * rd, kk);
+        y -= col[q] * xk;
+        if (lane == kk) y = xk;
+      }
+    }
+  }
+  if (lane < P) w[lane] = y;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2217,6 +2112,8 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     const size_t nb = (size_t)Lk.B * Lk.B, mult = s->rank == 0 ? (size_t)s->size : 1;
     if ((rc = nd_alloc(s, &s->d_xbuf, mult * nb)) || (rc = nd_alloc(s, &s->d_vbuf, mult * (size_t)Lk.B))) return fail(rc);
   }
+  s->dprof = pgx_tune("PGX_ND_DEPTHPROF") != nullptr;
+  if (const char* e = pgx_tune("PGX_ND_SOLVE_SMALL")) s->solve_small = atoi(e) != 0;  // per-depth table on stderr when the handle is destroyed
   if (ptime) {
     hipDeviceSynchronize();
     fprintf(stderr, "pgx_nd create: symbolic %.0f ms, assembly / leaf lists %.0f ms, maps, uploads, device allocations %.0f ms\n", tms(c_0, c_1),
@@ -2260,14 +2157,47 @@ extern "C" int pgx_nd_create_dist(const pgx_nd_matrix* A, pgx_comm* comm, int de
   return nd_create_impl(A, comm, device, hip_stream, out);
 }
 
+// PGX_ND_DEPTHPROF: where the device time of this handle's factorisations and solves went, tree depth by tree depth
+static void nd_dp_report(const pgx_nd* s) {
+  if (!s->dprof || s->dp_calls[0] + s->dp_calls[1] == 0) return;
+  const int nd = (int)s->dfirst.size() - 1;
+  const double nf = std::max(1, s->dp_calls[0]), ns = std::max(1, s->dp_calls[1]);
+  fprintf(stderr, "pgx_nd depth profile: n = %lld, %d factorisations, %d solves; per call, ms\n", (long long)s->n, s->dp_calls[0], s->dp_calls[1]);
+  fprintf(stderr, "%5s %8s %8s %8s %9s %8s %8s %7s %7s  batches (count x P+B)\n", "depth", "factor", "fwd", "bwd", "GF(pad)", "TF/s", "GB fact", "TB/s f", "TB/s s");
+  double tot[3] = {0, 0, 0}, totf = 0, totb = 0;
+  for (int d = nd - 1; d >= 0; --d) {
+    double fl = 0, by = 0;
+    std::string bl;
+    for (int l = s->dfirst[d]; l < s->dfirst[d + 1]; ++l) {
+      const NdLevel& Lv = s->lev[l];
+      if (!Lv.count) continue;
+      const double P = Lv.P, B = Lv.B;
+      fl += Lv.count * (2.0 / 3.0 * P * P * P + 2.0 * P * P * B + 2.0 * P * B * B);
+      by += Lv.count * 8.0 * ((P + B) * P + P * B);
+      char t[64];
+      snprintf(t, sizeof t, " %lldx(%d+%d)", (long long)Lv.count, Lv.P, Lv.B);
+      bl += t;
+    }
+    double m[3];
+    for (int ph = 0; ph < 3; ++ph) m[ph] = d < (int)s->dp_ms[ph].size() ? s->dp_ms[ph][d] / (ph ? ns : nf) : 0.0, tot[ph] += m[ph];
+    totf += fl, totb += by;
+    fprintf(stderr, "%5d %8.3f %8.3f %8.3f %9.1f %8.2f %8.3f %7.2f %7.2f %s\n", d, m[0], m[1], m[2], fl / 1e9, m[0] > 0 ? fl / m[0] / 1e9 : 0.0, by / 1e9,
+            m[0] > 0 ? by / m[0] / 1e9 : 0.0, m[1] + m[2] > 0 ? 2 * by / (m[1] + m[2]) / 1e9 : 0.0, bl.c_str());
+  }
+  fprintf(stderr, "%5s %8.3f %8.3f %8.3f %9.1f %8.2f %8.3f %7.2f %7.2f\n", "all", tot[0], tot[1], tot[2], totf / 1e9, tot[0] > 0 ? totf / tot[0] / 1e9 : 0.0,
+          totb / 1e9, tot[0] > 0 ? totb / tot[0] / 1e9 : 0.0, tot[1] + tot[2] > 0 ? 2 * totb / (tot[1] + tot[2]) / 1e9 : 0.0);
+}
+
 extern "C" void pgx_nd_destroy(pgx_nd* s) {
   if (!s) return;
   if (s->device >= 0) {
     hipSetDevice(s->device);
     if (s->st) hipStreamSynchronize(s->st);
+    nd_dp_report(s);
     for (void* p : s->allocs) hipFree(p);
     if (s->e0) hipEventDestroy(s->e0);
     if (s->e1) hipEventDestroy(s->e1);
+    for (hipEvent_t e : s->dp_ev) hipEventDestroy(e);
     if (s->ev_fork) hipEventDestroy(s->ev_fork);
     if (s->ev_info) hipEventDestroy(s->ev_info);
     if (s->h_info) hipHostFree(s->h_info);
@@ -2307,6 +2237,60 @@ extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* s
   if (solve_ms) *solve_ms = s->solve_ms;
   s->timing = enable != 0;
   s->factor_ms = s->solve_ms = 0;
+  return PGX_OK;
+}
+
+// per-depth profile: mark() records an event on the main stream and tags the interval it closes; collect() turns the
+// events of the finished call into milliseconds per (phase, depth)
+static void nd_dp_mark(pgx_nd* s, size_t& used, int phase, int depth) {
+  if (!s->dprof) return;
+  if (used >= s->dp_ev.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    s->dp_ev.push_back(e);
+    s->dp_tag.push_back({0, 0});
+  }
+  hipEventRecord(s->dp_ev[used], s->st);
+  s->dp_tag[used] = {phase, depth};
+  ++used;
+}
+static void nd_dp_collect(pgx_nd* s, size_t used) {
+  if (!s->dprof || used < 2) return;
+  hipEventSynchronize(s->dp_ev[used - 1]);
+  bool seen[3] = {false, false, false};
+  for (size_t i = 1; i < used; ++i) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, s->dp_ev[i - 1], s->dp_ev[i]);
+    const int ph = s->dp_tag[i].first, d = s->dp_tag[i].second;
+    if (ph < 0 || d < 0) continue;
+    if ((int)s->dp_ms[ph].size() <= d) s->dp_ms[ph].resize(d + 1, 0.0);
+    s->dp_ms[ph][d] += ms;
+    seen[ph] = true;
+  }
+  for (int ph = 0; ph < 3; ++ph) s->dp_calls[ph] += seen[ph];
+}
+
+// Diagnostic: device time per tree depth.  enable != 0 switches the recording on (and clears the sums); with arrays of
+// n_depths entries the accumulated milliseconds of the factorisations / forward / backward sweeps since then are returned
+// (calls[3] = number of factorisations, forward and backward sweeps summed).  n_depths in: capacity, out: tree depths.
+extern "C" int pgx_nd_depth_profile(pgx_nd* s, int enable, int32_t* n_depths, double* factor_ms, double* fwd_ms, double* bwd_ms,
+                                    int32_t* calls) {
+  if (!s) return PGX_EINVAL;
+  const int nd = (int)s->dfirst.size() - 1;
+  if (n_depths) {
+    const int cap = *n_depths;
+    *n_depths = nd;
+    double* out[3] = {factor_ms, fwd_ms, bwd_ms};
+    for (int ph = 0; ph < 3; ++ph)
+      if (out[ph])
+        for (int d = 0; d < std::min(cap, nd); ++d) out[ph][d] = d < (int)s->dp_ms[ph].size() ? s->dp_ms[ph][d] : 0.0;
+    if (calls)
+      for (int ph = 0; ph < 3; ++ph) calls[ph] = s->dp_calls[ph];
+  }
+  if (enable >= 0) {
+    s->dprof = enable != 0;
+    for (int ph = 0; ph < 3; ++ph) s->dp_ms[ph].clear(), s->dp_calls[ph] = 0;
+  }
   return PGX_OK;
 }
 
@@ -2481,6 +2465,8 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
   auto grp = [&](int d, int sub) -> const pgx_nd::Group& { return s->groups[s->gfirst[d] + (sub < 0 ? 0 : sub)]; };
   int rcp = PGX_OK;
   const int kc = s->kcut;
+  size_t dpn = 0;
+  nd_dp_mark(s, dpn, -1, -1);
   if (kc >= 0) {
     // subtrees below the cut, one after the other; their roots' fronts (depth kc) wait in the other working buffer
     if ((rcp = prep(grp(kc, -1)))) return rcp;
@@ -2494,10 +2480,12 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           if (d < maxdepth) extend(grp(d + 1, g));
         }
         eliminate(grp(d, g), pc);
+        nd_dp_mark(s, dpn, 0, d);
       }
       extend(grp(kc + 1, g));
     }
     eliminate(grp(kc, -1));
+    nd_dp_mark(s, dpn, 0, kc);
   }
   bool ahead = false;  // this depth's buffer has been prepared on prep_st
   for (int d = (kc >= 0 ? kc - 1 : maxdepth); d >= 0; --d) {
@@ -2537,7 +2525,9 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           hipLaunchKernelGGL(k_nd_pack, dim3(pb), dim3(256), 0, s->st, s->arena + s->fbase[s->ghost_slot[j]], M, P, B,
                              s->d_xbuf + (size_t)j * nb, 1);
     }
+    nd_dp_mark(s, dpn, 0, d);
   }
+  nd_dp_collect(s, dpn);
   if (s->timing) {
     hipEventRecord(s->e1, s->st);
     hipEventSynchronize(s->e1);
@@ -2580,6 +2570,8 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
   }
   if (s->timing) hipEventRecord(s->e0, s->st);
   const int maxdepth = (int)s->dfirst.size() - 2;
+  size_t dpn = 0;
+  nd_dp_mark(s, dpn, -1, -1);
   for (int d = maxdepth; d >= 0; --d) {  // forward: leaves to root; the batches of one depth run on forked streams
     hipEventRecord(s->ev_fork, s->st);
     int used = 0;
@@ -2589,6 +2581,19 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       const int64_t fs = (int64_t)M * P + (int64_t)P * B;
       if (Lv.count == 0) continue;
       hipStream_t q = nd_fork(s, used++);
+      if (s->solve_small && P <= 64 && M <= 256) {  // one wave per front: assemble + triangle + border rows
+#define ND_FS(NR)                                                                                                                    \
+  hipLaunchKernelGGL(k_nd_fwd_small<NR>, dim3((unsigned)Lv.count), dim3(64), 0, q, s->arena, Lv.poff, fs, Lv.start, P, M, s->d_fp, s->d_fb, \
+                     s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel, db, s->vec)
+        if (M <= 64)
+          ND_FS(1);
+        else if (M <= 128)
+          ND_FS(2);
+        else
+          ND_FS(4);
+#undef ND_FS
+        continue;
+      }
       hipLaunchKernelGGL(k_nd_fwd_assemble, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, M, s->d_fp, s->d_fb,
                          s->d_child0, s->d_child1, s->d_fP, s->d_vbase, s->d_dof_ptr, s->d_own_dofs, s->d_rel_ptr, s->d_rel,
                          db, s->vec);
@@ -2617,6 +2622,7 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
           NDHIP(hipMemcpyAsync(s->vec + Lv.voff + (int64_t)(s->ghost_slot[j] - Lv.start) * M + P, s->d_vbuf + (size_t)j * B,
                                sizeof(double) * B, hipMemcpyDeviceToDevice, s->st));
     }
+    nd_dp_mark(s, dpn, 1, d);
   }
   for (int d = 0; d <= maxdepth; ++d) {  // backward: root to leaves
     const bool xchg = s->size > 1 && d == s->kdist && s->lev[s->kbatch].B > 0;
@@ -2645,6 +2651,22 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       const int64_t fs = (int64_t)M * P + (int64_t)P * B;
       if (Lv.count == 0) continue;
       hipStream_t q = nd_fork(s, used++);
+      if (s->solve_small && P <= 64 && M <= 256) {
+        int pplog = 0;
+        while ((1 << pplog) < P) ++pplog;
+        const int gth = !(xchg && l == s->kbatch);
+#define ND_BS(NR)                                                                                                                    \
+  hipLaunchKernelGGL(k_nd_bwd_small<NR>, dim3((unsigned)Lv.count), dim3(64), 0, q, s->arena, Lv.poff, fs, Lv.start, P, M, pplog, s->d_fp, \
+                     s->d_fb, s->d_parent, s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec, gth)
+        if (M <= 64)
+          ND_BS(1);
+        else if (M <= 128)
+          ND_BS(2);
+        else
+          ND_BS(4);
+#undef ND_BS
+        continue;
+      }
       if (B > 0) {
         if (!(xchg && l == s->kbatch))
           hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, s->d_fb, s->d_parent,
@@ -2662,7 +2684,9 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       }
     }
     nd_join(s, used);
+    nd_dp_mark(s, dpn, 2, d);
   }
+  nd_dp_collect(s, dpn);
   if (s->size > 1) NDHIP(hipMemsetAsync(dx, 0, sizeof(double) * s->n, s->st));  // every rank writes its own dofs only
   hipLaunchKernelGGL(k_nd_write_x, dim3((unsigned)s->nfronts), dim3(128), 0, s->st, s->nfronts, s->d_fp, s->d_vbase,
                      s->d_dof_ptr, s->d_own_dofs, s->vec, dx);
