@@ -91,8 +91,5 @@ int main(int argc, char** argv) {
     dim3 grid(count, (B + 127) / 128, (B + 127) / 128);
     hipLaunchKernelGGL((k_nd_gemm8<false>), grid, dim3(512), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc);
   }, true);
-  timeit("k_nd_gemmw 256x128 xcd", [&]() {
-    hipLaunchKernelGGL((k_nd_gemmw<false>), dim3(nd_gemmw_grid(count, B, B)), dim3(512), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, count);
-  }, true);
   return 0;
 }
