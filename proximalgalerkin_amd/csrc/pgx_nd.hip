@@ -143,6 +143,7 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  bool lshape = true;       // PGX_ND_LSHAPE=0: the trailing update of an outer block as three rectangles (A/B)
   bool solve_small = true;  // PGX_ND_SOLVE_SMALL=0: the three-launch path for small fronts too (A/B)
   int panel_kind = 0;  // PGX_ND_PANEL: 0 MFMA (default), 1 LDS-blocked scalar, 2 register-column scalar panel kernel
   double factor_ms = 0, solve_ms = 0;
@@ -2113,7 +2114,8 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
     if ((rc = nd_alloc(s, &s->d_xbuf, mult * nb)) || (rc = nd_alloc(s, &s->d_vbuf, mult * (size_t)Lk.B))) return fail(rc);
   }
   s->dprof = pgx_tune("PGX_ND_DEPTHPROF") != nullptr;
-  if (const char* e = pgx_tune("PGX_ND_SOLVE_SMALL")) s->solve_small = atoi(e) != 0;  // per-depth table on stderr when the handle is destroyed
+  if (const char* e = pgx_tune("PGX_ND_SOLVE_SMALL")) s->solve_small = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;  // per-depth table on stderr when the handle is destroyed
   if (ptime) {
     hipDeviceSynchronize();
     fprintf(stderr, "pgx_nd create: symbolic %.0f ms, assembly / leaf lists %.0f ms, maps, uploads, device allocations %.0f ms\n", tms(c_0, c_1),
@@ -2322,13 +2324,13 @@ static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, 
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
   if (big && cgather)
-    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
   else if (big)
-    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
   else if (cgather)
-    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
   else
-    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc);
+    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -2452,10 +2454,21 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           }
           kb = ke;
         }
-        // trailing matrix beyond the outer block, without the Schur block
-        nd_launch_gemm(s, q, Lv, oe, P, oe, P, ob, oe);
-        nd_launch_gemm(s, q, Lv, oe, P, P, M, ob, oe);
-        nd_launch_gemm(s, q, Lv, P, M, oe, P, ob, oe);
+        // trailing matrix beyond the outer block, without the Schur block: one launch over the L-shaped region
+        if (s->lshape && P - oe > 0) {
+          const bool big = (P - oe) >= 256;
+          const int TS = big ? 128 : 64;
+          const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(TS, oe, M, P), 1);
+          NdGatherCtx gc{};
+          if (big)
+            hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P);
+          else
+            hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P);
+        } else {
+          nd_launch_gemm(s, q, Lv, oe, P, oe, P, ob, oe);
+          nd_launch_gemm(s, q, Lv, oe, P, P, M, ob, oe);
+          nd_launch_gemm(s, q, Lv, P, M, oe, P, ob, oe);
+        }
         ob = oe;
       }
       if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, cgather);

@@ -45,19 +45,42 @@ __device__ __forceinline__ double nd_bcast(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+
+// The trailing update of an outer block in ONE launch (round 5): C is the L-shaped region rows / columns [o, M) of the front without
+// its Schur block [Ps, M)^2 - region A = rows [o, Ps) x columns [o, M), region B = rows [Ps, M) x columns [o, Ps) - and blockIdx.y the
+// running tile number over A then B (three launches of 400-900 tiles each left the epilogues of one launch uncovered by the MFMAs of
+// the next).  nd_lshape_tiles gives the grid's y extent.
+__host__ __device__ inline int nd_lshape_tiles(int TS, int o, int M, int Ps) {
+  const int nc = (M - o + TS - 1) / TS, nrA = (Ps - o + TS - 1) / TS, nrB = (M - Ps + TS - 1) / TS;
+  return nrA * nc + nrB * nrA;
+}
+__device__ __forceinline__ void nd_lshape_tile(int TS, int t, int o, int M, int Ps, int& r0, int& c0, int& rmax, int& cmax) {
+  const int nc = (M - o + TS - 1) / TS, nrA = (Ps - o + TS - 1) / TS;
+  if (t < nrA * nc) {
+    r0 = o + TS * (t / nc), c0 = o + TS * (t % nc), rmax = Ps, cmax = M;
+  } else {
+    const int u = t - nrA * nc;
+    r0 = Ps + TS * (u / nrA), c0 = o + TS * (u % nrA), rmax = M, cmax = Ps;
+  }
+}
+
 // C -= A B on the rectangle rows [r0g, r1g) x cols [c0g, c1g) of every front of the level, A = F[rows, k0:k1),
 // B = F[k0:k1, cols); (32 WT) x (32 WT) tiles, 4 waves x (WT x WT) MFMA tiles of v_mfma_f64_16x16x4_f64, operands swapped
 // (D^T = B^T A^T) so that the 16 lanes of an MFMA row write 128 contiguous bytes of C.  The next k-chunk is prefetched
 // into registers while the current one feeds the matrix cores.
 template <int WT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
+                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
-  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
-  const int rmax = r1g, cmax = c1g;
+  int r0, c0, rmax, cmax;
+  if (lsP < 0) {
+    r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z, rmax = r1g, cmax = c1g;
+  } else {
+    nd_lshape_tile(TS, (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax);
+  }
   if (r0 >= rmax || c0 >= cmax) return;
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
@@ -154,13 +177,17 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
 // barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
 template <bool GATHER>
 __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc) {
+                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP) {
   constexpr int TS = 128, NT = 512;
   constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
-  const int r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z;
-  const int rmax = r1g, cmax = c1g;
+  int r0, c0, rmax, cmax;
+  if (lsP < 0) {
+    r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z, rmax = r1g, cmax = c1g;
+  } else {
+    nd_lshape_tile(TS, (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax);
+  }
   if (r0 >= rmax || c0 >= cmax) return;
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
