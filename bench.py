@@ -344,9 +344,16 @@ def make_comm(local_rank):
     transport so that the SAME launch runs with all ranks on one GPU, where RCCL refuses to start (tests/test_gpu_multiprocess.py)."""
     from proximalgalerkin_amd import comm as pcomm
 
-    if os.environ.get("BENCH_COMM", "rccl") == "shm":
-        return pcomm.shm_from_torch_distributed()
-    return pcomm.rccl_from_torch_distributed(local_rank)
+    try:
+        if os.environ.get("BENCH_COMM", "rccl") == "shm":
+            c = pcomm.shm_from_torch_distributed()
+            c.selfcheck(float(os.environ.get("PGX_COMM_SELFCHECK_TIMEOUT", "10")))
+            return c
+        return pcomm.rccl_from_torch_distributed(local_rank)  # runs the same self-check after ncclCommInitRank
+    except Exception as e:  # first contact between the ranks failed: say which call, leave at once (a hung collective cannot be undone)
+        sys.stderr.write(f"bench.py rank {os.environ.get('RANK', '0')}: communicator not usable - {e}\n")
+        sys.stderr.flush()
+        os._exit(3)
 
 
 def reduce_over_ranks(dist, dt, newton_total, outer_total, device):
@@ -720,7 +727,7 @@ def main():
                                                             "assembly, no tree parallelism beyond BLAS): where it is SLOWER than "
                                                             "`value` the fronts of this 2-D dissection are too small to feed the "
                                                             "threads, and the one-thread figure is the stronger CPU baseline"}
-            if cpu_n != N or args.degree != 1:
+            if cpu_n != N:  # (sample mesh == workload mesh: directly comparable for ANY degree - the else branch)
                 ex = extrapolate(v, cpu_n, N, ladder) if ladder else None
                 if ex:
                     ex["gpu_over_cpu"] = out["value"] / ex["value"]

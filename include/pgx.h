@@ -102,7 +102,7 @@ typedef struct {
   /* Newton linear solve (replaces ksp preonly + pc lu/mumps): FGMRES + multigrid V-cycle */
   double ksp_rtol;    /* relative TRUE residual target; 0 (default) = auto: 1e-10 for P1, 1e-11 for P2, chosen from the
                          measured effect on the final primal field */
-  int32_t ksp_max_it; /* default 200 */
+  int32_t ksp_max_it; /* default 200; a sharded P2 handle (no sparse-LU fallback) raises the DEFAULT to 400, an explicit value is kept */
   int32_t ksp_restart;/* default 30 (basis storage allows up to 50) */
   int32_t mg_nu;      /* pre/post smoothing sweeps, default 6 (even values run as fused double sweeps) */
   double mg_omega;    /* collective-Jacobi damping, default 0.75 */
@@ -257,6 +257,12 @@ int pgx_comm_halo(pgx_comm* c, double* f0, double* f1, uint64_t send_lo, uint64_
                   uint64_t send_hi, uint64_t n_send_hi, uint64_t recv_hi, uint64_t n_recv_hi);
 int pgx_comm_gather0(pgx_comm* c, const double* send, uint64_t n, double* recv0);
 int pgx_comm_scatter0(pgx_comm* c, const double* send0, uint64_t n, double* recv);
+/* Self-check before the first solve: one halo exchange with both strip neighbours and one packed all-reduce on a known pattern,
+ * verified, each bounded by timeout_s (<= 0: 10 s).  Collective.  host != 0 for a host_mode communicator.  On failure the text
+ * (pgx_comm_last_error) names the operation that failed or did not complete; the caller should end the process (a collective
+ * that hangs cannot be cancelled).  Replaces nothing in the reference - MPI_Init fails loudly by itself; RCCL over a mis-wired
+ * launch does not. */
+int pgx_comm_selfcheck(pgx_comm* c, int host, double timeout_s);
 void pgx_comm_free(pgx_comm* c);
 const char* pgx_comm_last_error(void);
 

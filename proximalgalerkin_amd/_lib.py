@@ -238,6 +238,7 @@ SYMBOLS = [
     ("pgx_comm_halo", C.c_int, [_COMM, c_double_p, c_double_p] + [C.c_uint64] * 8),
     ("pgx_comm_gather0", C.c_int, [_COMM, c_double_p, C.c_uint64, c_double_p]),
     ("pgx_comm_scatter0", C.c_int, [_COMM, c_double_p, C.c_uint64, c_double_p]),
+    ("pgx_comm_selfcheck", C.c_int, [_COMM, C.c_int, C.c_double]),
     ("pgx_comm_free", None, [_COMM]),
     ("pgx_comm_last_error", C.c_char_p, []),
     ("pgx_create_sharded", C.c_int,

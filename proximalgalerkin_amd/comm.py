@@ -28,6 +28,15 @@ class Communicator:
             _lib.load().pgx_comm_free(self._c)
             self._c = None
 
+    def selfcheck(self, timeout_s: float = 10.0, host_mode: bool = False):
+        """One verified halo exchange with both neighbours and one packed all-reduce, each bounded by `timeout_s` (include/pgx.h:
+        pgx_comm_selfcheck).  Collective.  Raises PgxError naming the operation that failed or did not complete - call it before
+        the first solve of a multi-rank run and END THE PROCESS on failure (a hung collective cannot be cancelled)."""
+        lib = _lib.load()
+        rc = lib.pgx_comm_selfcheck(self._c, int(host_mode), float(timeout_s))
+        if rc:
+            _comm_error(lib, "pgx_comm_selfcheck", rc)
+
     def __repr__(self):
         return f"Communicator({self.kind}, rank {self.rank} of {self.size})"
 
@@ -66,7 +75,12 @@ def rccl_from_torch_distributed(device: int):
     rc = lib.pgx_comm_rccl_init(box[0], rank, size, int(device), C.byref(ptr))
     if rc:
         _comm_error(lib, "pgx_comm_rccl_init", rc)
-    return Communicator(ptr, rank, size, "rccl")
+    c = Communicator(ptr, rank, size, "rccl")
+    if size > 1:  # first contact between the ranks: a mis-wired launch must end with a message, not with a watchdog kill
+        import os
+
+        c.selfcheck(float(os.environ.get("PGX_COMM_SELFCHECK_TIMEOUT", "10")))
+    return c
 
 
 def rccl_single(device: int = 0):

@@ -2,6 +2,8 @@
 // hierarchy, FGMRES, SNES-mirroring Newton driver, and the extern "C" ABI of include/pgx.h.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1670,9 +1672,29 @@ static int fetch_small(pgx_handle* h, const double* dsrc, size_t n, size_t hoff 
   const unsigned long long seq = ++h->seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->st, (int)n, dsrc, h->h_small_dev + hoff, (int)n2, dsrc2, h->h_small_dev + hoff2,
                      seq, h->h_seq_dev);
+  // Bounded wait: a collective or a kernel ahead of k_publish that never completes leaves hipStreamQuery at NotReady
+  // for ever - after PGX_COMM_TIMEOUT seconds (default 120; the transports' own limit) the call fails with PGX_ECOMM / PGX_EHIP and
+  // a message instead of spinning.  The poll backs off: a pause per probe, and after ~50 us without an answer a yield per batch of
+  // probes, so that eight ranks plus the BLAS threads of an oversubscribed host do not starve each other.
+  static const double limit_s = [] {
+    const char* t = getenv("PGX_COMM_TIMEOUT");
+    return t ? std::max(1.0, atof(t)) : 120.0;
+  }();
+  std::chrono::steady_clock::time_point t0;
+  bool timed = false;
   for (unsigned long spins = 1;; ++spins) {
     if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return PGX_OK;
+    __builtin_ia32_pause();
+    if (spins > 0x2000 && (spins & 0xff) == 0) std::this_thread::yield();
     if ((spins & 0x3fff) == 0) {  // a failed launch or a faulted kernel must not leave the host spinning
+      if (!timed) {
+        t0 = std::chrono::steady_clock::now();
+        timed = true;
+      } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+        h->err = "fetch_small: the device did not publish within PGX_COMM_TIMEOUT (" + std::to_string((int)limit_s) +
+                 " s): a kernel or a collective ahead of it on the stream does not complete" + (h->dist.on || h->lu_comm ? " (a peer rank is missing?)" : "");
+        return (h->dist.on || h->lu_comm) ? PGX_ECOMM : PGX_EHIP;
+      }
       const hipError_t e = hipStreamQuery(h->st);
       if (e == hipSuccess) {
         if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return PGX_OK;
@@ -1722,6 +1744,7 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
                          h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv, with_d);
     h->dh_interior = with_d != 0;  // the interior rows of the finest D stencil are in place (consumed by jacobian_dev(have_d))
     if (with_d == 2) h->dv_lean = true;
+    if (with_d == 1) h->dv_lean = false;  // a full fill of the CSR rows too
     return;
   }
   pgxk_resid_fill_p1(h->st, with_d, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
@@ -2602,8 +2625,8 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     // batched dot products come back as s_i^2 (W_i . w) - the coefficients the projection w' = w - sum_i (v_i . w) v_i applies to the
     // stored W_i - and the pass over w that only divided it by its norm (67 MB read + written per iteration) is gone.  Only where
     // the preconditioner is the single-precision cycle entered on level 0 (it is the one that takes the factor).
-    const bool lazy = h->lazy_norm && !h->lu_active && h->degree == 1 && m + 2 <= PGX_DOT_SCALE_MAX && !h->lev.empty() &&
-                      f32_cycle_ok(h, 0, o->mg_nu);
+    const bool lazy = h->lazy_norm && h->cgs_selective && !h->lu_active && h->degree == 1 && m + 2 <= PGX_DOT_SCALE_MAX && !h->lev.empty() &&
+                      f32_cycle_ok(h, 0, o->mg_nu);  // (the non-selective CGS2 kernels carry no scale factors: that mode runs un-lazy)
     PgxDotScale sc2;  // s_i^2
     std::vector<double> sv((size_t)m + 2, 1.0);  // s_i
     for (int i = 0; i < PGX_DOT_SCALE_MAX; ++i) sc2.s[i] = 1.0;
@@ -2667,10 +2690,6 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
             for (int i = 0; i <= j; ++i) h->h_small[(m + 2) + i] /= sv[i];
           }
         } else {
-          if (lazy) {
-            h->err = "PGX_CGS_SELECTIVE=0 needs PGX_LAZY_NORM=0";
-            return PGX_EINVAL;
-          }
           if (j + 1 <= 60) {
             pgxk_axpy_dot(h->st, nk, j + 1, h->V, nk, d_h1, wj, h->partials2, d_h2);
           } else {  // beyond the fused kernel's LDS capacity (61 slices of 2 KB): two separate passes
@@ -3150,9 +3169,20 @@ extern "C" int pgx_newton_solve(pgx_handle* h, const pgx_snes_opts* opts, int* r
   // overshot iterates of settings B, on which the patch cycle needs a few hundred iterations instead of ten - the sharded solve
   // keeps iterating on its un-restarted basis (up to 300 vectors).  512^2 settings B on 4 strips: the golden's Newton counts
   // 5,4,3,2,1,1,4,1 (tests/test_gpu_sharded.py).
-  if (h->dist.on && h->degree == 2) optv.ksp_max_it = std::max(optv.ksp_max_it, 400);
+  // sharded P2 has no sparse-LU fallback for a stagnating two-level cycle: it runs the Krylov method longer instead - but only where
+  // the caller left the default (an explicit ksp_max_it is the caller's decision; include/pgx.h)
+  if (h->dist.on && h->degree == 2 && optv.ksp_max_it == 200) optv.ksp_max_it = 400;
   const size_t n2 = 2 * (size_t)h->nd;
   PgxSolveScope scope(h->st, h->prof, &h->lu_active);
+  // EVERY way out of the Newton loop - also the early `return rc` of a failed Krylov solve, halo exchange or replica check - leaves
+  // a hierarchy whose finest D(psi) was refreshed in passing (and, lean, CSR rows that were not): no export / CSR product of a
+  // matrix that mixes iterates afterwards
+  struct JacStale {
+    pgx_handle* h;
+    ~JacStale() {
+      if (h->dh_interior || h->dv_lean) h->jac_valid = false;
+    }
+  } jac_stale{h};
   PgxRange range("pgx:newton_solve");
   int its = 0, lin = 0, rsn = 0;
   double fnorm = 0, fnorm0 = 0, ttol = 0;

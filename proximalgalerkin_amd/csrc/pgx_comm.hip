@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -719,6 +720,72 @@ extern "C" int pgx_comm_scatter0(pgx_comm* c, const double* send0, uint64_t n, d
   const int rc = c->scatter0(nullptr, send0, n, recv);
   if (rc) g_comm_error = c->err;
   return rc;
+}
+
+// Self-check of a communicator before the first solve (round 5): the two operations the sharded path
+// enqueues thousands of times - the exchange of ghost entries with both strip neighbours and the packed all-reduce - run ONCE on a
+// known pattern, are verified, and must complete within timeout_s.  A transport that is mis-wired (wrong device binding, two
+// copies of librccl in one process, a peer that never joined, an xGMI link that does not come up) then ends the run with a
+// message that NAMES the failing call instead of a watchdog kill minutes into the first solve.  Collective.  host != 0: the
+// communicator was created in host mode (buffers are host memory).
+extern "C" int pgx_comm_selfcheck(pgx_comm* c, int host, double timeout_s) {
+  if (!c) return PGX_EINVAL;
+  if (!(timeout_s > 0.0)) timeout_s = 10.0;
+  const size_t N = 256, L = 4 * N + 8;
+  const int rank = c->rank, size = c->size;
+  auto pat = [](int r, int part, size_t i) { return 1000.0 * r + 100000.0 * part + (double)i; };  // part 1: sent down, 2: sent up
+  std::vector<double> hbuf(L, -1.0);
+  for (size_t i = 0; i < N; ++i) hbuf[N + i] = pat(rank, 1, i), hbuf[2 * N + i] = pat(rank, 2, i);
+  for (size_t i = 0; i < 8; ++i) hbuf[4 * N + i] = (double)(rank + 1) * (double)(i + 1);
+  double* buf = hbuf.data();
+  hipStream_t st = nullptr;
+  double* dev = nullptr;
+  auto fail = [&](const std::string& m) {
+    c->err = "communicator self-check (rank " + std::to_string(rank) + " of " + std::to_string(size) + "): " + m;
+    g_comm_error = c->err;
+    return PGX_ECOMM;
+  };
+  if (!host) {
+    if (hipMalloc(&dev, L * sizeof(double)) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+      return fail("cannot allocate the test buffer / stream on the device");
+    if (hipMemcpy(dev, hbuf.data(), L * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the pattern failed");
+    buf = dev;
+  }
+  // a step = enqueue + bounded wait; on a timeout the stream still holds the stuck operation: nothing is freed, the caller exits
+  auto finish = [&](const char* what, int rc) -> int {
+    if (rc) return fail(std::string(what) + ": " + c->err);
+    if (host) return PGX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return PGX_OK;
+      if (q != hipErrorNotReady) return fail(std::string(what) + ": " + hipGetErrorString(q));
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+        return fail(std::string(what) + " was enqueued but did not complete within " + std::to_string((int)timeout_s) +
+                    " s - the peers are not reachable through this transport");
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  };
+  double* f[1] = {buf};
+  int rc = finish("halo exchange with the strip neighbours (ncclSend / ncclRecv for the RCCL transport)",
+                  c->halo(st, f, 1, N, N, 0, N, 2 * N, N, 3 * N, N));
+  if (rc) return rc;
+  rc = finish("packed all-reduce (ncclAllReduce for the RCCL transport)", c->allreduce(st, buf + 4 * N, 8));
+  if (rc) return rc;
+  if (!host) {
+    if (hipMemcpy(hbuf.data(), dev, L * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail("download of the result failed");
+    hipFree(dev);
+    hipStreamDestroy(st);
+  }
+  for (size_t i = 0; i < N; ++i) {
+    if (rank > 0 && hbuf[i] != pat(rank - 1, 2, i)) return fail("ghost entries from rank-1 arrived wrong (entry " + std::to_string(i) + ")");
+    if (rank + 1 < size && hbuf[3 * N + i] != pat(rank + 1, 1, i)) return fail("ghost entries from rank+1 arrived wrong (entry " + std::to_string(i) + ")");
+    if (hbuf[N + i] != pat(rank, 1, i) || hbuf[2 * N + i] != pat(rank, 2, i)) return fail("the exchange overwrote entries it only had to send");
+  }
+  const double tri = 0.5 * size * (size + 1);
+  for (size_t i = 0; i < 8; ++i)
+    if (hbuf[4 * N + i] != tri * (double)(i + 1)) return fail("all-reduce returned a wrong sum (entry " + std::to_string(i) + ")");
+  return PGX_OK;
 }
 
 extern "C" void pgx_comm_free(pgx_comm* c) { delete c; }

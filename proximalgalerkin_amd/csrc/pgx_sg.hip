@@ -683,7 +683,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   if (e == hipSuccess) e = hipMalloc((void**)&st_f, sizeof(double) * NFS * (size_t)std::max(nf, 1));
   if (e == hipSuccess) e = hipMemcpy(d_cells, cown.data(), sizeof(int32_t) * NPC * (size_t)nco, hipMemcpyHostToDevice);
   int rc_comm = PGX_OK;
-  if (e == hipSuccess) {
+  if (e == hipSuccess && nco > 0) {  // (a rank may own no cell at all - fewer cells than ranks: nothing to launch, zero contribution)
     // (the cell kernels below see the OWNED cells only: nco of them, compact)
     if (NPC == 4) {
       hipLaunchKernelGGL(k_sg_const_cells, dim3((nco + 127) / 128), dim3(128), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
@@ -722,7 +722,12 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
       }
     }
     pgx_scatter_run(h->st, sc_c, st_c, 1.0, 0, h->Jc);
-    if (h->partitioned) rc_comm = comm->allreduce(h->st, h->Jc, (size_t)tot);  // sum of the slabs (fixed rank order: identical on every rank)
+  }
+  // sum of the slabs (fixed rank order: identical on every rank).  EVERY rank enters the collective, also one whose local steps
+  // failed (its error is reported below, after the call): a rank that skipped it would leave the others waiting for the
+  // transport's timeout instead of an error
+  if (h->partitioned) rc_comm = comm->allreduce(h->st, h->Jc, (size_t)tot);
+  if (e == hipSuccess) {
     if (nf > 0) {
       hipLaunchKernelGGL(k_sg_const_facets<NPF>, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
                          h->Q, st_f);

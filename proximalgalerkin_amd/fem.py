@@ -27,6 +27,8 @@ def quadrature_rule(cell: str, degree: int, scheme: str | None = None):
     the oracle (tools/make_quadrature_tables.py).  `scheme` names a table of that file explicitly (basix.ufl.quadrature_element's
     `scheme` argument): "tri_deg6_12_b" is the second fully symmetric 12-point degree-6 rule (tools/quadrature_uniqueness.py)."""
     if cell == "quadrilateral":  # tensor Gauss-Legendre rule on the unit square, exact to `degree` in each variable
+        if scheme not in (None, "default"):  # basix would reject an unknown scheme name: so does this (ADVICE r04)
+            raise NotImplementedError(f"no quadrature table {scheme!r} for quadrilateral degree {degree}: the tensor Gauss rule is the only scheme")
         g, w = np.polynomial.legendre.leggauss(degree // 2 + 1)
         g, w = 0.5 * (g + 1.0), 0.5 * w
         n = len(g)

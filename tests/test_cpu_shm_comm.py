@@ -32,6 +32,9 @@ def _worker(rank, world, port, slot_bytes, out):
     lib = _lib.load()
     c = shm_from_torch_distributed(slot_bytes=slot_bytes, host_mode=True)
     res = {}
+    # the start-of-run self-check (pgx_comm_selfcheck): verified halo pattern with both neighbours + packed all-reduce
+    c.selfcheck(5.0, host_mode=True)
+    res["selfcheck"] = True
     # all-reduce, longer than one mailbox (chunked)
     n = 3000
     a = np.arange(n, dtype=np.float64) * (rank + 1)
@@ -74,6 +77,13 @@ def _worker(rank, world, port, slot_bytes, out):
         b = np.ones(4)
         res["peer_missing_rc"] = int(lib.pgx_comm_allreduce(c._c, _dp(b), 4))
         res["peer_missing_msg"] = lib.pgx_comm_last_error().decode()
+        # ... and the start-of-run self-check NAMES the operation that could not complete (what a first-contact RCCL failure
+        # must look like instead of a hang)
+        try:
+            c.selfcheck(2.0, host_mode=True)
+            res["selfcheck_without_peer"] = "passed"
+        except _lib.PgxError as e:
+            res["selfcheck_without_peer"] = str(e)
     c.free()
     out.put((rank, res))
     dist.destroy_process_group()
@@ -93,8 +103,10 @@ def test_shm_transport_between_processes(world, slot_bytes):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        assert got[r]["allreduce"] and got[r]["halo"], (r, got[r])
+        assert got[r]["selfcheck"] and got[r]["allreduce"] and got[r]["halo"], (r, got[r])
         if r > 0:
             assert got[r]["scatter0"]
     assert got[0]["gather0"]
     assert got[0]["peer_missing_rc"] == -6 and "did not arrive" in got[0]["peer_missing_msg"]
+    msg = got[0]["selfcheck_without_peer"]
+    assert "self-check" in msg and "halo exchange" in msg and "rank 0 of" in msg, msg
