@@ -68,6 +68,8 @@ struct pgx_handle {
   size_t fill_lds = 0;
   double *Kv = nullptr, *Mv = nullptr, *Dv = nullptr;
   bool jac_valid = false;
+  float2* zf_out = nullptr;  // FGMRES: the level-0 single-precision cycle leaves its result HERE as float2 (no fp64 copy); see fgmres
+  int z_f32 = 1;             // PGX_Z_F32=0: the Z_j of the Krylov method in fp64 (A/B)
   bool dv_lean = false;  // the interior rows of the CSR D values are stale (residual_dev(with_d = 2)); a full fill clears it
   // operator of the solution space (aliases the P1 arrays above for degree 1)
   int32_t *s_rowptr = nullptr, *s_colm = nullptr;
@@ -1220,6 +1222,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
   if (const char* e = pgx_tune("PGX_SMOOTH_D32")) h->smooth_d32 = atoi(e);
   if (const char* e = pgx_tune("PGX_HOST_POLL")) h->host_poll = atoi(e);
   if (const char* e = pgx_tune("PGX_LAZY_NORM")) h->lazy_norm = atoi(e);
+  if (const char* e = pgx_tune("PGX_Z_F32")) h->z_f32 = atoi(e);
   if (const char* e = pgx_tune("PGX_SPMV_D4")) h->spmv_d4 = atoi(e);
   if (const char* e = pgx_tune("PGX_LEAN_D")) h->lean_d = atoi(e);
   if (const char* e = pgx_tune("PGX_MG_F32")) h->mg_f32 = atoi(e);
@@ -1954,9 +1957,12 @@ static const float2* vcycle_f(pgx_handle* h, int l, const double* bu, const doub
     cdp = C.xp;
   }
   for (int s = 0; s < nl; ++s) {
-    const bool out64 = (s + 1 == nl) && outu;
+    const bool lastl = s + 1 == nl;
+    float2* const zf = (lastl && l == 0) ? h->zf_out : nullptr;  // the cycle's result stays float2, in the caller's buffer
+    const bool out64 = lastl && outu && !zf;
     pgxk_f_smooth(h->st, K, 0, L, h->alpha, cu, nullptr, nullptr, s == 0 ? &C : nullptr, s == 0 ? cf : nullptr, s == 0 ? cdu : nullptr,
-                  s == 0 ? cdp : nullptr, omega, remap, ou, out64 ? outu : nullptr, out64 ? outp : nullptr);
+                  s == 0 ? cdp : nullptr, omega, remap, zf ? zf : ou, out64 ? outu : nullptr, out64 ? outp : nullptr);
+    if (zf) return zf;
     std::swap(cu, ou);
   }
   return cu;
@@ -2627,6 +2633,12 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     // the preconditioner is the single-precision cycle entered on level 0 (it is the one that takes the factor).
     const bool lazy = h->lazy_norm && h->cgs_selective && !h->lu_active && h->degree == 1 && m + 2 <= PGX_DOT_SCALE_MAX && !h->lev.empty() &&
                       f32_cycle_ok(h, 0, o->mg_nu);  // (the non-selective CGS2 kernels carry no scale factors: that mode runs un-lazy)
+    // Z_j in single precision (round 5): on this path z_j leaves a float cycle, so storing it as one float2 field loses nothing - the
+    // cycle's last launch writes it in place, the operator apply reads it (k_st_spmv_r<true>), the solution update sums it
+    // (k_lincomb_f2): 100 MB less per Krylov iteration at 2048^2 than the fp64 pair.  w = J z_j, the basis V and H stay fp64.
+    const bool zf32 = h->z_f32 && !dist && !h->lu_active && h->degree == 1 && h->structured && !h->lev.empty() && h->lev[0].uniform &&
+                      h->spmv_stencil == 1 && f32_cycle_ok(h, 0, o->mg_nu);
+    float2* const Zf = reinterpret_cast<float2*>(h->Z);
     PgxDotScale sc2;  // s_i^2
     std::vector<double> sv((size_t)m + 2, 1.0);  // s_i
     for (int i = 0; i < PGX_DOT_SCALE_MAX; ++i) sc2.s[i] = 1.0;
@@ -2637,7 +2649,9 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
       {
         PhaseTimer t(h, 4);
         h->rhs_scale = lazy ? sv[j] : 1.0;
+        h->zf_out = zf32 ? Zf + (size_t)j * h->nd : nullptr;
         rc = precond(h, vj, zj, o->mg_nu, omega);
+        h->zf_out = nullptr;
         h->rhs_scale = 1.0;
         if (rc) return rc;
       }
@@ -2646,6 +2660,9 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
         if (dist) {
           spmv_dev(h, zj, h->w);
           gather_owned(h, h->w, h->V + (size_t)(j + 1) * nk);
+        } else if (zf32) {
+          double* const wn = h->V + (size_t)(j + 1) * n2;
+          pgxk_st_spmv(h->st, h->lev[0], h->alpha, nullptr, nullptr, h->xcd_remap ? 1 : 0, wn, wn + h->nd, Zf + (size_t)j * h->nd);
         } else {
           spmv_dev(h, zj, h->V + (size_t)(j + 1) * n2);
         }
@@ -2771,7 +2788,10 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     }
     for (int i = 0; i < j; ++i) h->h_small[i] = y[i];
     HIPCHK(hipMemcpyAsync(h->d_small, h->h_small, sizeof(double) * j, hipMemcpyHostToDevice, h->st));
-    pgxk_lincomb(h->st, n2, j, h->Z, n2, h->d_small, x, 1);
+    if (zf32)
+      pgxk_lincomb_f2(h->st, (size_t)h->nd, j, Zf, (size_t)h->nd, h->d_small, x, x + h->nd);
+    else
+      pgxk_lincomb(h->st, n2, j, h->Z, n2, h->d_small, x, 1);
     // (no synchronisation: the loop head recomputes the TRUE residual b - Jx - it decides convergence, not the Arnoldi estimate - and
     // its read-back is ordered behind the upload of y on the stream, so h_small is not touched again before that copy is done)
   }

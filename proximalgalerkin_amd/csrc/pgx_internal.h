@@ -158,7 +158,8 @@ void pgxk_st_smooth2(hipStream_t st, int post, const GridLevel& L, double alpha,
                      const GridLevel* C, const double* cu, const double* cp, const double* bu, const double* bp,
                      double omega, int remap, double* yu, double* yp);
 void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp, int remap, double* yu,
-                  double* yp);
+                  double* yp, const float2* xf = nullptr /* the iterate as ONE interleaved (u, psi) float2 field instead of (xu, xp); uniform levels only */);
+void pgxk_lincomb_f2(hipStream_t st, size_t n, int nv, const float2* Zf, size_t ldz, const double* y, double* xu, double* xp);
 void pgxk_pack_d4(hipStream_t st, const GridLevel& L);  // Dd4 <- Dh
 void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp,
                             const double* bu, const double* bp, const GridLevel& C, int remap, double* cbu,

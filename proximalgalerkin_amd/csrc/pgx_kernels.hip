@@ -1278,6 +1278,26 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_lincomb(size_t len2, int nv, cons
     x[i] = s;
   }
 }
+// (xu, xp)[v] += sum_i y[i] Zf_i[v] for float2-interleaved Z_i (see st_load_x): the solution update of a cycle whose Z_j are float
+__global__ void __launch_bounds__(PGX_BLOCK) k_lincomb_f2(size_t n, int nv, const float2* __restrict__ Zf, size_t ldz,
+                                                          const double* __restrict__ y, double* __restrict__ xu, double* __restrict__ xp) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double su = xu[i], sp = xp[i];
+    for (int v = 0; v < nv; ++v) {
+      const float2 a = Zf[v * ldz + i];
+      const double yv = y[v];
+      su += yv * (double)a.x;
+      sp += yv * (double)a.y;
+    }
+    xu[i] = su;
+    xp[i] = sp;
+  }
+}
+void pgxk_lincomb_f2(hipStream_t st, size_t n, int nv, const float2* Zf, size_t ldz, const double* y, double* xu, double* xp) {
+  const unsigned grid = (unsigned)std::min<size_t>((n + PGX_BLOCK - 1) / PGX_BLOCK, 256 * 32);
+  hipLaunchKernelGGL(k_lincomb_f2, dim3(grid), dim3(PGX_BLOCK), 0, st, n, nv, Zf, ldz, y, xu, xp);
+}
+
 void pgxk_lincomb(hipStream_t st, size_t len, int nv, const double* Z, size_t ldz, const double* y, double* x,
                   int accumulate) {
   hipLaunchKernelGGL(k_lincomb, stream_grid(len / 2), dim3(PGX_BLOCK), 0, st, len / 2, nv, (const double2*)Z,
@@ -2456,7 +2476,17 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
 // through the general per-point code with Dirichlet rows / columns as identity.
 // ------------------------------------------------------------------------------------------------
 #define PGX_SPMV_RY 24
-template <bool FAST>
+// XF: the iterate comes as ONE interleaved (u, psi) float2 field - what the single-precision V-cycle leaves (round 5: the FGMRES Z_j
+// are outputs of that cycle; stored and re-read as fp64 they were twice the bytes for no information) - xu then points at it
+template <bool XF>
+__device__ __forceinline__ double2 st_load_x(const double* __restrict__ xu, const double* __restrict__ xp, unsigned v) {
+  if (XF) {
+    const float2 t = reinterpret_cast<const float2*>(xu)[v];
+    return make_double2((double)t.x, (double)t.y);
+  }
+  return make_double2(xu[v], xp[v]);
+}
+template <bool FAST, bool XF = false>
 __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int n, const double* __restrict__ K,
                                              const double* __restrict__ M, const dsten_t* __restrict__ Dh, const StConst& sc,
                                              const uint8_t* __restrict__ mask, double alpha, const double* __restrict__ xu,
@@ -2473,12 +2503,14 @@ __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int
     double a = 0.0, c2 = 0.0;
     if (FAST) {
       const unsigned v = (unsigned)(gj * sx + gi);
-      a = xu[v];
-      c2 = xp[v];
+      const double2 t = st_load_x<XF>(xu, xp, v);
+      a = t.x;
+      c2 = t.y;
     } else if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny) {
       const int v = gj * sx + gi;
-      a = mask[v] ? 0.0 : xu[v];  // pre-masked image: Dirichlet columns of the u block contribute nothing
-      c2 = xp[v];
+      const double2 t = st_load_x<XF>(xu, xp, (unsigned)v);
+      a = mask[v] ? 0.0 : t.x;  // pre-masked image: Dirichlet columns of the u block contribute nothing
+      c2 = t.y;
     }
     ximg[lj * W + lane] = make_double2(a, c2);
   }
@@ -2526,7 +2558,7 @@ __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int
           au += alpha * c.kv[t] * xn.x + c.mv[t] * xn.y;
           ap += c.mv[t] * xn.x - c.dv[t] * xn.y;
         }
-        yu[v] = c.rowbc ? xu[v] : au;
+        yu[v] = c.rowbc ? st_load_x<XF>(xu, xp, (unsigned)v).x : au;
         yp[v] = ap;
       }
     }
@@ -2537,7 +2569,7 @@ __device__ __forceinline__ void st_spmv_tile(int tx, int ty, int nx, int ny, int
 // same rows, all in flight before the first LDS store - instead of the iterate first and, behind the barrier, seven D loads per
 // vertex (three of them re-reads of the neighbours' links).  The mirrored links come from the neighbours as in the smoother: the
 // left lane's register (DPP) and the (D2, D3) pair every row hands to the row above it through LDS.
-template <bool D4>
+template <bool D4, bool XF = false>
 __device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, const dsten_t* __restrict__ Dh, const double4* __restrict__ Dd4,
                                              const StConst& sc, double alpha, const double* __restrict__ xu,
                                              const double* __restrict__ xp, double* __restrict__ yu, double* __restrict__ yp,
@@ -2558,7 +2590,7 @@ __device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, cons
     const int lj = wave + NW * k;
     if (lj < HX) {
       const unsigned v = (unsigned)((j0 + lj) * sx + gi);
-      xa[k] = make_double2(xu[v], xp[v]);
+      xa[k] = st_load_x<XF>(xu, xp, v);
       if (lj <= RY) {  // row 0 only hands its upward links to row 1
         if (D4) {
           const double4 q = Dd4[v];
@@ -2609,6 +2641,7 @@ __device__ __forceinline__ void st_spmv_fast(int tx, int ty, int nx, int n, cons
   }
 }
 
+template <bool XF>
 __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, int n, RrGrid g, int nbnd,
                                                                 const double* __restrict__ K, const double* __restrict__ M,
                                                                 const dsten_t* __restrict__ Dh, const double4* __restrict__ Dd4,
@@ -2633,19 +2666,19 @@ __global__ void __launch_bounds__(PGX_ROWMAP_BLOCK) k_st_spmv_r(int nx, int ny, 
       ty = g.nfy + 1 + b / g.ntx;
       tx = b % g.ntx;
     }
-    st_spmv_tile<false>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
+    st_spmv_tile<false, XF>(tx, ty, nx, ny, n, K, M, Dh, sc, mask, alpha, xu, xp, yu, yp, ximg_ + PAD);
   } else {
     b = xcd_block(b - nbnd, gridDim.x - nbnd, remap);
     if (Dd4)
-      st_spmv_fast<true>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
+      st_spmv_fast<true, XF>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
     else
-      st_spmv_fast<false>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
+      st_spmv_fast<false, XF>(1 + b % g.nfx, 1 + b / g.nfx, nx, n, Dh, Dd4, sc, alpha, xu, xp, yu, yp, ximg_ + PAD, exch_ + PAD);
   }
 }
 
 // y = J x on a structured level, matrix-free (see above); levels without uniform interior stencils take k_st_apply<0>
 void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double* xu, const double* xp, int remap, double* yu,
-                  double* yp) {
+                  double* yp, const float2* xf) {
   if (!L.uniform) {
     pgxk_st_apply(st, 0, L, alpha, xu, xp, nullptr, nullptr, 0.0, remap ? 2 : 0, yu, yp);
     return;
@@ -2662,8 +2695,12 @@ void pgxk_st_spmv(hipStream_t st, const GridLevel& L, double alpha, const double
   g.nfy = std::min(g.nfy, g.nty - 1);
   if (!L.interior_free || g.nfx <= 0 || g.nfy <= 0) g.nfx = g.nfy = 0;
   const int nfast = g.nfx * g.nfy, nbnd = g.ntx * g.nty - nfast;
-  hipLaunchKernelGGL(k_st_spmv_r, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dd4,
-                     make_stconst(L), L.mask, alpha, xu, xp, remap, yu, yp);
+  if (xf)  // the iterate as one float2 field (pgxk_st_spmv_f2_ok levels only)
+    hipLaunchKernelGGL(k_st_spmv_r<true>, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dd4,
+                       make_stconst(L), L.mask, alpha, reinterpret_cast<const double*>(xf), nullptr, remap, yu, yp);
+  else
+    hipLaunchKernelGGL(k_st_spmv_r<false>, dim3(nbnd + nfast), dim3(PGX_ROWMAP_BLOCK), 0, st, L.nx, L.ny, L.n, g, nbnd, L.K, L.M, L.Dh, L.Dd4,
+                       make_stconst(L), L.mask, alpha, xu, xp, remap, yu, yp);
 }
 
 __global__ void __launch_bounds__(256) k_pack_d4(int n, const dsten_t* __restrict__ Dh, double4* __restrict__ Dd4) {

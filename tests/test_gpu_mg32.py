@@ -58,6 +58,7 @@ def reference(require_gpu):
     ({"PGX_HOST_POLL": 0}, {}),                                  # read-backs through hipMemcpyAsync + hipStreamSynchronize
     ({"PGX_SPMV_D4": 0}, {}),                                    # operator apply from the four D arrays
     ({"PGX_MG_MIN_NX": 2}, {}),                                  # 3 x 3 coarsest grid (round 3)
+    ({"PGX_Z_F32": 0}, {}),                                      # FGMRES Z_j as fp64 pairs (round 4) instead of one float2 field
 ])
 def test_single_precision_cycle_variants_match_the_oracle(reference, tuning, opts):
     N, n, x_ref, h_ref = reference
@@ -98,3 +99,13 @@ def test_single_precision_cycle_on_rectangular_grids_that_cut_every_tile(require
         x, h = _solve_rect(cells, tuning, {}, domain)
         assert h["Newton steps"] == h64["Newton steps"], (cells, tuning)
         assert np.linalg.norm(x[:n] - x64[:n]) <= 1e-10 * np.linalg.norm(x64[:n]), (cells, tuning)
+
+
+def test_float_storage_of_the_krylov_z_vectors_changes_nothing(require_gpu):
+    """Round 5: the Z_j of FGMRES are outputs of the single-precision cycle, stored as ONE float2 field each (the cycle's last launch
+    writes them, k_st_spmv_r<true> and k_lincomb_f2 read them).  A float cast to double and back is the identity, so against the
+    fp64-pair storage (PGX_Z_F32=0) every Newton count must agree and the final iterate must be BITWISE the same."""
+    a, ha = _solve(128, {}, {})
+    b, hb = _solve(128, {"PGX_Z_F32": 0}, {})
+    assert ha["Newton steps"] == hb["Newton steps"]
+    assert np.array_equal(a, b)
