@@ -143,6 +143,7 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  bool trsv_big = true;     // PGX_ND_TRSV_BIG=0: k_nd_trsv for the batches of few large fronts too (A/B)
   bool lshape = true;       // PGX_ND_LSHAPE=0: the trailing update of an outer block as three rectangles (A/B)
   bool solve_small = true;  // PGX_ND_SOLVE_SMALL=0: the three-launch path for small fronts too (A/B)
   int panel_kind = 0;  // PGX_ND_PANEL: 0 MFMA (default), 1 LDS-blocked scalar, 2 register-column scalar panel kernel
@@ -929,113 +930,13 @@ __global__ void k_nd_write_x(int64_t nfronts, const int32_t* __restrict__ fp, co
 // ---- dense kernels, batched over the fronts of one level (blockIdx.x = front within the level) ---------------------
 #include "pgx_nd_gemm.h"
 
-// LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level.  Blocked by 8 columns:
-// (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
-// (b) the 8 x rest block row of U by forward substitution, one thread per column, (c) rank-8 update of the trailing block
-// by all 256 threads: 3 barriers per 8 columns instead of 2 per column (84 -> ~20 us per launch near the root, where the
-// launches of a level form one dependent chain).
+// LU without pivoting of the nb x nb diagonal block at (kb,kb) of every front of the level (nd_diag_lu, pgx_nd_gemm.h).
 __global__ __launch_bounds__(256) void k_nd_diag(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
                                                  int* __restrict__ info, int64_t store_off, int P) {
   __shared__ double D[ND_NB][ND_NB + 1];
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M + (int64_t)kb * M + kb;
-  const int tid = threadIdx.x;
-  {  // all loads in flight before the first LDS write
-    double v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx = tid + 256 * q;
-      v[q] = idx < nb * nb ? F[(int64_t)(idx / nb) * M + idx % nb] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < nb * nb) D[idx % nb][idx / nb] = v[q];
-    }
-  }
-  __syncthreads();
-  for (int jb = 0; jb < nb; jb += 8) {
-    const int w = min(8, nb - jb);
-    if (tid < 64) {
-      const int r = tid;
-      const bool act = r >= jb && r < nb;
-      double a[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) a[c] = (act && c < w) ? D[r][jb + c] : 0.0;
-      int bad = 0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (c < w) {
-          const int pr = jb + c;
-          if (r == pr && fabs(a[c]) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported via info
-            a[c] = a[c] < 0 ? -1e-300 : 1e-300;
-            bad = 1;
-          }
-          double pv[8];
-#pragma unroll
-          for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? nd_bcast(a[c2], pr) : 0.0;
-          if (act && r > pr) {
-            const double l = a[c] / pv[c];
-            a[c] = l;
-#pragma unroll
-            for (int c2 = 0; c2 < 8; ++c2)
-              if (c2 > c) a[c2] -= l * pv[c2];
-          }
-        }
-      }
-      if (bad) atomicAdd(info, 1);
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (act && c < w) D[r][jb + c] = a[c];
-    }
-    __syncthreads();
-    const int rest = nb - jb - w;
-    if (rest > 0) {
-      if (tid < rest) {  // U12 = L11^{-1} A12, one column per thread
-        const int c = jb + w + tid;
-        double u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (i < w) {
-            double v = D[jb + i][c];
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-              if (m < i) v -= D[jb + i][jb + m] * u[m];
-            u[i] = v;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < w) D[jb + i][c] = u[i];
-      }
-      __syncthreads();
-      for (int idx = tid; idx < rest * rest; idx += 512) {  // two entries per trip, all LDS reads issued first
-        double v[2], lr[2][8], uc[2][8];
-        int rr[2], cc[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int id = min(idx + 256 * q, rest * rest - 1);
-          rr[q] = jb + w + id % rest, cc[q] = jb + w + id / rest;
-          v[q] = D[rr[q]][cc[q]];
-#pragma unroll
-          for (int m = 0; m < 8; ++m) lr[q][m] = D[rr[q]][jb + m], uc[q][m] = D[jb + m][cc[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m)
-            if (m < w) v[q] -= lr[q][m] * uc[q][m];
-          if (idx + 256 * q < rest * rest) D[rr[q]][cc[q]] = v[q];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // L11\\U11 is final: it goes to the compact factor store, where the panel solves (and the solve phase) read it
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * M * M + (int64_t)kb * M + kb;
   double* S = arena + store_off + (int64_t)blockIdx.x * ((int64_t)M * P + (int64_t)P * (M - P)) + (int64_t)kb * M + kb;
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int r = idx % nb, c = idx / nb;
-    S[(int64_t)c * M + r] = D[r][c];
-  }
+  nd_diag_lu(D, F, S, M, nb, info);
 }
 
 // panel solves against the factored diagonal block: chunk c < nch : columns [o0, o0+64) of the row panel, X <- L^{-1} X;
@@ -1507,17 +1408,121 @@ __global__ __launch_bounds__(256) void k_nd_trsv(const double* __restrict__ aren
   }
 }
 
+// The same solve for the levels of FEW LARGE fronts (round 5; batches of <= ND_BIG_COUNT fronts): near the root the solve phase is a
+// chain of slab launches - triangle, then everything outside it - and k_nd_trsv spends a full memory latency per 64-pivot block
+// (triangle -> LDS -> wave solve -> update loads -> reduce: ~35 us per 256-pivot slab).  Here ONE workgroup of 16 waves holds the whole
+// slab: waves 0-3 bring the four 64 x 64 triangles into LDS, waves 4-15 keep the six off-diagonal blocks in registers (two waves per
+// block: lane = row, 32 columns each), every load goes out before anything is computed, and the four block steps then run out of LDS
+// and registers (wave solve, partial products, combination: three barriers per step).
+#define ND_BIG_COUNT 256
+#define ND_BIG_LDS ((4 * 64 * 65 + 256 + 12 * 64) * sizeof(double))
+__global__ __launch_bounds__(1024) void k_nd_trsv_big(const double* __restrict__ arena, int64_t lev_off, int64_t fs,
+                                                      double* __restrict__ vec, int64_t voff, int M, int k0, int k1, int upper) {
+  extern __shared__ double nd_sm[];
+  double(*Ds)[64][65] = reinterpret_cast<double(*)[64][65]>(nd_sm);
+  double* ys = nd_sm + 4 * 64 * 65;
+  double(*red)[64] = reinterpret_cast<double(*)[64]>(ys + 256);
+  const double* F = arena + lev_off + (int64_t)blockIdx.x * fs;
+  double* w = vec + voff + (int64_t)blockIdx.x * M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbt = k1 - k0, nblk = (nbt + 63) / 64;
+  // off-diagonal blocks (block row, block column) in the order their block column is processed
+  const int prl[6] = {1, 2, 3, 2, 3, 3}, pcl[6] = {0, 0, 0, 1, 1, 2};
+  const int pru[6] = {2, 1, 0, 1, 0, 0}, pcu[6] = {3, 3, 3, 2, 2, 1};
+  double off[32];
+  int br = -1, bc = -1, half = 0;
+  if (wave >= 4) {
+    const int p = (wave - 4) >> 1;
+    half = (wave - 4) & 1;
+    br = upper ? pru[p] : prl[p];
+    bc = upper ? pcu[p] : pcl[p];
+    const int r = k0 + 64 * br + lane;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int c = k0 + 64 * bc + 32 * half + q;
+      off[q] = (br < nblk && bc < nblk && r < k1 && c < k1) ? F[(int64_t)c * M + r] : 0.0;
+    }
+  } else if (wave < nblk) {
+    const int kb = k0 + 64 * wave, nb = min(64, k1 - kb);
+    for (int c0 = 0; c0 < 64; c0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = (lane < nb && c0 + q < nb) ? F[(int64_t)(kb + c0 + q) * M + kb + lane] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Ds[wave][lane][c0 + q] = v[q];
+    }
+  }
+  if (tid < 256) ys[tid] = (k0 + tid < k1) ? w[k0 + tid] : 0.0;
+  __syncthreads();
+  for (int step = 0; step < nblk; ++step) {
+    const int b = upper ? nblk - 1 - step : step;
+    if (wave == 0) {
+      const int r = lane, nb = min(64, nbt - 64 * b);
+      double y = r < nb ? ys[64 * b + r] : 0.0;
+      if (!upper) {
+        for (int kc = 0; kc < nb; kc += 16) {
+          double d[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) d[q] = Ds[b][r][min(kc + q, 63)];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int k = kc + q;
+            if (k < nb) {  // uniform
+              const double yk = nd_bcast(y, k);
+              if (r > k && r < nb) y -= d[q] * yk;
+            }
+          }
+        }
+      } else {
+        const double dinv = r < nb ? 1.0 / Ds[b][r][r] : 0.0;
+        for (int kc = ((nb - 1) / 16) * 16; kc >= 0; kc -= 16) {
+          double d[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) d[q] = Ds[b][r][min(kc + q, 63)];
+#pragma unroll
+          for (int q = 15; q >= 0; --q) {
+            const int k = kc + q;
+            if (k < nb) {  // uniform
+              const double xk = nd_bcast(y * dinv, k);
+              if (r < k) y -= d[q] * xk;
+              if (r == k) y = xk;
+            }
+          }
+        }
+      }
+      if (r < nb) ys[64 * b + r] = y;
+    }
+    __syncthreads();
+    const bool mine = wave >= 4 && bc == b && br < nblk;  // this wave's block takes the block just solved
+    if (mine) {
+      const double* yb = ys + 64 * b + 32 * half;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 32; q += 2) {
+        a0 += off[q] * yb[q];
+        a1 += off[q + 1] * yb[q + 1];
+      }
+      red[wave - 4][lane] = a0 + a1;
+    }
+    __syncthreads();
+    if (mine && half == 0) ys[64 * br + lane] -= red[wave - 4][lane] + red[wave - 3][lane];
+    __syncthreads();
+  }
+  if (tid < 256 && k0 + tid < k1) w[k0 + tid] = ys[tid];
+}
+
 // w[r0:r1) -= F[r0:r1, c0:c1) w[c0:c1).  A workgroup takes ND_GR = 64 rows; its 4 waves split the columns (wave g takes
 // the columns c0 + g, c0 + g + 4, ...: 4x more workgroups and 4x shorter load chains than one thread per row with 256 rows
 // per block - the mid and top levels of the tree have few fronts and were latency-bound), partial sums meet in LDS.
 // Column c of the operand starts at F + cbase + (c - c0) * ld (compact store: ld = M inside the first P columns, the U12
 // block has its own base and ld = P).
 #define ND_GR 64
-__global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, int64_t fs,
-                                                 double* __restrict__ vec, int64_t voff, int M, int r0, int r1, int c0, int c1,
-                                                 int64_t cbase, int ld) {
+#define ND_GW 4  // waves per workgroup = column groups (8 waves, 16 loads per batch: measured SLOWER, ex 06 1024^2 solves 10.5 -> 12.2 ms)
+__global__ __launch_bounds__(64 * ND_GW) void k_nd_gemv(const double* __restrict__ arena, int64_t lev_off, int64_t fs,
+                                                        double* __restrict__ vec, int64_t voff, int M, int r0, int r1, int c0, int c1,
+                                                        int64_t cbase, int ld) {
   __shared__ double xs[256];
-  __shared__ double red[4][ND_GR];
+  __shared__ double red[ND_GW][ND_GR];
   const double* F = arena + lev_off + (int64_t)blockIdx.x * fs + cbase;
   double* w = vec + voff + (int64_t)blockIdx.x * M;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -1531,12 +1536,17 @@ __global__ __launch_bounds__(256) void k_nd_gemv(const double* __restrict__ aren
     if (r < r1) {
       const double* col = F + (int64_t)(k0 - c0) * ld + r;
 #pragma unroll 8
-      for (int k = g; k < kn; k += 4) a += col[(int64_t)k * ld] * xs[k];
+      for (int k = g; k < kn; k += ND_GW) a += col[(int64_t)k * ld] * xs[k];
     }
   }
   red[g][lane] = a;
   __syncthreads();
-  if (g == 0 && r < r1) w[r] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (g == 0 && r < r1) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < ND_GW; ++q) t += red[q][lane];
+    w[r] -= t;
+  }
 }
 
 // ---- solve phase of SMALL fronts (round 5): P <= 64, M <= 256 - ONE WAVE per front does what k_nd_fwd_assemble + k_nd_trsv + k_nd_gemv
@@ -2115,7 +2125,12 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   }
   s->dprof = pgx_tune("PGX_ND_DEPTHPROF") != nullptr;
   if (const char* e = pgx_tune("PGX_ND_SOLVE_SMALL")) s->solve_small = atoi(e) != 0;
-  if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;  // per-depth table on stderr when the handle is destroyed
+  if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_TRSV_BIG")) s->trsv_big = atoi(e) != 0;
+  if (s->trsv_big && hipFuncSetAttribute((const void*)k_nd_trsv_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_BIG_LDS) != hipSuccess) {
+    (void)hipGetLastError();
+    s->trsv_big = false;  // (no 140 KB of LDS per workgroup on this device: the four-wave kernel everywhere)
+  }  // per-depth table on stderr when the handle is destroyed
   if (ptime) {
     hipDeviceSynchronize();
     fprintf(stderr, "pgx_nd create: symbolic %.0f ms, assembly / leaf lists %.0f ms, maps, uploads, device allocations %.0f ms\n", tms(c_0, c_1),
@@ -2614,9 +2629,12 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
       // (rest of the pivot block AND the border rows) by a gemv over many workgroups
       for (int k0 = 0; k0 < P; k0 += ND_SLAB) {
         const int k1 = std::min(P, k0 + ND_SLAB);
-        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 0);
+        if (s->trsv_big && Lv.count <= ND_BIG_COUNT)
+          hipLaunchKernelGGL(k_nd_trsv_big, dim3((unsigned)Lv.count), dim3(1024), ND_BIG_LDS, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 0);
+        else
+          hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 0);
         if (k1 < M)
-          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + ND_GR - 1) / ND_GR)), dim3(256), 0, q, s->arena,
+          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((M - k1 + ND_GR - 1) / ND_GR)), dim3(64 * ND_GW), 0, q, s->arena,
                              Lv.poff, fs, s->vec, Lv.voff, M, k1, M, k0, k1, (int64_t)k0 * M, M);
       }
     }
@@ -2684,15 +2702,18 @@ extern "C" int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device
         if (!(xchg && l == s->kbatch))
           hipLaunchKernelGGL(k_nd_bwd_gather, dim3((unsigned)Lv.count), dim3(256), 0, q, Lv.start, P, s->d_fb, s->d_parent,
                              s->d_vbase, s->d_rel_ptr, s->d_rel, s->vec);
-        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + ND_GR - 1) / ND_GR)), dim3(256), 0, q, s->arena, Lv.poff,
+        hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((P + ND_GR - 1) / ND_GR)), dim3(64 * ND_GW), 0, q, s->arena, Lv.poff,
                            fs, s->vec, Lv.voff, M, 0, P, P, M, (int64_t)M * P, P);
       }
       const int nsl = (P + ND_SLAB - 1) / ND_SLAB;
       for (int sl = nsl - 1; sl >= 0; --sl) {
         const int k0 = sl * ND_SLAB, k1 = std::min(P, k0 + ND_SLAB);
-        hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 1);
+        if (s->trsv_big && Lv.count <= ND_BIG_COUNT)
+          hipLaunchKernelGGL(k_nd_trsv_big, dim3((unsigned)Lv.count), dim3(1024), ND_BIG_LDS, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 1);
+        else
+          hipLaunchKernelGGL(k_nd_trsv, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.poff, fs, s->vec, Lv.voff, M, k0, k1, 1);
         if (k0 > 0)
-          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + ND_GR - 1) / ND_GR)), dim3(256), 0, q, s->arena, Lv.poff,
+          hipLaunchKernelGGL(k_nd_gemv, dim3((unsigned)Lv.count, (unsigned)((k0 + ND_GR - 1) / ND_GR)), dim3(64 * ND_GW), 0, q, s->arena, Lv.poff,
                              fs, s->vec, Lv.voff, M, 0, k0, k0, k1, (int64_t)k0 * M, M);
       }
     }

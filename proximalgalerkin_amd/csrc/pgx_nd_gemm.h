@@ -46,6 +46,164 @@ __device__ __forceinline__ double nd_bcast(double v, int lane) {
 }
 
 
+// LU without pivoting of an nb x nb diagonal block (nb <= 64) by the 256 threads of a workgroup: F = the block in the working matrix
+// (leading dimension M), S = its place in the compact store, D = 64 x 65 doubles of LDS.  Blocked by 8 columns:
+// (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
+// (b) the 8 x rest block row of U by forward substitution, one thread per column, (c) rank-8 update of the trailing block
+// by all 256 threads: 3 barriers per 8 columns instead of 2 per column (84 -> ~20 us per launch near the root, where the
+// launches of a level form one dependent chain).
+__device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double* __restrict__ F, double* __restrict__ S, int M, int nb,
+                                           int* __restrict__ info) {
+  const int tid = threadIdx.x;
+  {  // all loads in flight before the first LDS write
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q;
+      v[q] = idx < nb * nb ? F[(int64_t)(idx / nb) * M + idx % nb] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < nb * nb) D[idx % nb][idx / nb] = v[q];
+    }
+  }
+  __syncthreads();
+  for (int jb = 0; jb < nb; jb += 8) {
+    const int w = min(8, nb - jb);
+    if (tid < 64) {
+      const int r = tid;
+      const bool act = r >= jb && r < nb;
+      double a[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a[c] = (act && c < w) ? D[r][jb + c] : 0.0;
+      int bad = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < w) {
+          const int pr = jb + c;
+          if (r == pr && fabs(a[c]) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported via info
+            a[c] = a[c] < 0 ? -1e-300 : 1e-300;
+            bad = 1;
+          }
+          double pv[8];
+#pragma unroll
+          for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? nd_bcast(a[c2], pr) : 0.0;
+          if (act && r > pr) {
+            const double l = a[c] / pv[c];
+            a[c] = l;
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2)
+              if (c2 > c) a[c2] -= l * pv[c2];
+          }
+        }
+      }
+      if (bad) atomicAdd(info, 1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (act && c < w) D[r][jb + c] = a[c];
+    }
+    __syncthreads();
+    const int rest = nb - jb - w;
+    if (rest > 0) {
+      if (tid < rest) {  // U12 = L11^{-1} A12, one column per thread
+        const int c = jb + w + tid;
+        double u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < w) {
+            double v = D[jb + i][c];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+              if (m < i) v -= D[jb + i][jb + m] * u[m];
+            u[i] = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < w) D[jb + i][c] = u[i];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < rest * rest; idx += 512) {  // two entries per trip, all LDS reads issued first
+        double v[2], lr[2][8], uc[2][8];
+        int rr[2], cc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int id = min(idx + 256 * q, rest * rest - 1);
+          rr[q] = jb + w + id % rest, cc[q] = jb + w + id / rest;
+          v[q] = D[rr[q]][cc[q]];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) lr[q][m] = D[rr[q]][jb + m], uc[q][m] = D[jb + m][cc[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+            if (m < w) v[q] -= lr[q][m] * uc[q][m];
+          if (idx + 256 * q < rest * rest) D[rr[q]][cc[q]] = v[q];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // L11\\U11 is final: it goes to the compact factor store, where the panel solves (and the solve phase) read it
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int r = idx % nb, c = idx / nb;
+    S[(int64_t)c * M + r] = D[r][c];
+  }
+}
+
+
+// Epilogue of the GATHER Schur updates: C(i, j) = S0[inv0[j], inv0[i]] + S1[inv1[j], inv1[i]] - acc for the wave's TJ x TI MFMA tiles
+// (lane l: row i = ri0 + 16 ti + (l & 15), column j = cj0 + 16 tj + (l >> 4) + 4 reg).  Round 5: BRANCHLESS - every index is formed
+// first (absent child / out-of-range / unmapped position -> a dummy read of entry 0, masked afterwards), the eight gathered loads of a
+// (tj, reg) column go out together, and all column maps of the wave are fetched before the first gather: the round-2 form wrapped
+// each load in its own `if`, which serialised a dependent index load and up to 2 x TI x 4 TJ gathers per lane one behind the other -
+// and these launches ARE their epilogue on the deep levels (K = P = 5 ... 64 against 2 x 8 bytes gathered + 8 written per entry).
+template <int TJ, int TI>
+__device__ __forceinline__ void nd_gather_epilogue(const NdGatherCtx& gc, const double* __restrict__ arena, int64_t f, double* __restrict__ F,
+                                                   int M, int ri0, int cj0, int rmax, int cmax, int l, const nd_v4d (&acc)[TJ][TI]) {
+  const NdGatherSrc g = nd_gather_src(gc, arena, f);
+  const double* const S0 = g.S0 ? g.S0 : arena;  // (a valid address for the masked dummy reads)
+  const double* const S1 = g.S1 ? g.S1 : arena;
+  int a0[TI], a1[TI];  // the lane's rows in the children's borders
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int i = ri0 + 16 * ti + (l & 15);
+    a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
+    a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
+  }
+  int b0[TJ][4], b1[TJ][4];  // ... and its columns
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = cj0 + 16 * tj + (l >> 4) + 4 * reg;
+      b0[tj][reg] = (g.S0 && j < cmax) ? g.I0[j] : -1;
+      b1[tj][reg] = (g.S1 && j < cmax) ? g.I1[j] : -1;
+    }
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = cj0 + 16 * tj + (l >> 4) + 4 * reg;
+      const int64_t c0o = (int64_t)b0[tj][reg] * g.M0, c1o = (int64_t)b1[tj][reg] * g.M1;
+      double v0[TI], v1[TI];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        v0[ti] = S0[(a0[ti] | b0[tj][reg]) >= 0 ? c0o + a0[ti] : 0];
+        v1[ti] = S1[(a1[ti] | b1[tj][reg]) >= 0 ? c1o + a1[ti] : 0];
+      }
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        const int i = ri0 + 16 * ti + (l & 15);
+        double v = (a0[ti] | b0[tj][reg]) >= 0 ? v0[ti] : 0.0;
+        if ((a1[ti] | b1[tj][reg]) >= 0) v += v1[ti];
+        if (i < rmax && j < cmax) F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
+      }
+    }
+}
+
 // The trailing update of an outer block in ONE launch (round 5): C is the L-shaped region rows / columns [o, M) of the front without
 // its Schur block [Ps, M)^2 - region A = rows [o, Ps) x columns [o, M), region B = rows [Ps, M) x columns [o, Ps) - and blockIdx.y the
 // running tile number over A then B (three launches of 400-900 tiles each left the epilogues of one launch uncovered by the MFMAs of
@@ -132,31 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
   }
   // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
   if (GATHER) {
-    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
-    int a0[WT], a1[WT];  // the lane's rows in the children's borders
-#pragma unroll
-    for (int ti = 0; ti < WT; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
-      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
-    }
-#pragma unroll
-    for (int tj = 0; tj < WT; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (j >= cmax) continue;
-        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
-#pragma unroll
-        for (int ti = 0; ti < WT; ++ti) {
-          const int i = r0 + wi + 16 * ti + (l & 15);
-          if (i >= rmax) continue;
-          double v = 0.0;
-          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
-          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
-          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
-        }
-      }
+    nd_gather_epilogue<WT, WT>(gc, arena, gc.f0 + blockIdx.x, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
     return;
   }
 #pragma unroll
@@ -237,31 +371,7 @@ __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena,
     }
   }
   if (GATHER) {
-    const NdGatherSrc g = nd_gather_src(gc, arena, gc.f0 + blockIdx.x);
-    int a0[4], a1[4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int i = r0 + wi + 16 * ti + (l & 15);
-      a0[ti] = (g.S0 && i < rmax) ? g.I0[i] : -1;
-      a1[ti] = (g.S1 && i < rmax) ? g.I1[i] : -1;
-    }
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = c0 + wj + 16 * tj + (l >> 4) + 4 * reg;
-        if (j >= cmax) continue;
-        const int b0 = g.S0 ? g.I0[j] : -1, b1 = g.S1 ? g.I1[j] : -1;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const int i = r0 + wi + 16 * ti + (l & 15);
-          if (i >= rmax) continue;
-          double v = 0.0;
-          if ((a0[ti] | b0) >= 0) v = g.S0[(int64_t)b0 * g.M0 + a0[ti]];
-          if ((a1[ti] | b1) >= 0) v += g.S1[(int64_t)b1 * g.M1 + a1[ti]];
-          F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
-        }
-      }
+    nd_gather_epilogue<2, 4>(gc, arena, gc.f0 + blockIdx.x, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
     return;
   }
 #pragma unroll
