@@ -143,6 +143,7 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  bool leftlook = true;     // PGX_ND_LEFTLOOK=0: right-looking rank-64 strip updates inside an outer block (A/B)
   bool trsv_big = true;     // PGX_ND_TRSV_BIG=0: k_nd_trsv for the batches of few large fronts too (A/B)
   bool lshape = true;       // PGX_ND_LSHAPE=0: the trailing update of an outer block as three rectangles (A/B)
   bool solve_small = true;  // PGX_ND_SOLVE_SMALL=0: the three-launch path for small fronts too (A/B)
@@ -2127,6 +2128,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if (const char* e = pgx_tune("PGX_ND_SOLVE_SMALL")) s->solve_small = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_TRSV_BIG")) s->trsv_big = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_LEFTLOOK")) s->leftlook = atoi(e) != 0;
   if (s->trsv_big && hipFuncSetAttribute((const void*)k_nd_trsv_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_BIG_LDS) != hipSuccess) {
     (void)hipGetLastError();
     s->trsv_big = false;  // (no 140 KB of LDS per workgroup on this device: the four-wave kernel everywhere)
@@ -2464,8 +2466,22 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           if (M - ke > 0) {
             const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
             nd_launch_panel(s->panel_kind, q, (unsigned)Lv.count, nch, s->arena, Lv.woff, M, kb, nb, Lv.poff, P);
-            nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
-            nd_launch_gemm(s, q, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
+            if (s->leftlook) {
+              // LEFT-LOOKING inside the outer block (round 5): only what the NEXT 64-pivot step reads is brought up to date - its block
+              // row [ke, kn) x [ke, M) and block column [kn, M) x [ke, kn), ONE launch over that L-shaped region - with ALL the pivots
+              // of the outer block eliminated so far (K = [ob, ke): rank 64, 128, 192).  The right-looking form updated the whole
+              // remaining strips of the outer block after every step (two launches, ~47 us of the ~96 us a step costs on the chain of
+              // a level near the root); the flops are the same, the rows and columns beyond the next block wait for their turn.
+              if (st + 1 < nsteps) {
+                const int kn = ke + (W / nsteps + (st + 1 < W % nsteps ? 1 : 0));
+                const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(64, ke, M, kn), 1);
+                NdGatherCtx gc{};
+                hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, ke, M, ke, M, ob, ke, Lv.poff, P, gc, kn);
+              }
+            } else {
+              nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
+              nd_launch_gemm(s, q, Lv, oe, M, ke, oe, kb, ke);  // column strip of the outer block, rows below it
+            }
           }
           kb = ke;
         }
