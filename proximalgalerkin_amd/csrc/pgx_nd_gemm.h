@@ -48,31 +48,39 @@ __device__ __forceinline__ double nd_bcast(double v, int lane) {
 
 // LU without pivoting of an nb x nb diagonal block (nb <= 64) by the 256 threads of a workgroup: F = the block in the working matrix
 // (leading dimension M), S = its place in the compact store, D = 64 x 65 doubles of LDS.  Blocked by 8 columns:
-// (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by lane shuffles, no barrier),
-// (b) the 8 x rest block row of U by forward substitution, one thread per column, (c) rank-8 update of the trailing block
-// by all 256 threads: 3 barriers per 8 columns instead of 2 per column (84 -> ~20 us per launch near the root, where the
-// launches of a level form one dependent chain).
+// (a) wave 0 factors the 8-column panel in registers (lane = row, pivot rows broadcast by v_readlane, no barrier),
+// (b) the 8 x rest block row of U by forward substitution, one thread per column (the coefficients are LDS broadcasts),
+// (c) the rank-8 update of the trailing block on the MATRIX CORES (round 5): its 16 x 16 tiles dealt to the four waves, the C tile
+//     loaded into the accumulator from LDS, two v_mfma_f64_16x16x4_f64 with the negated L tile as A operand, stored back.
+// Three barriers per 8 columns.  This launch is the one purely serial link of the diag -> panel -> update chain of a level near the
+// root; tools/native/nd_diag_bench.hip times it alone (s_memtime): the round-2 form took 72 000 cycles = 31 us for 64 pivots, of
+// which ~700 cycles PER PIVOT in (a) - an IEEE fp64 division per lane and pivot (~200 cycles) and two v_readlane per broadcast value -
+// and the rest in (c)'s 17 LDS reads per updated entry.  Now: the multiplier is a * (1 / pivot) with the reciprocal from v_rcp_f64 + two
+// Newton steps (the last bits of L differ from a true division's by <= 1 ulp; the factorisation stays backward stable and bitwise
+// reproducible), the index arithmetic of the load / store phases has no integer division, and (c) is 2 MFMAs per tile.
+__device__ __forceinline__ double nd_recip(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(fma(-p, r, 1.0), r, r);
+  return fma(fma(-p, r, 1.0), r, r);
+}
 __device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double* __restrict__ F, double* __restrict__ S, int M, int nb,
                                            int* __restrict__ info) {
-  const int tid = threadIdx.x;
-  {  // all loads in flight before the first LDS write
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // all loads in flight before the first LDS write: thread (lane, wave) takes rows lane of the columns wave, wave + 4, ...
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int idx = tid + 256 * q;
-      v[q] = idx < nb * nb ? F[(int64_t)(idx / nb) * M + idx % nb] : 0.0;
+      const int c = wave + 4 * q;
+      v[q] = (lane < nb && c < nb) ? F[(int64_t)c * M + lane] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < nb * nb) D[idx % nb][idx / nb] = v[q];
-    }
+    for (int q = 0; q < 16; ++q) D[lane][wave + 4 * q] = v[q];  // (zeros beyond nb: the MFMA tiles below read whole tiles)
   }
   __syncthreads();
   for (int jb = 0; jb < nb; jb += 8) {
     const int w = min(8, nb - jb);
-    if (tid < 64) {
-      const int r = tid;
+    if (wave == 0) {
+      const int r = lane;
       const bool act = r >= jb && r < nb;
       double a[8];
 #pragma unroll
@@ -80,7 +88,7 @@ __device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double*
       int bad = 0;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        if (c < w) {
+        if (c < w) {  // uniform
           const int pr = jb + c;
           if (r == pr && fabs(a[c]) < 1e-300) {  // exact / denormal zero pivot: static perturbation, reported via info
             a[c] = a[c] < 0 ? -1e-300 : 1e-300;
@@ -89,8 +97,9 @@ __device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double*
           double pv[8];
 #pragma unroll
           for (int c2 = 0; c2 < 8; ++c2) pv[c2] = c2 >= c ? nd_bcast(a[c2], pr) : 0.0;
+          const double rp = nd_recip(pv[c]);
           if (act && r > pr) {
-            const double l = a[c] / pv[c];
+            const double l = a[c] * rp;
             a[c] = l;
 #pragma unroll
             for (int c2 = 0; c2 < 8; ++c2)
@@ -105,54 +114,52 @@ __device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double*
     }
     __syncthreads();
     const int rest = nb - jb - w;
-    if (rest > 0) {
+    if (rest > 0) {  // (then w == 8)
       if (tid < rest) {  // U12 = L11^{-1} A12, one column per thread
-        const int c = jb + w + tid;
+        const int c = jb + 8 + tid;
         double u[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          if (i < w) {
-            double v = D[jb + i][c];
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-              if (m < i) v -= D[jb + i][jb + m] * u[m];
-            u[i] = v;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < w) D[jb + i][c] = u[i];
-      }
-      __syncthreads();
-      for (int idx = tid; idx < rest * rest; idx += 512) {  // two entries per trip, all LDS reads issued first
-        double v[2], lr[2][8], uc[2][8];
-        int rr[2], cc[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int id = min(idx + 256 * q, rest * rest - 1);
-          rr[q] = jb + w + id % rest, cc[q] = jb + w + id / rest;
-          v[q] = D[rr[q]][cc[q]];
-#pragma unroll
-          for (int m = 0; m < 8; ++m) lr[q][m] = D[rr[q]][jb + m], uc[q][m] = D[jb + m][cc[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+          double v = D[jb + i][c];
 #pragma unroll
           for (int m = 0; m < 8; ++m)
-            if (m < w) v[q] -= lr[q][m] * uc[q][m];
-          if (idx + 256 * q < rest * rest) D[rr[q]][cc[q]] = v[q];
+            if (m < i) v -= D[jb + i][jb + m] * u[m];
+          u[i] = v;
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) D[jb + i][c] = u[i];
+      }
+      __syncthreads();
+      // trailing block [jb + 8, nb)^2 -= L U in 16 x 16 tiles.  v_mfma_f64_16x16x4_f64: A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15],
+      // C / D[m = (l >> 4) + 4 reg][n = l & 15].  A tile may reach beyond nb (zeros there, see the load phase) or start before
+      // jb + 8 is a multiple of 16 - tiles are anchored at jb + 8 -, never beyond row / column 63 + 16: clamped reads, guarded stores.
+      const int nt = (rest + 15) / 16, n = lane & 15, g = lane >> 4;
+      for (int t = wave; t < nt * nt; t += 4) {
+        const int R0 = jb + 8 + 16 * (t % nt), C0 = jb + 8 + 16 * (t / nt);
+        const int rn = min(R0 + n, ND_NB - 1), cn = min(C0 + n, ND_NB - 1);
+        nd_v4d acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = D[min(R0 + g + 4 * q, ND_NB - 1)][cn];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double lf = -D[rn][jb + 4 * q + g];
+          const double uf = D[jb + 4 * q + g][cn];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lf, uf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (R0 + g + 4 * q < nb && C0 + n < nb) D[R0 + g + 4 * q][C0 + n] = acc[q];
       }
       __syncthreads();
     }
   }
   // L11\\U11 is final: it goes to the compact factor store, where the panel solves (and the solve phase) read it
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int r = idx % nb, c = idx / nb;
-    S[(int64_t)c * M + r] = D[r][c];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = wave + 4 * q;
+    if (lane < nb && c < nb) S[(int64_t)c * M + lane] = D[lane][c];
   }
 }
-
 
 // Epilogue of the GATHER Schur updates: C(i, j) = S0[inv0[j], inv0[i]] + S1[inv1[j], inv1[i]] - acc for the wave's TJ x TI MFMA tiles
 // (lane l: row i = ri0 + 16 ti + (l & 15), column j = cj0 + 16 tj + (l >> 4) + 4 reg).  Round 5: BRANCHLESS - every index is formed
