@@ -290,6 +290,18 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
     # the padded count (fronts of a level share one shape), reported beside it
     tflops = st["flops"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
     tflops_exec = st["flops_padded"] * sum(its_p) / (prof["lu_factor"] * 1e-3) / 1e12
+    # HBM bytes per factorisation from the committed rocprofv3 --pmc profile of the same workload (tools/profile_nd_traffic.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); its library hash travels with it
+    tj = _ladder("r05_nd_traffic_ex06_1024.json" if args.workload == "ex06" else "r05_nd_traffic_ex02_70.json")
+    traffic = traffic_src = None
+    default_size = (args.workload == "ex06" and N == 1024) or (args.workload != "ex06" and n == 70)
+    if tj and tj.get("per_factorisation") and default_size and world == 1:
+        traffic = tj["per_factorisation"]["traffic_GB"] * 1e9
+        traffic_src = {"file": "profiles/" + ("r05_nd_traffic_ex06_1024.json" if args.workload == "ex06" else "r05_nd_traffic_ex02_70.json"),
+                       "libpgx_sha256_16": tj.get("libpgx_sha256_16"), "per": "factorisation (all k_nd_* kernels of pgx_nd_factor)",
+                       "traffic_over_arena": tj["per_factorisation"].get("traffic_over_arena"),
+                       "note": "FETCH_SIZE counts every read that leaves an XCD's L2, Infinity-Cache hits included: most of it is the "
+                               "panel strips the 128 x 128 GEMM tiles re-stream (16 flop per staged byte), not compulsory traffic"}
     out = None
     if rank == 0:
         out = {
@@ -307,7 +319,7 @@ def bench_lu_workload(args, rank, world, local_rank, dist, backend):
                                    "assembly, diagonal blocks and panel solves included; the deep tree levels of 2-D problems are "
                                    "HBM-bound, DESIGN.md section 9)",
                          "bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_factorisation": st["flops"],
                          "executed_flops_per_factorisation_padded": st["flops_padded"], "executed_TFLOPs": tflops_exec,
                          "arena_GB": st["arena_doubles"] * 8 / 1e9,
@@ -563,11 +575,19 @@ def main():
     if not sharded and args.degree == 2 and not args.solves_only:
         try:  # P2: the patch sweep of the two-level cycle (k_patch_apply + k_patch_edges) on the inverses of the final Jacobian
             sm_ms, sm_bytes = problem.smoother_bench(reps=20)
+            p_traffic = p_src = None
+            ta, te = _ladder("r05_patch_apply_pmc_traffic.json"), _ladder("r05_patch_edges_pmc_traffic.json")
+            if ta and te and ta.get("cells") == N == te.get("cells"):  # the sweep = both kernels: their PMC traffic added
+                p_traffic = ta["hbm_traffic_bytes_per_launch"] + te["hbm_traffic_bytes_per_launch"]
+                p_src = {"files": [ta.get("file"), te.get("file")], "libpgx_sha256_16": ta.get("libpgx_sha256_16"), "date": ta.get("date"),
+                         "traffic_over_algorithmic": p_traffic / (ta["algorithmic_bytes_per_launch"] + te["algorithmic_bytes_per_launch"]),
+                         "k_patch_apply_traffic_over_algorithmic": ta.get("traffic_over_algorithmic"),
+                         "k_patch_edges_traffic_over_algorithmic": te.get("traffic_over_algorithmic")}
             smoother = {"kernel": "k_patch_apply<7, float, SYM> + k_patch_edges (one additive vertex-star patch sweep of the P2 level: float "
                                   "inverses in symmetric packing, 512 B per patch; the time-dominant kernel pair of the P2 solve: "
                                   "profiles/r04_config3_p2_2048_kernel_stats.csv)",
                         "bound": "hbm", "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                        "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": p_traffic, "traffic_source": p_src,
                         "algorithmic_bytes_per_launch": sm_bytes, "avg_launch_ms": sm_ms}
         except Exception as e:  # handles without the patch smoother (general meshes with vertex degree > 7)
             smoother = None
