@@ -254,7 +254,11 @@ class NDLU:
         return A.shape[0] == self.n and len(A.indices) == len(self._indices) and np.array_equal(A.indptr, self._indptr) \
             and np.array_equal(A.indices, self._indices)
 
-    def factor(self, A: sp.csr_matrix, check_pattern: bool = True):
+    def factor(self, A: sp.csr_matrix, check_pattern: bool = True, workers: int = 0):
+        """workers > 1: TREE-PARALLEL numeric phase - the subtrees hanging at tree depth ceil(log2(workers)) are factorised by
+        forked worker processes (one BLAS thread each) into a SHARED arena, the levels above them by this process with all BLAS
+        threads (what `mpirun -n N` + MUMPS does with a 2-D dissection: its fronts are too small for threaded BLAS alone to help,
+        bench.py's `cpu_baseline.all_cores`).  Same arithmetic, same results as the serial schedule."""
         A = A.tocsr()
         if not A.has_sorted_indices:
             A = A.sorted_indices()
@@ -264,19 +268,105 @@ class NDLU:
         nt = self.nt
         upd = [None] * nt
         fronts = [None] * nt
+        par = self._parallel_plan(workers) if workers and workers > 1 else None
         if self.arena is None:
             self.aoff = np.concatenate(([0], np.cumsum(self.p * self.p + 2 * self.p * self.b)))
-            self.arena = np.zeros(int(self.aoff[-1]))
+            if par is not None:  # anonymous SHARED mappings: the workers write their factors, pivots and root Schur blocks into them
+                import mmap
+
+                self._mm = [mmap.mmap(-1, max(8, 8 * int(self.aoff[-1]))), mmap.mmap(-1, max(4, 4 * int(self.p.sum()))),
+                            mmap.mmap(-1, max(8, 8 * int(par["uoff"][-1])))]
+                self.arena = np.frombuffer(self._mm[0], dtype=np.float64)[: int(self.aoff[-1])]
+                self.pivs = np.frombuffer(self._mm[1], dtype=np.int32)[: int(self.p.sum())]
+                self.root_upd = np.frombuffer(self._mm[2], dtype=np.float64)[: int(par["uoff"][-1])]
+                self.poff = np.concatenate(([0], np.cumsum(self.p)))
+            else:
+                self.arena = np.zeros(int(self.aoff[-1]))
         else:
             self.arena.fill(0.0)
         src, dst, aptr = self.asm_src, self.asm_dst, self.asm_ptr
+        if par is not None and hasattr(self, "pivs"):
+            self._factor_parallel(par, workers, data, upd, fronts, src, dst, aptr)
+            self.fronts = fronts
+            return
         for (lo, hi), big in zip(self.level_ranges, self.level_big):
             with _threads(None if big else 1):
-                self._factor_range(lo, hi, data, upd, fronts, src, dst, aptr)
+                self._factor_range(range(lo, hi), data, upd, fronts, src, dst, aptr)
         self.fronts = fronts
 
-    def _factor_range(self, lo, hi, data, upd, fronts, src, dst, aptr):
-        for q in range(lo, hi):
+    def _parallel_plan(self, workers):
+        """Cut of the elimination tree for `workers` processes: roots = the fronts at depth kc = ceil(log2(workers)) (fewer where a
+        branch ends earlier), per-root schedules (deepest level first, as the serial schedule orders them), the schedule of the
+        fronts above the cut, offsets of the roots' Schur blocks in the shared buffer.  None if the tree is too shallow."""
+        if getattr(self, "_plan", None) is not None and self._plan["workers"] == workers:
+            return self._plan
+        kc = int(np.ceil(np.log2(workers)))
+        depth = self.depth
+        if int(depth.max()) < kc + 2:
+            return None
+        parent = np.full(self.nt, -1, dtype=np.int64)
+        for t, ch in enumerate(self.children):
+            for c in ch:
+                parent[c] = t
+        roots = [int(t) for t in range(self.nt) if depth[t] == kc]
+        sub_of = np.full(self.nt, -1, dtype=np.int64)
+        for i, r in enumerate(roots):
+            sub_of[r] = i
+        for t in sorted(range(self.nt), key=lambda t: depth[t]):  # parents before children
+            if depth[t] > kc and parent[t] >= 0:
+                sub_of[t] = sub_of[parent[t]]
+        qsub = sub_of[self.sched]
+        plan = {"workers": workers, "kc": kc, "roots": roots, "sub_q": [np.flatnonzero(qsub == i) for i in range(len(roots))],
+                "top_q": np.flatnonzero(qsub < 0), "uoff": np.concatenate(([0], np.cumsum([int(self.b[r]) ** 2 for r in roots]))),
+                "sub_fronts": [self.sched[np.flatnonzero(qsub == i)] for i in range(len(roots))]}
+        self._plan = plan
+        return plan
+
+    def _front_views(self, t):
+        p, b = int(self.p[t]), int(self.b[t])
+        buf = self.arena[self.aoff[t]: self.aoff[t] + p * p + 2 * p * b]
+        return (buf[: p * p].reshape((p, p), order="F"), self.pivs[self.poff[t]: self.poff[t] + p],
+                buf[p * p: p * p + p * b].reshape((p, b), order="F"), buf[p * p + p * b:].reshape((b, p), order="F"))
+
+    def _factor_parallel(self, par, workers, data, upd, fronts, src, dst, aptr):
+        import os
+
+        roots, uoff = par["roots"], par["uoff"]
+        pending = list(range(len(roots)))
+        running = {}
+        failed = False
+        while pending or running:
+            while pending and len(running) < workers:
+                i = pending.pop(0)
+                pid = os.fork()
+                if pid == 0:  # worker: its subtree, one BLAS thread, results into the shared buffers; never returns
+                    code = 1
+                    try:
+                        with _threads(1):
+                            self._factor_range(par["sub_q"][i], data, upd, fronts, src, dst, aptr, shared=True)
+                        r = roots[i]
+                        if upd[r] is not None:
+                            self.root_upd[uoff[i]: uoff[i + 1]] = np.asarray(upd[r]).ravel(order="F")
+                        code = 0
+                    finally:
+                        os._exit(code)
+                running[pid] = i
+            pid, status = os.wait()
+            if pid in running:
+                del running[pid]
+                failed |= status != 0
+        if failed:
+            raise RuntimeError("NDLU: a worker of the tree-parallel factorisation failed (singular pivot block or out of memory)")
+        for i, r in enumerate(roots):  # what the levels above need from below: the roots' Schur blocks; what the solves need: views
+            b = int(self.b[r])
+            upd[r] = self.root_upd[uoff[i]: uoff[i + 1]].reshape((b, b), order="F") if b else None
+            for t in par["sub_fronts"][i]:
+                fronts[int(t)] = self._front_views(int(t))
+        with _threads(None):
+            self._factor_range(par["top_q"], data, upd, fronts, src, dst, aptr, shared=True)
+
+    def _factor_range(self, qs, data, upd, fronts, src, dst, aptr, shared=False):
+        for q in qs:
             t, k = int(self.sched[q]), int(self.sched_k[q])
             p, b = int(self.p[t]), int(self.b[t])
             # the factor blocks live in one arena that is allocated once and reused by every factorisation (fresh pages cost more
@@ -309,12 +399,24 @@ class NDLU:
             if info != 0:
                 raise ZeroDivisionError(f"NDLU: singular pivot block in front {t} (dgetrf info {info})")
             if b:
+                F12o, F21o = F12, F21
                 F12 = lapack.dlaswp(F12, piv, overwrite_a=1)
                 F12 = blas.dtrsm(1.0, lu, F12, side=0, lower=1, trans_a=0, diag=1, overwrite_b=1)
                 F21 = blas.dtrsm(1.0, lu, F21, side=1, lower=0, trans_a=0, diag=0, overwrite_b=1)
                 F22 = blas.dgemm(-1.0, F21, F12, beta=1.0, c=F22, overwrite_c=1)
                 upd[t] = F22
-            fronts[t] = (lu, piv, F12, F21)
+                if shared:  # the factors must END UP in the arena (the wrappers work in place on these Fortran-ordered views; if one
+                    if not np.shares_memory(F12, F12o):  # ever returned a copy, put it back)
+                        F12o[...] = F12
+                    if not np.shares_memory(F21, F21o):
+                        F21o[...] = F21
+            if shared:
+                if not np.shares_memory(lu, F11):
+                    F11[...] = lu
+                self.pivs[self.poff[t]: self.poff[t] + p] = piv
+                fronts[t] = self._front_views(t)
+            else:
+                fronts[t] = (lu, piv, F12, F21)
 
     def solve(self, rhs):
         with _threads(self.solve_threads):
@@ -380,9 +482,10 @@ class NDLinearSolve:
     """`linear_solve(J, rhs)` callback for pg_oracle.newton_solve: analyse once per pattern, factorise every call, solve with
     iterative refinement on the exact matrix (stops at a relative residual of 1e-15 or when it no longer improves)."""
 
-    def __init__(self, node_of_dof, node_coords, leaf_nodes=32, verbose=False, max_refine=3):
+    def __init__(self, node_of_dof, node_coords, leaf_nodes=32, verbose=False, max_refine=3, workers=0):
         self.node_of_dof, self.node_coords = node_of_dof, node_coords
         self.leaf_nodes, self.verbose, self.max_refine = leaf_nodes, verbose, max_refine
+        self.workers = workers  # > 1: tree-parallel numeric factorisation (NDLU.factor)
         self.nd = None
         self.t_factor = self.t_solve = 0.0
         self.n_factor = 0
@@ -395,7 +498,7 @@ class NDLinearSolve:
         if self.nd is None or not self.nd.same_pattern(J):
             self.nd = NDLU(J, self.node_of_dof, self.node_coords, self.leaf_nodes, self.verbose)
         t = time.perf_counter()
-        self.nd.factor(J, check_pattern=False)
+        self.nd.factor(J, check_pattern=False, workers=self.workers)
         t1 = time.perf_counter()
         x = self.nd.solve(rhs)
         bn = np.linalg.norm(rhs)

@@ -162,11 +162,13 @@ __device__ __forceinline__ void nd_diag_lu(double (*D)[ND_NB + 1], const double*
 }
 
 // Epilogue of the GATHER Schur updates: C(i, j) = S0[inv0[j], inv0[i]] + S1[inv1[j], inv1[i]] - acc for the wave's TJ x TI MFMA tiles
-// (lane l: row i = ri0 + 16 ti + (l & 15), column j = cj0 + 16 tj + (l >> 4) + 4 reg).  Round 5: BRANCHLESS - every index is formed
-// first (absent child / out-of-range / unmapped position -> a dummy read of entry 0, masked afterwards), the eight gathered loads of a
-// (tj, reg) column go out together, and all column maps of the wave are fetched before the first gather: the round-2 form wrapped
-// each load in its own `if`, which serialised a dependent index load and up to 2 x TI x 4 TJ gathers per lane one behind the other -
-// and these launches ARE their epilogue on the deep levels (K = P = 5 ... 64 against 2 x 8 bytes gathered + 8 written per entry).
+// (lane l: row i = ri0 + 16 ti + (l & 15), column j = cj0 + 16 tj + (l >> 4) + 4 reg).  One implementation for both tile sizes
+// (round 5), branch-free: every index is formed first (absent child / out-of-range / unmapped position -> a dummy read of entry 0,
+// masked afterwards), the gathers of a (tj, reg) column go out together and all column maps are fetched before the first gather.
+// Measured: no faster than the round-2 form with an `if` around each load, and neither is a variant with all 32 gathers of a 64 x 64
+// tile in flight at once - these launches (2.1 TB/s of gathered + written bytes on the mid levels, where K = P <= 64 makes them
+// nearly pure gathers) are not bound by how many loads a lane has outstanding; 8-byte accesses in runs of 16 lanes are what the
+// MFMA accumulator layout offers the memory system.
 template <int TJ, int TI>
 __device__ __forceinline__ void nd_gather_epilogue(const NdGatherCtx& gc, const double* __restrict__ arena, int64_t f, double* __restrict__ F,
                                                    int M, int ri0, int cj0, int rmax, int cmax, int l, const nd_v4d (&acc)[TJ][TI]) {
