@@ -93,6 +93,12 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads=
         xk = x.copy()
         sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
         ND.MAX_THREADS = nthreads
+        # more than one thread: TREE-PARALLEL factorisation - forked workers on the subtrees of the dissection (one BLAS thread each),
+        # the levels above them with all threads (oracle/nd_lu.py NDLU.factor(workers=)): threaded BLAS alone cannot feed the cores
+        # from the small fronts of a 2-D dissection (round 4 measured it SLOWER than one thread)
+        ls.workers = min(nthreads, 16) if nthreads > 1 else 0
+        if ls.workers:
+            ls.nd.prepare_parallel(ls.workers)
         ls.t_factor = ls.t_solve = 0.0
         ls.n_factor = 0
         steps, t0 = 0, time.perf_counter()
@@ -743,10 +749,9 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"value": v2, "unit": "Newton iterations/s", "cores": threads[1],
                                                     "sample": f"{steps2} Newton step(s) ({secs2:.1f} s), same mesh and code, "
                                                               f"{threads[1]} BLAS threads", "detail": detail2,
-                                                    "note": "threaded LAPACK/BLAS inside the same multifrontal code (no parallel "
-                                                            "assembly, no tree parallelism beyond BLAS): where it is SLOWER than "
-                                                            "`value` the fronts of this 2-D dissection are too small to feed the "
-                                                            "threads, and the one-thread figure is the stronger CPU baseline"}
+                                                    "note": "tree-parallel numeric factorisation (forked workers, one per subtree of the "
+                                                            "dissection, up to 16; the levels above them with threaded BLAS), threaded "
+                                                            "BLAS in the solves; assembly stays serial numpy"}
             if cpu_n != N:  # (sample mesh == workload mesh: directly comparable for ANY degree - the else branch)
                 ex = extrapolate(v, cpu_n, N, ladder) if ladder else None
                 if ex:

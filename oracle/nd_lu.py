@@ -258,7 +258,8 @@ class NDLU:
         """workers > 1: TREE-PARALLEL numeric phase - the subtrees hanging at tree depth ceil(log2(workers)) are factorised by
         forked worker processes (one BLAS thread each) into a SHARED arena, the levels above them by this process with all BLAS
         threads (what `mpirun -n N` + MUMPS does with a 2-D dissection: its fronts are too small for threaded BLAS alone to help,
-        bench.py's `cpu_baseline.all_cores`).  Same arithmetic, same results as the serial schedule."""
+        bench.py's `cpu_baseline.all_cores`).  Same algorithm as the serial schedule; the summation order inside threaded BLAS calls of
+        the top levels may differ, so results agree to the solver's accuracy, not bitwise."""
         A = A.tocsr()
         if not A.has_sorted_indices:
             A = A.sorted_indices()
@@ -269,19 +270,11 @@ class NDLU:
         upd = [None] * nt
         fronts = [None] * nt
         par = self._parallel_plan(workers) if workers and workers > 1 else None
+        if par is not None:
+            self.prepare_parallel(workers, touch=False)
         if self.arena is None:
             self.aoff = np.concatenate(([0], np.cumsum(self.p * self.p + 2 * self.p * self.b)))
-            if par is not None:  # anonymous SHARED mappings: the workers write their factors, pivots and root Schur blocks into them
-                import mmap
-
-                self._mm = [mmap.mmap(-1, max(8, 8 * int(self.aoff[-1]))), mmap.mmap(-1, max(4, 4 * int(self.p.sum()))),
-                            mmap.mmap(-1, max(8, 8 * int(par["uoff"][-1])))]
-                self.arena = np.frombuffer(self._mm[0], dtype=np.float64)[: int(self.aoff[-1])]
-                self.pivs = np.frombuffer(self._mm[1], dtype=np.int32)[: int(self.p.sum())]
-                self.root_upd = np.frombuffer(self._mm[2], dtype=np.float64)[: int(par["uoff"][-1])]
-                self.poff = np.concatenate(([0], np.cumsum(self.p)))
-            else:
-                self.arena = np.zeros(int(self.aoff[-1]))
+            self.arena = np.zeros(int(self.aoff[-1]))
         else:
             self.arena.fill(0.0)
         src, dst, aptr = self.asm_src, self.asm_dst, self.asm_ptr
@@ -293,6 +286,26 @@ class NDLU:
             with _threads(None if big else 1):
                 self._factor_range(range(lo, hi), data, upd, fronts, src, dst, aptr)
         self.fronts = fronts
+
+    def prepare_parallel(self, workers, touch=True):
+        """The SHARED buffers of the tree-parallel factorisation (anonymous shared mappings: factors, pivots, the subtree roots' Schur
+        blocks), allocated once; touch=True also writes every page (bench.py: factor storage is in place before the clock starts)."""
+        par = self._parallel_plan(workers)
+        if par is None or hasattr(self, "pivs"):
+            return par
+        import mmap
+
+        self.aoff = np.concatenate(([0], np.cumsum(self.p * self.p + 2 * self.p * self.b)))
+        self._mm = [mmap.mmap(-1, max(8, 8 * int(self.aoff[-1]))), mmap.mmap(-1, max(4, 4 * int(self.p.sum()))),
+                    mmap.mmap(-1, max(8, 8 * int(par["uoff"][-1])))]
+        self.arena = np.frombuffer(self._mm[0], dtype=np.float64)[: int(self.aoff[-1])]
+        self.pivs = np.frombuffer(self._mm[1], dtype=np.int32)[: int(self.p.sum())]
+        self.root_upd = np.frombuffer(self._mm[2], dtype=np.float64)[: int(par["uoff"][-1])]
+        self.poff = np.concatenate(([0], np.cumsum(self.p)))
+        if touch:
+            self.arena.fill(1.0)
+            self.root_upd.fill(1.0)
+        return par
 
     def _parallel_plan(self, workers):
         """Cut of the elimination tree for `workers` processes: roots = the fronts at depth kc = ceil(log2(workers)) (fewer where a

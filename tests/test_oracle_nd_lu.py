@@ -124,3 +124,33 @@ def test_nd_lu_runs_example_02_like_superlu():
     assert list(its0) == list(its1)
     assert np.linalg.norm(x0 - x1) <= 1e-4 * np.linalg.norm(x0)  # both stop at the Newton tolerance 1e-6 (1e-5 on the first step)
     assert ls.last_relres < 1e-12
+
+
+def test_tree_parallel_factorisation_equals_the_serial_one():
+    """NDLU.factor(workers=4): the four subtrees at tree depth 2 factorised by forked workers into the shared arena, the two levels
+    above them by the parent - the solution of a late-Newton-like system equals the serial schedule's to the solver's accuracy,
+    pivots and factors of EVERY front are readable from the parent (the solve phase walks all of them), and a second factorisation
+    reuses the shared buffers."""
+    import numpy as np
+
+    from oracle import nd_lu as ND
+    from oracle import pg_oracle as O
+
+    N = 48
+    coords, cells = O.create_rectangle(N, N)
+    prob = O.ObstacleP1(coords, cells, O.boundary_vertices_rectangle(N, N))
+    x = np.zeros(2 * prob.n)
+    r = np.hypot(coords[:, 0], coords[:, 1])
+    x[prob.n:] = np.where(r < 0.35, -300.0, -1.0)  # exp(psi) underflows to exact zeros in the contact zone
+    J = prob.jacobian(x, 50.0).tocsr()
+    b = np.random.default_rng(3).standard_normal(J.shape[0])
+    serial = ND.NDLinearSolve(*ND.nodes_of_problem(prob))
+    xs = serial(J, b)
+    par = ND.NDLinearSolve(*ND.nodes_of_problem(prob), workers=4)
+    xp = par(J, b)
+    assert par.nd._plan is not None and len(par.nd._plan["roots"]) == 4
+    # (alpha = 50 and exact zeros in D: condition number ~1e10 - refinement stops at 1e-11 for either schedule)
+    assert par.last_relres < 1e-9 and serial.last_relres < 1e-9 and par.last_relres < 100 * serial.last_relres + 1e-12
+    assert np.linalg.norm(xp - xs) <= 1e-6 * np.linalg.norm(xs)
+    xp2 = par(J, b)  # refactorisation into the same shared buffers
+    assert np.array_equal(xp2, xp) or np.linalg.norm(xp2 - xp) <= 1e-12 * np.linalg.norm(xp)
