@@ -143,6 +143,9 @@ struct pgx_nd {
   double *d_xbuf = nullptr, *d_vbuf = nullptr;
   bool factored = false;
   bool timing = false;
+  int outer = 512;          // PGX_ND_OUTER: pivots per outer block = rank of the trailing updates (multiple of 64).  512 since round 5: with
+                            // left-looking steps inside the block, ex 02 at 70^3 990 -> 965 ms, ex 06 at 1024^2 100.1 -> 99.5 ms against 256
+                            // on the same box (768 / 1024: within 0.5 %); with round 2`s right-looking strips 512 had lost on ex 06
   bool leftlook = true;     // PGX_ND_LEFTLOOK=0: right-looking rank-64 strip updates inside an outer block (A/B)
   bool trsv_big = true;     // PGX_ND_TRSV_BIG=0: k_nd_trsv for the batches of few large fronts too (A/B)
   bool lshape = true;       // PGX_ND_LSHAPE=0: the trailing update of an outer block as three rectangles (A/B)
@@ -2129,6 +2132,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_TRSV_BIG")) s->trsv_big = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_LEFTLOOK")) s->leftlook = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_OUTER")) s->outer = std::max(64, (atoi(e) / 64) * 64);
   if (s->trsv_big && hipFuncSetAttribute((const void*)k_nd_trsv_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_BIG_LDS) != hipSuccess) {
     (void)hipGetLastError();
     s->trsv_big = false;  // (no 140 KB of LDS per workgroup on this device: the four-wave kernel everywhere)
@@ -2454,7 +2458,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       // diagonal block, both panel solves, then rank-64 updates of the outer block's row and column STRIPS only.  The
       // rest of the trailing pivot block and panels gets ONE rank-ND_OUTER update per outer block (arithmetic intensity
       // ND_OUTER/8 flop/byte: MFMA-bound instead of HBM-bound), the Schur block F22 ONE update with K = P at the end.
-      const int nouter = (P + ND_OUTER - 1) / ND_OUTER;
+      const int nouter = (P + s->outer - 1) / s->outer;
       int ob = 0;
       for (int ou = 0; ou < nouter; ++ou) {
         const int W = P / nouter + (ou < P % nouter ? 1 : 0), oe = ob + W;

@@ -9,7 +9,7 @@
 #define ND_TS 64   // panel chunk
 #define ND_KC 16   // GEMM k-chunk staged in LDS
 #define ND_SLAB 256 // pivots per triangular-solve launch in the solve phase
-#define ND_OUTER 256 // pivots per outer block of the factorisation (rank of the big trailing updates)
+#define ND_OUTER 256 // (historical default of the outer block; pgx_nd::outer decides, PGX_ND_OUTER)
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 // Parent-centric assembly fused into the Schur update (GATHER variants of the GEMM kernels): the border block of a front is never
