@@ -64,6 +64,24 @@ def extrapolate(v_measured, n_measured, n_workload, ladder, size_key="N"):
 
 
 def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads=(1,), degree: int = 1, min_steps: int = 4):
+    """cpu_baseline_inprocess in a CHILD process (`bench.py --cpu-leg <json>`): the all-cores leg forks worker processes for the
+    subtrees of the dissection, and the benchmark process itself holds a HIP context by now - the child never touches the GPU (a
+    forked child of a GPU process is allowed to, but its forks then copy the driver's mappings: measured, the tree-parallel
+    factorisation gained nothing when forked from the GPU process and 3.4 x from a clean one).  The child is started as a child
+    process and waited for; nothing is exec'ed over this one."""
+    import subprocess
+
+    arg = json.dumps({"n_sample": n_sample, "settings": settings, "budget_s": budget_s, "threads": list(threads), "degree": degree,
+                      "min_steps": min_steps})
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")  # the oracle is numpy / scipy: no device
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", arg], capture_output=True, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[")]
+    if r.returncode or not lines:
+        raise RuntimeError(f"cpu_baseline child failed (rc {r.returncode}): {r.stderr.strip()[-400:]}")
+    return [tuple(x) for x in json.loads(lines[-1])]
+
+
+def cpu_baseline_inprocess(n_sample: int, settings: dict, budget_s: float = 20.0, threads=(1,), degree: int = 1, min_steps: int = 4):
     """Oracle (numpy assembly + exact Newton with the nested-dissection multifrontal LU of oracle/nd_lu.py - the ordering class and
     the BLAS-3 structure a CPU user gets from `pc_type lu` / MUMPS, obstacle_pg.py:129-131) timed on this host: the SAME LVPP run on
     an n_sample^2 mesh of Lagrange degree `degree`, stopped after the first Newton step that ends beyond budget_s AND after at
@@ -92,7 +110,7 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads=
         x = np.zeros(2 * prob.n)
         xk = x.copy()
         sched = O.AlphaSchedule(settings["alpha_scheme"], settings["alpha_max"])
-        ND.MAX_THREADS = nthreads
+        ND.MAX_THREADS = min(nthreads, 16)  # (the top fronts of a 2-D dissection do not feed more; 64 threads of a shared host thrash)
         # more than one thread: TREE-PARALLEL factorisation - forked workers on the subtrees of the dissection (one BLAS thread each),
         # the levels above them with all threads (oracle/nd_lu.py NDLU.factor(workers=)): threaded BLAS alone cannot feed the cores
         # from the small fronts of a 2-D dissection (round 4 measured it SLOWER than one thread)
@@ -106,7 +124,7 @@ def cpu_baseline(n_sample: int, settings: dict, budget_s: float = 20.0, threads=
         def over():
             return time.perf_counter() - t0 > budget_s and steps >= min_steps
 
-        with threadpool_limits(nthreads):
+        with threadpool_limits(min(nthreads, 16)):
             for k in range(settings["max_outer"]):
                 alpha = sched.update(k)
                 F = prob.residual(x, xk, alpha)
@@ -403,6 +421,11 @@ def self_launch(n):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg":  # the CPU-baseline child (cpu_baseline): no torch, no GPU
+        a = json.loads(sys.argv[2])
+        runs = cpu_baseline_inprocess(a["n_sample"], a["settings"], a["budget_s"], tuple(a["threads"]), a["degree"], a["min_steps"])
+        print(json.dumps([list(r) for r in runs]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -722,7 +745,7 @@ def main():
             # line must not carry a P1 baseline)
             cpu_n = min(args.cpu_n, N) if args.degree == 1 else min(args.cpu_n // 2, N)
             hi = host_info()
-            all_cores = min(hi["host_cores_usable"] or 1, 64)  # one socket's worth: beyond it the fronts of a 2-D dissection starve
+            all_cores = min(hi["host_cores_usable"] or 1, 16)  # the box's CPU share per GPU (16): 16 subtree workers, 16 BLAS threads above them
             threads = [args.cpu_threads] + ([all_cores] if all_cores > args.cpu_threads and not args.no_cpu_all_cores else [])
             runs = cpu_baseline(cpu_n, S, threads=threads, degree=args.degree)
             v, steps, secs, detail = runs[0]
@@ -748,7 +771,7 @@ def main():
                 v2, steps2, secs2, detail2 = runs[1]
                 out["cpu_baseline"]["all_cores"] = {"value": v2, "unit": "Newton iterations/s", "cores": threads[1],
                                                     "sample": f"{steps2} Newton step(s) ({secs2:.1f} s), same mesh and code, "
-                                                              f"{threads[1]} BLAS threads", "detail": detail2,
+                                                              f"{threads[1]} worker processes / BLAS threads", "detail": detail2,
                                                     "note": "tree-parallel numeric factorisation (forked workers, one per subtree of the "
                                                             "dissection, up to 16; the levels above them with threaded BLAS), threaded "
                                                             "BLAS in the solves; assembly stays serial numpy"}
