@@ -590,7 +590,7 @@ def main():
         f32 = sm_bytes < 60.0 * n
         sm_traffic, sm_src = (None, None)
         if f32 and N == 2048:
-            tj = _ladder("r04_fsmooth_pmc_traffic.json")
+            tj = _ladder("r05_fsmooth_pmc_traffic.json")
             if tj and tj.get("cells") == N:
                 sm_traffic = tj["hbm_traffic_bytes_per_launch"]
                 sm_src = {k: tj.get(k) for k in ("file", "kernel", "libpgx_sha256_16", "date", "traffic_over_algorithmic")}
@@ -667,8 +667,8 @@ def main():
         if kind == 0 and args.degree == 2:
             name = ("k_bspmv_bal (P2 operator apply: nnz-balanced CSR-stream SpMV of [[aK,M],[M,-D]]; on this uniform mesh K and M are "
                     "read through a one-byte (K,M)-pair dictionary: 13 B per entry instead of 28)")
-        traffic, src = pmc_traffic(("r04_p2stspmv_pmc_traffic.json" if kind == 3 else "r03_p2spmv_pmc_traffic.json") if args.degree == 2 else
-                                   {0: "r04_spmv_pmc_traffic.json", 1: "r04_stspmv_pmc_traffic.json"}.get(kind, "none"))
+        traffic, src = pmc_traffic(("r05_p2stspmv_pmc_traffic.json" if kind == 3 else "r03_p2spmv_pmc_traffic.json") if args.degree == 2 else
+                                   {0: "r05_spmv_pmc_traffic.json", 1: "r05_stspmv_pmc_traffic.json"}.get(kind, "none"))
         gbs = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": name + (", rank 0's strip" if sharded else ""), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
