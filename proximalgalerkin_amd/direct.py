@@ -73,6 +73,21 @@ class DirectSolver:
         self._check(self._lib.pgx_nd_timing(self._h, int(enable), C.byref(f), C.byref(s)), "pgx_nd_timing")
         return f.value, s.value
 
+    def depth_profile(self, enable=None):
+        """Device time per TREE DEPTH (0 = root) of the factorisations / forward sweeps / backward sweeps since recording was switched
+        on (include/pgx_nd.h: pgx_nd_depth_profile).  enable=True starts (and clears), False stops, None only reads.  Returns
+        {"factor_ms": [...], "fwd_ms": [...], "bwd_ms": [...], "calls": (factorisations, forward sweeps, backward sweeps)}."""
+        n = C.c_int32(0)
+        self._check(self._lib.pgx_nd_depth_profile(self._h, -1, C.byref(n), None, None, None, None), "pgx_nd_depth_profile")
+        nd = n.value
+        f, fw, bw = (np.zeros(nd) for _ in range(3))
+        calls = np.zeros(3, dtype=np.int32)
+        n = C.c_int32(nd)
+        flag = -1 if enable is None else int(bool(enable))
+        self._check(self._lib.pgx_nd_depth_profile(self._h, flag, C.byref(n), f.ctypes.data_as(L.c_double_p), fw.ctypes.data_as(L.c_double_p),
+                                                   bw.ctypes.data_as(L.c_double_p), calls.ctypes.data_as(L.c_int32_p)), "pgx_nd_depth_profile")
+        return {"factor_ms": f, "fwd_ms": fw, "bwd_ms": bw, "calls": tuple(int(c) for c in calls)}
+
     def export_symbolic(self) -> dict:
         """The level/front/destination maps the device numeric phase uses (tests emulate it with numpy)."""
         lib, h = self._lib, self._h

@@ -184,3 +184,43 @@ def test_assembly_variants_agree_on_an_unstructured_p2_matrix(require_gpu, monke
     xr = spla.splu(J.tocsc()).solve(b)
     assert np.linalg.norm(xs["1"] - xr) <= 1e-7 * np.linalg.norm(xr)
     assert np.linalg.norm(xs["1"] - xs["0"]) <= 1e-9 * np.linalg.norm(xs["0"])
+
+
+@pytest.mark.parametrize("switch", ["PGX_ND_SOLVE_SMALL", "PGX_ND_TRSV_BIG", "PGX_ND_LSHAPE", "PGX_ND_LEFTLOOK", "PGX_ND_OUTER"])
+def test_round5_schedules_agree_with_the_round4_ones(require_gpu, monkeypatch, switch):
+    """Every piece of the numeric phase that round 5 rebuilt has its round-4 form behind a tuning key: the one-wave solve sweeps of the
+    small fronts, the register-resident slab solve of the large ones, the L-shaped trailing update, the left-looking 64-pivot steps,
+    the 512-pivot outer blocks (PGX_ND_OUTER=256 / 128: three to six outer blocks in the root of this matrix).  On a late example-06
+    matrix with fronts of every kind (leaves, frame-fused, P > 64 with slabs, a 770-pivot root) both forms are backward stable LU
+    factorisations / solves of the same matrix in the same order: solutions agree to rounding; the per-depth profile
+    (pgx_nd_depth_profile) accounts for every factorisation and sweep."""
+    from proximalgalerkin_amd.direct import DirectSolver
+
+    N = 128
+    c6, e6 = O.create_rectangle(N, N, (0.0, 0.0), (1.0, 1.0))
+    g = G.GradientConstraintP2(c6, e6)
+    x = np.zeros(g.ntot)
+    x[g.n2:] = 0.3 * np.sin(np.arange(2 * g.nv))
+    J = g.jacobian(x, 4.0).tocsr()
+    J.sort_indices()
+    nod = np.concatenate([np.arange(g.n2), np.arange(g.nv), np.arange(g.nv)]).astype(np.int32)
+    b = np.random.default_rng(11).standard_normal(J.shape[0])
+    xs = {}
+    for val in ("default", "128" if switch == "PGX_ND_OUTER" else "0"):
+        if val == "default":
+            monkeypatch.delenv(switch, raising=False)
+        else:
+            monkeypatch.setenv(switch, val)
+        ds = DirectSolver(J.indptr, J.indices, nod, g.dof_coords, device=0)
+        ds.depth_profile(True)
+        ds.factor(J.data)
+        xs[val] = ds.solve(b)
+        ds.solve(b)
+        prof = ds.depth_profile(False)
+        assert prof["calls"] == (1, 2, 2)
+        assert len(prof["factor_ms"]) >= 10 and np.all(prof["factor_ms"] > 0) and np.all(prof["fwd_ms"] > 0) and np.all(prof["bwd_ms"] > 0)
+        assert ds.stats()["perturbed_pivots"] == 0
+        assert _berr(J, xs[val], b) <= 1e-13
+        ds.close()
+    a, c = xs.values()
+    assert np.linalg.norm(a - c) <= 1e-9 * np.linalg.norm(c)
