@@ -2530,6 +2530,13 @@ static int lu_factor(pgx_handle* h) {
   return rc;
 }
 
+// FGMRES keeps its Z_j as float2 fields (round 5) where they leave the single-precision cycle and the operator apply is the
+// matrix-free stencil kernel: one predicate for the solver and for pgx_spmv_bench, which replays the solver's sequence
+static inline bool z_f32_active(const pgx_handle* h, int nu) {
+  return h->z_f32 && !h->dist.on && !h->lu_active && h->degree == 1 && h->structured && !h->lev.empty() && h->lev[0].uniform &&
+         h->spmv_stencil == 1 && f32_cycle_ok(h, 0, nu);
+}
+
 static int precond(pgx_handle* h, const double* b, double* z, int nu, double omega) {
   if (h->lu_active) {
     int rc = pgx_nd_solve(h->lu, b, z, 1);
@@ -2636,8 +2643,7 @@ static int fgmres(pgx_handle* h, const double* b, double* x, const pgx_snes_opts
     // Z_j in single precision (round 5): on this path z_j leaves a float cycle, so storing it as one float2 field loses nothing - the
     // cycle's last launch writes it in place, the operator apply reads it (k_st_spmv_r<true>), the solution update sums it
     // (k_lincomb_f2): 100 MB less per Krylov iteration at 2048^2 than the fp64 pair.  w = J z_j, the basis V and H stay fp64.
-    const bool zf32 = h->z_f32 && !dist && !h->lu_active && h->degree == 1 && h->structured && !h->lev.empty() && h->lev[0].uniform &&
-                      h->spmv_stencil == 1 && f32_cycle_ok(h, 0, o->mg_nu);
+    const bool zf32 = z_f32_active(h, o->mg_nu);
     float2* const Zf = reinterpret_cast<float2*>(h->Z);
     PgxDotScale sc2;  // s_i^2
     std::vector<double> sv((size_t)m + 2, 1.0);  // s_i
@@ -3011,6 +3017,7 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
   const bool mg = !cold && h->structured && h->degree == 1 && !h->dist.on && !h->lu_active && h->lev.size() > 1;
   pgx_snes_opts od;
   pgx_default_opts(&od);
+  const bool zf = mg && z_f32_active(h, od.mg_nu);
   const size_t flush = std::min<size_t>((size_t)h->restart * n2, ((size_t)512 << 20) / sizeof(double));
   // nine rounds of (batch with applies, batch without), median of the differences: clock and power drift between two ~50 ms
   // batches is of the order of the quantity measured
@@ -3021,12 +3028,19 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
       HIPCHK(hipEventRecord(h->e0, h->st));
       for (int k = 0; k < reps; ++k) {
         if (mg) {
+          h->zf_out = zf ? reinterpret_cast<float2*>(h->Z) : nullptr;  // as in fgmres: the cycle leaves z as ONE float2 field ...
           const int rc = precond(h, h->V, h->Z, od.mg_nu, od.mg_omega);
+          h->zf_out = nullptr;
           if (rc) return rc;
         } else {
           pgxk_multidot(h->st, flush, 1, h->Z, 0, h->Z, h->partials, h->d_small);
         }
-        if (pass == 0) spmv_dev(h, mg ? h->Z : h->V, h->w);
+        if (pass == 0) {
+          if (zf)  // ... and the apply reads it (k_st_spmv_r<true>)
+            pgxk_st_spmv(h->st, h->lev[0], h->alpha, nullptr, nullptr, h->xcd_remap ? 1 : 0, h->w, h->w + h->nd, reinterpret_cast<const float2*>(h->Z));
+          else
+            spmv_dev(h, mg ? h->Z : h->V, h->w);
+        }
       }
       HIPCHK(hipEventRecord(h->e1, h->st));
       HIPCHK(hipEventSynchronize(h->e1));
@@ -3040,9 +3054,9 @@ static int spmv_bench_impl(pgx_handle* h, int reps, double* avg_ms, double* byte
   *avg_ms = diff[diff.size() / 2];
   if (bytes) {
     if (h->spmv_stencil && h->structured && h->degree == 1)
-      // matrix-free: x read once (16 B per vertex), y written (16 B), half-stored D stencil (4 x 8 B), Dirichlet mask (1 B);
-      // K and M are seven constants each
-      *bytes = (16.0 + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
+      // matrix-free: x read once (16 B per vertex; 8 B as the float2 field of an FGMRES z_j), y written (16 B), half-stored D stencil
+      // (4 x 8 B), Dirichlet mask (1 B); K and M are seven constants each
+      *bytes = ((zf ? 8.0 : 16.0) + 16.0 + 4.0 * sizeof(dsten_t) + 1.0) * h->nd;
     else if (h->degree == 2 && h->p2st.state == 2 && h->p2st.select && (!h->dist.on || h->p2st.dist_enable) && h->spmv_stream && h->spmv_bal) {
       // structured P2 apply: 46 D values per interior group (SoA copy), nothing else of the matrix; the frame rows in CSR form
       // (column + K + M + D = 28 B per entry, the row list); x read once; y written

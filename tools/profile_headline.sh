@@ -22,10 +22,10 @@ for what in "$@"; do
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 tools/spmv_bench.py 2048 0 > $OUT/pmc_write.log 2>&1 || exit 1
       python3 tools/pmc_summary.py --kernel k_bspmv_stream --traffic --cells 2048 --algorithmic-bytes 973570116 \
         --out $OUT/spmv_pmc_traffic.json $OUT/pmc_fetch $OUT/pmc_write > /dev/null || exit 1 ;;
-    stspmv)  # the matrix-free operator apply: 65 B x 2049^2 vertices
+    stspmv)  # the matrix-free operator apply in the solver's sequence (x = the float2 z_j of FGMRES): 57 B x 2049^2 vertices
       rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_sfetch -o f -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_sfetch.log 2>&1 || exit 1
       rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_swrite -o w -- python3 tools/spmv_bench.py 2048 1 > $OUT/pmc_swrite.log 2>&1 || exit 1
-      python3 tools/pmc_summary.py --kernel k_st_spmv_r --traffic --cells 2048 --algorithmic-bytes 272896065 \
+      python3 tools/pmc_summary.py --kernel "k_st_spmv_r<true>" --traffic --cells 2048 --algorithmic-bytes 239308857 \
         --out $OUT/stspmv_pmc_traffic.json $OUT/pmc_sfetch $OUT/pmc_swrite > /dev/null || exit 1 ;;
     p2stspmv)  # the structured P2 operator apply (pgx_p2st.hip): 496 B x 2045^2 interior groups at 2048^2
       rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfetch -o f -- python3 tools/p2_spmv_bench.py 2048 > $OUT/pmc_pfetch.log 2>&1 || exit 1

@@ -12,7 +12,7 @@ run() {  # name, counter, program args...
 }
 run st FETCH_SIZE python3 tools/spmv_bench.py 2048 1
 run st WRITE_SIZE python3 tools/spmv_bench.py 2048 1
-python3 tools/pmc_summary.py --kernel k_st_spmv_r --traffic --cells 2048 --algorithmic-bytes 272896065 --out $OUT/stspmv_pmc_traffic.json $OUT/st_FETCH_SIZE $OUT/st_WRITE_SIZE > /dev/null || exit 1
+python3 tools/pmc_summary.py --kernel "k_st_spmv_r<true>" --traffic --cells 2048 --algorithmic-bytes 239308857 --out $OUT/stspmv_pmc_traffic.json $OUT/st_FETCH_SIZE $OUT/st_WRITE_SIZE > /dev/null || exit 1
 run csr FETCH_SIZE python3 tools/spmv_bench.py 2048 0
 run csr WRITE_SIZE python3 tools/spmv_bench.py 2048 0
 python3 tools/pmc_summary.py --kernel k_bspmv_stream --traffic --cells 2048 --algorithmic-bytes 973570116 --out $OUT/spmv_pmc_traffic.json $OUT/csr_FETCH_SIZE $OUT/csr_WRITE_SIZE > /dev/null || exit 1
