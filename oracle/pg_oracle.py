@@ -440,7 +440,11 @@ class ObstacleLagrange:
     """Same discrete problem as ObstacleP1 for Lagrange degree 1 or 2 (equal order for u and psi).
     Dofs per field: vertices [0,nv) then (degree 2) edges [nv, nv+ne). x = [u | psi]."""
 
-    def __init__(self, coords, cells, degree=1, phi=phi_set, f=0.0, quadrature="tri_deg6_12", g_bc=0.0):
+    def __init__(self, coords, cells, degree=1, phi=phi_set, f=0.0, quadrature="tri_deg6_12", g_bc=0.0, midside=None):
+        """midside (ne, 2), optional: coordinates of the geometry's mid-side node on every edge (edge numbering of build_edges) -
+        ORDER-2 GEOMETRY as the reference's own meshes have it (generate_mesh_gmsh.py:30-33 `Mesh.ElementOrder 2`,
+        lvpp/mesh_generation.py:88,158): the cell map is x(xi) = sum_a X_a N2_a(xi) with the six P2 shape functions, Jacobians
+        and physical gradients are evaluated per quadrature point (what DOLFINx / FFCx do for a P2 coordinate element)."""
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.degree = int(degree)
@@ -466,22 +470,42 @@ class ObstacleLagrange:
         self.isbc = np.zeros(self.n, dtype=bool)
         self.isbc[self.bc] = True
         x = self.coords[self.cells]
-        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
-        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
-        self.detJ = np.abs(det)
-        invJ = np.empty_like(J)
-        invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
-        invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
-        self.invJ = invJ
-        # physical gradients at quadrature points: (nc,nq,nd,2)
-        self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)
-        wdet = self.detJ[:, None] * self.wq[None]
+        if midside is None:
+            J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+            det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+            self.detJ = np.abs(det)
+            invJ = np.empty_like(J)
+            invJ[:, 0, 0], invJ[:, 0, 1] = J[:, 1, 1] / det, -J[:, 0, 1] / det
+            invJ[:, 1, 0], invJ[:, 1, 1] = -J[:, 1, 0] / det, J[:, 0, 0] / det
+            self.invJ = invJ
+            # physical gradients at quadrature points: (nc,nq,nd,2)
+            self.Gq = np.einsum("qak,ckd->cqad", self.dNq, invJ)
+            wdet = self.detJ[:, None] * self.wq[None]
+            Nlin = np.stack([1.0 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
+            xq = np.einsum("qa,cad->cqd", Nlin, x)
+        else:
+            # isoparametric map of degree 2: geometry nodes = the 3 vertices + the mid-side node of local edge i (opposite vertex i)
+            self.midside = np.ascontiguousarray(midside, dtype=np.float64)
+            X6 = np.concatenate([x, self.midside[self.cell_edges]], axis=1)  # (nc,6,2)
+            N2, dN2 = lagrange_tabulate(2, self.Xq[:, 0], self.Xq[:, 1])  # (nq,6), (nq,6,2)
+            J = np.einsum("cad,qak->cqdk", X6, dN2)  # J[c,q,d,k] = d x_d / d xi_k
+            det = J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]
+            if np.any(det <= 0) and np.any(det >= 0):
+                raise ValueError("order-2 geometry: the cell map is not orientation preserving at every quadrature point")
+            invJ = np.empty_like(J)  # invJ[c,q,k,d] = d xi_k / d x_d
+            invJ[..., 0, 0], invJ[..., 0, 1] = J[..., 1, 1] / det, -J[..., 0, 1] / det
+            invJ[..., 1, 0], invJ[..., 1, 1] = -J[..., 1, 0] / det, J[..., 0, 0] / det
+            self.invJq = invJ
+            self.Gq = np.einsum("qak,cqkd->cqad", self.dNq, invJ)
+            wdet = np.abs(det) * self.wq[None]
+            self.detJ = wdet.sum(axis=1) / self.wq.sum()  # (mean |det|: 2 x cell area; diagnostics only)
+            xq = np.einsum("qa,cad->cqd", N2, X6)
+            if self.degree == 2:
+                self.dof_coords = np.concatenate([self.coords, self.midside])
         self.wdet = wdet
         self.Ke = np.einsum("cq,cqad,cqbd->cab", wdet, self.Gq, self.Gq)
         self.Me = np.einsum("cq,qa,qb->cab", wdet, self.Nq, self.Nq)
         self.me = wdet @ self.Nq
-        Nlin = np.stack([1.0 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
-        xq = np.einsum("qa,cad->cqd", Nlin, x)
         self.phi_q = phi(xq.reshape(-1, 2).T.copy()).reshape(self.nc, -1)
         self.b_phi = np.bincount(self.cell_dofs.ravel(), weights=((wdet * self.phi_q) @ self.Nq).ravel(), minlength=self.n)
         self._build_pattern()

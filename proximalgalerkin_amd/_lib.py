@@ -199,6 +199,7 @@ _COMM = C.c_void_p
 SYMBOLS = [
     ("pgx_default_opts", None, [C.POINTER(pgx_snes_opts)]),
     ("pgx_create", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), C.c_int, C.POINTER(_H)]),
+    ("pgx_create_curved", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_problem), c_double_p, C.c_int, C.POINTER(_H)]),
     ("pgx_destroy", None, [_H]),
     ("pgx_last_error", C.c_char_p, [_H]),
     ("pgx_num_dofs", C.c_int, [_H, C.POINTER(C.c_int64)]),

@@ -68,6 +68,7 @@ struct pgx_handle {
   size_t fill_lds = 0;
   double *Kv = nullptr, *Mv = nullptr, *Dv = nullptr;
   bool jac_valid = false;
+  double* geoq = nullptr;  // order-2 geometry (pgx_create_curved): [cell][quadrature point][5] = |det J|, J^-1; nullptr = affine cells
   float2* zf_out = nullptr;  // FGMRES: the level-0 single-precision cycle leaves its result HERE as float2 (no fp64 copy); see fgmres
   int z_f32 = 1;             // PGX_Z_F32=0: the Z_j of the Krylov method in fp64 (A/B)
   bool dv_lean = false;  // the interior rows of the CSR D values are stale (residual_dev(with_d = 2)); a full fill clears it
@@ -1176,6 +1177,9 @@ static int build_multigrid_dist(pgx_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// pgx_create_curved hands its geometry table to create_impl through this slot (same thread, cleared on return)
+static thread_local const double* g_create_geoq = nullptr;
+
 static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, const pgx_partition* part, pgx_comm* comm,
                        pgx_handle** out) {
   if (!m || !p || !out) {
@@ -1386,6 +1390,15 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     DALLOC(h->gbc, nd);
     DALLOC(h->bphi, nd);
     HIPCHK(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    if (g_create_geoq) {  // isoparametric cells of order 2: weights and inverse Jacobians per quadrature point (pgx_p2.hip)
+      if (p->degree != 2 || h->structured || part) {
+        h->err = "pgx_create_curved: order-2 geometry is implemented for degree-2 fields on unstructured meshes (isoparametric P2); "
+                 "a degree-1 run flattens the cells to their vertices";
+        return PGX_EINVAL;
+      }
+      DALLOC(h->geoq, (size_t)5 * nc * p->nq);
+      HIPCHK(hipMemcpy(h->geoq, g_create_geoq, sizeof(double) * 5 * (size_t)nc * p->nq, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(h->cells, m->cells, sizeof(int32_t) * 3 * (size_t)nc, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->mask, hmask.data(), nd, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nd, hipMemcpyHostToDevice));
@@ -1409,7 +1422,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     if (e == hipSuccess) e = hipMalloc((void**)&stash, sizeof(double) * 8 * (size_t)nc);
     if (e == hipSuccess) {
       if (p->degree == 2)
-        pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->p2_v2c_ptr, h->p2_v2c_ent, stash, h->bphi);
+        pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->p2_v2c_ptr, h->p2_v2c_ent, stash, h->bphi, h->geoq);
       else
         pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->v2c_ptr, h->v2c_ent, stash, h->bphi);
       e = hipStreamSynchronize(h->st);
@@ -1432,9 +1445,9 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       DALLOC(h->s_M, h->s_nnz);
       DALLOC(h->s_D, h->s_nnz);
       pgxk_fill_rows_p2(h->st, 0, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
-                        h->coords, nullptr, h->q2, h->s_K);
+                        h->coords, nullptr, h->q2, h->s_K, h->geoq);
       pgxk_fill_rows_p2(h->st, 1, nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos, h->cdofs,
-                        h->coords, nullptr, h->q2, h->s_M);
+                        h->coords, nullptr, h->q2, h->s_M, h->geoq);
       if (h->spmv_dict && h->spmv_bal && h->s_blk) {
         const int rc = build_km_dictionary(h);
         if (rc) return rc;
@@ -1516,6 +1529,16 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
 
 extern "C" int pgx_create(const pgx_mesh* m, const pgx_problem* p, int device, pgx_handle** out) {
   return create_impl(m, p, device, nullptr, nullptr, out);
+}
+extern "C" int pgx_create_curved(const pgx_mesh* m, const pgx_problem* p, const double* geoq, int device, pgx_handle** out) {
+  if (!geoq) {
+    g_create_error = "pgx_create_curved: null geometry table";
+    return PGX_EINVAL;
+  }
+  g_create_geoq = geoq;
+  const int rc = create_impl(m, p, device, nullptr, nullptr, out);
+  g_create_geoq = nullptr;
+  return rc;
 }
 extern "C" int pgx_create_lu_dist(const pgx_mesh* m, const pgx_problem* p, pgx_comm* comm, int device, pgx_handle** out) {
   if (!comm) {
@@ -1734,7 +1757,7 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
   PhaseTimer t(h, 0);
   if (h->degree == 2) {
     pgxk_residual_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->mask, h->gbc, x, h->xk, h->alpha, h->f, h->q2,
-                           h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_stash, F);
+                           h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_stash, F, h->geoq);
     pgxk_residual_final(h->st, h->nd, h->mask, h->gbc, h->bphi, x, F);
     return;
   }
@@ -1760,10 +1783,10 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
     PhaseTimer t(h, 1);
     if (h->degree == 2) {
       pgxk_fill_rows_p2(h->st, 2, h->nd, h->s_fill_lds, h->s_rowptr, h->p2_v2c_ptr, h->p2_v2c_ent, h->p2_v2c_pos,
-                        h->cdofs, h->coords, x + h->nd, h->q2, h->s_D);
+                        h->cdofs, h->coords, x + h->nd, h->q2, h->s_D, h->geoq);
       // Galerkin coarse block T^T D_P2 T == D in the P1 basis with the P2 psi (same quadrature), for the P1 hierarchy
       pgxk_fill_rows_p1_Dp2(h->st, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cdofs, h->coords,
-                            x + h->nd, h->q2, h->Dv);
+                            x + h->nd, h->q2, h->Dv, h->geoq);
     } else if (h->resid_grid && h->structured && !h->lev.empty() && h->lev[0].uniform) {
       // uniform structured mesh: D(psi) comes from the same element kernel the Newton driver uses (its residual output goes to
       // scratch), so pgx_jacobian_fill + pgx_csr_export put THAT kernel under the entry-wise oracle comparison of the parity tests
@@ -3118,7 +3141,7 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
     PhaseTimer t(h, 6);
     if (h->degree == 2 && !h->dist.on) {
       pgxk_observables_p2_cells(h->st, h->nc, h->nd, h->cdofs, h->coords, h->x, h->xk, h->alpha, h->f, h->q2,
-                                h->obs_partials, h->obs_blocks);
+                                h->obs_partials, h->obs_blocks, h->geoq);
       pgxk_observables_final(h->st, h->obs_blocks, h->obs_partials, h->d_out6);
     } else if (h->dist.on && h->degree == 2) {
       const Dist& D = h->dist;  // P2 on a strip: the owned cells' partial sums, one packed all-reduce (raw sums, as below)

@@ -190,25 +190,27 @@ struct QuadTab2 {
 // stash: [8 * nc] (bphi) / [16 * nc] (residual: u part then psi part) scratch, entries parked at cell * 8 + a and summed per
 // dof through the dof -> (cell, local dof) lists of the P2 plan: no atomics, bitwise reproducible
 void pgxk_bphi_p2(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords, const double* phi_q,
-                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi);
+                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi,
+                  const double* geo = nullptr /* [cell][point][5]: order-2 geometry, pgx_p2.hip */);
 void pgxk_residual_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                             const uint8_t* mask, const double* gbc, const double* x, const double* xk, double alpha,
-                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F);
+                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F,
+                            const double* geo = nullptr);
 void pgxk_residual_final(hipStream_t st, int n, const uint8_t* mask, const double* gbc, const double* bphi,
                          const double* x, double* F);
 void pgxk_fill_rows_p2(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr,
                        const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs,
-                       const double* coords, const double* psi, QuadTab2 q, double* out);
+                       const double* coords, const double* psi, QuadTab2 q, double* out, const double* geo = nullptr);
 void pgxk_fill_rows_p1_Dp2(hipStream_t st, int nv, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                            const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs, const double* coords,
-                           const double* psi, QuadTab2 q, double* out);
+                           const double* psi, QuadTab2 q, double* out, const double* geo = nullptr);
 void pgxk_p2_restrict(hipStream_t st, int nv, int n2, const int32_t* v2e_ptr, const int32_t* v2e, const uint8_t* mask1,
                       const double* ru2, const double* rp2, double* bu1, double* bp1);
 void pgxk_p2_prolong_add(hipStream_t st, int nv, int n2, const int32_t* edge_ends, const double* cu, const double* cp,
                          double* xu, double* xp);
 void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                                const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
-                               int nblocks);
+                               int nblocks, const double* geo = nullptr);
 void pgxk_observables_final(hipStream_t st, int nblocks, const double* partials, double* out6);
 void pgxk_observables_final_raw(hipStream_t st, int nblocks, const double* partials, double* out6);  // plain sums (sharded)
 // vertex-star patch smoother of the P2 level (pgx_patch.hip)

@@ -1,5 +1,8 @@
 // P2 (quadratic Lagrange) element kernels for gfx950: obstacle_pg.py `-p 2` (obstacle_pg.py:68-70,288).
-// Geometry stays affine (P1); dofs per field are [vertices | edge midpoints], local edge i opposite local
+// Geometry: affine (from the cell's three vertices) or, since round 5, ISOPARAMETRIC of order 2 - every kernel takes an optional
+// `geo` table [cell][quadrature point][5] = |det J|, J^-1 row-major of the quadratic cell map at that point (host:
+// fem.Mesh.geometry_at; the reference's own meshes are gmsh meshes of element order 2, generate_mesh_gmsh.py:30-33) and then
+// evaluates weights and physical gradients per point.  Dofs per field are [vertices | edge midpoints], local edge i opposite local
 // vertex i.  Same structure as the P1 kernels of pgx_kernels.hip:
 //   k_residual_p2        cell-parallel element residual, fp64 HW atomics
 //   k_fill_rows_p2<MODE> row-parallel owner-computes fill of the P2 K / M / D(psi) CSR blocks (LDS-staged)
@@ -29,10 +32,21 @@ __device__ __forceinline__ Geom2 geom2(const double* __restrict__ coords, int v0
   return g;
 }
 
+__device__ __forceinline__ Geom2 geom2q(const double* __restrict__ geo, size_t cq) {
+  const double* p = geo + 5 * cq;
+  Geom2 g;
+  g.adet = p[0];
+  g.iJ[0][0] = p[1];
+  g.iJ[0][1] = p[2];
+  g.iJ[1][0] = p[3];
+  g.iJ[1][1] = p[4];
+  return g;
+}
+
 __global__ void __launch_bounds__(PGX_BLOCK) k_bphi_p2(int nc, const int32_t* __restrict__ cdofs,
                                                        const double* __restrict__ coords,
                                                        const double* __restrict__ phi_q, QuadTab2 q,
-                                                       double* __restrict__ stash) {
+                                                       double* __restrict__ stash, const double* __restrict__ geo) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   int d[6];
@@ -41,17 +55,19 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_bphi_p2(int nc, const int32_t* __
   const Geom2 g = geom2(coords, d[0], d[1], d[2]);
   double b[6] = {0, 0, 0, 0, 0, 0};
   for (int k = 0; k < q.nq; ++k) {
-    const double wp = q.w[k] * phi_q[(size_t)c * q.nq + k];
+    // (affine: the weight 1.0 here and |det J| once below - bit for bit the arithmetic of rounds 1-4)
+    const double wp = (geo ? geo[5 * ((size_t)c * q.nq + k)] : 1.0) * (q.w[k] * phi_q[(size_t)c * q.nq + k]);
 #pragma unroll
     for (int a = 0; a < 6; ++a) b[a] += wp * q.N[k][a];
   }
+  const double sc = geo ? 1.0 : g.adet;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) stash[8 * (size_t)c + a] = g.adet * b[a];  // index = the dof lists' (cell * 8 + a)
+  for (int a = 0; a < 6; ++a) stash[8 * (size_t)c + a] = sc * b[a];  // index = the dof lists' (cell * 8 + a)
 }
 void pgxk_bphi_p2(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords, const double* phi_q,
-                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi) {
+                  QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi, const double* geo) {
   hipLaunchKernelGGL(k_bphi_p2, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cdofs, coords,
-                     phi_q, q, stash);
+                     phi_q, q, stash, geo);
   pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, bphi);
 }
 
@@ -62,7 +78,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_p2(int nc, int n, const 
                                                            const double* __restrict__ gbc,
                                                            const double* __restrict__ x,
                                                            const double* __restrict__ xk, double alpha, double f,
-                                                           QuadTab2 q, double* __restrict__ stash) {
+                                                           QuadTab2 q, double* __restrict__ stash,
+                                                           const double* __restrict__ geo) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   int d[6];
@@ -76,8 +93,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_p2(int nc, int n, const 
     Fu[a] = 0.0;
     Fp[a] = 0.0;
   }
-  const Geom2 g = geom2(coords, d[0], d[1], d[2]);
+  const Geom2 g0 = geom2(coords, d[0], d[1], d[2]);
   for (int k = 0; k < q.nq; ++k) {
+    const Geom2 g = geo ? geom2q(geo, (size_t)c * q.nq + k) : g0;
     double uq = 0, pq = 0, dq = 0, gx = 0, gy = 0;
     double G[6][2];
 #pragma unroll
@@ -109,9 +127,10 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_residual_p2(int nc, int n, const 
 }
 void pgxk_residual_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                             const uint8_t* mask, const double* gbc, const double* x, const double* xk, double alpha,
-                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F) {
+                            double f, QuadTab2 q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* F,
+                            const double* geo) {
   hipLaunchKernelGGL(k_residual_p2, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, n, cdofs,
-                     coords, mask, gbc, x, xk, alpha, f, q, stash);
+                     coords, mask, gbc, x, xk, alpha, f, q, stash, geo);
   pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, F);
   pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash + 8 * (size_t)nc, F + n);
 }
@@ -126,7 +145,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p2(int n, const int32_t
                                                             const int32_t* __restrict__ cdofs,
                                                             const double* __restrict__ coords,
                                                             const double* __restrict__ psi, QuadTab2 q,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, const double* __restrict__ geo) {
   extern __shared__ double acc[];
   const int i0 = blockIdx.x * PGX_BLOCK;
   const int i = i0 + threadIdx.x;
@@ -144,7 +163,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p2(int n, const int32_t
       int d[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) d[b] = cdofs[6 * c + b];
-      const Geom2 g = geom2(coords, d[0], d[1], d[2]);
+      const Geom2 g0 = geom2(coords, d[0], d[1], d[2]);
       double ps[6];
       if (MODE == 2) {
 #pragma unroll
@@ -152,6 +171,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p2(int n, const int32_t
       }
       double r[6] = {0, 0, 0, 0, 0, 0};
       for (int k2 = 0; k2 < q.nq; ++k2) {
+        const Geom2 g = geo ? geom2q(geo, (size_t)c * q.nq + k2) : g0;
         const double wd = g.adet * q.w[k2];
         if (MODE == 0) {
           const double Ga0 = q.dN[k2][a][0] * g.iJ[0][0] + q.dN[k2][a][1] * g.iJ[1][0];
@@ -187,17 +207,17 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p2(int n, const int32_t
 }
 void pgxk_fill_rows_p2(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr,
                        const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs,
-                       const double* coords, const double* psi, QuadTab2 q, double* out) {
+                       const double* coords, const double* psi, QuadTab2 q, double* out, const double* geo) {
   dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
   if (mode == 0)
     hipLaunchKernelGGL(k_fill_rows_p2<0>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cdofs,
-                       coords, psi, q, out);
+                       coords, psi, q, out, geo);
   else if (mode == 1)
     hipLaunchKernelGGL(k_fill_rows_p2<1>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cdofs,
-                       coords, psi, q, out);
+                       coords, psi, q, out, geo);
   else
     hipLaunchKernelGGL(k_fill_rows_p2<2>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cdofs,
-                       coords, psi, q, out);
+                       coords, psi, q, out, geo);
 }
 
 // D in the P1 basis with psi a P2 function: rows of the P1 plan (vertex -> incident cells)
@@ -208,7 +228,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p1_Dp2(int nv, const in
                                                                 const int32_t* __restrict__ cdofs,
                                                                 const double* __restrict__ coords,
                                                                 const double* __restrict__ psi, QuadTab2 q,
-                                                                double* __restrict__ out) {
+                                                                double* __restrict__ out, const double* __restrict__ geo) {
   extern __shared__ double acc[];
   const int i0 = blockIdx.x * PGX_BLOCK;
   const int i = i0 + threadIdx.x;
@@ -236,7 +256,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p1_Dp2(int nv, const in
         double pq = 0.0;
 #pragma unroll
         for (int b = 0; b < 6; ++b) pq += ps[b] * q.N[k2][b];
-        const double wa = g.adet * q.w[k2] * exp(pq) * q.L[k2][a];
+        const double wa = (geo ? geo[5 * ((size_t)c * q.nq + k2)] : g.adet) * q.w[k2] * exp(pq) * q.L[k2][a];
         r[0] += wa * q.L[k2][0];
         r[1] += wa * q.L[k2][1];
         r[2] += wa * q.L[k2][2];
@@ -251,9 +271,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_p1_Dp2(int nv, const in
 }
 void pgxk_fill_rows_p1_Dp2(hipStream_t st, int nv, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                            const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cdofs, const double* coords,
-                           const double* psi, QuadTab2 q, double* out) {
+                           const double* psi, QuadTab2 q, double* out, const double* geo) {
   hipLaunchKernelGGL(k_fill_rows_p1_Dp2, dim3((nv + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), lds_bytes, st, nv,
-                     rowptr, v2c_ptr, v2c_ent, v2c_pos, cdofs, coords, psi, q, out);
+                     rowptr, v2c_ptr, v2c_ent, v2c_pos, cdofs, coords, psi, q, out, geo);
 }
 
 // r1 = T^T r2 (P1 hat = P2 vertex function + 1/2 of the adjacent edge functions); u rows of Dirichlet
@@ -310,7 +330,8 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_p2(int nc, int n, con
                                                               const double* __restrict__ coords,
                                                               const double* __restrict__ x,
                                                               const double* __restrict__ xk, double alpha, double f,
-                                                              QuadTab2 q, double* __restrict__ partials) {
+                                                              QuadTab2 q, double* __restrict__ partials,
+                                                              const double* __restrict__ geo) {
   __shared__ double sm[6][PGX_BLOCK / WAVE];
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
@@ -324,8 +345,9 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_p2(int nc, int n, con
       uk[a] = xk[d[a]];
       pk[a] = xk[n + d[a]];
     }
-    const Geom2 g = geom2(coords, d[0], d[1], d[2]);
+    const Geom2 g0 = geom2(coords, d[0], d[1], d[2]);
     for (int k = 0; k < q.nq; ++k) {
+      const Geom2 g = geo ? geom2q(geo, (size_t)c * q.nq + k) : g0;
       double uq = 0, pq = 0, ukq = 0, pkq = 0, gx = 0, gy = 0, hx = 0, hy = 0;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -366,7 +388,7 @@ __global__ void __launch_bounds__(PGX_BLOCK) k_observables_p2(int nc, int n, con
 }
 void pgxk_observables_p2_cells(hipStream_t st, int nc, int n, const int32_t* cdofs, const double* coords,
                                const double* x, const double* xk, double alpha, double f, QuadTab2 q, double* partials,
-                               int nblocks) {
+                               int nblocks, const double* geo) {
   hipLaunchKernelGGL(k_observables_p2, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cdofs, coords, x, xk, alpha, f, q,
-                     partials);
+                     partials, geo);
 }

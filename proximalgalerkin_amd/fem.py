@@ -52,13 +52,64 @@ class Mesh:
     """Simplicial mesh. `structured=(nx, ny)` marks the right-diagonal triangulation with vertex
     v=j*(nx+1)+i (enables the geometric-multigrid preconditioner)."""
 
-    def __init__(self, coords, cells, structured=None, partition=None):
+    def __init__(self, coords, cells, structured=None, partition=None, midside=None):
         self.geometry = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         if self.geometry.ndim != 2 or self.geometry.shape[1] != 2 or self.cells.ndim != 2 or self.cells.shape[1] != 3:
             raise ValueError("expected coords (nv,2) and triangle cells (nc,3)")
         self.structured = tuple(int(s) for s in structured) if structured else None
         self.partition = partition  # StripPartition: this Mesh is one rank's strip (owned + ghost vertex rows)
+        # ORDER-2 GEOMETRY (round 5): `midside[e]` = the geometry's mid-side node on edge e (numbering of edges()), as a gmsh mesh of
+        # element order 2 carries it (the reference's own meshes: generate_mesh_gmsh.py:30-33, lvpp/mesh_generation.py:88,158).  The
+        # cell map is then x(xi) = sum_a X_a N2_a(xi) over the 3 vertices + 3 mid-side nodes (local edge i opposite local vertex i).
+        # Where every mid-side node IS its edge's midpoint the map is affine: the attribute is dropped and the affine kernels run.
+        self.midside = None
+        if midside is not None:
+            midside = np.ascontiguousarray(midside, dtype=np.float64)
+            e = self.edges()[0]
+            if midside.shape != (len(e), 2):
+                raise ValueError(f"midside must be (n_edges, 2) = {(len(e), 2)}")
+            straight = 0.5 * (self.geometry[e[:, 0]] + self.geometry[e[:, 1]])
+            length = np.linalg.norm(self.geometry[e[:, 0]] - self.geometry[e[:, 1]], axis=1)
+            if np.any(np.linalg.norm(midside - straight, axis=1) > 1e-13 * length):
+                self.midside = midside
+
+    @property
+    def curved(self):
+        return self.midside is not None
+
+    def flattened(self):
+        """The same mesh with affine cells (mid-side nodes dropped): what a degree-1 run uses (include/pgx.h: pgx_create_curved)."""
+        return Mesh(self.geometry, self.cells, structured=self.structured, partition=self.partition) if self.curved else self
+
+    def geometry_at(self, points):
+        """Cell map at reference points (nq, 2): physical points xq (nc, nq, 2) and the per-point geometry the curved kernels read,
+        geo (nc, nq, 5) = |det J|, then J^-1 row-major (iJ[k][d] = d xi_k / d x_d: physical gradient G_a[d] = sum_k dN_a[k] iJ[k][d]).
+        Affine meshes: the same quantities, constant over a cell."""
+        X, Y = np.asarray(points)[:, 0], np.asarray(points)[:, 1]
+        x = self.geometry[self.cells]
+        if not self.curved:
+            N = np.stack([1.0 - X - Y, X, Y], axis=1)
+            xq = np.einsum("qa,cad->cqd", N, x)
+            J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)[:, None].repeat(len(X), axis=1)
+        else:
+            L0, L1, L2 = 1.0 - X - Y, X, Y
+            N = np.stack([L0 * (2 * L0 - 1), L1 * (2 * L1 - 1), L2 * (2 * L2 - 1), 4 * L1 * L2, 4 * L0 * L2, 4 * L0 * L1], axis=1)
+            z = np.zeros_like(X)
+            dN = np.stack([np.stack([-(4 * L0 - 1), -(4 * L0 - 1)], axis=1), np.stack([4 * L1 - 1, z], axis=1),
+                           np.stack([z, 4 * L2 - 1], axis=1), np.stack([4 * L2, 4 * L1], axis=1),
+                           np.stack([-4 * L2, 4 * (L0 - L2)], axis=1), np.stack([4 * (L0 - L1), -4 * L1], axis=1)], axis=1)  # (nq,6,2)
+            X6 = np.concatenate([x, self.midside[self.edges()[1]]], axis=1)
+            xq = np.einsum("qa,cad->cqd", N, X6)
+            J = np.einsum("cad,qak->cqdk", X6, dN)
+        det = J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]
+        if np.any(det <= 0) and np.any(det >= 0):
+            raise ValueError("the cell map is not orientation preserving at every quadrature point (tangled order-2 geometry?)")
+        geo = np.empty(det.shape + (5,))
+        geo[..., 0] = np.abs(det)
+        geo[..., 1], geo[..., 2] = J[..., 1, 1] / det, -J[..., 0, 1] / det
+        geo[..., 3], geo[..., 4] = -J[..., 1, 0] / det, J[..., 0, 0] / det
+        return xq, np.ascontiguousarray(geo)
 
     @property
     def num_vertices(self):
@@ -328,6 +379,8 @@ class FunctionSpace:
         x = self.mesh.geometry
         if self.degree == 1:
             return x
+        if getattr(self.mesh, "curved", False):  # isoparametric: an edge dof sits on the geometry's mid-side node
+            return np.concatenate([x, self.mesh.midside])
         e = self.mesh.edges()[0]
         return np.concatenate([x, 0.5 * (x[e[:, 0]] + x[e[:, 1]])])
 
@@ -618,6 +671,8 @@ class QuadratureFunction(_FormOperand):
         self.values = np.zeros((mesh.num_cells, len(self.weights)))
 
     def physical_points(self):
+        if getattr(self.mesh, "curved", False):
+            return self.mesh.geometry_at(self.points)[0]
         X, Y = self.points[:, 0], self.points[:, 1]
         N = np.stack([1.0 - X - Y, X, Y], axis=1)
         x = self.mesh.geometry[self.mesh.cells]  # (nc,3,2)
@@ -626,6 +681,10 @@ class QuadratureFunction(_FormOperand):
     def interpolate(self, fn, chunk=1 << 20):
         """fn takes x of shape (2, npts) like a dolfinx interpolation callable."""
         nc, nq = self.values.shape
+        if getattr(self.mesh, "curved", False):  # order-2 geometry: the quadrature points sit on the curved cells
+            xq = self.physical_points().reshape(-1, 2).T
+            self.values[:] = np.asarray(fn(np.ascontiguousarray(xq))).reshape(-1, nq)
+            return
         X, Y = self.points[:, 0], self.points[:, 1]
         N = np.stack([1.0 - X - Y, X, Y], axis=1)
         for s in range(0, nc, chunk):

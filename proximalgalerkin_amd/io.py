@@ -171,20 +171,35 @@ def _triangles(pts, cells):
     """vertex triangles of a 2-D mesh given as linear or quadratic (order-2 geometry) triangles, counter-clockwise, compact"""
     from . import fem
 
-    tri = (cells["triangle"] if "triangle" in cells else cells["triangle6"][:, :3]).copy()
+    six = None if "triangle" in cells else np.asarray(cells["triangle6"]).copy()
+    tri = (cells["triangle"] if six is None else six[:, :3]).copy()
     p = np.asarray(pts)[:, :2]
     a, b, c = p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]]
     neg = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) < 0
     tri[neg] = tri[neg][:, [0, 2, 1]]
-    used = np.unique(tri)  # drops the edge-midpoint nodes of an order-2 geometry
+    used = np.unique(tri)  # the vertices; the mid-side nodes of an order-2 geometry become the mesh's `midside` attribute
     remap = np.full(len(p), -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
-    return fem.Mesh(np.ascontiguousarray(p[used]), np.ascontiguousarray(remap[tri], dtype=np.int32))
+    vt = np.ascontiguousarray(remap[tri], dtype=np.int32)
+    if six is None:
+        return fem.Mesh(np.ascontiguousarray(p[used]), vt)
+    # order-2 geometry (round 5): gmsh / VTK / XDMF `triangle6` = v0 v1 v2 m01 m12 m20.  After the orientation swap v1 <-> v2 the
+    # mid-side nodes of the new edges (0,1), (1,2), (2,0) are the old m20, m12, m01.  One node per edge -> the mesh's edge numbering.
+    mids = six[:, 3:6].copy()
+    mids[neg] = mids[neg][:, [2, 1, 0]]
+    mesh = fem.Mesh(np.ascontiguousarray(p[used]), vt)
+    edges, cell_edges = mesh.edges()  # local edge i is OPPOSITE local vertex i: (1,2), (0,2), (0,1)  <-  m12, m20, m01
+    midside = np.empty((len(edges), 2))
+    midside[cell_edges[:, 0]] = p[mids[:, 1]]
+    midside[cell_edges[:, 1]] = p[mids[:, 2]]
+    midside[cell_edges[:, 2]] = p[mids[:, 0]]
+    return fem.Mesh(mesh.geometry, mesh.cells, midside=midside)
 
 
 def mesh_from_msh(path):
-    """A 2-D `fem.Mesh` from the triangles of a gmsh file (z dropped, counter-clockwise orientation enforced, order-2 geometry
-    reduced to its vertices): what obstacle_pg.py:64-65 obtains from `xdmf.read_mesh`."""
+    """A 2-D `fem.Mesh` from the triangles of a gmsh file (z dropped, counter-clockwise orientation enforced; the mid-side nodes of
+    an order-2 geometry are KEPT as `mesh.midside` since round 5 - isoparametric P2 cells for `-p 2`): what
+    obstacle_pg.py:64-65 obtains from `xdmf.read_mesh`."""
     pts, cells, _ = read_msh(path)
     return _triangles(pts, cells)
 

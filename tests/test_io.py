@@ -4,7 +4,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 import pytest
 
-from proximalgalerkin_amd import io
+from proximalgalerkin_amd import fem, io
 
 MSH22 = """$MeshFormat
 2.2 0 8
@@ -206,3 +206,23 @@ def test_generate_disk_writes_the_reference_named_xdmf_files(tmp_path):
         assert np.array_equal(m.cells, ref.cells) and np.abs(m.geometry - ref.geometry).max() == 0.0
         sizes.append(m.num_cells)
     assert 3.0 < sizes[1] / sizes[0] < 5.0  # h halves: about four times the cells
+
+
+def test_order2_triangles_keep_their_mid_side_nodes():
+    """io.read_mesh on a gmsh mesh of element order 2 (round 5): the vertices form the fem.Mesh as before, the mid-side nodes are kept
+    per edge (`mesh.midside`, edge numbering of mesh.edges()) - on the unit circle for the boundary edges of the committed disk, at
+    the edge midpoints inside - and `mesh.flattened()` is the affine mesh a degree-1 run uses."""
+    m = io.read_mesh(GOLD / "disk_h0.2_order2.msh")
+    assert m.curved and m.midside.shape == (len(m.edges()[0]), 2)
+    e, ce = m.edges()
+    straight = 0.5 * (m.geometry[e[:, 0]] + m.geometry[e[:, 1]])
+    boundary = np.bincount(ce.ravel(), minlength=len(e)) == 1
+    assert np.allclose(np.linalg.norm(m.midside[boundary], axis=1), 1.0, atol=1e-12)
+    assert np.abs(m.midside[~boundary] - straight[~boundary]).max() < 1e-14
+    assert np.linalg.norm(m.midside[boundary] - straight[boundary], axis=1).min() > 1e-3
+    xq, geo = m.geometry_at(fem.quadrature_rule("triangle", 6)[0])
+    w = fem.quadrature_rule("triangle", 6)[1]
+    assert abs((geo[..., 0] * w).sum() - np.pi) < 2e-5  # the curved cells tile the disk (the polygon misses 2e-2)
+    flat = m.flattened()
+    assert not flat.curved and np.array_equal(flat.cells, m.cells) and np.array_equal(flat.geometry, m.geometry)
+    assert not io.read_mesh(GOLD / "disk_h0.2.xdmf").curved

@@ -77,3 +77,47 @@ def test_p2_golden_fixture():
     x, h = O.solve_problem(p, 100, "double_exponential", 1e2, 1e-4)
     assert h["Newton steps"] == g["hist_Newton_steps"].tolist()
     assert np.linalg.norm(x[:p.n] - g["x_final"][:p.n]) <= 1e-11 * np.linalg.norm(g["x_final"][:p.n])
+
+
+def _curved_disk(h=0.3):
+    """the polygonal disk mesh of fem.create_disk with the mid-side nodes of its boundary edges on the unit circle (what gmsh writes
+    for Mesh.ElementOrder 2: generate_mesh_gmsh.py:30-33)"""
+    from proximalgalerkin_amd import fem
+
+    m = fem.create_disk(h)
+    e, ce = O.build_edges(m.cells, m.num_vertices)
+    mid = 0.5 * (m.geometry[e[:, 0]] + m.geometry[e[:, 1]])
+    straight = mid.copy()
+    b = np.flatnonzero(np.bincount(ce.ravel(), minlength=len(e)) == 1)
+    mid[b] /= np.linalg.norm(mid[b], axis=1)[:, None]
+    return m, straight, mid
+
+
+def test_order2_geometry_in_the_oracle():
+    """ObstacleLagrange(midside=...): the isoparametric cell map of degree 2 (round 5).  Straight mid-side nodes reproduce the affine
+    element matrices to rounding; curved ones integrate over the DISK (area -> pi at O(h^4) instead of the polygon's O(h^2)); the
+    Jacobian is still the derivative of the residual (finite differences), and constants are in the kernel of the stiffness matrix
+    on the interior (the gradient of the mapped basis functions sums to zero at every quadrature point)."""
+    m, straight, mid = _curved_disk(0.3)
+    affine = O.ObstacleLagrange(m.geometry, m.cells, 2)
+    same = O.ObstacleLagrange(m.geometry, m.cells, 2, midside=straight)
+    assert abs(affine.K - same.K).max() < 1e-13 and abs(affine.M - same.M).max() < 1e-15 and abs(affine.b_phi - same.b_phi).max() < 1e-15
+    errs = []
+    for h in (0.3, 0.15):
+        mh, _, midh = _curved_disk(h)
+        p = O.ObstacleLagrange(mh.geometry, mh.cells, 2, midside=midh)
+        errs.append((abs(p.wdet.sum() - np.pi), abs(O.ObstacleLagrange(mh.geometry, mh.cells, 2).wdet.sum() - np.pi)))
+        assert abs(p.M.sum() - p.wdet.sum()) < 1e-12  # the basis is a partition of unity on the curved cells too
+        assert np.abs(p.Gq.sum(axis=2)).max() < 1e-11  # ... and its gradients sum to zero
+    assert errs[0][0] < 2e-3 * errs[0][1] and errs[1][0] < errs[0][0] / 10  # 16x per halving for the curved cells, 4x for the polygon
+    p = O.ObstacleLagrange(m.geometry, m.cells, 2, midside=mid)
+    rng = np.random.default_rng(2)
+    x, xk = 0.1 * rng.standard_normal(2 * p.n), 0.1 * rng.standard_normal(2 * p.n)
+    J = p.jacobian(x, 2.0)
+    v = rng.standard_normal(2 * p.n)
+    v[p.bc] = 0.0
+    eps = 1e-6
+    fd = (p.residual(x + eps * v, xk, 2.0) - p.residual(x - eps * v, xk, 2.0)) / (2 * eps)
+    assert np.linalg.norm(J @ v - fd) < 1e-7 * np.linalg.norm(fd)
+    x_ref, h_ref = O.solve_problem(p, 100, "double_exponential", 1e2, 1e-4)
+    assert all(r > 0 for r in h_ref["Newton steps"]) and np.all(np.isfinite(x_ref))
