@@ -146,6 +146,7 @@ struct pgx_nd {
   int outer = 512;          // PGX_ND_OUTER: pivots per outer block = rank of the trailing updates (multiple of 64).  512 since round 5: with
                             // left-looking steps inside the block, ex 02 at 70^3 990 -> 965 ms, ex 06 at 1024^2 100.1 -> 99.5 ms against 256
                             // on the same box (768 / 1024: within 0.5 %); with round 2`s right-looking strips 512 had lost on ex 06
+  int tile_order = 1;       // PGX_ND_TILEORDER=0: plain blockIdx -> tile mapping in the GEMM kernels (A/B; pgx_nd_gemm.h nd_block_tile)
   bool leftlook = true;     // PGX_ND_LEFTLOOK=0: right-looking rank-64 strip updates inside an outer block (A/B)
   bool trsv_big = true;     // PGX_ND_TRSV_BIG=0: k_nd_trsv for the batches of few large fronts too (A/B)
   bool lshape = true;       // PGX_ND_LSHAPE=0: the trailing update of an outer block as three rectangles (A/B)
@@ -2132,6 +2133,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if (const char* e = pgx_tune("PGX_ND_LSHAPE")) s->lshape = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_TRSV_BIG")) s->trsv_big = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_LEFTLOOK")) s->leftlook = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_TILEORDER")) s->tile_order = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_OUTER")) s->outer = std::max(64, (atoi(e) / 64) * 64);
   if (s->trsv_big && hipFuncSetAttribute((const void*)k_nd_trsv_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_BIG_LDS) != hipSuccess) {
     (void)hipGetLastError();
@@ -2345,13 +2347,13 @@ static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, 
   const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
   NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
   if (big && cgather)
-    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
+    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
   else if (big)
-    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
+    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
   else if (cgather)
-    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
+    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
   else
-    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1);
+    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -2480,7 +2482,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
                 const int kn = ke + (W / nsteps + (st + 1 < W % nsteps ? 1 : 0));
                 const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(64, ke, M, kn), 1);
                 NdGatherCtx gc{};
-                hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, ke, M, ke, M, ob, ke, Lv.poff, P, gc, kn);
+                hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, ke, M, ke, M, ob, ke, Lv.poff, P, gc, kn, s->tile_order);
               }
             } else {
               nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
@@ -2496,9 +2498,9 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(TS, oe, M, P), 1);
           NdGatherCtx gc{};
           if (big)
-            hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P);
+            hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order);
           else
-            hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P);
+            hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order);
         } else {
           nd_launch_gemm(s, q, Lv, oe, P, oe, P, ob, oe);
           nd_launch_gemm(s, q, Lv, oe, P, P, M, ob, oe);

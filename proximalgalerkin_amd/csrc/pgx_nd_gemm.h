@@ -213,6 +213,35 @@ __device__ __forceinline__ void nd_gather_epilogue(const NdGatherCtx& gc, const 
     }
 }
 
+// Which tile a workgroup computes (round 5, `order` = 1; 0 = the plain blockIdx mapping of rounds 2-4).  The dispatcher hands
+// consecutive workgroups (x fastest, then y, z) to the eight XCDs in turn, each with a private 4 MB L2: with the plain mapping the
+// tiles of one front were `count` workgroups apart, never resident together, so every tile fetched its L and U panels from HBM / MALL
+// (4.2 MB per (128 + 512) front instead of the 1 MB the panels hold), and near the root one XCD walked down a tile COLUMN of one front,
+// re-reading all its L panels per column.  Now XCD c = n mod 8 owns a CONTIGUOUS run of (front, tile) pairs - the fronts one after the
+// other, the tiles of a front in groups of 8 tile rows walked column by column, so that the ~64 tiles resident on an XCD form an
+// 8 x 8 block sharing 8 L and 8 U panels.  The runs are balanced to the number of workgroups each XCD really receives, which makes
+// n -> (front, tile) a bijection.
+__device__ __forceinline__ bool nd_block_tile(int order, int nt, int& front, int& t) {
+  if (!order) {
+    front = (int)blockIdx.x;
+    t = -1;
+    return true;
+  }
+  const int64_t n = (int64_t)blockIdx.x + (int64_t)gridDim.x * ((int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+  const int64_t T = (int64_t)gridDim.x * nt, q = T >> 3, r = T & 7;
+  const int c = (int)(n & 7);
+  const int64_t m = c * q + (c < r ? c : r) + (n >> 3);
+  front = (int)(m / nt);
+  t = (int)(m - (int64_t)front * nt);
+  return true;
+}
+// tile t of an nr x nc rectangle of tiles in groups of 8 rows, column by column inside a group
+__device__ __forceinline__ void nd_grouped(int t, int nr, int nc, int& tr, int& tc) {
+  const int g = t / (8 * nc), gr = min(8, nr - 8 * g), w = t - g * 8 * nc;
+  tc = w / gr;
+  tr = 8 * g + (w - tc * gr);
+}
+
 // The trailing update of an outer block in ONE launch (round 5): C is the L-shaped region rows / columns [o, M) of the front without
 // its Schur block [Ps, M)^2 - region A = rows [o, Ps) x columns [o, M), region B = rows [Ps, M) x columns [o, Ps) - and blockIdx.y the
 // running tile number over A then B (three launches of 400-900 tiles each left the epilogues of one launch uncovered by the MFMAs of
@@ -221,13 +250,23 @@ __host__ __device__ inline int nd_lshape_tiles(int TS, int o, int M, int Ps) {
   const int nc = (M - o + TS - 1) / TS, nrA = (Ps - o + TS - 1) / TS, nrB = (M - Ps + TS - 1) / TS;
   return nrA * nc + nrB * nrA;
 }
-__device__ __forceinline__ void nd_lshape_tile(int TS, int t, int o, int M, int Ps, int& r0, int& c0, int& rmax, int& cmax) {
+__device__ __forceinline__ void nd_lshape_tile(int TS, int t, int o, int M, int Ps, int& r0, int& c0, int& rmax, int& cmax,
+                                               int order = 0) {
   const int nc = (M - o + TS - 1) / TS, nrA = (Ps - o + TS - 1) / TS;
+  int tr, tc;
   if (t < nrA * nc) {
-    r0 = o + TS * (t / nc), c0 = o + TS * (t % nc), rmax = Ps, cmax = M;
+    if (order)
+      nd_grouped(t, nrA, nc, tr, tc);
+    else
+      tr = t / nc, tc = t % nc;
+    r0 = o + TS * tr, c0 = o + TS * tc, rmax = Ps, cmax = M;
   } else {
     const int u = t - nrA * nc;
-    r0 = Ps + TS * (u / nrA), c0 = o + TS * (u % nrA), rmax = M, cmax = Ps;
+    if (order)
+      nd_grouped(u, (M - Ps + TS - 1) / TS, nrA, tr, tc);
+    else
+      tr = u / nrA, tc = u % nrA;
+    r0 = Ps + TS * tr, c0 = o + TS * tc, rmax = M, cmax = Ps;
   }
 }
 
@@ -237,21 +276,24 @@ __device__ __forceinline__ void nd_lshape_tile(int TS, int t, int o, int M, int 
 // into registers while the current one feeds the matrix cores.
 template <int WT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP) {
+                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
-  int r0, c0, rmax, cmax;
+  int r0, c0, rmax, cmax, front, t;
+  nd_block_tile(order, (int)(gridDim.y * gridDim.z), front, t);
   if (lsP < 0) {
-    r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z, rmax = r1g, cmax = c1g;
+    int tr = (int)blockIdx.y, tc = (int)blockIdx.z;
+    if (order) nd_grouped(t, (int)gridDim.y, (int)gridDim.z, tr, tc);
+    r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
   } else {
-    nd_lshape_tile(TS, (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax);
+    nd_lshape_tile(TS, order ? t : (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax, order);
   }
   if (r0 >= rmax || c0 >= cmax) return;
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
+  double* F = arena + lev_off + (int64_t)front * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
-  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels (compact store)
+  const double* S = arena + store_off + (int64_t)front * (MP + (int64_t)P * (M - P));  // A, B: solved panels (compact store)
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const int wi = (wv >> 1) * 16 * WT, wj = (wv & 1) * 16 * WT;
   nd_v4d acc[WT][WT];  // [tj][ti]
@@ -299,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
   }
   // D[m][n] = sum_k U[k][j=m] L[i=n][k]: lane l holds n = l&15 (row i of C), m = (l>>4) + 4*reg (column j of C)
   if (GATHER) {
-    nd_gather_epilogue<WT, WT>(gc, arena, gc.f0 + blockIdx.x, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
+    nd_gather_epilogue<WT, WT>(gc, arena, gc.f0 + front, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
     return;
   }
 #pragma unroll
@@ -320,21 +362,24 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
 // barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
 template <bool GATHER>
 __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP) {
+                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order) {
   constexpr int TS = 128, NT = 512;
   constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
-  int r0, c0, rmax, cmax;
+  int r0, c0, rmax, cmax, front, t;
+  nd_block_tile(order, (int)(gridDim.y * gridDim.z), front, t);
   if (lsP < 0) {
-    r0 = r0g + TS * (int)blockIdx.y, c0 = c0g + TS * (int)blockIdx.z, rmax = r1g, cmax = c1g;
+    int tr = (int)blockIdx.y, tc = (int)blockIdx.z;
+    if (order) nd_grouped(t, (int)gridDim.y, (int)gridDim.z, tr, tc);
+    r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
   } else {
-    nd_lshape_tile(TS, (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax);
+    nd_lshape_tile(TS, order ? t : (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax, order);
   }
   if (r0 >= rmax || c0 >= cmax) return;
-  double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;  // C: working matrix
+  double* F = arena + lev_off + (int64_t)front * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
-  const double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));  // A, B: solved panels
+  const double* S = arena + store_off + (int64_t)front * (MP + (int64_t)P * (M - P));  // A, B: solved panels
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const int wi = (wv >> 2) * 64, wj = (wv & 3) * 32;
   nd_v4d acc[2][4];  // [tj][ti]
@@ -380,7 +425,7 @@ __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena,
     }
   }
   if (GATHER) {
-    nd_gather_epilogue<2, 4>(gc, arena, gc.f0 + blockIdx.x, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
+    nd_gather_epilogue<2, 4>(gc, arena, gc.f0 + front, F, M, r0 + wi, c0 + wj, rmax, cmax, l, acc);
     return;
   }
 #pragma unroll
