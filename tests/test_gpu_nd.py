@@ -186,7 +186,7 @@ def test_assembly_variants_agree_on_an_unstructured_p2_matrix(require_gpu, monke
     assert np.linalg.norm(xs["1"] - xs["0"]) <= 1e-9 * np.linalg.norm(xs["0"])
 
 
-@pytest.mark.parametrize("switch", ["PGX_ND_SOLVE_SMALL", "PGX_ND_TRSV_BIG", "PGX_ND_LSHAPE", "PGX_ND_LEFTLOOK", "PGX_ND_OUTER"])
+@pytest.mark.parametrize("switch", ["PGX_ND_SOLVE_SMALL", "PGX_ND_TRSV_BIG", "PGX_ND_LSHAPE", "PGX_ND_LEFTLOOK", "PGX_ND_OUTER", "PGX_ND_TILEORDER"])
 def test_round5_schedules_agree_with_the_round4_ones(require_gpu, monkeypatch, switch):
     """Every piece of the numeric phase that round 5 rebuilt has its round-4 form behind a tuning key: the one-wave solve sweeps of the
     small fronts, the register-resident slab solve of the large ones, the L-shaped trailing update, the left-looking 64-pivot steps,
@@ -224,3 +224,4 @@ def test_round5_schedules_agree_with_the_round4_ones(require_gpu, monkeypatch, s
         ds.close()
     a, c = xs.values()
     assert np.linalg.norm(a - c) <= 1e-9 * np.linalg.norm(c)
+
