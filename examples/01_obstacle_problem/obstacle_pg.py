@@ -37,7 +37,7 @@ if __name__ == "__main__":
     if args.filename is not None:
         from proximalgalerkin_amd.io import read_mesh
 
-        msh = read_mesh(args.filename)  # .xdmf (inline data) or gmsh .msh; order-2 geometry reduced to vertices
+        msh = read_mesh(args.filename)  # .xdmf / gmsh .msh; order-2 triangles keep their mid-side nodes (curved cells)
     else:
         msh = (fem.create_disk(args.disk_h) if args.disk_h > 0.0 else
                fem.create_rectangle(((-1.0, -1.0), (1.0, 1.0)), (args.N, args.N)))

@@ -123,9 +123,11 @@ int pgx_create(const pgx_mesh* mesh, const pgx_problem* prob, int device, pgx_ha
  * examples/01_obstacle_problem/generate_mesh_gmsh.py:30-33, and DOLFINx then integrates on the curved cells).  geoq
  * [n_cells][nq][5] holds, for every quadrature point of prob->qpts on every cell, |det J| and the four entries of J^-1 (row-major:
  * d xi_k / d x_d) of the quadratic cell map x(xi) = sum_a X_a N2_a(xi) - what a binding reads off the coordinate element
- * (fem.Mesh.geometry_at here); prob->phi_q is phi at the PHYSICAL quadrature points of that map.  Implemented for degree-2 fields on
- * unstructured meshes (isoparametric P2: residual, Jacobian blocks, b_phi and observables evaluate weights and physical gradients
- * per quadrature point, csrc/pgx_p2.hip); degree 1 returns PGX_EINVAL - flatten the cells to their vertices for `-p 1`. */
+ * (fem.Mesh.geometry_at here); prob->phi_q is phi at the PHYSICAL quadrature points of that map.  Unstructured, unpartitioned
+ * meshes; degree 2 = isoparametric P2 (csrc/pgx_p2.hip), degree 1 = hat functions on the quadratic cells, the reference's default
+ * run on its own meshes (the k_*_c kernels of csrc/pgx_kernels.hip): residual, Jacobian blocks, b_phi and the observables evaluate
+ * weights and physical gradients per quadrature point, nothing is constant per cell.  A structured or partitioned mesh is
+ * PGX_EINVAL (those have affine cells by construction). */
 int pgx_create_curved(const pgx_mesh* mesh, const pgx_problem* prob, const double* geoq, int device, pgx_handle** out);
 void pgx_destroy(pgx_handle* h);
 const char* pgx_last_error(const pgx_handle* h); /* h may be NULL: error of the last failed pgx_create */

@@ -1391,9 +1391,9 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     DALLOC(h->bphi, nd);
     HIPCHK(hipMemcpy(h->coords, m->coords, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     if (g_create_geoq) {  // isoparametric cells of order 2: weights and inverse Jacobians per quadrature point (pgx_p2.hip)
-      if (p->degree != 2 || h->structured || part) {
-        h->err = "pgx_create_curved: order-2 geometry is implemented for degree-2 fields on unstructured meshes (isoparametric P2); "
-                 "a degree-1 run flattens the cells to their vertices";
+      if (h->structured || part) {
+        h->err = "pgx_create_curved: order-2 geometry is implemented for unstructured, unpartitioned meshes (degree-1 and degree-2 "
+                 "fields); structured grids have affine cells by construction";
         return PGX_EINVAL;
       }
       DALLOC(h->geoq, (size_t)5 * nc * p->nq);
@@ -1424,7 +1424,7 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
       if (p->degree == 2)
         pgxk_bphi_p2(h->st, nc, nd, h->cdofs, h->coords, phi_q, h->q2, h->p2_v2c_ptr, h->p2_v2c_ent, stash, h->bphi, h->geoq);
       else
-        pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->v2c_ptr, h->v2c_ent, stash, h->bphi);
+        pgxk_bphi(h->st, nc, n, h->cells, h->coords, phi_q, h->q, h->v2c_ptr, h->v2c_ent, stash, h->bphi, h->geoq);
       e = hipStreamSynchronize(h->st);
     }
     hipFree(phi_q);
@@ -1436,10 +1436,13 @@ static int create_impl(const pgx_mesh* m, const pgx_problem* p, int device, cons
     DALLOC(h->Kv, h->nnz);
     DALLOC(h->Mv, h->nnz);
     DALLOC(h->Dv, h->nnz);
+    // (order-2 geometry: per-point geometry for a degree-1 discretisation; the P1 level BELOW a degree-2 one is a preconditioner
+    // level and keeps the affine operators of the vertices)
+    const double* geo1 = p->degree == 1 ? h->geoq : nullptr;
     pgxk_fill_rows(h->st, 0, n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
-                   nullptr, h->q, h->Kv);
+                   nullptr, h->q, h->Kv, geo1);
     pgxk_fill_rows(h->st, 1, n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
-                   nullptr, h->q, h->Mv);
+                   nullptr, h->q, h->Mv, geo1);
     if (p->degree == 2) {
       DALLOC(h->s_K, h->s_nnz);
       DALLOC(h->s_M, h->s_nnz);
@@ -1774,7 +1777,7 @@ static void residual_dev(pgx_handle* h, const double* x, double* F, int with_d =
     return;
   }
   pgxk_resid_fill_p1(h->st, with_d, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells,
-                     h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv);
+                     h->coords, h->mask, h->gbc, h->bphi, x, h->xk, h->alpha, h->f, h->q, F, h->Dv, h->geoq);
 }
 
 // have_d: D(psi) at this x was already produced by residual_dev(..., with_d=1)
@@ -1797,7 +1800,7 @@ static int jacobian_dev(pgx_handle* h, const double* x, bool have_d = false) {
       have_d = true;
     } else {
       pgxk_fill_rows(h->st, 2, h->n, h->fill_lds, h->rowptr, h->v2c_ptr, h->v2c_ent, h->v2c_pos, h->cells, h->coords,
-                     x + h->n, h->q, h->Dv);
+                     x + h->n, h->q, h->Dv, h->geoq);
     }
   }
   if (h->structured) {
@@ -3160,7 +3163,7 @@ extern "C" int pgx_observables(pgx_handle* h, double out[6]) {
       if (rc) return rc;
     } else {
       pgxk_observables(h->st, h->nc, h->n, h->cells, h->coords, h->x, h->xk, h->alpha, h->f, h->q, h->obs_partials,
-                       h->obs_blocks, h->d_out6);
+                       h->obs_blocks, h->d_out6, 0, h->geoq);
     }
   }
   {

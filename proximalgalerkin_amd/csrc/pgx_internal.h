@@ -102,19 +102,20 @@ void pgxk_mg_tail_select(int v);  // 1 (default): k_mg_tail2; 0: the round-2 ker
 // ---- launch wrappers (pgx_kernels.hip). All asynchronous on `st`. -----------------------------
 // stash: [4 * nc] scratch (element contributions parked at cell * 4 + a, summed per vertex through the v2c lists: no atomics)
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
-               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi);
+               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi,
+               const double* geo = nullptr /* order-2 geometry: [cell][point][5], the curved twins k_*_c of pgx_kernels.hip */);
 void pgxk_gather_ent(hipStream_t st, int n, const int32_t* ptr, const int32_t* ent, const double* stash, double* out);
 // mode 0: K, 1: M, 2: D(psi)
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                     const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
-                    const double* psi, QuadTab q, double* out);
+                    const double* psi, QuadTab q, double* out, const double* geo = nullptr);
 // mode 0: y = J x ; 1: y = b - J x ; 2: y = x + omega*Binv*(b - J x) (collective Jacobi; first!=0: x taken as 0)
 void pgxk_bspmv(hipStream_t st, int mode, int n, const int32_t* rowptr, const int32_t* colm, const double* K,
                 const double* M, const double* D, double alpha, const double* xu, const double* xp, const double* bu,
                 const double* bp, double omega, int first, double* yu, double* yp);
 void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
                       const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks, double* out6,
-                      int raw = 0);
+                      int raw = 0, const double* geo = nullptr);
 int pgxk_observables_blocks(int nc);
 
 // vectors (length len)
@@ -245,7 +246,8 @@ void pgxk_p2_rows_csr(hipStream_t st, int nrows, const int32_t* rows, const int3
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                         const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
-                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout);
+                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout,
+                        const double* geo = nullptr);
 void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_t lds_bytes, const int32_t* rowptr,
                           const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                           const double* coords, const uint8_t* mask, const double* gbc, const double* bphi, const double* x,

@@ -81,6 +81,211 @@ __device__ __forceinline__ P1Geom p1_geom(double x0, double y0, double x1, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// ORDER-2 GEOMETRY, degree-1 fields (round 5): P1 hat functions on the reference triangle, mapped by the quadratic cell map of a
+// 6-node triangle - what the reference's default run computes on its own meshes (obstacle_pg.py -p 1 on the order-2 disk of
+// generate_mesh_gmsh.py:30-33).  `geo` = [cell][quadrature point][5]: |det J|, then J^-1 row-major (d xi_k / d x_d), tabulated by
+// the host (fem.Mesh.geometry_at) and shared with the P2 kernels (pgx_p2.hip).  Nothing is constant per cell any more: stiffness,
+// mass, load and the latent terms are all sums over the form's quadrature rule, as FFCx generates them for a non-affine cell.
+// Same row-parallel structure and summation order as the affine kernels above (no atomics, bitwise reproducible); these kernels
+// only run on file meshes - the structured fast path has affine cells by construction.
+// ------------------------------------------------------------------------------------------------
+struct P1GeomQ {
+  double wd;       // w_k |det J(x_k)|
+  double G[3][2];  // physical gradients of the three hat functions at x_k
+};
+__device__ __forceinline__ P1GeomQ p1_geom_q(const double* __restrict__ geo, size_t cq, double w) {
+  const double* p = geo + 5 * cq;
+  P1GeomQ g;
+  g.wd = w * p[0];
+  // reference gradients (-1,-1), (1,0), (0,1) times J^-1
+  g.G[1][0] = p[1];
+  g.G[1][1] = p[2];
+  g.G[2][0] = p[3];
+  g.G[2][1] = p[4];
+  g.G[0][0] = -(p[1] + p[3]);
+  g.G[0][1] = -(p[2] + p[4]);
+  return g;
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_bphi_c(int nc, const double* __restrict__ phi_q, QuadTab q,
+                                                      double* __restrict__ stash, const double* __restrict__ geo) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  double b0 = 0, b1 = 0, b2 = 0;
+  for (int k = 0; k < q.nq; ++k) {
+    const double wp = q.w[k] * geo[5 * ((size_t)c * q.nq + k)] * phi_q[(size_t)c * q.nq + k];
+    b0 += wp * q.N[k][0];
+    b1 += wp * q.N[k][1];
+    b2 += wp * q.N[k][2];
+  }
+  stash[4 * (size_t)c] = b0;
+  stash[4 * (size_t)c + 1] = b1;
+  stash[4 * (size_t)c + 2] = b2;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(PGX_BLOCK) k_fill_rows_c(int n, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ v2c_ptr,
+                                                           const int32_t* __restrict__ v2c_ent,
+                                                           const int32_t* __restrict__ v2c_pos,
+                                                           const int32_t* __restrict__ cells,
+                                                           const double* __restrict__ psi, QuadTab q,
+                                                           double* __restrict__ out, const double* __restrict__ geo) {
+  extern __shared__ double acc[];
+  const int i0 = blockIdx.x * PGX_BLOCK;
+  const int i = i0 + threadIdx.x;
+  const int iend = min(i0 + PGX_BLOCK, n);
+  const int base = rowptr[i0];
+  const int len = rowptr[iend] - base;
+  for (int k = threadIdx.x; k < len; k += PGX_BLOCK) acc[k] = 0.0;
+  __syncthreads();
+  if (i < n) {
+    double* row = acc + (rowptr[i] - base);
+    const int ke = v2c_ptr[i + 1];
+    for (int k = v2c_ptr[i]; k < ke; ++k) {
+      const int e = v2c_ent[k];
+      const int c = e >> 2, a = e & 3;
+      const int pos = v2c_pos[k];
+      double p0 = 0, p1 = 0, p2 = 0;
+      if (MODE == 2) p0 = psi[cells[3 * c]], p1 = psi[cells[3 * c + 1]], p2 = psi[cells[3 * c + 2]];
+      double d[3] = {0.0, 0.0, 0.0};
+      for (int k2 = 0; k2 < q.nq; ++k2) {
+        const P1GeomQ g = p1_geom_q(geo, (size_t)c * q.nq + k2, q.w[k2]);
+        if (MODE == 0) {
+#pragma unroll
+          for (int b = 0; b < 3; ++b) d[b] += g.wd * (g.G[a][0] * g.G[b][0] + g.G[a][1] * g.G[b][1]);
+        } else {
+          double wa = g.wd * q.N[k2][a];
+          if (MODE == 2) wa *= exp(p0 * q.N[k2][0] + p1 * q.N[k2][1] + p2 * q.N[k2][2]);
+          d[0] += wa * q.N[k2][0];
+          d[1] += wa * q.N[k2][1];
+          d[2] += wa * q.N[k2][2];
+        }
+      }
+      row[pos & 0xff] += d[0];
+      row[(pos >> 8) & 0xff] += d[1];
+      row[(pos >> 16) & 0xff] += d[2];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < len; k += PGX_BLOCK) out[base + k] = acc[k];
+}
+
+template <bool WRITE_D>
+__global__ void __launch_bounds__(PGX_BLOCK) k_resid_fill_p1_c(int n, const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ v2c_ptr,
+                                                               const int32_t* __restrict__ v2c_ent,
+                                                               const int32_t* __restrict__ v2c_pos,
+                                                               const int32_t* __restrict__ cells,
+                                                               const uint8_t* __restrict__ mask,
+                                                               const double* __restrict__ gbc,
+                                                               const double* __restrict__ bphi,
+                                                               const double* __restrict__ x,
+                                                               const double* __restrict__ xk, double alpha, double f,
+                                                               QuadTab q, double* __restrict__ F,
+                                                               double* __restrict__ Dout, const double* __restrict__ geo) {
+  extern __shared__ double acc[];
+  const int i0 = blockIdx.x * PGX_BLOCK;
+  const int i = i0 + threadIdx.x;
+  const int iend = min(i0 + PGX_BLOCK, n);
+  const int base = rowptr[i0];
+  const int len = rowptr[iend] - base;
+  if (WRITE_D) {
+    for (int k = threadIdx.x; k < len; k += PGX_BLOCK) acc[k] = 0.0;
+    __syncthreads();
+  }
+  if (i < n) {
+    double* row = acc + (rowptr[i] - base);
+    double Fu = 0.0, Fp = 0.0;
+    const int ke = v2c_ptr[i + 1];
+    for (int k = v2c_ptr[i]; k < ke; ++k) {
+      const int e = v2c_ent[k];
+      const int c = e >> 2, a = e & 3;
+      const int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
+      double u[3], p[3], dp[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        u[b] = mask[v[b]] ? gbc[v[b]] : x[v[b]];
+        p[b] = x[n + v[b]];
+        dp[b] = p[b] - xk[n + v[b]];
+      }
+      double d[3] = {0.0, 0.0, 0.0};
+      for (int k2 = 0; k2 < q.nq; ++k2) {
+        const P1GeomQ g = p1_geom_q(geo, (size_t)c * q.nq + k2, q.w[k2]);
+        const double N0 = q.N[k2][0], N1 = q.N[k2][1], N2 = q.N[k2][2];
+        const double uq = u[0] * N0 + u[1] * N1 + u[2] * N2;
+        const double dq = dp[0] * N0 + dp[1] * N1 + dp[2] * N2;
+        const double ex = exp(p[0] * N0 + p[1] * N1 + p[2] * N2);
+        const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
+        const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
+        const double wa = g.wd * q.N[k2][a];
+        Fu += g.wd * alpha * (g.G[a][0] * gx + g.G[a][1] * gy) + wa * (dq - alpha * f);
+        Fp += wa * (uq - ex);
+        d[0] += wa * ex * N0;
+        d[1] += wa * ex * N1;
+        d[2] += wa * ex * N2;
+      }
+      if (WRITE_D) {
+        const int pos = v2c_pos[k];
+        row[pos & 0xff] += d[0];
+        row[(pos >> 8) & 0xff] += d[1];
+        row[(pos >> 16) & 0xff] += d[2];
+      }
+    }
+    F[i] = mask[i] ? x[i] - gbc[i] : Fu;
+    F[n + i] = Fp - bphi[i];
+  }
+  if (WRITE_D) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < len; k += PGX_BLOCK) Dout[base + k] = acc[k];
+  }
+}
+
+__global__ void __launch_bounds__(PGX_BLOCK) k_observables_c(int nc, int n, const int32_t* __restrict__ cells,
+                                                             const double* __restrict__ x, const double* __restrict__ xk,
+                                                             double alpha, double f, QuadTab q, double* __restrict__ partials,
+                                                             const double* __restrict__ geo) {
+  __shared__ double sm[PGX_BLOCK / WAVE];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    const int v[3] = {cells[3 * c], cells[3 * c + 1], cells[3 * c + 2]};
+    double u[3], p[3], uk[3], pk[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[a] = x[v[a]];
+      p[a] = x[n + v[a]];
+      uk[a] = xk[v[a]];
+      pk[a] = xk[n + v[a]];
+    }
+    for (int k = 0; k < q.nq; ++k) {
+      const P1GeomQ g = p1_geom_q(geo, (size_t)c * q.nq + k, q.w[k]);
+      const double wd = g.wd;
+      const double gx = u[0] * g.G[0][0] + u[1] * g.G[1][0] + u[2] * g.G[2][0];
+      const double gy = u[0] * g.G[0][1] + u[1] * g.G[1][1] + u[2] * g.G[2][1];
+      const double hx = gx - (uk[0] * g.G[0][0] + uk[1] * g.G[1][0] + uk[2] * g.G[2][0]);
+      const double hy = gy - (uk[0] * g.G[0][1] + uk[1] * g.G[1][1] + uk[2] * g.G[2][1]);
+      const double uq = u[0] * q.N[k][0] + u[1] * q.N[k][1] + u[2] * q.N[k][2];
+      const double pq = p[0] * q.N[k][0] + p[1] * q.N[k][1] + p[2] * q.N[k][2];
+      const double ukq = uk[0] * q.N[k][0] + uk[1] * q.N[k][1] + uk[2] * q.N[k][2];
+      const double pkq = pk[0] * q.N[k][0] + pk[1] * q.N[k][1] + pk[2] * q.N[k][2];
+      s[0] += wd * (0.5 * (gx * gx + gy * gy) - f * uq);
+      s[1] += wd * (pkq - pq) / alpha * uq;
+      s[2] += wd * (uq < 0.0 ? -uq : 0.0);
+      s[3] += wd * (pkq < pq ? (pq - pkq) / alpha : 0.0);
+      const double du = uq - ukq;
+      s[4] += wd * (hx * hx + hy * hy + du * du);
+      const double de = exp(pq) - exp(pkq);
+      s[5] += wd * de * de;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double r = block_sum(s[k], sm);
+    if (threadIdx.x == 0) partials[blockIdx.x * 6 + k] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // b_phi = int phi w_i  (obstacle_pg.py:122 "- phi * w * dx"), assembled once at create
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PGX_BLOCK) k_bphi(int nc, const int32_t* __restrict__ cells,
@@ -120,9 +325,12 @@ void pgxk_gather_ent(hipStream_t st, int n, const int32_t* ptr, const int32_t* e
 }
 
 void pgxk_bphi(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* phi_q,
-               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi) {
-  hipLaunchKernelGGL(k_bphi, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cells, coords, phi_q,
-                     q, stash);
+               QuadTab q, const int32_t* v2c_ptr, const int32_t* v2c_ent, double* stash, double* bphi, const double* geo) {
+  if (geo)
+    hipLaunchKernelGGL(k_bphi_c, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, phi_q, q, stash, geo);
+  else
+    hipLaunchKernelGGL(k_bphi, dim3((nc + PGX_BLOCK - 1) / PGX_BLOCK), dim3(PGX_BLOCK), 0, st, nc, cells, coords, phi_q,
+                       q, stash);
   pgxk_gather_ent(st, n, v2c_ptr, v2c_ent, stash, bphi);
 }
 
@@ -417,8 +625,18 @@ __global__ void __launch_bounds__(PGX_RF_TX * PGX_RF_TY) k_resid_fill_grid(
 void pgxk_resid_fill_p1(hipStream_t st, int write_d, int n, size_t lds_bytes, const int32_t* rowptr,
                         const int32_t* v2c_ptr, const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells,
                         const double* coords, const uint8_t* mask, const double* gbc, const double* bphi,
-                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout) {
+                        const double* x, const double* xk, double alpha, double f, QuadTab q, double* F, double* Dout,
+                        const double* geo) {
   dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (geo) {
+    if (write_d)
+      hipLaunchKernelGGL((k_resid_fill_p1_c<true>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, mask, gbc,
+                         bphi, x, xk, alpha, f, q, F, Dout, geo);
+    else
+      hipLaunchKernelGGL((k_resid_fill_p1_c<false>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, mask, gbc,
+                         bphi, x, xk, alpha, f, q, F, Dout, geo);
+    return;
+  }
   if (write_d)
     hipLaunchKernelGGL((k_resid_fill_p1<true, false>), grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells,
                        coords, mask, gbc, bphi, x, xk, alpha, f, q, 0, 0, F, Dout);
@@ -454,8 +672,17 @@ void pgxk_resid_fill_grid(hipStream_t st, int write_d, const GridLevel& L, size_
 
 void pgxk_fill_rows(hipStream_t st, int mode, int n, size_t lds_bytes, const int32_t* rowptr, const int32_t* v2c_ptr,
                     const int32_t* v2c_ent, const int32_t* v2c_pos, const int32_t* cells, const double* coords,
-                    const double* psi, QuadTab q, double* out) {
+                    const double* psi, QuadTab q, double* out, const double* geo) {
   dim3 grid((n + PGX_BLOCK - 1) / PGX_BLOCK), block(PGX_BLOCK);
+  if (geo) {
+    if (mode == 0)
+      hipLaunchKernelGGL(k_fill_rows_c<0>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, psi, q, out, geo);
+    else if (mode == 1)
+      hipLaunchKernelGGL(k_fill_rows_c<1>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, psi, q, out, geo);
+    else
+      hipLaunchKernelGGL(k_fill_rows_c<2>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, psi, q, out, geo);
+    return;
+  }
   if (mode == 0)
     hipLaunchKernelGGL(k_fill_rows<0>, grid, block, lds_bytes, st, n, rowptr, v2c_ptr, v2c_ent, v2c_pos, cells, coords,
                        psi, q, out);
@@ -893,9 +1120,12 @@ int pgxk_observables_blocks(int nc) {
 
 void pgxk_observables(hipStream_t st, int nc, int n, const int32_t* cells, const double* coords, const double* x,
                       const double* xk, double alpha, double f, QuadTab q, double* partials, int nblocks,
-                      double* out6, int raw) {
-  hipLaunchKernelGGL(k_observables, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cells, coords, x, xk, alpha, f, q,
-                     partials);
+                      double* out6, int raw, const double* geo) {
+  if (geo)
+    hipLaunchKernelGGL(k_observables_c, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cells, x, xk, alpha, f, q, partials, geo);
+  else
+    hipLaunchKernelGGL(k_observables, dim3(nblocks), dim3(PGX_BLOCK), 0, st, nc, n, cells, coords, x, xk, alpha, f, q,
+                       partials);
   hipLaunchKernelGGL(k_observables_final, dim3(1), dim3(PGX_BLOCK), 0, st, nblocks, partials, out6, raw);
 }
 

@@ -9,9 +9,10 @@ the kind DOLFINx writes are read and written by proximalgalerkin_amd/h5.py, resu
     read_xdmf(path, name)               XDMF with the heavy data in HDF5 (DOLFINx's default: read through the pure-Python reader
                                         proximalgalerkin_amd/h5.py - contiguous, unfiltered datasets, default format bounds) or
                                         INLINE (dolfinx.io.XDMFFile(..., encoding=XDMFFile.Encoding.ASCII))
-    read_mesh(path) / read_tet_mesh     -> fem.Mesh / (TetMesh, MeshTags) from either format; ORDER-2 geometry (6-node triangles,
-                                        10-node tetrahedra: generate_mesh_gmsh.py:31, mesh_generation.py:88,158) is reduced to
-                                        its vertices - the solvers use affine cells
+    read_mesh(path) / read_tet_mesh     -> fem.Mesh / (TetMesh, MeshTags) from either format; ORDER-2 geometry (generate_mesh_gmsh.py:31,
+                                        mesh_generation.py:88,158): 6-node triangles keep their mid-side nodes (`mesh.midside`:
+                                        curved cells in example 01), 10-node tetrahedra are reduced to
+                                        their vertices
     write_vtu(path, points, cells, ...) VTK unstructured grid (XML, ASCII) with point / cell data; linear and quadratic
                                         triangles, linear tetrahedra
 """
@@ -216,7 +217,7 @@ def read_mesh(path, name: str = "mesh"):
 def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     """(TetMesh, MeshTags) of example 02's `file` branch (signorini_dolfinx.py:406-409: read_mesh + read_meshtags "facet_tags";
     the half-sphere of lvpp/mesh_generation.py:86-168 has order-2 geometry): tetrahedra and tagged boundary triangles from a
-    gmsh .msh file (physical groups) or an inline-data XDMF file, both reduced to their vertices."""
+    gmsh .msh file (physical groups) or an inline-data XDMF file, both reduced to their vertices (order-2 tetrahedra: affine cells)."""
     from .signorini import MeshTags, TetMesh
 
     path = Path(path)

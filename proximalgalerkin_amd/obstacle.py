@@ -42,10 +42,6 @@ def setup_problem(msh: fem.Mesh, polynomial_order: int = 1, petsc_options: dict 
     quadrature_degree: 6 is the reference's (:106); 1 selects the vertex rule (mass lumping), with which the system is the
     finite-difference one of obstacle_finite_difference.jl (tests/test_gpu_fd_pin.py).  quadrature_scheme names a table of
     tables/quadrature.json explicitly ("tri_deg6_12_b": the second admissible 12-point degree-6 rule)."""
-    if getattr(msh, "curved", False) and polynomial_order != 2:
-        # order-2 geometry is integrated isoparametrically for `-p 2` (csrc/pgx_p2.hip); a degree-1 run keeps the affine cells of
-        # rounds 1-4 - the mesh, the quadrature points of phi and the kernels must agree on that
-        msh = msh.flattened()
     V = fem.functionspace(msh, ("Lagrange", polynomial_order), ncomp=2)  # :68-70
     alpha = fem.Constant(msh, 1.0)  # :73
     f = fem.Constant(msh, 0.0)  # :74

@@ -206,14 +206,14 @@ class NonlinearProblem:
             self._lu_comm = lu_comm
             rc = lib.pgx_create_lu_dist(C.byref(pm), C.byref(pp), lu_comm._c, int(device), C.byref(h))
             _lib.check(lib, None, rc, "pgx_create_lu_dist")
-        elif part is None and getattr(mesh, "curved", False) and V.degree == 2:
-            # order-2 geometry + degree-2 fields = isoparametric P2 (round 5): weights and inverse Jacobians of the quadratic cell map
-            # at every quadrature point (fem.Mesh.geometry_at); phi was interpolated at the curved cells' quadrature points
+        elif part is None and getattr(mesh, "curved", False):
+            # order-2 geometry (round 5): degree-2 fields = isoparametric P2, degree-1 fields = hat functions on the quadratic cells
+            # (the reference's default run on its own meshes).  Weights and inverse Jacobians of the quadratic cell map at every
+            # quadrature point (fem.Mesh.geometry_at); phi was interpolated at the curved cells' quadrature points
             self._keep_geo = mesh.geometry_at(self._keep[2])[1]
             rc = lib.pgx_create_curved(C.byref(pm), C.byref(pp), _lib.dptr(self._keep_geo), int(device), C.byref(h))
             _lib.check(lib, None, rc, "pgx_create_curved")
         elif part is None:
-            # (a degree-1 run on an order-2 mesh flattens the cells to their vertices: include/pgx.h pgx_create_curved)
             rc = lib.pgx_create(C.byref(pm), C.byref(pp), int(device), C.byref(h))
             _lib.check(lib, None, rc, "pgx_create")
         else:  # this mesh is one rank's strip: every call below is collective over part.comm (include/pgx.h)

@@ -1,7 +1,8 @@
-"""Isoparametric P2 on ORDER-2 GEOMETRY (round 5): the reference's own meshes are gmsh meshes of element order 2
-(examples/01_obstacle_problem/generate_mesh_gmsh.py:30-33, src/lvpp/mesh_generation.py:88,158), and DOLFINx integrates `-p 2` on the
-curved cells.  The HIP path (pgx_create_curved: weights and inverse Jacobians of the quadratic cell map per quadrature point in every
-P2 kernel, csrc/pgx_p2.hip) against the CPU oracle with the same map (oracle/pg_oracle.py ObstacleLagrange(midside=...)) on the
+"""ORDER-2 GEOMETRY (round 5): the reference's own meshes are gmsh meshes of element order 2
+(examples/01_obstacle_problem/generate_mesh_gmsh.py:30-33, src/lvpp/mesh_generation.py:88,158), and DOLFINx integrates `-p 1` (its
+default) and `-p 2` on the curved cells.  The HIP path (pgx_create_curved: weights and inverse Jacobians of the quadratic cell map per
+quadrature point - in every P2 kernel, csrc/pgx_p2.hip, and in the k_*_c twins of the P1 kernels, csrc/pgx_kernels.hip) against the
+CPU oracle with the same map (oracle/pg_oracle.py ObstacleLagrange(midside=...)) on the
 committed order-2 disk mesh: kernels to 1e-12, the full LVPP run with identical Newton counts and the primal field to 1e-10; the
 affine fast path when every mid-side node is its edge's midpoint; and the closed-form solution on the disk, which the curved cells
 approach with a far smaller error constant than the polygon."""
@@ -34,15 +35,16 @@ def _disk(h, curved=True):
     return fem.Mesh(m.geometry, m.cells, midside=mid)
 
 
-def test_curved_p2_kernels_match_the_oracle(require_gpu):
+@pytest.mark.parametrize("degree", [1, 2])
+def test_curved_kernels_match_the_oracle(require_gpu, degree):
     from proximalgalerkin_amd import io
     from proximalgalerkin_amd.obstacle import setup_problem
 
     mesh = io.read_mesh(GOLD / "disk_h0.2_order2.msh")
     assert mesh.curved and abs(np.linalg.norm(mesh.midside, axis=1).max() - 1.0) < 1e-12
-    problem, sol, sol_k, alpha = setup_problem(mesh, 2)
-    prob = O.ObstacleLagrange(mesh.geometry, mesh.cells, 2, midside=mesh.midside)
-    flat = O.ObstacleLagrange(mesh.geometry, mesh.cells, 2)
+    problem, sol, sol_k, alpha = setup_problem(mesh, degree)
+    prob = O.ObstacleLagrange(mesh.geometry, mesh.cells, degree, midside=mesh.midside)
+    flat = O.ObstacleLagrange(mesh.geometry, mesh.cells, degree)
     assert sol.function_space.block_size == prob.n
     rng = np.random.default_rng(3)
     x, xk = rng.standard_normal(2 * prob.n) * 0.1, rng.standard_normal(2 * prob.n) * 0.1
@@ -66,13 +68,14 @@ def test_curved_p2_kernels_match_the_oracle(require_gpu):
     problem.close()
 
 
-def test_curved_p2_full_run_matches_the_oracle(require_gpu):
+@pytest.mark.parametrize("degree", [1, 2])
+def test_curved_full_run_matches_the_oracle(require_gpu, degree):
     from proximalgalerkin_amd import io
     from proximalgalerkin_amd.obstacle import COLUMNS, solve_problem
 
     mesh = io.read_mesh(GOLD / "disk_h0.2_order2.msh")
-    sol, newton, hist = solve_problem(mesh, 2, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
-    prob = O.ObstacleLagrange(mesh.geometry, mesh.cells, 2, midside=mesh.midside)
+    sol, newton, hist = solve_problem(mesh, degree, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+    prob = O.ObstacleLagrange(mesh.geometry, mesh.cells, degree, midside=mesh.midside)
     x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
     assert hist["Newton steps"] == h_ref["Newton steps"]
     assert _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-10
@@ -80,18 +83,19 @@ def test_curved_p2_full_run_matches_the_oracle(require_gpu):
         assert np.allclose(hist[c], h_ref[c], rtol=1e-7, atol=1e-11), c
 
 
-def test_straight_midside_nodes_take_the_affine_path_and_degree_1_flattens(require_gpu):
+def test_straight_midside_nodes_take_the_affine_path(require_gpu):
     """A mesh whose mid-side nodes ARE the edge midpoints is affine: `Mesh.curved` is False and the run is bit for bit the run on the
-    plain mesh.  A degree-1 run on a curved mesh flattens the cells (include/pgx.h: pgx_create_curved) and equals the affine oracle."""
+    plain mesh (degree 1 and 2); `flattened()` of a curved mesh is the polygon of rounds 1-4."""
     from proximalgalerkin_amd.obstacle import solve_problem
 
     straight, plain = _disk(0.3, curved=False), _disk(0.3, curved=False).flattened()
     assert not straight.curved
-    a = solve_problem(straight, 2, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
-    b = solve_problem(plain, 2, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
-    assert a[2]["Newton steps"] == b[2]["Newton steps"] and np.array_equal(a[0].x.array, b[0].x.array)
+    for degree in (1, 2):
+        a = solve_problem(straight, degree, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+        b = solve_problem(plain, degree, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+        assert a[2]["Newton steps"] == b[2]["Newton steps"] and np.array_equal(a[0].x.array, b[0].x.array)
     curved = _disk(0.3)
-    sol, newton, hist = solve_problem(curved, 1, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
+    sol, newton, hist = solve_problem(curved.flattened(), 1, 100, "double_exponential", 1e2, 1e-4, verbose=False, return_history=True)
     prob = O.ObstacleP1(curved.geometry, curved.cells, curved.exterior_vertices())
     x_ref, h_ref = O.solve_problem(prob, 100, "double_exponential", 1e2, 1e-4)
     assert hist["Newton steps"] == h_ref["Newton steps"] and _rel(sol.x.array[:prob.n], x_ref[:prob.n]) < 1e-10
