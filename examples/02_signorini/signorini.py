@@ -4,8 +4,8 @@ Counterpart of /root/reference/examples/02_signorini/signorini_dolfinx.py with t
 --disp --gap --n-tol --n-max-iterations --quadrature-degree --max-iterations --tol --alpha_scheme --alpha_0 --alpha_c and the two mesh
 branches (the reference's sub-command words `native` / `file` are accepted): `--nx --ny --nz` (native,
 :361-386: a tetrahedral unit cube, BASELINE.json config 5) or `--filename mesh.msh|mesh.xdmf --contact-tag --displacement-tag`
-(file, :406-409: tetrahedra + tagged boundary triangles, e.g. the half sphere of generate_mesh.py; order-2 geometry is reduced to
-its vertices, XDMF must carry inline data).  `--degree {1,2}`, default 2 as in the reference (:68-73); the native mesh is hexahedral
+(file, :406-409: tetrahedra + tagged boundary triangles, e.g. the half sphere of generate_mesh.py - an ORDER-2 mesh like the
+reference's: `--degree 2` is isoparametric on its 10-node tetrahedra, `--degree 1` uses the vertices; XDMF must carry inline data).  `--degree {1,2}`, default 2 as in the reference (:68-73); the native mesh is hexahedral
 as in the reference (`--cell-type hexahedron`, Q1 / Q2 elements); BASELINE.json config 5 is
 `--cell-type tetrahedron --degree 1 --nx 70 --ny 70 --nz 70`.
 """

@@ -44,7 +44,7 @@ typedef struct {
                             * contact facets.  Then n_vertices counts the P2 NODES (mesh vertices, then one node per edge; `coords`
                             * holds the edge midpoints for them), cells is [n_cells][10]: 4 vertices, then the edge nodes of
                             * (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); facets is [n_facets][6]: 3 vertices, then the edge nodes of
-                            * (0,1) (0,2) (1,2).  Cells stay affine (geometry from the vertices).  bc_dofs: component * n_nodes +
+                            * (0,1) (0,2) (1,2).  Cells are affine (geometry from the vertices) unless created by pgx_sg_create_curved.  bc_dofs: component * n_nodes +
                             * node; pgx_sg_contact_vertices returns the node of every psi dof. */
   int32_t cell_type;       /* 0: tetrahedra (above).  1: hexahedra - the reference's native mesh (:376-383) - with Q_d elements, d = degree
                             * (0 / 1 -> Q1, 2 -> Q2): cells is [n_cells][(d+1)^3], facets [n_facets][(d+1)^2] (quadrilaterals), local nodes
@@ -64,6 +64,22 @@ typedef struct {
 } pgx_sg_problem;
 
 int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int device, pgx_sg_handle** out);
+/* ORDER-2 GEOMETRY (round 5): the reference's half sphere is a mesh of 10-node tetrahedra (src/lvpp/mesh_generation.py:88,158
+ * `order=2`) and DOLFINx integrates on the curved cells.  With pgx_sg_mesh.degree = 2 the ten nodes of a cell ARE its geometry nodes
+ * (`coords` of an edge node = the mesh's mid-edge node instead of the midpoint): the discretisation is isoparametric P2.  The
+ * geometry enters through two tables a binding reads off the coordinate element: */
+typedef struct {
+  int32_t nq;              /* cell quadrature on the reference tetrahedron (weights sum 1/6).  The reference leaves this integral's
+                            * degree to UFL's estimator (signorini_dolfinx.py:237-239 has no metadata on dx); <= 512 points */
+  const double* qpts;      /* [nq][3] */
+  const double* qwts;      /* [nq] */
+  const double* cell_geo;  /* [n_cells][nq][10]: |det J|, then J^-1 row-major (d xi_k / d x_d) of x(xi) = sum_a X_a N2_a(xi) */
+  const double* facet_geo; /* [n_facets][prob->nq][2]: surface element |x_xi x x_eta| of the 6-node contact facet and its z
+                            * coordinate at the facet quadrature points of pgx_sg_problem */
+} pgx_sg_curved;
+/* Single handle, tetrahedra, degree 2 only (PGX_EINVAL otherwise; a degree-1 run uses the vertices).  Everything else as pgx_sg_create. */
+int pgx_sg_create_curved(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, const pgx_sg_curved* curved, int device,
+                         pgx_sg_handle** out);
 /* One handle per GPU over a pgx_comm (BASELINE.json config 5: 4 GPUs).  The ELEMENTS are partitioned (round 4): the cells are cut
  * into comm->size slabs of equal count along the longest axis of the mesh, every rank assembles the elasticity blocks of its own
  * slab only and one all-reduce sums the constant matrix - the owned-cell assembly of a distributed DOLFINx mesh

@@ -490,7 +490,7 @@ class ObstacleLagrange:
             N2, dN2 = lagrange_tabulate(2, self.Xq[:, 0], self.Xq[:, 1])  # (nq,6), (nq,6,2)
             J = np.einsum("cad,qak->cqdk", X6, dN2)  # J[c,q,d,k] = d x_d / d xi_k
             det = J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]
-            if np.any(det <= 0) and np.any(det >= 0):
+            if np.any(det.min(axis=1) * det.max(axis=1) <= 0):  # (a cell may be negatively oriented as a whole: |det J| is what enters)
                 raise ValueError("order-2 geometry: the cell map is not orientation preserving at every quadrature point")
             invJ = np.empty_like(J)  # invJ[c,q,k,d] = d xi_k / d x_d
             invJ[..., 0, 0], invJ[..., 0, 1] = J[..., 1, 1] / det, -J[..., 0, 1] / det

@@ -212,16 +212,68 @@ def _p2_tri(L):
     return np.concatenate([L * (2 * L - 1), np.stack([4 * L[:, a] * L[:, b] for a, b in TRI_EDGES], axis=1)], axis=1)
 
 
+def tet_gauss_jacobi(degree):
+    """Collapsed-coordinate (Stroud conical product) Gauss-Jacobi rule on the reference tetrahedron, exact to `degree`:
+    n = degree // 2 + 1 points per direction, (points (n^3, 3), weights summing to 1/6).  Basix's "GJ" scheme; its DEFAULT on
+    simplices of low degree is Xiao-Gimbutas, whose tables are not available offline - any rule of the degree integrates the same
+    polynomials exactly, the curved cells' rational integrands differ at the level of the quadrature error (parity unpinned)."""
+    from scipy.special import roots_jacobi
+
+    n = degree // 2 + 1
+    x0, w0 = roots_jacobi(n, 0.0, 0.0)
+    x1, w1 = roots_jacobi(n, 1.0, 0.0)
+    x2, w2 = roots_jacobi(n, 2.0, 0.0)
+    a, b, c = 0.5 * (x2 + 1.0), 0.5 * (x1 + 1.0), 0.5 * (x0 + 1.0)  # a: weight (1-a)^2, b: weight (1-b)
+    wa, wb, wc = w2 / 8.0, w1 / 4.0, w0 / 2.0
+    A, B, Cc = np.meshgrid(a, b, c, indexing="ij")
+    W = wa[:, None, None] * wb[None, :, None] * wc[None, None, :]
+    pts = np.stack([(Cc * (1 - B) * (1 - A)).ravel(), (B * (1 - A)).ravel(), A.ravel()], axis=1)
+    return np.ascontiguousarray(pts), np.ascontiguousarray(W.ravel())
+
+
+def _p2_tet_grad(L):
+    """reference gradients of the ten P2 shape functions on the tetrahedron at barycentric points L (nq, 4) -> (nq, 10, 3);
+    node order: 4 vertices, then the edges of TET_EDGES"""
+    gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    G = np.empty((len(L), 10, 3))
+    for a in range(4):
+        G[:, a] = (4 * L[:, a] - 1)[:, None] * gref[a][None]
+    for k, (a, b) in enumerate(TET_EDGES):
+        G[:, 4 + k] = 4 * (L[:, a][:, None] * gref[b][None] + L[:, b][:, None] * gref[a][None])
+    return G
+
+
+def _p2_tri_grad(L):
+    """reference gradients (d/dxi, d/deta) of the six P2 shape functions on the triangle at barycentric points L (nq, 3)"""
+    gref = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    G = np.empty((len(L), 6, 2))
+    for a in range(3):
+        G[:, a] = (4 * L[:, a] - 1)[:, None] * gref[a][None]
+    for k, (a, b) in enumerate(TRI_EDGES):
+        G[:, 3 + k] = 4 * (L[:, a][:, None] * gref[b][None] + L[:, b][:, None] * gref[a][None])
+    return G
+
+
 class SignoriniP2:
     """Same interface as SignoriniP1 with nv := number of P2 nodes."""
 
-    def __init__(self, coords, cells, contact_facets, bc_facets, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25, quadrature="tri_deg4_gj9"):
+    def __init__(self, coords, cells, contact_facets, bc_facets, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25, quadrature="tri_deg4_gj9",
+                 midside=None, cell_quadrature_degree=5):
+        """midside (n_edges, 3), optional: the geometry's mid-edge nodes (edge order of p2_numbering: sorted (min, max) vertex pairs)
+        of a mesh of 10-node tetrahedra - the reference's half sphere is one (lvpp/mesh_generation.py:88,158 `order=2`).  The
+        discretisation is then ISOPARAMETRIC: cell map x(xi) = sum_a X_a N2_a(xi) over the ten nodes, Jacobians and physical
+        gradients per quadrature point, cell integrals by a rule of degree `cell_quadrature_degree` (the reference leaves this
+        integral's degree to UFL's estimator: 2 for the integrand on a simplex + 3 for det J of a quadratic tetrahedron = 5 as far
+        as that can be told offline), facet integrals with the surface element |x_xi x x_eta| of the 6-node facets and g = x_z of
+        the CURVED facet at the form's degree-4 points."""
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
         self.edges, self.cells10, self.facets6 = p2_numbering(cells, facets)
         self.nvert = len(coords)
-        self.node_coords = np.concatenate([coords, 0.5 * (coords[self.edges[:, 0]] + coords[self.edges[:, 1]])])
+        self.curved = midside is not None
+        self.node_coords = np.concatenate([coords, 0.5 * (coords[self.edges[:, 0]] + coords[self.edges[:, 1]])
+                                           if midside is None else np.ascontiguousarray(midside, dtype=np.float64)])
         self.coords, self.cells, self.facets = coords, cells, facets
         nn = self.nv = len(self.node_coords)
         self.nc, self.nf = len(cells), len(facets)
@@ -241,27 +293,44 @@ class SignoriniP2:
         self.isbc = np.zeros(3 * nn, dtype=bool)
         self.isbc[self.bc] = True
         # elasticity block
-        a_, b_ = 0.5854101966249685, 0.1381966011250105
-        Lq = np.full((4, 4), b_) + (a_ - b_) * np.eye(4)  # barycentric points of the degree-2 rule
-        wq = np.full(4, 1.0 / 24.0)
-        x = coords[cells]
-        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 3] - x[:, 0]], axis=2)
-        det = np.linalg.det(J)
-        invJ = np.linalg.inv(J)
-        gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
-        G1 = np.einsum("ak,ckd->cad", gref, invJ)  # gradients of the barycentric coordinates (nc,4,3)
-        Ae = np.zeros((self.nc, 10, 3, 10, 3))
         mu, lm = self.mu, self.lmbda
-        for q in range(4):
-            L = Lq[q]
-            G = np.empty((self.nc, 10, 3))
-            for a in range(4):
-                G[:, a] = (4 * L[a] - 1) * G1[:, a]
-            for k, (a, b) in enumerate(TET_EDGES):
-                G[:, 4 + k] = 4 * (L[a] * G1[:, b] + L[b] * G1[:, a])
-            GG = np.einsum("cad,cbd->cab", G, G)
-            Ae += (wq[q] * np.abs(det))[:, None, None, None, None] * (
-                lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G) + mu * np.einsum("cab,ij->caibj", GG, np.eye(3)))
+        Ae = np.zeros((self.nc, 10, 3, 10, 3))
+        if not self.curved:
+            a_, b_ = 0.5854101966249685, 0.1381966011250105
+            Lq = np.full((4, 4), b_) + (a_ - b_) * np.eye(4)  # barycentric points of the degree-2 rule
+            wq = np.full(4, 1.0 / 24.0)
+            x = coords[cells]
+            J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 3] - x[:, 0]], axis=2)
+            det = np.linalg.det(J)
+            invJ = np.linalg.inv(J)
+            gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+            G1 = np.einsum("ak,ckd->cad", gref, invJ)  # gradients of the barycentric coordinates (nc,4,3)
+            for q in range(4):
+                L = Lq[q]
+                G = np.empty((self.nc, 10, 3))
+                for a in range(4):
+                    G[:, a] = (4 * L[a] - 1) * G1[:, a]
+                for k, (a, b) in enumerate(TET_EDGES):
+                    G[:, 4 + k] = 4 * (L[a] * G1[:, b] + L[b] * G1[:, a])
+                GG = np.einsum("cad,cbd->cab", G, G)
+                Ae += (wq[q] * np.abs(det))[:, None, None, None, None] * (
+                    lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G) + mu * np.einsum("cab,ij->caibj", GG, np.eye(3)))
+        else:
+            self.cell_qpts, self.cell_qwts = tet_gauss_jacobi(cell_quadrature_degree)
+            Lc = np.concatenate([1.0 - self.cell_qpts.sum(axis=1, keepdims=True), self.cell_qpts], axis=1)
+            dN = _p2_tet_grad(Lc)  # (nq,10,3)
+            X10 = self.node_coords[self.cells10]  # (nc,10,3)
+            J = np.einsum("cad,qak->cqdk", X10, dN)  # d x_d / d xi_k
+            det = np.linalg.det(J)
+            if np.any(det.min(axis=1) * det.max(axis=1) <= 0):  # (a cell may be negatively oriented as a whole: |det J| is what enters)
+                raise ValueError("order-2 geometry: the cell map is not orientation preserving at every quadrature point")
+            invJ = np.linalg.inv(J)  # [c,q,k,d] = d xi_k / d x_d
+            self.cell_geo = np.ascontiguousarray(np.concatenate([np.abs(det)[..., None], invJ.reshape(self.nc, -1, 9)], axis=2))
+            for q in range(len(self.cell_qwts)):
+                G = np.einsum("ak,ckd->cad", dN[q], invJ[:, q])
+                GG = np.einsum("cad,cbd->cab", G, G)
+                Ae += (self.cell_qwts[q] * np.abs(det[:, q]))[:, None, None, None, None] * (
+                    lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G) + mu * np.einsum("cab,ij->caibj", GG, np.eye(3)))
         c10 = self.cells10
         rows = (c10[:, :, None, None, None] + nn * np.arange(3)[None, None, :, None, None])
         cols = (c10[:, None, None, :, None] + nn * np.arange(3)[None, None, None, None, :])
@@ -272,17 +341,27 @@ class SignoriniP2:
         L3 = np.stack([1 - self.Xq[:, 0] - self.Xq[:, 1], self.Xq[:, 0], self.Xq[:, 1]], axis=1)
         self.Nq = _p2_tri(L3)  # (nq,6)
         xf = coords[facets]
-        farea2 = np.linalg.norm(np.cross(xf[:, 1] - xf[:, 0], xf[:, 2] - xf[:, 0]), axis=1)
-        self.wdet = farea2[:, None] * self.wq[None]
-        Mref = np.einsum("q,qa,qb->ab", self.wq, self.Nq, self.Nq)
-        Me = farea2[:, None, None] * Mref[None]
         f6 = self.facets6
+        if not self.curved:
+            farea2 = np.linalg.norm(np.cross(xf[:, 1] - xf[:, 0], xf[:, 2] - xf[:, 0]), axis=1)
+            self.wdet = farea2[:, None] * self.wq[None]
+            Mref = np.einsum("q,qa,qb->ab", self.wq, self.Nq, self.Nq)
+            Me = farea2[:, None, None] * Mref[None]
+            zq = np.einsum("qa,fa->fq", L3, xf[:, :, 2])
+        else:
+            X6 = self.node_coords[f6]  # (nf,6,3)
+            dT = _p2_tri_grad(L3)  # (nq,6,2)
+            t = np.einsum("fad,qak->fqdk", X6, dT)  # tangents x_xi, x_eta
+            ds = np.linalg.norm(np.cross(t[..., 0], t[..., 1]), axis=2)  # surface element (nf,nq)
+            self.wdet = ds * self.wq[None]
+            Me = np.einsum("fq,qa,qb->fab", self.wdet, self.Nq, self.Nq)
+            zq = np.einsum("qa,fa->fq", self.Nq, X6[:, :, 2])
+            self.facet_geo = np.ascontiguousarray(np.stack([ds, zq], axis=2))
         pf = n2psi[f6]
         self.pf = pf
         r = np.repeat(pf, 6, axis=1).ravel()
         c = np.tile(f6, (1, 6)).ravel()
         self.MG = sp.coo_matrix((Me.ravel(), (r, c)), shape=(self.npsi, nn)).tocsr()
-        zq = np.einsum("qa,fa->fq", L3, xf[:, :, 2])
         self.b_g = np.bincount(pf.ravel(), weights=((self.wdet * (zq - self.gap)) @ self.Nq).ravel(), minlength=self.npsi)
         self._rp = np.repeat(pf, 6, axis=1).ravel()
         self._cp = np.tile(pf, (1, 6)).ravel()

@@ -155,6 +155,16 @@ class pgx_sg_problem(C.Structure):
     ]
 
 
+class pgx_sg_curved(C.Structure):  # include/pgx_sg.h: order-2 geometry of a mesh of 10-node tetrahedra
+    _fields_ = [
+        ("nq", C.c_int32),
+        ("qpts", c_double_p),
+        ("qwts", c_double_p),
+        ("cell_geo", c_double_p),
+        ("facet_geo", c_double_p),
+    ]
+
+
 class pgx_qvi_problem(C.Structure):  # include/pgx_qvi.h
     _fields_ = [
         ("nq", C.c_int32),
@@ -289,6 +299,7 @@ SYMBOLS = [
     # example 02: Signorini contact (include/pgx_sg.h)
     ("pgx_sg_create", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.c_int, C.POINTER(_H)]),
     ("pgx_sg_create_dist", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), _COMM, C.c_int, C.POINTER(_H)]),
+    ("pgx_sg_create_curved", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.POINTER(pgx_sg_curved), C.c_int, C.POINTER(_H)]),
     ("pgx_sg_partition_info", C.c_int, [_H, c_int64_p, c_int64_p]),
     ("pgx_sg_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
     ("pgx_sg_destroy", None, [_H]),

@@ -22,6 +22,7 @@ struct SgQuad {
 };
 
 static thread_local std::string g_sg_error;
+static thread_local const pgx_sg_curved* g_sg_curved = nullptr;  // set by pgx_sg_create_curved around sg_create
 
 struct pgx_sg_handle : MixedBase {
   int nv = 0, nc = 0, nf = 0, npsi = 0;  // nv = number of NODES (degree 2: vertices + edge midpoints)
@@ -29,6 +30,7 @@ struct pgx_sg_handle : MixedBase {
   SgQuad Q{};
   double alpha = 1.0, gap = 0.0, mu = 0.0, lmbda = 0.0;
   double *coords = nullptr, *gbc = nullptr, *bg = nullptr;
+  double* fgeo = nullptr;  // order-2 geometry (pgx_sg_create_curved): [facet][point][2] = surface element, z of the curved facet; else nullptr
   int32_t *facets = nullptr, *fpsi = nullptr;
   // deterministic facet assembly (pgx_scatter.h): k_sg_exp parks [slot * nf + facet]; one thread per destination sums
   PgxScatter sc_D, sc_b;  // D(psi): 9 slots per facet -> CSR positions; <exp(psi), w>: 3 slots per facet -> residual rows
@@ -200,11 +202,45 @@ __global__ __launch_bounds__(64) void k_sg_const_cells_tab(int nc, const int32_t
     }
 }
 
+// ISOPARAMETRIC cells (round 5: 10-node tetrahedra of an order-2 mesh, pgx_sg_create_curved): as k_sg_const_cells_tab, but |det J| and
+// J^-1 come per (cell, quadrature point) from the caller's table geo[cell][q][10] - what a binding reads off the coordinate element -
+// instead of once per cell from four nodes.  tab = [nq weights | nq x NPC x 3 reference gradients].
+template <int NPC>
+__global__ __launch_bounds__(64) void k_sg_const_cells_geo(int nc, double mu, double lmbda, int nq, const double* __restrict__ tab,
+                                                           const double* __restrict__ geo, double* __restrict__ stash) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const double* dN = tab + nq;
+  const double* gc = geo + (size_t)c * nq * 10;
+  constexpr int ND = 3 * NPC;
+  for (int A = 0; A < NPC; ++A)
+    for (int B = 0; B < NPC; ++B) {
+      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int q = 0; q < nq; ++q) {
+        const double* g = gc + (size_t)q * 10;  // g[0] = |det J|, g[1 + 3 k + d] = d xi_k / d x_d
+        const double* ra = dN + ((size_t)q * NPC + A) * 3;
+        const double* rb = dN + ((size_t)q * NPC + B) * 3;
+        double gA[3], gB[3];
+        for (int d = 0; d < 3; ++d) {
+          gA[d] = ra[0] * g[1 + d] + ra[1] * g[4 + d] + ra[2] * g[7 + d];
+          gB[d] = rb[0] * g[1 + d] + rb[1] * g[4 + d] + rb[2] * g[7 + d];
+        }
+        const double wq = tab[q] * g[0];
+        const double gg = gA[0] * gB[0] + gA[1] * gB[1] + gA[2] * gB[2];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) acc[i][j] += wq * (lmbda * gA[i] * gB[j] + mu * gA[j] * gB[i] + (i == j ? mu * gg : 0.0));
+      }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) stash[(size_t)((A * 3 + i) * ND + (B * 3 + j)) * nc + c] = acc[i][j];
+    }
+}
+
 // facet mass coupling (+M on (u_z, psi), -M on (psi, u_z)) and b_g = <g, w>, once
 template <int NPF>
 __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* __restrict__ facets, const int32_t* __restrict__ fpsi,
                                                          const double* __restrict__ coords, double gap, SgQuad Q,
-                                                         double* __restrict__ stash /* [(2 NPF^2 + NPF) * nf]: matrix slots, then b_g */) {
+                                                         double* __restrict__ stash /* [(2 NPF^2 + NPF) * nf]: matrix slots, then b_g */,
+                                                         const double* __restrict__ fgeo /* curved facets: [f][q][2], else nullptr */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int32_t* fv = facets + NPF * (size_t)f;
@@ -221,8 +257,8 @@ __global__ __launch_bounds__(128) void k_sg_const_facets(int nf, const int32_t* 
     for (int b = 0; b < NPF; ++b) Me[a][b] = 0.0;
   }
   for (int q = 0; q < Q.nq; ++q) {
-    const double wd = Q.w[q] * area2;
-    const double zq = Q.L[q][0] * X[0][2] + Q.L[q][1] * X[1][2] + Q.L[q][2] * X[2][2];
+    const double wd = Q.w[q] * (fgeo ? fgeo[2 * ((size_t)f * Q.nq + q)] : area2);
+    const double zq = fgeo ? fgeo[2 * ((size_t)f * Q.nq + q) + 1] : Q.L[q][0] * X[0][2] + Q.L[q][1] * X[1][2] + Q.L[q][2] * X[2][2];
     for (int a = 0; a < NPF; ++a) {
       g[a] += wd * (zq - gap) * Q.N[q][a];
       for (int b = 0; b < NPF; ++b) Me[a][b] += wd * Q.N[q][a] * Q.N[q][b];
@@ -250,7 +286,8 @@ __global__ void k_sg_jac_init(int64_t nnz, const uint8_t* __restrict__ kind, con
 template <int NPF>
 __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const int32_t* __restrict__ facets,
                                                 const int32_t* __restrict__ fpsi, const double* __restrict__ coords,
-                                                const double* __restrict__ x, SgQuad Q, double* __restrict__ stash) {
+                                                const double* __restrict__ x, SgQuad Q, double* __restrict__ stash,
+                                                const double* __restrict__ fgeo) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int32_t* fv = facets + NPF * (size_t)f;
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(128) void k_sg_exp(int mode, int nf, int nu, const 
   for (int q = 0; q < Q.nq; ++q) {
     double pq = 0.0;
     for (int a = 0; a < NPF; ++a) pq += pv[a] * Q.N[q][a];
-    const double e = Q.w[q] * area2 * exp(pq);
+    const double e = Q.w[q] * (fgeo ? fgeo[2 * ((size_t)f * Q.nq + q)] : area2) * exp(pq);
     for (int a = 0; a < NPF; ++a) {
       be[a] += e * Q.N[q][a];
       for (int b = 0; b < NPF; ++b) De[a][b] += e * Q.N[q][a] * Q.N[q][b];
@@ -334,16 +371,16 @@ void pgx_sg_handle::residual_dev(const double* xin, double* Fout) {
   if (h->nf > 0) {
     if (h->npf == 6)
       hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                         h->Q, h->stash);
+                         h->Q, h->stash, h->fgeo);
     else if (h->npf == 4)
       hipLaunchKernelGGL(k_sg_exp<4>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                         h->Q, h->stash);
+                         h->Q, h->stash, h->fgeo);
     else if (h->npf == 9)
       hipLaunchKernelGGL(k_sg_exp<9>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                         h->Q, h->stash);
+                         h->Q, h->stash, h->fgeo);
     else
       hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 1, h->nf, nu, h->facets, h->fpsi, h->coords, xin,
-                         h->Q, h->stash);
+                         h->Q, h->stash, h->fgeo);
     pgx_scatter_run(h->st, h->sc_b, h->stash, 1.0, 1, Fout);
   }
 }
@@ -355,16 +392,16 @@ void pgx_sg_handle::jacobian_dev(const double* xin) {
   if (h->nf > 0) {
     if (h->npf == 6)
       hipLaunchKernelGGL(k_sg_exp<6>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
-                         h->coords, xin, h->Q, h->stash);
+                         h->coords, xin, h->Q, h->stash, h->fgeo);
     else if (h->npf == 4)
       hipLaunchKernelGGL(k_sg_exp<4>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
-                         h->coords, xin, h->Q, h->stash);
+                         h->coords, xin, h->Q, h->stash, h->fgeo);
     else if (h->npf == 9)
       hipLaunchKernelGGL(k_sg_exp<9>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
-                         h->coords, xin, h->Q, h->stash);
+                         h->coords, xin, h->Q, h->stash, h->fgeo);
     else
       hipLaunchKernelGGL(k_sg_exp<3>, dim3((h->nf + 127) / 128), dim3(128), 0, h->st, 0, h->nf, 3 * h->nv, h->facets, h->fpsi,
-                         h->coords, xin, h->Q, h->stash);
+                         h->coords, xin, h->Q, h->stash, h->fgeo);
     pgx_scatter_run(h->st, h->sc_D, h->stash, 1.0, 1, h->Jv);
   }
   h->jac_valid = true;
@@ -656,6 +693,10 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   MXHIP(hipMemcpy(h->coords, m->coords, sizeof(double) * 3 * nv, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->facets, m->facets, sizeof(int32_t) * NPF * (size_t)nf, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->fpsi, fpsi.data(), sizeof(int32_t) * fpsi.size(), hipMemcpyHostToDevice));
+  if (g_sg_curved && nf > 0) {  // curved contact facets: surface element and z per quadrature point, read by every facet kernel
+    MXALLOC(h->fgeo, 2 * (size_t)nf * p->nq);
+    MXHIP(hipMemcpy(h->fgeo, g_sg_curved->facet_geo, sizeof(double) * 2 * (size_t)nf * p->nq, hipMemcpyHostToDevice));
+  }
   MXHIP(hipMemcpy(h->mask, hmask.data(), nu, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->gbc, hg.data(), sizeof(double) * nu, hipMemcpyHostToDevice));
   MXHIP(hipMemcpy(h->rowptr, rowptr.data(), sizeof(int32_t) * (ntot + 1), hipMemcpyHostToDevice));
@@ -687,6 +728,31 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
     // (the cell kernels below see the OWNED cells only: nco of them, compact)
     if (NPC == 4) {
       hipLaunchKernelGGL(k_sg_const_cells, dim3((nco + 127) / 128), dim3(128), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
+    } else if (NPC == 10 && g_sg_curved) {
+      // isoparametric P2: reference gradients of the ten shape functions at the caller's cell quadrature points (node order of
+      // include/pgx_sg.h: 4 vertices, then the edges (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)), geometry per point from the caller's table
+      const pgx_sg_curved* cv = g_sg_curved;
+      const int nqc = cv->nq;
+      std::vector<double> tab((size_t)nqc + (size_t)nqc * 10 * 3);
+      static const double gref[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+      static const int ed[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+      for (int q = 0; q < nqc; ++q) {
+        tab[q] = cv->qwts[q];
+        const double X = cv->qpts[3 * q], Y = cv->qpts[3 * q + 1], Z = cv->qpts[3 * q + 2];
+        const double L[4] = {1.0 - X - Y - Z, X, Y, Z};
+        double* r = tab.data() + nqc + (size_t)q * 10 * 3;
+        for (int a = 0; a < 4; ++a)
+          for (int d = 0; d < 3; ++d) r[3 * a + d] = (4.0 * L[a] - 1.0) * gref[a][d];
+        for (int k = 0; k < 6; ++k)
+          for (int d = 0; d < 3; ++d) r[3 * (4 + k) + d] = 4.0 * (L[ed[k][0]] * gref[ed[k][1]][d] + L[ed[k][1]] * gref[ed[k][0]][d]);
+      }
+      double *d_tab = nullptr, *d_geo = nullptr;
+      e = hipMalloc((void**)&d_tab, sizeof(double) * tab.size());
+      if (e == hipSuccess) tmp.push_back(d_tab), e = hipMalloc((void**)&d_geo, sizeof(double) * 10 * (size_t)nqc * nc);
+      if (e == hipSuccess) tmp.push_back(d_geo), e = hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(d_geo, cv->cell_geo, sizeof(double) * 10 * (size_t)nqc * nc, hipMemcpyHostToDevice);
+      if (e == hipSuccess)  // (a curved handle is never partitioned: owned cell k IS cell k of the caller's table)
+        hipLaunchKernelGGL(k_sg_const_cells_geo<10>, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, h->mu, h->lmbda, nqc, d_tab, d_geo, st_c);
     } else if (NPC == 10) {
       hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
     } else {  // hexahedra: Gauss-Legendre (d + 1)^3 on [0,1]^3, tensor Lagrange reference gradients
@@ -730,7 +796,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   if (e == hipSuccess) {
     if (nf > 0) {
       hipLaunchKernelGGL(k_sg_const_facets<NPF>, dim3((nf + 127) / 128), dim3(128), 0, h->st, nf, h->facets, h->fpsi, h->coords, h->gap,
-                         h->Q, st_f);
+                         h->Q, st_f, h->fgeo);
       pgx_scatter_run(h->st, sc_f, st_f, 1.0, 1, h->Jc);  // the +-M_G slots are disjoint from the elasticity slots
       pgx_scatter_run(h->st, sc_g, st_f + 2 * NF2 * (size_t)nf, 1.0, 0, h->bg);
     }
@@ -785,6 +851,19 @@ static int sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* co
 
 extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int device, pgx_sg_handle** out) {
   return sg_create(m, p, nullptr, device, out);
+}
+extern "C" int pgx_sg_create_curved(const pgx_sg_mesh* m, const pgx_sg_problem* p, const pgx_sg_curved* cv, int device,
+                                    pgx_sg_handle** out) {
+  if (!m || !cv || m->degree != 2 || m->cell_type != 0 || cv->nq <= 0 || cv->nq > 512 || !cv->qpts || !cv->qwts || !cv->cell_geo ||
+      (m->n_facets > 0 && !cv->facet_geo)) {
+    g_sg_error = "pgx_sg_create_curved: order-2 geometry is implemented for degree-2 fields on tetrahedra (isoparametric P2: "
+                 "pgx_sg_mesh.degree = 2, cell_type = 0) and needs the cell rule and both geometry tables";
+    return PGX_EINVAL;
+  }
+  g_sg_curved = cv;
+  const int rc = sg_create(m, p, nullptr, device, out);
+  g_sg_curved = nullptr;
+  return rc;
 }
 extern "C" int pgx_sg_partition_info(const pgx_sg_handle* h, int64_t* owned_cells, int64_t* total_cells) {
   if (!h) return PGX_EINVAL;

@@ -26,6 +26,18 @@ def quadrature_rule(cell: str, degree: int, scheme: str | None = None):
     """(points (nq,2), weights (nq,)) on the reference triangle. Tables live in ONE file shared with
     the oracle (tools/make_quadrature_tables.py).  `scheme` names a table of that file explicitly (basix.ufl.quadrature_element's
     `scheme` argument): "tri_deg6_12_b" is the second fully symmetric 12-point degree-6 rule (tools/quadrature_uniqueness.py)."""
+    if cell == "tetrahedron":  # collapsed-coordinate Gauss-Jacobi rule (basix's "GJ" scheme), exact to `degree`; weights sum to 1/6
+        if scheme not in (None, "default", "GJ"):
+            raise NotImplementedError(f"no quadrature table {scheme!r} for tetrahedron degree {degree}: Gauss-Jacobi is the only scheme")
+        from scipy.special import roots_jacobi
+
+        n = degree // 2 + 1
+        (x0, w0), (x1, w1), (x2, w2) = roots_jacobi(n, 0.0, 0.0), roots_jacobi(n, 1.0, 0.0), roots_jacobi(n, 2.0, 0.0)
+        a, b, c = 0.5 * (x2 + 1.0), 0.5 * (x1 + 1.0), 0.5 * (x0 + 1.0)
+        A, B, Cc = np.meshgrid(a, b, c, indexing="ij")
+        W = (w2 / 8.0)[:, None, None] * (w1 / 4.0)[None, :, None] * (w0 / 2.0)[None, None, :]
+        pts = np.stack([(Cc * (1 - B) * (1 - A)).ravel(), (B * (1 - A)).ravel(), A.ravel()], axis=1)
+        return np.ascontiguousarray(pts), np.ascontiguousarray(W.ravel())
     if cell == "quadrilateral":  # tensor Gauss-Legendre rule on the unit square, exact to `degree` in each variable
         if scheme not in (None, "default"):  # basix would reject an unknown scheme name: so does this (ADVICE r04)
             raise NotImplementedError(f"no quadrature table {scheme!r} for quadrilateral degree {degree}: the tensor Gauss rule is the only scheme")
@@ -103,7 +115,7 @@ class Mesh:
             xq = np.einsum("qa,cad->cqd", N, X6)
             J = np.einsum("cad,qak->cqdk", X6, dN)
         det = J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]
-        if np.any(det <= 0) and np.any(det >= 0):
+        if np.any(det.min(axis=1) * det.max(axis=1) <= 0):  # (a cell may be negatively oriented as a whole: |det J| is what enters)
             raise ValueError("the cell map is not orientation preserving at every quadrature point (tangled order-2 geometry?)")
         geo = np.empty(det.shape + (5,))
         geo[..., 0] = np.abs(det)

@@ -11,8 +11,8 @@ the kind DOLFINx writes are read and written by proximalgalerkin_amd/h5.py, resu
                                         INLINE (dolfinx.io.XDMFFile(..., encoding=XDMFFile.Encoding.ASCII))
     read_mesh(path) / read_tet_mesh     -> fem.Mesh / (TetMesh, MeshTags) from either format; ORDER-2 geometry (generate_mesh_gmsh.py:31,
                                         mesh_generation.py:88,158): 6-node triangles keep their mid-side nodes (`mesh.midside`:
-                                        curved cells in example 01), 10-node tetrahedra are reduced to
-                                        their vertices
+                                        curved cells in example 01), 10-node tetrahedra their mid-edge nodes
+                                        (`TetMesh.midside`: isoparametric P2 in example 02)
     write_vtu(path, points, cells, ...) VTK unstructured grid (XML, ASCII) with point / cell data; linear and quadratic
                                         triangles, linear tetrahedra
 """
@@ -217,7 +217,8 @@ def read_mesh(path, name: str = "mesh"):
 def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     """(TetMesh, MeshTags) of example 02's `file` branch (signorini_dolfinx.py:406-409: read_mesh + read_meshtags "facet_tags";
     the half-sphere of lvpp/mesh_generation.py:86-168 has order-2 geometry): tetrahedra and tagged boundary triangles from a
-    gmsh .msh file (physical groups) or an inline-data XDMF file, both reduced to their vertices (order-2 tetrahedra: affine cells)."""
+    gmsh .msh file (physical groups) or an inline-data XDMF file.  10-node tetrahedra keep their mid-edge nodes (`mesh.midside`, round
+    5: isoparametric P2 in example 02; a degree-1 run uses the vertices)."""
     from .signorini import MeshTags, TetMesh
 
     path = Path(path)
@@ -230,7 +231,8 @@ def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
         pts, cells, tags = read_msh(path)
         tname = "triangle" if "triangle" in cells else "triangle6"
         fconn, fval = cells[tname], tags[tname]
-    tet = (cells["tetra"] if "tetra" in cells else cells["tetra10"][:, :4]).copy()
+    ten = None if "tetra" in cells else np.asarray(cells["tetra10"]).copy()
+    tet = (cells["tetra"] if ten is None else ten[:, :4]).copy()
     fconn = fconn[:, :3]
     p = np.asarray(pts, dtype=np.float64)[:, :3]
     # positive orientation
@@ -240,7 +242,19 @@ def read_tet_mesh(path, name: str = "mesh", tags_name: str = "facet_tags"):
     used = np.unique(tet)
     remap = np.full(len(p), -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
-    mesh = TetMesh(np.ascontiguousarray(p[used]), np.ascontiguousarray(remap[tet], dtype=np.int32))
+    midside = None
+    if ten is not None:
+        # order-2 geometry (round 5): the six mid-edge nodes of a 10-node tetrahedron follow the vertices in the FILE's edge order -
+        # gmsh: (0,1) (1,2) (0,2) (0,3) (2,3) (1,3); XDMF / VTK: (0,1) (1,2) (0,2) (0,3) (1,3) (2,3).  An edge is its vertex pair,
+        # so the node of every edge goes to its place in TetMesh.edges()' numbering whatever the cell's orientation.
+        order = ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)) if path.suffix.lower() == ".xdmf" else ((0, 1), (1, 2), (0, 2), (0, 3), (2, 3), (1, 3))
+        nvu = len(used)
+        pair = np.sort(np.concatenate([remap[ten[:, list(e)]] for e in order]), axis=1)
+        node = np.concatenate([ten[:, 4 + k] for k in range(6)])
+        key = pair[:, 0] * nvu + pair[:, 1]
+        ukey, first = np.unique(key, return_index=True)
+        midside = np.ascontiguousarray(p[node[first]])  # (edges in sorted (min, max) order = TetMesh.edges())
+    mesh = TetMesh(np.ascontiguousarray(p[used]), np.ascontiguousarray(remap[tet], dtype=np.int32), midside)
     tagged_facets = {int(t): np.ascontiguousarray(remap[fconn[fval == t]], dtype=np.int32) for t in np.unique(fval) if t != 0}
     return mesh, MeshTags(tagged_facets)
 
@@ -278,6 +292,18 @@ def write_xdmf_tet(path, mesh, facet_tags, tags=None, name: str = "mesh", tags_n
     inline (Format="XML") data items - the encoding `read_xdmf` accepts (dolfinx: `XDMFFile(..., encoding=XDMFFile.Encoding.ASCII)`)."""
     path = Path(path)
     p, t = np.asarray(mesh.geometry), np.asarray(mesh.cells)
+    ttype, npe = "Tetrahedron", 4
+    if getattr(mesh, "midside", None) is not None:  # order-2 geometry: Tetrahedron_10 in XDMF / VTK node order, mid-edge nodes appended
+        e = mesh.edges()
+        nv = len(p)
+        key = e[:, 0] * nv + e[:, 1]
+        mids = []
+        for a, b in ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)):
+            pr = np.sort(t[:, [a, b]].astype(np.int64), axis=1)
+            mids.append(nv + np.searchsorted(key, pr[:, 0] * nv + pr[:, 1]))
+        t = np.concatenate([t, np.stack(mids, axis=1)], axis=1)
+        p = np.concatenate([p, mesh.midside])
+        ttype, npe = "Tetrahedron_10", 10
     tags = sorted(facet_tags._t) if tags is None else list(tags)
     fc = [np.asarray(facet_tags.find(k)) for k in tags]
     allf = np.concatenate(fc) if fc else np.zeros((0, 3), dtype=np.int32)
@@ -285,8 +311,8 @@ def write_xdmf_tet(path, mesh, facet_tags, tags=None, name: str = "mesh", tags_n
     path.parent.mkdir(parents=True, exist_ok=True)
     with open(path, "w") as f:
         f.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n<Grid Name="%s" GridType="Uniform">\n' % name)
-        f.write('<Topology TopologyType="Tetrahedron" NumberOfElements="%d" NodesPerElement="4">\n<DataItem Dimensions="%d 4" NumberType="Int" '
-                'Format="XML">\n%s\n</DataItem></Topology>\n' % (len(t), len(t), "\n".join(" ".join(map(str, c)) for c in t)))
+        f.write('<Topology TopologyType="%s" NumberOfElements="%d" NodesPerElement="%d">\n<DataItem Dimensions="%d %d" NumberType="Int" '
+                'Format="XML">\n%s\n</DataItem></Topology>\n' % (ttype, len(t), npe, len(t), npe, "\n".join(" ".join(map(str, c)) for c in t)))
         f.write('<Geometry GeometryType="XYZ"><DataItem Dimensions="%d 3" Format="XML">\n%s\n</DataItem></Geometry>\n</Grid>\n'
                 % (len(p), "\n".join("%.17g %.17g %.17g" % tuple(x) for x in p)))
         f.write('<Grid Name="%s" GridType="Uniform">\n<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n'

@@ -25,12 +25,53 @@ def _ball_map(p):
     return p * s[:, None]
 
 
-def create_half_sphere(model_name=None, order: int = 1, center=(0.0, 0.0, 0.5), res: float = 0.02, r: float = 0.4, comm=None, rank: int = 0,
+def _untangle(coords, cells, edges, curved, ratio=0.2):
+    """Mid-edge nodes of a valid order-2 tetrahedral mesh: `curved` where the quadratic cell maps allow it.  Where the cube's faces meet,
+    the map to the ball opens a 90 degree dihedral angle to 180 degrees: a tetrahedron with two faces on the surface keeps a positive
+    volume, but its QUADRATIC map can fold once the surface edges bulge outward (33 of 648 cells at res = 0.15).  gmsh untangles such
+    cells by optimisation; here the offset of every edge of an offending cell is halved until det J, sampled at the vertices, the edge
+    midpoints and the degree-5 quadrature points, stays within `ratio` of its maximum over the cell (the mesh stays conforming: an
+    edge has ONE node)."""
+    from . import fem
+    from .signorini import _TET_EDGES
+
+    nv = len(coords)
+    key = edges[:, 0] * nv + edges[:, 1]
+    c = cells.astype(np.int64)
+    ce = np.stack([np.searchsorted(key, np.minimum(c[:, a], c[:, b]) * nv + np.maximum(c[:, a], c[:, b])) for a, b in _TET_EDGES], axis=1)
+    pts = np.concatenate([fem.quadrature_rule("tetrahedron", 5)[0], np.eye(4)[:, 1:], 0.5 * (np.eye(4)[[a for a, _ in _TET_EDGES]] + np.eye(4)[[b for _, b in _TET_EDGES]])[:, 1:]])
+    L = np.concatenate([1.0 - pts.sum(axis=1, keepdims=True), pts], axis=1)
+    gref = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    dN = np.empty((len(L), 10, 3))
+    for a in range(4):
+        dN[:, a] = (4 * L[:, a] - 1)[:, None] * gref[a][None]
+    for k, (a, b) in enumerate(_TET_EDGES):
+        dN[:, 4 + k] = 4 * (L[:, a][:, None] * gref[b][None] + L[:, b][:, None] * gref[a][None])
+    straight = 0.5 * (coords[edges[:, 0]] + coords[edges[:, 1]])
+    x = coords[cells]
+    sgn = np.sign(np.linalg.det(np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 3] - x[:, 0]], axis=2)))
+    theta = np.ones(len(edges))
+    for _ in range(12):
+        mid = straight + theta[:, None] * (curved - straight)
+        X10 = np.concatenate([x, mid[ce]], axis=1)
+        det = np.linalg.det(np.einsum("cad,qak->cqdk", X10, dN)) * sgn[:, None]
+        bad = det.min(axis=1) < ratio * det.max(axis=1)
+        if not bad.any():
+            break
+        theta[np.unique(ce[bad])] *= 0.5
+    else:
+        theta[np.unique(ce[bad])] = 0.0
+    return straight + theta[:, None] * (curved - straight)
+
+
+def create_half_sphere(model_name=None, order: int = 2, center=(0.0, 0.0, 0.5), res: float = 0.02, r: float = 0.4, comm=None, rank: int = 0,
                        sphere_surface: int = 2, flat_surface: int = 1):
     """Half ball of radius `r` below the plane z = center[2] (the reference's geometry, `mesh_generation.py:86-168`): tetrahedra,
     curved surface tagged `sphere_surface` (the potential contact surface of example 02), flat top tagged `flat_surface` (where the
     displacement is prescribed).  Returns (TetMesh, None, MeshTags): the reference's (mesh, cell_tags, facet_tags); the cell tags
-    (one physical volume) carry no information and are not modelled."""
+    (one physical volume) carry no information and are not modelled.  order = 2 (the reference's default, :88): the mid-edge nodes
+    of the 10-node tetrahedra are the images of the grid's edge midpoints under the same map (`mesh.midside`; on the curved surface they
+    lie ON the sphere) - isoparametric P2 in example 02 since round 5; order = 1: vertices only."""
     if order not in (1, 2):
         raise ValueError("order must be 1 or 2")
     n = max(2, 2 * int(np.ceil(np.pi * r / (4.0 * res))))  # a quarter circle of the surface spans n/2 cells of length ~res; even
@@ -49,6 +90,10 @@ def create_half_sphere(model_name=None, order: int = 1, center=(0.0, 0.0, 0.5), 
     cells = np.ascontiguousarray(np.stack([np.stack(t, axis=1) for t in tets], axis=1).reshape(-1, 4), dtype=np.int32)
     coords = np.ascontiguousarray(np.asarray(center, dtype=float)[None, :] + r * _ball_map(P))
     mesh = TetMesh(coords, cells)
+    if order == 2:
+        e = mesh.edges()
+        curved = np.asarray(center, dtype=float)[None, :] + r * _ball_map(0.5 * (P[e[:, 0]] + P[e[:, 1]]))
+        mesh = TetMesh(coords, cells, _untangle(coords, cells, e, curved))
     # exterior facets: flat <=> all three vertices come from the plane z = 0 of the cube (mapped to z = center[2] exactly)
     on_top = np.isclose(P[:, 2], 0.0)
     ext = mesh.facets_where(lambda x: np.ones(x.shape[1], dtype=bool))

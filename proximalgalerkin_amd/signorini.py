@@ -24,10 +24,45 @@ from .problem import ConvergenceError, _SNES
 AlphaScheme = Literal["constant", "linear", "doubling"]
 
 
+_TET_EDGES = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+_TRI_EDGES = ((0, 1), (0, 2), (1, 2))
+
+
 @dataclass
 class TetMesh:
     geometry: np.ndarray  # (nv,3)
     cells: np.ndarray  # (nc,4)
+    # ORDER-2 GEOMETRY (round 5): the geometry's mid-edge node of every edge, edges ordered by their (min, max) vertex pair - the
+    # numbering of `edges()` and of p2_nodes - as a mesh of 10-node tetrahedra carries them (the reference's half sphere:
+    # lvpp/mesh_generation.py:88,158).  None, or every node at its edge's midpoint: affine cells.
+    midside: np.ndarray | None = None
+
+    def __post_init__(self):
+        if self.midside is not None:
+            self.midside = np.ascontiguousarray(self.midside, dtype=np.float64)
+            e = self.edges()
+            if self.midside.shape != (len(e), 3):
+                raise ValueError(f"midside must be (n_edges, 3) = {(len(e), 3)}")
+            straight = 0.5 * (self.geometry[e[:, 0]] + self.geometry[e[:, 1]])
+            length = np.linalg.norm(self.geometry[e[:, 0]] - self.geometry[e[:, 1]], axis=1)
+            if not np.any(np.linalg.norm(self.midside - straight, axis=1) > 1e-13 * length):
+                self.midside = None
+
+    @property
+    def curved(self):
+        return self.midside is not None
+
+    def flattened(self):
+        """the same mesh with affine cells (what a degree-1 run uses)"""
+        return TetMesh(self.geometry, self.cells) if self.curved else self
+
+    def edges(self):
+        """(ne, 2) sorted unique (min, max) vertex pairs - the edge numbering of p2_nodes and of `midside`"""
+        c = self.cells.astype(np.int64)
+        nv = self.geometry.shape[0]
+        pairs = np.sort(np.concatenate([c[:, list(e)] for e in _TET_EDGES]), axis=1)
+        ukey = np.unique(pairs[:, 0] * nv + pairs[:, 1])
+        return np.stack([ukey // nv, ukey % nv], axis=1)
 
     def facets_where(self, pred):
         """Exterior triangles (vertex triples) whose three vertices satisfy pred(x) (locate_entities_boundary, :369-373)."""
@@ -51,13 +86,11 @@ class MeshTags:
         return self._t.get(int(tag), np.zeros((0, 3), dtype=np.int32))
 
 
-_TET_EDGES = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
-_TRI_EDGES = ((0, 1), (0, 2), (1, 2))
 
 
 def p2_nodes(mesh: TetMesh, *facet_sets):
     """Degree-2 node numbering of include/pgx_sg.h: the mesh vertices, then one node per edge (edges ordered by their (min, max)
-    vertex pair), at the edge midpoint.  Returns (node_coords, cells10, [facets6 for every facet set])."""
+    vertex pair), at the edge midpoint (a curved mesh: at the geometry's mid-edge node).  Returns (node_coords, cells10, [facets6 for every facet set])."""
     cells = mesh.cells.astype(np.int64)
     nv = mesh.geometry.shape[0]
     pairs = np.sort(np.concatenate([cells[:, list(e)] for e in _TET_EDGES]), axis=1)
@@ -66,7 +99,8 @@ def p2_nodes(mesh: TetMesh, *facet_sets):
     nc = len(cells)
     cells10 = np.ascontiguousarray(np.concatenate([cells, nv + inv.reshape(6, nc).T], axis=1), dtype=np.int32)
     e0, e1 = ukey // nv, ukey % nv
-    coords = np.ascontiguousarray(np.concatenate([mesh.geometry, 0.5 * (mesh.geometry[e0] + mesh.geometry[e1])]))
+    mid = mesh.midside if getattr(mesh, "midside", None) is not None else 0.5 * (mesh.geometry[e0] + mesh.geometry[e1])
+    coords = np.ascontiguousarray(np.concatenate([mesh.geometry, mid]))  # order-2 geometry: an edge node sits on the mid-edge node
     out = []
     for f in facet_sets:
         f = np.asarray(f, dtype=np.int64).reshape(-1, 3)
@@ -174,13 +208,47 @@ def native_tags(mesh: TetMesh) -> tuple[MeshTags, dict]:
     return MeshTags({1: top, 2: bottom}), {"contact": (2,), "displacement": (1,)}
 
 
+def curved_tables(node_coords, cells10, facets6, cell_qpts, facet_qpts):
+    """The two geometry tables of include/pgx_sg.h `pgx_sg_curved` for a mesh of 10-node tetrahedra: per cell and cell quadrature
+    point |det J| and J^-1 (row-major, d xi_k / d x_d) of x(xi) = sum_a X_a N2_a(xi); per contact facet and facet quadrature point the
+    surface element |x_xi x x_eta| of the 6-node triangle and its z coordinate.  Node orders of p2_nodes."""
+    gref3 = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    L = np.concatenate([1.0 - cell_qpts.sum(axis=1, keepdims=True), cell_qpts], axis=1)
+    dN = np.empty((len(L), 10, 3))
+    for a in range(4):
+        dN[:, a] = (4 * L[:, a] - 1)[:, None] * gref3[a][None]
+    for k, (a, b) in enumerate(_TET_EDGES):
+        dN[:, 4 + k] = 4 * (L[:, a][:, None] * gref3[b][None] + L[:, b][:, None] * gref3[a][None])
+    J = np.einsum("cad,qak->cqdk", node_coords[cells10], dN)
+    det = np.linalg.det(J)
+    if np.any(det.min(axis=1) * det.max(axis=1) <= 0):  # (a cell may be negatively oriented as a whole: |det J| is what enters)
+        raise ValueError("order-2 geometry: the cell map is not orientation preserving at every quadrature point")
+    cgeo = np.ascontiguousarray(np.concatenate([np.abs(det)[..., None], np.linalg.inv(J).reshape(len(cells10), len(L), 9)], axis=2))
+    gref2 = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    L3 = np.stack([1.0 - facet_qpts[:, 0] - facet_qpts[:, 1], facet_qpts[:, 0], facet_qpts[:, 1]], axis=1)
+    N6 = np.concatenate([L3 * (2 * L3 - 1), np.stack([4 * L3[:, a] * L3[:, b] for a, b in _TRI_EDGES], axis=1)], axis=1)
+    dT = np.empty((len(L3), 6, 2))
+    for a in range(3):
+        dT[:, a] = (4 * L3[:, a] - 1)[:, None] * gref2[a][None]
+    for k, (a, b) in enumerate(_TRI_EDGES):
+        dT[:, 3 + k] = 4 * (L3[:, a][:, None] * gref2[b][None] + L3[:, b][:, None] * gref2[a][None])
+    X6 = node_coords[facets6]
+    t = np.einsum("fad,qak->fqdk", X6, dT)
+    ds = np.linalg.norm(np.cross(t[..., 0], t[..., 1]), axis=2)
+    zq = np.einsum("qa,fa->fq", N6, X6[:, :, 2])
+    return cgeo, np.ascontiguousarray(np.stack([ds, zq], axis=2))
+
+
 class SignoriniProblem:
     """x = [u_x | u_y | u_z | psi (contact vertices ordered by vertex id)]."""
 
     def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None, degree=1,
-                 bc_facets=None):
+                 bc_facets=None, cell_quadrature_degree=5):
         """degree 2 (the reference's default): the Dirichlet NODES come from `bc_vertices` if given (node ids of p2_nodes), else from
-        `bc_facets` (the displacement facets: vertices and edge nodes).  State layout [u_x | u_y | u_z | psi] over the P2 nodes."""
+        `bc_facets` (the displacement facets: vertices and edge nodes).  State layout [u_x | u_y | u_z | psi] over the P2 nodes.
+        A CURVED TetMesh (order-2 geometry, `mesh.midside`) with degree 2 is discretised isoparametrically (pgx_sg_create_curved);
+        the cell integrals then use a Gauss-Jacobi rule of degree `cell_quadrature_degree` - the reference leaves that degree to
+        UFL's estimator (2 for the integrand + 3 for det J of a quadratic tetrahedron).  Degree 1 uses the vertices."""
         self._lib = lib = _lib.load()
         self.mesh = mesh
         self.degree = int(degree)
@@ -203,7 +271,7 @@ class SignoriniProblem:
                 raise ValueError("degree 2 needs the Dirichlet nodes or the displacement FACETS (their edge nodes are constrained as well)")
             coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets if bc_vertices is None else np.zeros((0, 3), np.int32))
             bv = (np.unique(bf6.ravel()) if bc_vertices is None else np.asarray(bc_vertices)).astype(np.int64)
-        elif self.degree == 1:
+        elif self.degree == 1:  # (a curved TetMesh: the vertices - affine cells)
             coords, cells = mesh.geometry, mesh.cells
             facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
             bv = np.asarray(bc_vertices, dtype=np.int64)
@@ -219,7 +287,17 @@ class SignoriniProblem:
         pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
                                  _lib.iptr(bc), _lib.dptr(vals))
         self._h = C.c_void_p()
-        if comm is None:
+        curved = self.cell_type == 0 and self.degree == 2 and getattr(mesh, "curved", False)
+        if curved and comm is not None:
+            raise NotImplementedError("order-2 geometry: single handle only (include/pgx_sg.h pgx_sg_create_curved)")
+        if curved:
+            # isoparametric P2 on the 10-node tetrahedra: the library takes the geometry as tables over the quadrature points
+            qp3, qw3 = fem.quadrature_rule("tetrahedron", int(cell_quadrature_degree))
+            cgeo, fgeo = curved_tables(coords, cells, facets, qp3, pts)
+            self._keep_curved = (qp3, qw3, cgeo, fgeo)
+            cv = _lib.pgx_sg_curved(len(qw3), _lib.dptr(qp3), _lib.dptr(qw3), _lib.dptr(cgeo), _lib.dptr(fgeo))
+            rc = lib.pgx_sg_create_curved(C.byref(pm), C.byref(pp), C.byref(cv), int(device), C.byref(self._h))
+        elif comm is None:
             rc = lib.pgx_sg_create(C.byref(pm), C.byref(pp), int(device), C.byref(self._h))
         else:  # one handle per GPU, distributed sparse LU (include/pgx_sg.h); every call below is collective
             self._comm = comm

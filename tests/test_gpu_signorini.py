@@ -108,8 +108,9 @@ def test_half_sphere_through_the_mesh_file_workflow(require_gpu, tmp_path, degre
     if degree == 1:
         prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), np.unique(mt.find(1).ravel()), gap=0.0, disp=disp)
         coords, top = mesh.geometry, np.unique(mt.find(1).ravel())
-    else:
-        prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.0, disp=disp)
+    else:  # the half sphere is an ORDER-2 mesh (the reference's default, mesh_generation.py:88): isoparametric P2 since round 5
+        assert mesh.curved and np.abs(mesh.midside - mesh0.midside).max() == 0.0
+        prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.0, disp=disp, midside=mesh.midside)
         coords, top = prob.node_coords, prob.bc_nodes
     xr, itr, itsr = S.solve_contact_problem(prob)
     assert (it, iterations) == (itr, itsr), (it, iterations, itr, itsr)
@@ -178,6 +179,46 @@ def test_degree2_full_lvpp_run_matches_oracle(require_gpu, n, gap):
     # the degree-2 displacement agrees with the degree-1 one on a finer mesh to discretisation accuracy (independent discretisations)
     uz = x[2 * prob.nv:3 * prob.nv]
     assert abs(uz[prob.bc_nodes] + 0.25).max() == 0.0
+
+
+def test_isoparametric_p2_kernels_on_the_order2_half_sphere_match_the_oracle(require_gpu):
+    """pgx_sg_create_curved (round 5): the ten nodes of a tetrahedron are its geometry nodes, |det J| and J^-1 per quadrature point of a
+    degree-5 cell rule, surface element and z of the 6-node contact facets per facet point - against the oracle with the same map
+    (oracle/sg_oracle.py SignoriniP2(midside=...)) on the natively meshed order-2 half sphere: residual, Jacobian (the elasticity block
+    on its own scale and D(psi) on its own), SpMV <= 1e-12; NOT the affine discretisation's values; the contact surface's area is the
+    sphere's to 3e-3 where the flat facets miss 2e-2."""
+    from proximalgalerkin_amd import mesh_generation
+    from proximalgalerkin_amd import signorini as G
+
+    mesh, _, mt = mesh_generation.create_half_sphere(res=0.15)
+    assert mesh.curved
+    problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.01, -0.1, degree=2, bc_facets=mt.find(1))
+    prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1, midside=mesh.midside)
+    flat = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1)
+    assert problem.ndofs == prob.ntot and np.array_equal(problem.contact_vertices, prob.cverts)
+    assert np.array_equal(problem.node_coords, prob.node_coords)
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal(prob.ntot) * 0.05
+    x[3 * prob.nv:] = -np.abs(rng.standard_normal(prob.npsi)) * np.where(rng.random(prob.npsi) < 0.4, 400.0, 2.0)
+    xk = rng.standard_normal(prob.ntot) * 0.05
+    nu3 = 3 * prob.nv
+    for alpha in (2.0, 64.0):
+        problem.set_alpha(alpha)
+        problem.set_prev(xk)
+        F, fn = problem.residual(x)
+        Fr = prob.residual(x, xk, alpha)
+        assert _rel(F, Fr) < 1e-12 and abs(fn - np.linalg.norm(Fr)) <= 1e-12 * np.linalg.norm(Fr)
+        assert _rel(F, flat.residual(x, xk, alpha)) > 1e-3
+        J = problem.jacobian(x)
+        Jr = prob.jacobian(x, alpha).tocsr()
+        assert abs(J - Jr).max() <= 1e-12 * abs(Jr).max()
+        assert abs(J[nu3:, nu3:] - Jr[nu3:, nu3:]).max() <= 1e-12 * abs(Jr[nu3:, nu3:]).max()
+        assert abs(J[nu3:, :nu3] - Jr[nu3:, :nu3]).max() <= 1e-12 * abs(Jr[nu3:, :nu3]).max()  # the facet mass coupling on its own scale
+        v = rng.standard_normal(prob.ntot)
+        assert _rel(problem.spmv(v), Jr @ v) < 1e-12
+    area = 2 * np.pi * 0.4**2
+    assert abs(prob.MG.sum() - area) < 3e-3 and abs(flat.MG.sum() - area) > 1e-2
+    problem.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------

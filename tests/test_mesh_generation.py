@@ -34,6 +34,41 @@ def test_half_sphere_is_a_valid_tagged_tetrahedral_mesh(tmp_path):
     m2, mt2 = io.read_tet_mesh(path)
     assert np.array_equal(m2.geometry, m.geometry) and np.array_equal(m2.cells, m.cells)
     assert np.array_equal(mt2.find(1), ft.find(1)) and np.array_equal(mt2.find(2), ft.find(2))
+    # ORDER 2 is the default, as in the reference (mesh_generation.py:88): mid-edge nodes ride along, through the file too
+    assert m.curved and m2.curved and np.array_equal(m2.midside, m.midside) and "Tetrahedron_10" in path.read_text()
+    m1 = mesh_generation.create_half_sphere(res=0.05, r=r, center=c, order=1)[0]
+    assert not m1.curved and np.array_equal(m1.geometry, m.geometry) and np.array_equal(m1.cells, m.cells)
+
+
+def test_order2_half_sphere_has_valid_quadratic_cells_and_a_better_volume():
+    """The mid-edge nodes of create_half_sphere(order=2): images of the grid's edge midpoints under the cube -> ball map, pulled back
+    towards the straight midpoint where the quadratic cell map would fold (`_untangle`).  Every cell's det J keeps its sign at the
+    degree-5 quadrature points with a bounded ratio; surface edges that were not pulled back have their node ON the sphere; the
+    volume and the curved area of the quadratic cells beat the flat ones' by a factor that grows under refinement."""
+    from proximalgalerkin_amd import fem, mesh_generation
+    from proximalgalerkin_amd import signorini as G
+
+    r, c = 0.4, np.array([0.0, 0.0, 0.5])
+    gain = []
+    for res in (0.15, 0.08):
+        m, _, ft = mesh_generation.create_half_sphere(res=res, r=r, center=tuple(c))
+        coords, cells10, (f6,) = G.p2_nodes(m, ft.find(2))
+        qp, qw = fem.quadrature_rule("tetrahedron", 5)
+        fq, fw = fem.quadrature_rule("triangle", 4)
+        assert abs(qw.sum() - 1.0 / 6.0) < 1e-15
+        cg, fg = G.curved_tables(coords, cells10, f6, qp, fq)
+        assert cg[:, :, 0].min() > 0.15 * cg[:, :, 0].max(axis=1).min()
+        e = m.edges()
+        on = np.isclose(np.linalg.norm(m.geometry[e] - c, axis=2), r).all(axis=1) & (m.geometry[e][:, :, 2] < c[2] - 1e-12).any(axis=1)
+        dist = np.abs(np.linalg.norm(m.midside[on] - c, axis=1) - r)
+        assert (dist < 1e-12).mean() > 0.5  # most surface edges carry their node on the sphere; the pulled-back ones lie inside
+        assert np.all(np.linalg.norm(m.midside - c, axis=1) <= r * (1 + 1e-12))
+        vol, area = (cg[:, :, 0] * qw).sum(), (fg[:, :, 0] * fw).sum()
+        X = m.geometry[m.cells]
+        vflat = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))).sum() / 6.0
+        gain.append(abs(vflat - 2 / 3 * np.pi * r**3) / abs(vol - 2 / 3 * np.pi * r**3))
+        assert abs(area - 2 * np.pi * r**2) < 3e-3
+    assert gain[0] > 4 and gain[1] > 7, gain
 
 
 def test_half_disk():

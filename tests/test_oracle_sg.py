@@ -68,3 +68,42 @@ def test_lvpp_run_ends_in_contact_without_penetration():
     # rigid plane at z = gap = 0 below a body pushed down by 0.25: the bottom face rests on the plane
     assert np.abs(uz[prob.cverts]).max() < 1e-6
     assert np.allclose(uz[top], -0.25)
+
+
+def test_order2_tetrahedra_in_the_oracle():
+    """SignoriniP2(midside=...): isoparametric P2 on 10-node tetrahedra (round 5).  Straight mid-edge nodes reproduce the affine
+    matrices to rounding (a degree-5 rule integrates the affine cells' quadratic integrand exactly); on the order-2 half sphere the
+    Jacobian is the derivative of the residual, the rigid translations are in the kernel of the elasticity block, and the facet
+    coupling sums to the area of the CURVED contact surface."""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    from proximalgalerkin_amd import mesh_generation
+
+    coords, cells = S.create_unit_cube_tets(2, 2, 1)
+    cf = S.boundary_facets_where(coords, cells, lambda x: np.isclose(x[:, 2], 0.0))
+    bf = S.boundary_facets_where(coords, cells, lambda x: np.isclose(x[:, 2], 1.0))
+    a = S.SignoriniP2(coords, cells, cf, bf)
+    b = S.SignoriniP2(coords, cells, cf, bf, midside=0.5 * (coords[a.edges[:, 0]] + coords[a.edges[:, 1]]))
+    assert abs(a.A - b.A).max() < 1e-13 * abs(a.A).max() and abs(a.MG - b.MG).max() < 1e-15 and abs(a.b_g - b.b_g).max() < 1e-15
+    pts, w = S.tet_gauss_jacobi(5)
+    assert len(w) == 27 and abs(w.sum() - 1 / 6) < 1e-16 and pts.min() > 0 and pts.sum(axis=1).max() < 1
+
+    mesh, _, ft = mesh_generation.create_half_sphere(res=0.2)
+    p = S.SignoriniP2(mesh.geometry, mesh.cells, ft.find(2), ft.find(1), disp=-0.1, midside=mesh.midside)
+    flat = S.SignoriniP2(mesh.geometry, mesh.cells, ft.find(2), ft.find(1), disp=-0.1)
+    assert np.array_equal(p.edges, mesh.edges())
+    area = 2 * np.pi * 0.4**2
+    assert abs(p.MG.sum() - area) < 1.2e-2 < 3e-2 < abs(flat.MG.sum() - area)  # (res 0.2: a third of the surface edges were pulled back)
+    nn = p.nv
+    for i in range(3):  # rigid translations: sigma(const) = 0
+        t = np.zeros(3 * nn)
+        t[i * nn:(i + 1) * nn] = 1.0
+        assert abs(p.A @ t).max() < 1e-9 * abs(p.A).max()
+    rng = np.random.default_rng(5)
+    x, xk = 0.01 * rng.standard_normal(p.ntot), 0.01 * rng.standard_normal(p.ntot)
+    v = rng.standard_normal(p.ntot)
+    v[p.bc] = 0.0
+    eps = 1e-6
+    fd = (p.residual(x + eps * v, xk, 2.0) - p.residual(x - eps * v, xk, 2.0)) / (2 * eps)
+    assert np.linalg.norm(p.jacobian(x, 2.0) @ v - fd) < 1e-7 * np.linalg.norm(fd)
