@@ -66,8 +66,9 @@ typedef struct {
 int pgx_sg_create(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, int device, pgx_sg_handle** out);
 /* ORDER-2 GEOMETRY (round 5): the reference's half sphere is a mesh of 10-node tetrahedra (src/lvpp/mesh_generation.py:88,158
  * `order=2`) and DOLFINx integrates on the curved cells.  With pgx_sg_mesh.degree = 2 the ten nodes of a cell ARE its geometry nodes
- * (`coords` of an edge node = the mesh's mid-edge node instead of the midpoint): the discretisation is isoparametric P2.  The
- * geometry enters through two tables a binding reads off the coordinate element: */
+ * (`coords` of an edge node = the mesh's mid-edge node instead of the midpoint): the discretisation is isoparametric P2; with degree 1
+ * the mesh arrays hold the vertices only (P1 fields on the quadratic cells).  In both cases the geometry itself enters through two
+ * tables a binding reads off the coordinate element: */
 typedef struct {
   int32_t nq;              /* cell quadrature on the reference tetrahedron (weights sum 1/6).  The reference leaves this integral's
                             * degree to UFL's estimator (signorini_dolfinx.py:237-239 has no metadata on dx); <= 512 points */
@@ -77,7 +78,7 @@ typedef struct {
   const double* facet_geo; /* [n_facets][prob->nq][2]: surface element |x_xi x x_eta| of the 6-node contact facet and its z
                             * coordinate at the facet quadrature points of pgx_sg_problem */
 } pgx_sg_curved;
-/* Single handle, tetrahedra, degree 2 only (PGX_EINVAL otherwise; a degree-1 run uses the vertices).  Everything else as pgx_sg_create. */
+/* Single handle, tetrahedra, degree 1 or 2 (PGX_EINVAL otherwise).  Everything else as pgx_sg_create. */
 int pgx_sg_create_curved(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, const pgx_sg_curved* curved, int device,
                          pgx_sg_handle** out);
 /* One handle per GPU over a pgx_comm (BASELINE.json config 5: 4 GPUs).  The ELEMENTS are partitioned (round 4): the cells are cut

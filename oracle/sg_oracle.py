@@ -56,7 +56,10 @@ def boundary_facets_where(coords, cells, pred):
 
 class SignoriniP1:
     def __init__(self, coords, cells, contact_facets, bc_vertices, E=2.0e4, nu=0.3, gap=0.0, disp=-0.25,
-                 quadrature="tri_deg4_gj9"):
+                 quadrature="tri_deg4_gj9", midside=None, cell_quadrature_degree=3):
+        """midside (n_edges, 3), optional: ORDER-2 GEOMETRY (see SignoriniP2) - P1 fields on the quadratic cells and facets of a mesh of
+        10-node tetrahedra; the cell integral by a rule of degree `cell_quadrature_degree` (UFL's estimate: 0 for the integrand of
+        constant reference gradients + 3 for det J)."""
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
@@ -88,6 +91,24 @@ class SignoriniP1:
         GG = np.einsum("cad,cbd->cab", G, G)
         Ae = (lm * np.einsum("cai,cbj->caibj", G, G) + mu * np.einsum("caj,cbi->caibj", G, G)
               + mu * np.einsum("cab,ij->caibj", GG, np.eye(3))) * vol[:, None, None, None, None]
+        self.curved = midside is not None
+        if self.curved:
+            self.edges, self.cells10, self.facets6 = p2_numbering(self.cells, self.facets)
+            self.geom_coords = np.concatenate([self.coords, np.ascontiguousarray(midside, dtype=np.float64)])
+            self.cell_qpts, self.cell_qwts = tet_gauss_jacobi(cell_quadrature_degree)
+            Lc = np.concatenate([1.0 - self.cell_qpts.sum(axis=1, keepdims=True), self.cell_qpts], axis=1)
+            Jq = np.einsum("cad,qak->cqdk", self.geom_coords[self.cells10], _p2_tet_grad(Lc))
+            detq = np.linalg.det(Jq)
+            if np.any(detq.min(axis=1) * detq.max(axis=1) <= 0):
+                raise ValueError("order-2 geometry: the cell map is not orientation preserving at every quadrature point")
+            invq = np.linalg.inv(Jq)
+            self.cell_geo = np.ascontiguousarray(np.concatenate([np.abs(detq)[..., None], invq.reshape(self.nc, -1, 9)], axis=2))
+            Ae = np.zeros_like(Ae)
+            for q in range(len(self.cell_qwts)):
+                Gq = np.einsum("ak,ckd->cad", gref, invq[:, q])
+                GGq = np.einsum("cad,cbd->cab", Gq, Gq)
+                Ae += (self.cell_qwts[q] * np.abs(detq[:, q]))[:, None, None, None, None] * (
+                    lm * np.einsum("cai,cbj->caibj", Gq, Gq) + mu * np.einsum("caj,cbi->caibj", Gq, Gq) + mu * np.einsum("cab,ij->caibj", GGq, np.eye(3)))
         rows = (self.cells[:, :, None, None, None] + self.nv * np.arange(3)[None, None, :, None, None])
         cols = (self.cells[:, None, None, :, None] + self.nv * np.arange(3)[None, None, None, None, :])
         rows, cols = np.broadcast_arrays(rows, cols)
@@ -98,13 +119,21 @@ class SignoriniP1:
         self.wdet = self.farea2[:, None] * self.wq[None]  # (nf,nq)
         Mref = np.einsum("q,qa,qb->ab", self.wq, self.Lq, self.Lq)
         Me = self.farea2[:, None, None] * Mref[None]
+        zq = np.einsum("qa,fa->fq", self.Lq, xf[:, :, 2])
+        if self.curved:
+            X6 = self.geom_coords[self.facets6]
+            t = np.einsum("fad,qak->fqdk", X6, _p2_tri_grad(self.Lq))
+            ds = np.linalg.norm(np.cross(t[..., 0], t[..., 1]), axis=2)
+            self.wdet = ds * self.wq[None]
+            Me = np.einsum("fq,qa,qb->fab", self.wdet, self.Lq, self.Lq)
+            zq = np.einsum("qa,fa->fq", _p2_tri(self.Lq), X6[:, :, 2])
+            self.facet_geo = np.ascontiguousarray(np.stack([ds, zq], axis=2))
         pf = self.v2psi[self.facets]
         self.pf = pf
         r = np.repeat(pf, 3, axis=1).ravel()
         c = np.tile(self.facets, (1, 3)).ravel()
         # MG[psi_a, vertex b] = <N_a, N_b>_Gamma  (npsi x nv)
         self.MG = sp.coo_matrix((Me.ravel(), (r, c)), shape=(self.npsi, self.nv)).tocsr()
-        zq = np.einsum("qa,fa->fq", self.Lq, xf[:, :, 2])
         self.b_g = np.bincount(pf.ravel(), weights=((self.wdet * (zq - self.gap)) @ self.Lq).ravel(), minlength=self.npsi)
         self._rp = np.repeat(pf, 3, axis=1).ravel()
         self._cp = np.tile(pf, (1, 3)).ravel()

@@ -726,24 +726,25 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   int rc_comm = PGX_OK;
   if (e == hipSuccess && nco > 0) {  // (a rank may own no cell at all - fewer cells than ranks: nothing to launch, zero contribution)
     // (the cell kernels below see the OWNED cells only: nco of them, compact)
-    if (NPC == 4) {
+    if (NPC == 4 && !g_sg_curved) {
       hipLaunchKernelGGL(k_sg_const_cells, dim3((nco + 127) / 128), dim3(128), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
-    } else if (NPC == 10 && g_sg_curved) {
-      // isoparametric P2: reference gradients of the ten shape functions at the caller's cell quadrature points (node order of
-      // include/pgx_sg.h: 4 vertices, then the edges (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)), geometry per point from the caller's table
+    } else if ((NPC == 10 || NPC == 4) && g_sg_curved) {
+      // order-2 geometry: reference gradients of the field's shape functions at the caller's cell quadrature points - P2: ten (node
+      // order of include/pgx_sg.h: 4 vertices, then the edges (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)), isoparametric; P1: the four
+      // constant gradients of the barycentric coordinates on the quadratic cells - geometry per point from the caller's table
       const pgx_sg_curved* cv = g_sg_curved;
       const int nqc = cv->nq;
-      std::vector<double> tab((size_t)nqc + (size_t)nqc * 10 * 3);
+      std::vector<double> tab((size_t)nqc + (size_t)nqc * NPC * 3);
       static const double gref[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
       static const int ed[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
       for (int q = 0; q < nqc; ++q) {
         tab[q] = cv->qwts[q];
         const double X = cv->qpts[3 * q], Y = cv->qpts[3 * q + 1], Z = cv->qpts[3 * q + 2];
         const double L[4] = {1.0 - X - Y - Z, X, Y, Z};
-        double* r = tab.data() + nqc + (size_t)q * 10 * 3;
+        double* r = tab.data() + nqc + (size_t)q * NPC * 3;
         for (int a = 0; a < 4; ++a)
-          for (int d = 0; d < 3; ++d) r[3 * a + d] = (4.0 * L[a] - 1.0) * gref[a][d];
-        for (int k = 0; k < 6; ++k)
+          for (int d = 0; d < 3; ++d) r[3 * a + d] = (NPC == 4 ? 1.0 : 4.0 * L[a] - 1.0) * gref[a][d];
+        for (int k = 0; k < (NPC == 10 ? 6 : 0); ++k)
           for (int d = 0; d < 3; ++d) r[3 * (4 + k) + d] = 4.0 * (L[ed[k][0]] * gref[ed[k][1]][d] + L[ed[k][1]] * gref[ed[k][0]][d]);
       }
       double *d_tab = nullptr, *d_geo = nullptr;
@@ -752,7 +753,8 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
       if (e == hipSuccess) tmp.push_back(d_geo), e = hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMemcpy(d_geo, cv->cell_geo, sizeof(double) * 10 * (size_t)nqc * nc, hipMemcpyHostToDevice);
       if (e == hipSuccess)  // (a curved handle is never partitioned: owned cell k IS cell k of the caller's table)
-        hipLaunchKernelGGL(k_sg_const_cells_geo<10>, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, h->mu, h->lmbda, nqc, d_tab, d_geo, st_c);
+        hipLaunchKernelGGL(k_sg_const_cells_geo<(NPC == 10 ? 10 : 4)>, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, h->mu, h->lmbda, nqc,
+                           d_tab, d_geo, st_c);
     } else if (NPC == 10) {
       hipLaunchKernelGGL(k_sg_const_cells_p2, dim3((nco + 63) / 64), dim3(64), 0, h->st, nco, d_cells, h->coords, h->mu, h->lmbda, st_c);
     } else {  // hexahedra: Gauss-Legendre (d + 1)^3 on [0,1]^3, tensor Lagrange reference gradients
@@ -854,10 +856,10 @@ extern "C" int pgx_sg_create(const pgx_sg_mesh* m, const pgx_sg_problem* p, int 
 }
 extern "C" int pgx_sg_create_curved(const pgx_sg_mesh* m, const pgx_sg_problem* p, const pgx_sg_curved* cv, int device,
                                     pgx_sg_handle** out) {
-  if (!m || !cv || m->degree != 2 || m->cell_type != 0 || cv->nq <= 0 || cv->nq > 512 || !cv->qpts || !cv->qwts || !cv->cell_geo ||
+  if (!m || !cv || m->degree < 0 || m->degree > 2 || m->cell_type != 0 || cv->nq <= 0 || cv->nq > 512 || !cv->qpts || !cv->qwts || !cv->cell_geo ||
       (m->n_facets > 0 && !cv->facet_geo)) {
-    g_sg_error = "pgx_sg_create_curved: order-2 geometry is implemented for degree-2 fields on tetrahedra (isoparametric P2: "
-                 "pgx_sg_mesh.degree = 2, cell_type = 0) and needs the cell rule and both geometry tables";
+    g_sg_error = "pgx_sg_create_curved: order-2 geometry is implemented on tetrahedra (pgx_sg_mesh.cell_type = 0, degree 1 or 2) and "
+                 "needs the cell rule and both geometry tables";
     return PGX_EINVAL;
   }
   g_sg_curved = cv;

@@ -243,12 +243,13 @@ class SignoriniProblem:
     """x = [u_x | u_y | u_z | psi (contact vertices ordered by vertex id)]."""
 
     def __init__(self, mesh: TetMesh, contact_facets, bc_vertices, E, nu, gap, disp, quadrature_degree=4, device=0, comm=None, degree=1,
-                 bc_facets=None, cell_quadrature_degree=5):
+                 bc_facets=None, cell_quadrature_degree=None):
         """degree 2 (the reference's default): the Dirichlet NODES come from `bc_vertices` if given (node ids of p2_nodes), else from
         `bc_facets` (the displacement facets: vertices and edge nodes).  State layout [u_x | u_y | u_z | psi] over the P2 nodes.
-        A CURVED TetMesh (order-2 geometry, `mesh.midside`) with degree 2 is discretised isoparametrically (pgx_sg_create_curved);
-        the cell integrals then use a Gauss-Jacobi rule of degree `cell_quadrature_degree` - the reference leaves that degree to
-        UFL's estimator (2 for the integrand + 3 for det J of a quadratic tetrahedron).  Degree 1 uses the vertices."""
+        A CURVED TetMesh (order-2 geometry, `mesh.midside`) is integrated on its quadratic cells and facets (pgx_sg_create_curved):
+        degree 2 isoparametrically, degree 1 with P1 fields on the curved cells; the cell integrals then use a Gauss-Jacobi rule of
+        degree `cell_quadrature_degree` - the reference leaves that degree to UFL's estimator: 2 (degree - 1) for the integrand + 3 for
+        det J of a quadratic tetrahedron, the default here."""
         self._lib = lib = _lib.load()
         self.mesh = mesh
         self.degree = int(degree)
@@ -271,7 +272,7 @@ class SignoriniProblem:
                 raise ValueError("degree 2 needs the Dirichlet nodes or the displacement FACETS (their edge nodes are constrained as well)")
             coords, cells, (facets, bf6) = p2_nodes(mesh, contact_facets, bc_facets if bc_vertices is None else np.zeros((0, 3), np.int32))
             bv = (np.unique(bf6.ravel()) if bc_vertices is None else np.asarray(bc_vertices)).astype(np.int64)
-        elif self.degree == 1:  # (a curved TetMesh: the vertices - affine cells)
+        elif self.degree == 1:
             coords, cells = mesh.geometry, mesh.cells
             facets = np.ascontiguousarray(contact_facets, dtype=np.int32)
             bv = np.asarray(bc_vertices, dtype=np.int64)
@@ -287,13 +288,18 @@ class SignoriniProblem:
         pp = _lib.pgx_sg_problem(float(E), float(nu), float(gap), len(wts), _lib.dptr(pts), _lib.dptr(wts), len(bc),
                                  _lib.iptr(bc), _lib.dptr(vals))
         self._h = C.c_void_p()
-        curved = self.cell_type == 0 and self.degree == 2 and getattr(mesh, "curved", False)
+        curved = self.cell_type == 0 and getattr(mesh, "curved", False)
         if curved and comm is not None:
             raise NotImplementedError("order-2 geometry: single handle only (include/pgx_sg.h pgx_sg_create_curved)")
         if curved:
             # isoparametric P2 on the 10-node tetrahedra: the library takes the geometry as tables over the quadrature points
-            qp3, qw3 = fem.quadrature_rule("tetrahedron", int(cell_quadrature_degree))
-            cgeo, fgeo = curved_tables(coords, cells, facets, qp3, pts)
+            qdeg = 2 * (self.degree - 1) + 3 if cell_quadrature_degree is None else int(cell_quadrature_degree)
+            qp3, qw3 = fem.quadrature_rule("tetrahedron", qdeg)
+            if self.degree == 2:
+                cgeo, fgeo = curved_tables(coords, cells, facets, qp3, pts)
+            else:  # P1 fields: the geometry tables come from the 10-node cells / 6-node facets, the mesh arrays stay the vertices'
+                gcoords, g10, (g6,) = p2_nodes(mesh, facets)
+                cgeo, fgeo = curved_tables(gcoords, g10, g6, qp3, pts)
             self._keep_curved = (qp3, qw3, cgeo, fgeo)
             cv = _lib.pgx_sg_curved(len(qw3), _lib.dptr(qp3), _lib.dptr(qw3), _lib.dptr(cgeo), _lib.dptr(fgeo))
             rc = lib.pgx_sg_create_curved(C.byref(pm), C.byref(pp), C.byref(cv), int(device), C.byref(self._h))

@@ -105,11 +105,12 @@ def test_half_sphere_through_the_mesh_file_workflow(require_gpu, tmp_path, degre
     # the displacement presses the pole slightly below the plane z = 0; the reference's default -0.25 (and -0.12 at degree 2) ends in
     # SNES_DIVERGED_DTOL on this coarse mesh in the oracle as well (full Newton steps, no line search)
     it, iterations, x, cv = G.solve_contact_problem(mesh, mt, bcs, degree=degree, disp=disp, verbose=False, return_solution=True)
+    # the half sphere is an ORDER-2 mesh (the reference's default, mesh_generation.py:88): curved cells and facets since round 5
+    assert mesh.curved and np.abs(mesh.midside - mesh0.midside).max() == 0.0
     if degree == 1:
-        prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), np.unique(mt.find(1).ravel()), gap=0.0, disp=disp)
+        prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), np.unique(mt.find(1).ravel()), gap=0.0, disp=disp, midside=mesh.midside)
         coords, top = mesh.geometry, np.unique(mt.find(1).ravel())
-    else:  # the half sphere is an ORDER-2 mesh (the reference's default, mesh_generation.py:88): isoparametric P2 since round 5
-        assert mesh.curved and np.abs(mesh.midside - mesh0.midside).max() == 0.0
+    else:
         prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.0, disp=disp, midside=mesh.midside)
         coords, top = prob.node_coords, prob.bc_nodes
     xr, itr, itsr = S.solve_contact_problem(prob)
@@ -181,22 +182,30 @@ def test_degree2_full_lvpp_run_matches_oracle(require_gpu, n, gap):
     assert abs(uz[prob.bc_nodes] + 0.25).max() == 0.0
 
 
-def test_isoparametric_p2_kernels_on_the_order2_half_sphere_match_the_oracle(require_gpu):
-    """pgx_sg_create_curved (round 5): the ten nodes of a tetrahedron are its geometry nodes, |det J| and J^-1 per quadrature point of a
-    degree-5 cell rule, surface element and z of the 6-node contact facets per facet point - against the oracle with the same map
-    (oracle/sg_oracle.py SignoriniP2(midside=...)) on the natively meshed order-2 half sphere: residual, Jacobian (the elasticity block
-    on its own scale and D(psi) on its own), SpMV <= 1e-12; NOT the affine discretisation's values; the contact surface's area is the
+@pytest.mark.parametrize("degree", [1, 2])
+def test_curved_cell_kernels_on_the_order2_half_sphere_match_the_oracle(require_gpu, degree):
+    """pgx_sg_create_curved (round 5): |det J| and J^-1 of the quadratic cell map per point of the cell rule (degree 2 (k - 1) + 3),
+    surface element and z of the 6-node contact facets per facet point; degree 2: the ten nodes of a tetrahedron are its geometry nodes
+    (isoparametric), degree 1: P1 fields on the same curved cells - against the oracle with the same map (oracle/sg_oracle.py
+    Signorini*(midside=...)) on the natively meshed order-2 half sphere: residual, Jacobian (the elasticity block, the facet coupling
+    and D(psi) each on its own scale), SpMV <= 1e-12; NOT the affine discretisation's values; the contact surface's area is the
     sphere's to 3e-3 where the flat facets miss 2e-2."""
     from proximalgalerkin_amd import mesh_generation
     from proximalgalerkin_amd import signorini as G
 
     mesh, _, mt = mesh_generation.create_half_sphere(res=0.15)
     assert mesh.curved
-    problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.01, -0.1, degree=2, bc_facets=mt.find(1))
-    prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1, midside=mesh.midside)
-    flat = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1)
+    if degree == 2:
+        problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.01, -0.1, degree=2, bc_facets=mt.find(1))
+        prob = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1, midside=mesh.midside)
+        flat = S.SignoriniP2(mesh.geometry, mesh.cells, mt.find(2), mt.find(1), gap=0.01, disp=-0.1)
+        assert np.array_equal(problem.node_coords, prob.node_coords)
+    else:
+        bv = np.unique(mt.find(1).ravel())
+        problem = G.SignoriniProblem(mesh, mt.find(2), bv, 2.0e4, 0.3, 0.01, -0.1, degree=1)
+        prob = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), bv, gap=0.01, disp=-0.1, midside=mesh.midside)
+        flat = S.SignoriniP1(mesh.geometry, mesh.cells, mt.find(2), bv, gap=0.01, disp=-0.1)
     assert problem.ndofs == prob.ntot and np.array_equal(problem.contact_vertices, prob.cverts)
-    assert np.array_equal(problem.node_coords, prob.node_coords)
     rng = np.random.default_rng(14)
     x = rng.standard_normal(prob.ntot) * 0.05
     x[3 * prob.nv:] = -np.abs(rng.standard_normal(prob.npsi)) * np.where(rng.random(prob.npsi) < 0.4, 400.0, 2.0)
