@@ -93,7 +93,7 @@ int pgx_gc_jacobian_fill(pgx_gc_handle* h, const double* x);
 /* mixed CSR matrix of the last fill (BC rows/cols of u = identity); NULL arrays -> sizes only */
 int pgx_gc_csr_export(pgx_gc_handle* h, int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* col, double* vals);
 int pgx_gc_spmv(pgx_gc_handle* h, const double* x, double* y);
-/* opts: snes_* and ksp_rtol (true relative residual of the refined LU solve; 0 = 1e-12), ksp_max_it (refinement steps) */
+/* opts: snes_* and ksp_rtol (true relative residual of the refined LU solve; 0 = 1e-10, the target of example 01's Newton solves; 1e-12 until round 5), ksp_max_it (refinement steps) */
 int pgx_gc_newton_solve(pgx_gc_handle* h, const pgx_snes_opts* opts, int* reason, int* its, int* lin_its);
 int pgx_gc_l2_increment(pgx_gc_handle* h, double* out); /* || u - u_prev ||_L2 */
 /* accumulated device ms since the last reset: [0] residual [1] jacobian [2] LU factor [3] LU solves [4] spmv [5] total */

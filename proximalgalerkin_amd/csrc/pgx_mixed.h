@@ -293,7 +293,7 @@ static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_
     *relres = 0.0;
     return PGX_OK;
   }
-  const double tol = o->ksp_rtol > 0.0 ? o->ksp_rtol : 1e-12;
+  const double tol = o->ksp_rtol > 0.0 ? o->ksp_rtol : 1e-10;
   const int maxit = std::max(1, std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 6, 20));
   auto lusolve = [&](const double* rhs, double* out) -> int {
     MxTimer t(h, 3);
@@ -334,7 +334,7 @@ static int mx_newton_linear(MixedBase* h, const pgx_snes_opts* opts, int newton_
   int rc;
   *ns = 0;
   if (h->lazy_lu && newton_it > 0 && h->lu_factored && !h->stale_failed) {
-    const double tol = opts->ksp_rtol > 0.0 ? opts->ksp_rtol : 1e-12;
+    const double tol = opts->ksp_rtol > 0.0 ? opts->ksp_rtol : 1e-10;
     double bnorm = 0;
     if ((rc = mx_norm(h, h->rhs, &bnorm))) return rc;
     if (bnorm > 0.0 && std::isfinite(bnorm)) {
