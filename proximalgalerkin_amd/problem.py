@@ -203,6 +203,8 @@ class NonlinearProblem:
         h = C.c_void_p()
         self.partition = part = getattr(mesh, "partition", None)
         if part is None and lu_comm is not None:
+            if getattr(mesh, "curved", False):
+                raise NotImplementedError("order-2 geometry runs on a single handle (pgx_create_curved); mesh.flattened() gives the affine cells")
             self._lu_comm = lu_comm
             rc = lib.pgx_create_lu_dist(C.byref(pm), C.byref(pp), lu_comm._c, int(device), C.byref(h))
             _lib.check(lib, None, rc, "pgx_create_lu_dist")
