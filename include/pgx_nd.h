@@ -71,6 +71,17 @@ int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st);
 int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device);
 /* x = A^{-1} b; b, x device pointers (on_device != 0) or host; b == x allowed. */
 int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
+/* SYMMETRIC matrices (round 5): the Newton matrices of examples 01 and 06 are symmetric indefinite saddle-point matrices, that of
+ * example 02 becomes one when the rows of the latent block are negated.  After pgx_nd_set_symmetric(s, 1) pgx_nd_factor reads the
+ * caller's values as those of a symmetric matrix (both triangles still passed, the pattern is the general one) and computes
+ * L D L^T in LU clothing: half the flops - the U panels are written as scaled transposes of the L panels, the Schur updates run on
+ * the tiles on and below the diagonal.  The factors it stores and pgx_nd_solve are those of the general path (same accuracy class:
+ * no pivoting across blocks either way).  The request is honoured on a single-rank handle with the default schedule and silently
+ * ignored otherwise (pgx_nd_is_symmetric tells); a matrix that is NOT symmetric gets the factorisation of its lower triangle's
+ * symmetric completion - wrap the solve in refinement on the exact operator, as every caller in this library does.
+ * Replaces: -pc_factor_mat_solver_type mumps with -mat_mumps_sym / MatSetOption(A, MAT_SYMMETRIC, PETSC_TRUE). */
+int pgx_nd_set_symmetric(pgx_nd* s, int on);
+int pgx_nd_is_symmetric(const pgx_nd* s);
 /* accumulated device time of the last factor / solve calls in ms (HIP events; 0 until pgx_nd_timing(s,1)) */
 int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
 

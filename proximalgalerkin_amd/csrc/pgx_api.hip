@@ -2512,6 +2512,9 @@ static int ensure_lu(pgx_handle* h) {
     h->lu = nullptr;
     return rc;
   }
+  // [[alpha K, M], [M, -D(psi)]] with identity Dirichlet rows AND columns is symmetric: L D L^T in LU clothing, half the flops
+  // (include/pgx_nd.h; ignored on a distributed handle); the factorisation preconditions FGMRES on the exact operator either way
+  pgx_nd_set_symmetric(h->lu, 1);
   DALLOC(h->Jmix, 4 * (size_t)nnz);
   return PGX_OK;
 }

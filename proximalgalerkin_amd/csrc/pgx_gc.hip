@@ -662,6 +662,8 @@ static int gc_create_impl(pgx_gc_handle* h, const pgx_mesh* m, const pgx_gc_prob
     h->lu = nullptr;
     return rc;
   }
+  // the Newton matrix [[alpha K, G^T], [G, -N(psi)]] is symmetric (indefinite): L D L^T in LU clothing, half the flops (pgx_nd.h)
+  pgx_nd_set_symmetric(h->lu, 1);
   GCALLOC(h->coords, 2 * (size_t)nv);
   GCALLOC(h->cdofs, 6 * (size_t)nc);
   GCALLOC(h->mask, n2);
@@ -897,6 +899,7 @@ static int gcg_create_impl(pgx_gc_handle* h, const pgx_gc_spaces* sp, const pgx_
     h->lu = nullptr;
     return rc;
   }
+  pgx_nd_set_symmetric(h->lu, 1);  // (symmetric Newton matrix, as above)
   const int nq = p->nq;
   GCALLOC(h->coords, 2 * (size_t)nvert);
   GCALLOC(h->cells3, 3 * (size_t)nc);

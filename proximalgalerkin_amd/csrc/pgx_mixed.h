@@ -42,6 +42,12 @@ struct MixedBase {
   // NEVER pays on these problems - 0 of 36 stale attempts converged within 10 iterations on example 06 at 1024^2 (13.8 -> 16.8 s),
   // 0 of 3 on example 02 at 70^3: between two Newton iterates the latent block N(psi) / D(psi) moves by orders of magnitude
   // where the constraint switches, and the 1e-12 true-residual bar leaves a stale factorisation no room.
+  // Symmetrisation for the sparse LU (round 5): rows >= lu_flip_from of the Newton matrix are NEGATED on the way into pgx_nd_factor and
+  // the same rows of every right-hand side on the way into pgx_nd_solve - x = J^-1 b = (S J)^-1 (S b), S = diag(I, -I).  Example 02's
+  // [[alpha A, M_G^T], [-M_G, D]] becomes the symmetric [[alpha A, M_G^T], [M_G, -D]], which the LU factorises at half the flops
+  // (pgx_nd_set_symmetric).  -1: off.  The rows are the last ones of the CSR, so their values are one contiguous range.
+  int64_t lu_flip_from = -1;
+  double* lu_flip_buf = nullptr;
   int lazy_lu = 0, lazy_budget = 10;
   bool lu_factored = false, stale_failed = false;
   long lazy_hits = 0, lazy_misses = 0, lazy_its = 0;
@@ -274,6 +280,38 @@ static int mx_out(MixedBase* h, double* dst, const double* src, int64_t len = 0)
   return PGX_OK;
 }
 
+static __global__ void k_mx_negate(int64_t len, double* __restrict__ v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) v[i] = -v[i];
+}
+static __global__ void k_mx_copy_flip(int64_t len, int64_t from, const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) y[i] = i >= from ? -x[i] : x[i];
+}
+// pgx_nd_factor of the current Jacobian / pgx_nd_solve, through the row flip of MixedBase::lu_flip_from
+static int mx_lu_factor(MixedBase* h) {
+  if (h->lu_flip_from < 0 || h->lu_flip_from >= h->ntot) return pgx_nd_factor(h->lu, h->Jv, 1);
+  const int64_t k0 = h->h_rowptr[h->lu_flip_from], len = h->nnz - k0;
+  // in place, stream-ordered: negate the tail rows, enqueue the factorisation (every kernel that reads the values is enqueued
+  // inside the call), negate back - the exact operator of the refinement keeps its signs
+  if (len > 0) hipLaunchKernelGGL(k_mx_negate, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, len, h->Jv + k0);
+  const int rc = pgx_nd_factor(h->lu, h->Jv, 1);
+  if (len > 0) hipLaunchKernelGGL(k_mx_negate, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, len, h->Jv + k0);
+  return rc;
+}
+static int mx_lu_solve(MixedBase* h, const double* rhs, double* out) {
+  if (h->lu_flip_from < 0 || h->lu_flip_from >= h->ntot) return pgx_nd_solve(h->lu, rhs, out, 1);
+  if (!h->lu_flip_buf) {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(double) * (size_t)h->ntot) != hipSuccess) return PGX_ENOMEM;
+    h->allocs.push_back(q);
+    h->lu_flip_buf = (double*)q;
+  }
+  hipLaunchKernelGGL(k_mx_copy_flip, dim3((unsigned)((h->ntot + 255) / 256)), dim3(256), 0, h->st, h->ntot, h->lu_flip_from, rhs,
+                     h->lu_flip_buf);
+  return pgx_nd_solve(h->lu, h->lu_flip_buf, out, 1);
+}
+
 // dx = J^{-1} b by LU + iterative refinement on the exact operator; returns the true relative residual
 static int mx_dot(MixedBase* h, const double* a, const double* b, double* out);
 static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, double tol, int* nsolves, double* relres,
@@ -297,7 +335,7 @@ static int mx_linear_solve(MixedBase* h, const double* b, double* dx, const pgx_
   const int maxit = std::max(1, std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 6, 20));
   auto lusolve = [&](const double* rhs, double* out) -> int {
     MxTimer t(h, 3);
-    int r2 = pgx_nd_solve(h->lu, rhs, out, 1);
+    int r2 = mx_lu_solve(h, rhs, out);
     if (r2) h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
     return r2;
   };
@@ -355,7 +393,7 @@ static int mx_newton_linear(MixedBase* h, const pgx_snes_opts* opts, int newton_
   }
   {
     MxTimer t(h, 2);
-    rc = pgx_nd_factor(h->lu, h->Jv, 1);
+    rc = mx_lu_factor(h);
   }
   if (rc) {
     h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
@@ -523,7 +561,7 @@ static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, 
     for (int j = 0; j < max_m; ++j) {
       {
         MxTimer t(h, 3);
-        if ((rc = pgx_nd_solve(h->lu, V(j), h->z, 1))) {
+        if ((rc = mx_lu_solve(h, V(j), h->z))) {
           h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
           return rc;
         }
@@ -566,7 +604,7 @@ static int mx_gmres_lu(MixedBase* h, const double* b, double* dx, double bnorm, 
     for (int i = 1; i < k; ++i) mx_axpby(h, y[i], V(i), 1.0, h->r);
     {
       MxTimer t(h, 3);
-      if ((rc = pgx_nd_solve(h->lu, h->r, h->z, 1))) {
+      if ((rc = mx_lu_solve(h, h->r, h->z))) {
         h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
         return rc;
       }
@@ -615,7 +653,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
     h->jacobian_dev(h->xw);
     {
       MxTimer t(h, 2);
-      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+      rc = mx_lu_factor(h);
     }
     if (rc) {
       h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);
@@ -763,7 +801,7 @@ static int mx_newton_solve_bt(MixedBase* h, const pgx_snes_opts* opts, int* reas
     h->jacobian_dev(h->xw);
     {
       MxTimer t(h, 2);
-      rc = pgx_nd_factor(h->lu, h->Jv, 1);
+      rc = mx_lu_factor(h);
     }
     if (rc) {
       h->err = std::string("direct solver: ") + pgx_nd_last_error(h->lu);

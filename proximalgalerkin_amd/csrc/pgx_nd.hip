@@ -146,6 +146,14 @@ struct pgx_nd {
   int outer = 512;          // PGX_ND_OUTER: pivots per outer block = rank of the trailing updates (multiple of 64).  512 since round 5: with
                             // left-looking steps inside the block, ex 02 at 70^3 990 -> 965 ms, ex 06 at 1024^2 100.1 -> 99.5 ms against 256
                             // on the same box (768 / 1024: within 0.5 %); with round 2`s right-looking strips 512 had lost on ex 06
+  // SYMMETRIC MODE (round 5, pgx_nd_set_symmetric): the caller's matrix is symmetric (A = A^T; indefinite is fine - there is no pivoting
+  // across blocks either way).  The factorisation is then L D L^T in LU clothing: U12 = D11 L21^T is written by the panel kernel as the
+  // scaled transpose of the L panel it has just solved - no U panel solve, no assembly of the pivot rows right of the pivot block -, the
+  // updates of the pivot block run on its lower part (block columns instead of L-shaped regions) and the Schur updates on the tiles on
+  // and below the diagonal; every gather of a child's Schur block reads (row, col) at (max, min).  Half the flops of the factorisation;
+  // the compact store and the solve phase are unchanged (U is materialised).  PGX_ND_SYM=0 ignores the request (A/B).
+  int sym = 0;
+  bool sym_allowed = true;
   int tile_order = 1;       // PGX_ND_TILEORDER=0: plain blockIdx -> tile mapping in the GEMM kernels (A/B; pgx_nd_gemm.h nd_block_tile)
   bool leftlook = true;     // PGX_ND_LEFTLOOK=0: right-looking rank-64 strip updates inside an outer block (A/B)
   bool trsv_big = true;     // PGX_ND_TRSV_BIG=0: k_nd_trsv for the batches of few large fronts too (A/B)
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, int P, con
                                                    const int32_t* __restrict__ child1, const int32_t* __restrict__ fM,
                                                    const int32_t* __restrict__ fP, const int64_t* __restrict__ fbase,
                                                    const int64_t* __restrict__ vbase, const int32_t* __restrict__ inv0,
-                                                   const int32_t* __restrict__ inv1, double* __restrict__ arena) {
+                                                   const int32_t* __restrict__ inv1, double* __restrict__ arena, int sym) {
   const int64_t f = f0 + blockIdx.x;
   const int c0 = child0[f], c1 = child1[f];
   double* F = arena + fbase[f];
@@ -841,7 +849,9 @@ __global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, int P, con
   if (c1 >= 0) M1 = fM[c1], S1 = arena + fbase[c1] + (int64_t)fP[c1] * M1 + fP[c1];
   // the FRAME of the front only: the P pivot columns whole, then the pivot rows of the B border columns; the border block is
   // assembled by the Schur update itself (GATHER variants of the GEMM kernels)
-  const unsigned uM = (unsigned)M, uP = (unsigned)P, mp = uM * uP, total = mp + uP * (uM - uP), step = gridDim.y * blockDim.x;
+  // (symmetric mode: the pivot columns only - the pivot rows right of the pivot block are never read, U12 = D L21^T - and a child's
+  // entry (row, col) from (max, min): only the lower triangles of Schur blocks are valid)
+  const unsigned uM = (unsigned)M, uP = (unsigned)P, mp = uM * uP, total = sym ? mp : mp + uP * (uM - uP), step = gridDim.y * blockDim.x;
   for (unsigned e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += step) {
     unsigned c, r;
     if (e < mp) {
@@ -853,11 +863,19 @@ __global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, int P, con
     const unsigned idx = c * uM + r;
     double v = 0.0;
     if (S0) {
-      const int a = I0[c], b = I0[r];
+      int a = I0[c], b = I0[r];
+      if (sym && b < a) {
+        const int t = a;
+        a = b, b = t;
+      }
       if ((a | b) >= 0) v = S0[(int64_t)a * M0 + b];
     }
     if (S1) {
-      const int a = I1[c], b = I1[r];
+      int a = I1[c], b = I1[r];
+      if (sym && b < a) {
+        const int t = a;
+        a = b, b = t;
+      }
       if ((a | b) >= 0) v += S1[(int64_t)a * M1 + b];
     }
     F[idx] = v;
@@ -1214,15 +1232,16 @@ __global__ __launch_bounds__(256) void k_nd_panel_r(double* __restrict__ arena, 
 // LDS layouts (r = equation, m = unknown): column panel r*68 + m, row panel m*80 + r - both fill from memory along lanes
 // and give the A-operand reads (r = l&15, m = 4s + (l>>4)) the minimal two passes.
 __global__ __launch_bounds__(256) void k_nd_panel_m(double* __restrict__ arena, int64_t lev_off, int M, int kb, int nb,
-                                                    int64_t store_off, int P) {
+                                                    int64_t store_off, int P, int sym) {
   __shared__ double Lh[64 * 80];
   double* F = arena + lev_off + (int64_t)blockIdx.x * M * M;
   const int64_t MP = (int64_t)M * P;
   double* S = arena + store_off + (int64_t)blockIdx.x * (MP + (int64_t)P * (M - P));
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, n = l & 15, g = l >> 4;
   const int R = M - kb - nb, nch = (R + ND_TS - 1) / ND_TS;
-  const bool isL = (int)blockIdx.y >= nch;
-  const int o0 = kb + nb + ND_TS * (isL ? (int)blockIdx.y - nch : (int)blockIdx.y);
+  // symmetric mode: the grid holds the nch chunks of the COLUMN panel only; the row panel is its scaled transpose (written below)
+  const bool isL = sym || (int)blockIdx.y >= nch;
+  const int o0 = kb + nb + ND_TS * (sym ? (int)blockIdx.y : (isL ? (int)blockIdx.y - nch : (int)blockIdx.y));
   const int wd = min(ND_TS, M - o0);
   const double* Dg = S + (int64_t)kb * M + kb;
   const int sr = isL ? 68 : 1, sm = isL ? 1 : 80;
@@ -1300,13 +1319,23 @@ __global__ __launch_bounds__(256) void k_nd_panel_m(double* __restrict__ arena, 
         const int p = 16 * a + g + 4 * q;
         if (p < nb) S[sbase + p * pstr] = acc[a][q];
       }
+    if (sym) {  // U12 = D11 L21^T: entry (pivot kb + p, column c) = u_pp * L(c, kb + p), at the row panel's place in the store
+      const int64_t ubase = c < P ? (int64_t)c * M + kb : MP + (int64_t)(c - P) * P + kb;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = 16 * a + g + 4 * q;
+          if (p < nb) S[ubase + p] = Dg[(int64_t)p * M + p] * acc[a][q];
+        }
+    }
   }
 }
 
 static void nd_launch_panel(int kind, hipStream_t q, unsigned count, unsigned nch, double* arena, int64_t woff, int M, int kb,
-                            int nb, int64_t poff, int P) {
+                            int nb, int64_t poff, int P, int sym = 0) {
   if (kind == 0) {
-    hipLaunchKernelGGL(k_nd_panel_m, dim3(count, 2 * nch), dim3(256), 0, q, arena, woff, M, kb, nb, poff, P);
+    hipLaunchKernelGGL(k_nd_panel_m, dim3(count, sym ? nch : 2 * nch), dim3(256), 0, q, arena, woff, M, kb, nb, poff, P, sym);
     return;
   }
   if (kind == 1) {
@@ -1740,11 +1769,19 @@ __global__ __launch_bounds__(64) void k_nd_leaf(double* __restrict__ arena, int6
       }
       double v = 0.0;
       if (g.S0) {
-        const int a = g.I0[c], b = g.I0[r];
+        int a = g.I0[c], b = g.I0[r];
+        if (gc.sym && b < a) {  // symmetric mode: (row, col) of a child's Schur block from (max, min)
+          const int t = a;
+          a = b, b = t;
+        }
         if ((a | b) >= 0) v = g.S0[(int64_t)a * g.M0 + b];
       }
       if (g.S1) {
-        const int a = g.I1[c], b = g.I1[r];
+        int a = g.I1[c], b = g.I1[r];
+        if (gc.sym && b < a) {
+          const int t = a;
+          a = b, b = t;
+        }
         if ((a | b) >= 0) v += g.S1[(int64_t)a * g.M1 + b];
       }
       T[e] = v;
@@ -2134,6 +2171,7 @@ static int nd_create_impl(const pgx_nd_matrix* A, pgx_comm* comm, int device, vo
   if (const char* e = pgx_tune("PGX_ND_TRSV_BIG")) s->trsv_big = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_LEFTLOOK")) s->leftlook = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_TILEORDER")) s->tile_order = atoi(e) != 0;
+  if (const char* e = pgx_tune("PGX_ND_SYM")) s->sym_allowed = atoi(e) != 0;
   if (const char* e = pgx_tune("PGX_ND_OUTER")) s->outer = std::max(64, (atoi(e) / 64) * 64);
   if (s->trsv_big && hipFuncSetAttribute((const void*)k_nd_trsv_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_BIG_LDS) != hipSuccess) {
     (void)hipGetLastError();
@@ -2256,6 +2294,17 @@ extern "C" int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st) {
   return PGX_OK;
 }
 
+extern "C" int pgx_nd_set_symmetric(pgx_nd* s, int on) {
+  if (!s) return PGX_EINVAL;
+  // eligible: the parent-centric (gather) assembly on ONE rank with the uncut schedule and the MFMA panel kernel - everything the
+  // configurations of BASELINE.json run; otherwise the request is ignored and the general LU runs (pgx_nd_is_symmetric tells)
+  const bool ok = s->sym_allowed && s->device >= 0 && s->size == 1 && s->kcut < 0 && s->gather && s->d_inv[0] && s->d_inv[1] && s->panel_kind == 0;
+  s->sym = (on && ok) ? 1 : 0;
+  s->factored = false;
+  return PGX_OK;
+}
+extern "C" int pgx_nd_is_symmetric(const pgx_nd* s) { return s ? s->sym : 0; }
+
 extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms) {
   if (!s) return PGX_EINVAL;
   if (factor_ms) *factor_ms = s->factor_ms;
@@ -2339,21 +2388,28 @@ static void nd_join(pgx_nd* s, int nused) {
 
 // cgather: C is not read but assembled from the children's Schur blocks (the border block of a parent-centrically assembled front)
 static void nd_launch_gemm(pgx_nd* s, hipStream_t q, const NdLevel& Lv, int r0, int r1, int c0, int c1, int k0, int k1,
-                           bool cgather = false) {
+                           bool cgather = false, int symskip = 0) {
   if (r1 <= r0 || c1 <= c0 || k1 <= k0) return;
   const int M = Lv.P + Lv.B;
   const bool big = (r1 - r0) >= 256 && (c1 - c0) >= 256;
   const int TS = big ? 128 : 64;
-  const dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
-  NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
+  dim3 grid((unsigned)Lv.count, (unsigned)((r1 - r0 + TS - 1) / TS), (unsigned)((c1 - c0 + TS - 1) / TS));
+  if (symskip > 0) {  // symmetric mode: only the tiles on / below the (band) diagonal are launched (pgx_nd_gemm.h nd_sym_tile)
+    const int nlow = nd_sym_tiles((int)grid.y, (int)grid.z, symskip - 1);
+    if (nlow <= 65535)
+      grid = dim3((unsigned)Lv.count, (unsigned)nlow, 1);
+    else
+      symskip = -symskip;
+  }
+  NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase, s->sym};
   if (big && cgather)
-    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
+    hipLaunchKernelGGL(k_nd_gemm8<true>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order, symskip);
   else if (big)
-    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
+    hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order, symskip);
   else if (cgather)
-    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
+    hipLaunchKernelGGL((k_nd_gemm<2, true>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order, symskip);
   else
-    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order);
+    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, r0, r1, c0, c1, k0, k1, Lv.poff, Lv.P, gc, -1, s->tile_order, symskip);
 }
 
 extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
@@ -2400,7 +2456,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 2048));
       while ((int64_t)gy * Lv.count > (int64_t)1 << 22 && gy > 1) gy /= 2;
       hipLaunchKernelGGL(k_nd_gather, dim3((unsigned)Lv.count, gy), dim3(256), 0, s->st, Lv.start, M, Lv.P, s->d_child0, s->d_child1, s->d_fM,
-                         s->d_fP, s->d_fbase, s->d_vbase, s->d_inv[0], s->d_inv[1], s->arena);
+                         s->d_fP, s->d_fbase, s->d_vbase, s->d_inv[0], s->d_inv[1], s->arena, s->sym);
     }
     if (G.nz1 > G.nz0) {
       int blocks = (int)std::min<int64_t>((G.nz1 - G.nz0 + 255) / 256, 256 * 64);
@@ -2437,7 +2493,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
         // one wave per front: assemble in LDS, eliminate in registers; a leaf writes factors + Schur block once, a front with
         // children its factors - its border block comes from the GATHER Schur update below
         const size_t lds = ((size_t)M * P + (size_t)P * B) * sizeof(double);
-        const NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase};
+        const NdGatherCtx gc{Lv.start, s->d_child0, s->d_child1, s->d_fM, s->d_fP, s->d_inv[0], s->d_inv[1], s->d_fbase, s->d_vbase, s->sym};
 #define ND_LEAF(TWO, CH)                                                                                                          \
   hipLaunchKernelGGL((k_nd_leaf<TWO, CH>), dim3((unsigned)Lv.count), dim3(64), lds, q, s->arena, Lv.woff, Lv.poff, Lv.start, M, P, \
                      s->d_fp, s->d_leaf_ptr, s->d_leaf_loc, s->d_leaf_src, dv, s->d_info, gc)
@@ -2451,7 +2507,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
             ND_LEAF(true, true);
           else
             ND_LEAF(false, true);
-          if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, true);
+          if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, true, s->sym ? 1 : 0);
         }
 #undef ND_LEAF
         continue;
@@ -2471,8 +2527,15 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           hipLaunchKernelGGL(k_nd_diag, dim3((unsigned)Lv.count), dim3(256), 0, q, s->arena, Lv.woff, M, kb, nb, s->d_info, Lv.poff, P);
           if (M - ke > 0) {
             const unsigned nch = (unsigned)((M - ke + ND_TS - 1) / ND_TS);
-            nd_launch_panel(s->panel_kind, q, (unsigned)Lv.count, nch, s->arena, Lv.woff, M, kb, nb, Lv.poff, P);
-            if (s->leftlook) {
+            nd_launch_panel(s->panel_kind, q, (unsigned)Lv.count, nch, s->arena, Lv.woff, M, kb, nb, Lv.poff, P, s->sym);
+            if (s->sym) {
+              // symmetric, left-looking: the next step reads its diagonal block and its block COLUMN only - rows [ke, M) x columns
+              // [ke, kn), a rectangle (the block row is the scaled transpose the panel kernel writes)
+              if (st + 1 < nsteps) {
+                const int kn = ke + (W / nsteps + (st + 1 < W % nsteps ? 1 : 0));
+                nd_launch_gemm(s, q, Lv, ke, M, ke, kn, ob, ke);
+              }
+            } else if (s->leftlook) {
               // LEFT-LOOKING inside the outer block (round 5): only what the NEXT 64-pivot step reads is brought up to date - its block
               // row [ke, kn) x [ke, M) and block column [kn, M) x [ke, kn), ONE launch over that L-shaped region - with ALL the pivots
               // of the outer block eliminated so far (K = [ob, ke): rank 64, 128, 192).  The right-looking form updated the whole
@@ -2482,7 +2545,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
                 const int kn = ke + (W / nsteps + (st + 1 < W % nsteps ? 1 : 0));
                 const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(64, ke, M, kn), 1);
                 NdGatherCtx gc{};
-                hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, ke, M, ke, M, ob, ke, Lv.poff, P, gc, kn, s->tile_order);
+                hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, ke, M, ke, M, ob, ke, Lv.poff, P, gc, kn, s->tile_order, 0);
               }
             } else {
               nd_launch_gemm(s, q, Lv, ke, oe, ke, M, kb, ke);  // row strip of the outer block, all remaining columns
@@ -2492,15 +2555,19 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
           kb = ke;
         }
         // trailing matrix beyond the outer block, without the Schur block: one launch over the L-shaped region
-        if (s->lshape && P - oe > 0) {
+        if (s->sym) {
+          // symmetric: the lower part of the pivot block and the columns below it - rows [oe, M) x columns [oe, P) without the tiles more
+          // than one above the diagonal
+          nd_launch_gemm(s, q, Lv, oe, M, oe, P, ob, oe, false, 2);
+        } else if (s->lshape && P - oe > 0) {
           const bool big = (P - oe) >= 256;
           const int TS = big ? 128 : 64;
           const dim3 grid((unsigned)Lv.count, (unsigned)nd_lshape_tiles(TS, oe, M, P), 1);
           NdGatherCtx gc{};
           if (big)
-            hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order);
+            hipLaunchKernelGGL(k_nd_gemm8<false>, grid, dim3(512), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order, 0);
           else
-            hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order);
+            hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, q, s->arena, Lv.woff, M, oe, M, oe, M, ob, oe, Lv.poff, P, gc, P, s->tile_order, 0);
         } else {
           nd_launch_gemm(s, q, Lv, oe, P, oe, P, ob, oe);
           nd_launch_gemm(s, q, Lv, oe, P, P, M, ob, oe);
@@ -2508,7 +2575,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
         }
         ob = oe;
       }
-      if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, cgather);
+      if (B > 0) nd_launch_gemm(s, q, Lv, P, M, P, M, 0, P, cgather, (s->sym && cgather) ? 1 : 0);
     }
     nd_join(s, used);
   };

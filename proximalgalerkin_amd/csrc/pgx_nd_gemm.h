@@ -18,6 +18,8 @@ struct NdGatherCtx {
   int64_t f0;  // first front of the batch
   const int32_t *child0, *child1, *fM, *fP, *inv0, *inv1;
   const int64_t *fbase, *vbase;
+  int sym;  // symmetric mode (pgx_nd_set_symmetric): only the LOWER triangle of a child's Schur block is valid - entry (row, col) is
+            // read at (max, min)
 };
 struct NdGatherSrc {
   const double *S0, *S1;
@@ -200,15 +202,19 @@ __device__ __forceinline__ void nd_gather_epilogue(const NdGatherCtx& gc, const 
       double v0[TI], v1[TI];
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
-        v0[ti] = S0[(a0[ti] | b0[tj][reg]) >= 0 ? c0o + a0[ti] : 0];
-        v1[ti] = S1[(a1[ti] | b1[tj][reg]) >= 0 ? c1o + a1[ti] : 0];
+        // (row a, column b) of the child's block sits at b * M + a; in symmetric mode above the diagonal at a * M + b
+        const int64_t p0 = (gc.sym && a0[ti] < b0[tj][reg]) ? (int64_t)a0[ti] * g.M0 + b0[tj][reg] : c0o + a0[ti];
+        const int64_t p1 = (gc.sym && a1[ti] < b1[tj][reg]) ? (int64_t)a1[ti] * g.M1 + b1[tj][reg] : c1o + a1[ti];
+        v0[ti] = S0[(a0[ti] | b0[tj][reg]) >= 0 ? p0 : 0];
+        v1[ti] = S1[(a1[ti] | b1[tj][reg]) >= 0 ? p1 : 0];
       }
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
         const int i = ri0 + 16 * ti + (l & 15);
         double v = (a0[ti] | b0[tj][reg]) >= 0 ? v0[ti] : 0.0;
         if ((a1[ti] | b1[tj][reg]) >= 0) v += v1[ti];
-        if (i < rmax && j < cmax) F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
+        // (symmetric mode: an entry above the diagonal of the Schur block has no reader - not written)
+        if (i < rmax && j < cmax && !(gc.sym && j > i)) F[(int64_t)j * M + i] = v - acc[tj][ti][reg];
       }
     }
 }
@@ -240,6 +246,43 @@ __device__ __forceinline__ void nd_grouped(int t, int nr, int nc, int& tr, int& 
   const int g = t / (8 * nc), gr = min(8, nr - 8 * g), w = t - g * 8 * nc;
   tc = w / gr;
   tr = 8 * g + (w - tc * gr);
+}
+
+// SYMMETRIC MODE: the tiles (tr, tc) of an nr x nc rectangle of tiles with tc <= tr + band (band 0: on and below the diagonal - a Schur
+// block, read back through (max, min) only; band 1: one tile above it as well - the pivot block, whose diagonal blocks of <= 64 pivots may
+// straddle a tile boundary), numbered for the grouped order of nd_grouped: groups of 8 tile rows, column by column inside a group.
+// Enumerating the allowed tiles - instead of launching the rectangle and returning from the others - keeps the eight XCDs' runs of
+// consecutive tiles equally long (the first version skipped: the XCD that held the last rows of a 119 x 119 triangle had twice the
+// average work and the halved flops showed as no gain at all near the root).  The loops are over <= nr / 8 groups: scalar work.
+__host__ __device__ inline int nd_sym_group_count(int g, int nr, int nc, int band, int& rows_g, int& nfull) {
+  rows_g = nr - 8 * g < 8 ? nr - 8 * g : 8;
+  nfull = 8 * g + band + 1 < nc ? 8 * g + band + 1 : nc;  // columns every row of the group may use
+  int cnt = nfull * rows_g;
+  for (int c = nfull, len = rows_g - 1; c < nc && len > 0; ++c, --len) cnt += len;
+  return cnt;
+}
+__host__ __device__ inline int nd_sym_tiles(int nr, int nc, int band) {
+  int tot = 0, rows_g, nfull;
+  for (int g = 0; 8 * g < nr; ++g) tot += nd_sym_group_count(g, nr, nc, band, rows_g, nfull);
+  return tot;
+}
+__device__ __forceinline__ void nd_sym_tile(int t, int nr, int nc, int band, int& tr, int& tc) {
+  int g = 0, rows_g, nfull;
+  for (;; ++g) {
+    const int cnt = nd_sym_group_count(g, nr, nc, band, rows_g, nfull);
+    if (t < cnt || 8 * (g + 1) >= nr) break;
+    t -= cnt;
+  }
+  if (t < nfull * rows_g) {
+    tc = t / rows_g;
+    tr = 8 * g + (t - tc * rows_g);
+    return;
+  }
+  t -= nfull * rows_g;
+  int c = nfull, len = rows_g - 1;
+  while (t >= len && len > 1) t -= len, ++c, --len;
+  tc = c;
+  tr = 8 * g + (rows_g - len) + t;  // rows of the group with r + band >= c: the last `len` ones
 }
 
 // The trailing update of an outer block in ONE launch (round 5): C is the L-shaped region rows / columns [o, M) of the front without
@@ -276,14 +319,18 @@ __device__ __forceinline__ void nd_lshape_tile(int TS, int t, int o, int M, int 
 // into registers while the current one feeds the matrix cores.
 template <int WT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order) {
+                                                 int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order, int symskip) {
   constexpr int TS = 32 * WT;
   constexpr int NLD = ND_KC * TS / 256;  // elements of each operand a thread stages per chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
   int r0, c0, rmax, cmax, front, t;
   nd_block_tile(order, (int)(gridDim.y * gridDim.z), front, t);
-  if (lsP < 0) {
+  if (symskip > 0) {  // the grid's y extent = nd_sym_tiles(...): only the allowed tiles exist
+    int tr, tc;
+    nd_sym_tile(order ? t : (int)blockIdx.y, (r1g - r0g + TS - 1) / TS, (c1g - c0g + TS - 1) / TS, symskip - 1, tr, tc);
+    r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
+  } else if (lsP < 0) {
     int tr = (int)blockIdx.y, tc = (int)blockIdx.z;
     if (order) nd_grouped(t, (int)gridDim.y, (int)gridDim.z, tr, tc);
     r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
@@ -291,6 +338,8 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
     nd_lshape_tile(TS, order ? t : (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax, order);
   }
   if (r0 >= rmax || c0 >= cmax) return;
+  // symskip < 0: the rectangle is launched whole and the tiles above the band return (fallback for grids beyond 65535 tiles)
+  if (symskip < 0 && c0 > r0 + (-symskip - 1) * TS) return;
   double* F = arena + lev_off + (int64_t)front * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
   const double* S = arena + store_off + (int64_t)front * (MP + (int64_t)P * (M - P));  // A, B: solved panels (compact store)
@@ -362,14 +411,18 @@ __global__ __launch_bounds__(256, 2) void k_nd_gemm(double* __restrict__ arena, 
 // barriers hide behind three others' MFMAs; 1.5x the LDS reads per flop of the 4-wave version, still far from the LDS bound.
 template <bool GATHER>
 __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena, int64_t lev_off, int M, int r0g, int r1g,
-                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order) {
+                                                     int c0g, int c1g, int k0, int k1, int64_t store_off, int P, NdGatherCtx gc, int lsP, int order, int symskip) {
   constexpr int TS = 128, NT = 512;
   constexpr int NLD = ND_KC * TS / NT;  // 4 elements of each operand per thread and chunk
   __shared__ double As[ND_KC][TS + 8];
   __shared__ double Bs[TS][ND_KC + 1];
   int r0, c0, rmax, cmax, front, t;
   nd_block_tile(order, (int)(gridDim.y * gridDim.z), front, t);
-  if (lsP < 0) {
+  if (symskip > 0) {  // the grid's y extent = nd_sym_tiles(...): only the allowed tiles exist
+    int tr, tc;
+    nd_sym_tile(order ? t : (int)blockIdx.y, (r1g - r0g + TS - 1) / TS, (c1g - c0g + TS - 1) / TS, symskip - 1, tr, tc);
+    r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
+  } else if (lsP < 0) {
     int tr = (int)blockIdx.y, tc = (int)blockIdx.z;
     if (order) nd_grouped(t, (int)gridDim.y, (int)gridDim.z, tr, tc);
     r0 = r0g + TS * tr, c0 = c0g + TS * tc, rmax = r1g, cmax = c1g;
@@ -377,6 +430,8 @@ __global__ __launch_bounds__(512, 4) void k_nd_gemm8(double* __restrict__ arena,
     nd_lshape_tile(TS, order ? t : (int)blockIdx.y, r0g, r1g, lsP, r0, c0, rmax, cmax, order);
   }
   if (r0 >= rmax || c0 >= cmax) return;
+  // symskip < 0: the rectangle is launched whole and the tiles above the band return (fallback for grids beyond 65535 tiles)
+  if (symskip < 0 && c0 > r0 + (-symskip - 1) * TS) return;
   double* F = arena + lev_off + (int64_t)front * M * M;  // C: working matrix
   const int64_t MP = (int64_t)M * P;
   const double* S = arena + store_off + (int64_t)front * (MP + (int64_t)P * (M - P));  // A, B: solved panels

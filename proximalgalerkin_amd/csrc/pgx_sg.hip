@@ -676,6 +676,16 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
     h->lu = nullptr;
     return rc;
   }
+  // [[alpha A, M_G^T], [-M_G, D(psi)]] with the rows of the latent block negated is the symmetric [[alpha A, M_G^T], [M_G, -D]]
+  // (the Dirichlet rows AND columns of u are identity / zero): the LU takes it at half the flops (pgx_mixed.h lu_flip_from, pgx_nd.h);
+  // PGX_SG_SYM=0 keeps the general LU of the matrix as UFL's derivative gives it (A/B)
+  {
+    const char* e = pgx_tune("PGX_SG_SYM");
+    if (!(e && atoi(e) == 0) && !comm) {
+      pgx_nd_set_symmetric(h->lu, 1);
+      if (pgx_nd_is_symmetric(h->lu)) h->lu_flip_from = nu;
+    }
+  }
   int32_t* d_cells = nullptr;
   MXALLOC(h->coords, 3 * (size_t)nv);
   MXALLOC(h->facets, NPF * (size_t)nf);

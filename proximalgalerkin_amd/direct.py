@@ -73,6 +73,12 @@ class DirectSolver:
         self._check(self._lib.pgx_nd_timing(self._h, int(enable), C.byref(f), C.byref(s)), "pgx_nd_timing")
         return f.value, s.value
 
+    def set_symmetric(self, on=True):
+        """The matrix is symmetric (indefinite is fine): L D L^T in LU clothing, half the flops of the factorisation (include/pgx_nd.h:
+        pgx_nd_set_symmetric).  Returns whether the handle honours the request (single rank, default schedule)."""
+        self._check(self._lib.pgx_nd_set_symmetric(self._h, int(bool(on))), "pgx_nd_set_symmetric")
+        return bool(self._lib.pgx_nd_is_symmetric(self._h))
+
     def depth_profile(self, enable=None):
         """Device time per TREE DEPTH (0 = root) of the factorisations / forward sweeps / backward sweeps since recording was switched
         on (include/pgx_nd.h: pgx_nd_depth_profile).  enable=True starts (and clears), False stops, None only reads.  Returns

@@ -195,6 +195,7 @@ class GradientConstraintProblem:
         K.sort_indices()
         self.set_alpha(alpha)
         lu = DirectSolver(K.indptr, K.indices, np.arange(n2, dtype=np.int32), self.dof_coords, device=device)
+        lu.set_symmetric(True)  # the stiffness matrix with identity Dirichlet rows and columns
         lu.factor(K.data)
         b = -F[:n2]
         u = lu.solve(b)

@@ -111,6 +111,9 @@ class _MaskedLU:
         self.rows = np.repeat(np.arange(n), np.diff(A.indptr))
         self.diag = self.rows == A.indices
         self.lu = DirectSolver(A.indptr, A.indices, np.arange(n, dtype=np.int32), coords, device=device)
+        # Hessians / stiffness matrices with rows AND columns of the bound set replaced by the identity: symmetric whenever A is
+        if abs(A - A.T).max() <= 1e-12 * abs(A).max():
+            self.lu.set_symmetric(True)
 
     def factor(self, bound: np.ndarray):
         keep = ~(bound[self.rows] | bound[self.A.indices])

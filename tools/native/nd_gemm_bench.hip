@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
   reset();
   {
     dim3 grid(count, (B + 63) / 64, (B + 63) / 64);
-    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, 0);
+    hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, 0, 0);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(ref, arena + lev_off, ws * count * 8, hipMemcpyDeviceToDevice));
   }
@@ -87,11 +87,11 @@ int main(int argc, char** argv) {
     printf("tile order %d\n", order);
     timeit("k_nd_gemm<2> 64x64", [&]() {
       dim3 grid(count, (B + 63) / 64, (B + 63) / 64);
-      hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, order);
+      hipLaunchKernelGGL((k_nd_gemm<2, false>), grid, dim3(256), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, order, 0);
     }, true);
     timeit("k_nd_gemm8 128x128", [&]() {
       dim3 grid(count, (B + 127) / 128, (B + 127) / 128);
-      hipLaunchKernelGGL((k_nd_gemm8<false>), grid, dim3(512), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, order);
+      hipLaunchKernelGGL((k_nd_gemm8<false>), grid, dim3(512), 0, 0, arena, lev_off, M, P, M, P, M, 0, P, store_off, P, gc, -1, order, 0);
     }, true);
   }
   return 0;
