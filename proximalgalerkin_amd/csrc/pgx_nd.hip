@@ -861,6 +861,7 @@ __global__ __launch_bounds__(256) void k_nd_gather(int64_t f0, int M, int P, con
       c = uP + q / uP, r = q - (q / uP) * uP;
     }
     const unsigned idx = c * uM + r;
+    if (sym && r + 64 <= c) continue;  // above every diagonal block (<= 64 pivots wide): the pivot block's upper part has no reader
     double v = 0.0;
     if (S0) {
       int a = I0[c], b = I0[r];
