@@ -78,6 +78,9 @@ int pgx_gc_create(const pgx_mesh* mesh, const pgx_gc_problem* prob, int device, 
 int pgx_gc_create_dist(const pgx_mesh* mesh, const pgx_gc_problem* prob, pgx_comm* comm, int device, pgx_gc_handle** out);
 /* symbolic statistics of the handle's sparse LU (flop counts, arena size: include/pgx_nd.h) */
 int pgx_gc_lu_stats(const pgx_gc_handle* h, pgx_nd_stats* st);
+/* 1: the handle's sparse LU runs in symmetric mode (pgx_nd_set_symmetric: the Newton matrix of example 06 is symmetric) - the
+ * factorisation then executes about half of pgx_nd_stats.flops */
+int pgx_gc_lu_is_symmetric(const pgx_gc_handle* h);
 void pgx_gc_destroy(pgx_gc_handle* h);
 const char* pgx_gc_last_error(const pgx_gc_handle* h);
 int pgx_gc_num_dofs(const pgx_gc_handle* h, int64_t* ntot);

@@ -93,6 +93,8 @@ int pgx_sg_create_dist(const pgx_sg_mesh* mesh, const pgx_sg_problem* prob, pgx_
 int pgx_sg_partition_info(const pgx_sg_handle* h, int64_t* owned_cells, int64_t* total_cells);
 /* symbolic statistics of the handle's sparse LU (flop counts, arena size: include/pgx_nd.h) */
 int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st);
+/* 1: the handle's sparse LU runs in symmetric mode (the latent rows are negated on the way into it: csrc/pgx_mixed.h lu_flip_from) */
+int pgx_sg_lu_is_symmetric(const pgx_sg_handle* h);
 void pgx_sg_destroy(pgx_sg_handle* h);
 const char* pgx_sg_last_error(const pgx_sg_handle* h);
 int pgx_sg_num_dofs(const pgx_sg_handle* h, int64_t* ntot, int64_t* npsi);

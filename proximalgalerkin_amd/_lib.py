@@ -281,6 +281,7 @@ SYMBOLS = [
     ("pgx_gc_create_general", C.c_int, [C.POINTER(pgx_gc_spaces), C.POINTER(pgx_gc_problem), C.c_int, C.POINTER(_H)]),
     ("pgx_gc_create_dist", C.c_int, [C.POINTER(pgx_mesh), C.POINTER(pgx_gc_problem), _COMM, C.c_int, C.POINTER(_H)]),
     ("pgx_gc_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
+    ("pgx_gc_lu_is_symmetric", C.c_int, [_H]),
     ("pgx_gc_destroy", None, [_H]),
     ("pgx_gc_last_error", C.c_char_p, [_H]),
     ("pgx_gc_num_dofs", C.c_int, [_H, c_int64_p]),
@@ -304,6 +305,7 @@ SYMBOLS = [
     ("pgx_sg_create_curved", C.c_int, [C.POINTER(pgx_sg_mesh), C.POINTER(pgx_sg_problem), C.POINTER(pgx_sg_curved), C.c_int, C.POINTER(_H)]),
     ("pgx_sg_partition_info", C.c_int, [_H, c_int64_p, c_int64_p]),
     ("pgx_sg_lu_stats", C.c_int, [_H, C.POINTER(pgx_nd_stats)]),
+    ("pgx_sg_lu_is_symmetric", C.c_int, [_H]),
     ("pgx_sg_destroy", None, [_H]),
     ("pgx_sg_last_error", C.c_char_p, [_H]),
     ("pgx_sg_num_dofs", C.c_int, [_H, c_int64_p, c_int64_p]),

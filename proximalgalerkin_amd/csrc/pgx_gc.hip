@@ -1033,6 +1033,7 @@ extern "C" int pgx_gc_create_dist(const pgx_mesh* m, const pgx_gc_problem* p, pg
   return gc_create(m, p, comm, device, out);
 }
 extern "C" int pgx_gc_lu_stats(const pgx_gc_handle* h, pgx_nd_stats* st) { return h ? pgx_nd_get_stats(h->lu, st) : PGX_EINVAL; }
+extern "C" int pgx_gc_lu_is_symmetric(const pgx_gc_handle* h) { return h ? pgx_nd_is_symmetric(h->lu) : 0; }
 
 #define GCNEED(h)                  \
   if (!(h)) return PGX_EINVAL;     \

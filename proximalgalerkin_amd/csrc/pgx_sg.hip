@@ -884,6 +884,7 @@ extern "C" int pgx_sg_partition_info(const pgx_sg_handle* h, int64_t* owned_cell
   return PGX_OK;
 }
 extern "C" int pgx_sg_lu_stats(const pgx_sg_handle* h, pgx_nd_stats* st) { return h ? pgx_nd_get_stats(h->lu, st) : PGX_EINVAL; }
+extern "C" int pgx_sg_lu_is_symmetric(const pgx_sg_handle* h) { return h ? pgx_nd_is_symmetric(h->lu) : 0; }
 extern "C" int pgx_sg_create_dist(const pgx_sg_mesh* m, const pgx_sg_problem* p, pgx_comm* comm, int device,
                                   pgx_sg_handle** out) {
   if (!comm) {

@@ -396,7 +396,9 @@ class SignoriniProblem:
     def lu_stats(self) -> dict:
         st = _lib.pgx_nd_stats()
         self._check(self._lib.pgx_sg_lu_stats(self._h, C.byref(st)), "pgx_sg_lu_stats")
-        return {k: getattr(st, k) for k, _ in st._fields_}
+        out = {k: getattr(st, k) for k, _ in st._fields_}
+        out["symmetric"] = bool(self._lib.pgx_sg_lu_is_symmetric(self._h))  # L D L^T in LU clothing: about half of `flops` executed
+        return out
 
     def profile(self, enable=True):
         ms = (C.c_double * 6)()
