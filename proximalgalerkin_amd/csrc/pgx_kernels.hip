@@ -2705,7 +2705,9 @@ void pgxk_st_resid_restrict(hipStream_t st, const GridLevel& L, double alpha, co
 // - interior tiles with the scalar stencils, pair sums and no tests, boundary tiles (blocks [0, nbnd), scheduled first)
 // through the general per-point code with Dirichlet rows / columns as identity.
 // ------------------------------------------------------------------------------------------------
-#define PGX_SPMV_RY 24
+#ifndef PGX_SPMV_RY
+#define PGX_SPMV_RY 27  // (round 5: 24 -> 27 image rows per tile: 2508 instead of 2838 workgroups at 2048^2, 49.6-49.9 against 50.4-50.7 us on the same box)
+#endif
 // XF: the iterate comes as ONE interleaved (u, psi) float2 field - what the single-precision V-cycle leaves (round 5: the FGMRES Z_j
 // are outputs of that cycle; stored and re-read as fp64 they were twice the bytes for no information) - xu then points at it
 template <bool XF>
