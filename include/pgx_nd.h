@@ -82,6 +82,10 @@ int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
  * Replaces: -pc_factor_mat_solver_type mumps with -mat_mumps_sym / MatSetOption(A, MAT_SYMMETRIC, PETSC_TRUE). */
 int pgx_nd_set_symmetric(pgx_nd* s, int on);
 int pgx_nd_is_symmetric(const pgx_nd* s);
+/* Test hooks, host arithmetic only (callable without a GPU): the enumeration of the tiles a symmetric GEMM launch computes - the tiles
+ * (tr, tc) of an nr x nc rectangle with tc <= tr + band, in groups of 8 tile rows walked column by column. */
+int pgx_nd_sym_tile_count(int nr, int nc, int band);
+void pgx_nd_sym_tile_at(int t, int nr, int nc, int band, int* tr, int* tc);
 /* accumulated device time of the last factor / solve calls in ms (HIP events; 0 until pgx_nd_timing(s,1)) */
 int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms);
 

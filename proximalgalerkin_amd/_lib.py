@@ -272,6 +272,8 @@ SYMBOLS = [
     ("pgx_nd_depth_profile", C.c_int, [_H, C.c_int, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
     ("pgx_nd_set_symmetric", C.c_int, [_H, C.c_int]),
     ("pgx_nd_is_symmetric", C.c_int, [_H]),
+    ("pgx_nd_sym_tile_count", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("pgx_nd_sym_tile_at", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pgx_nd_export_levels", C.c_int, [_H, c_int64_p, c_int64_p, c_int32_p, c_int32_p, c_int64_p, c_int32_p]),
     ("pgx_nd_export_fronts", C.c_int,
      [_H, c_int64_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int64_p, c_int32_p, c_int64_p, c_int32_p]),

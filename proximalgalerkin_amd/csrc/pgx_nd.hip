@@ -2305,6 +2305,14 @@ extern "C" int pgx_nd_set_symmetric(pgx_nd* s, int on) {
   return PGX_OK;
 }
 extern "C" int pgx_nd_is_symmetric(const pgx_nd* s) { return s ? s->sym : 0; }
+// test hook (host arithmetic only, no GPU): the tile enumeration of the symmetric GEMM launches - number of tiles (tr, tc) of an
+// nr x nc rectangle with tc <= tr + band, and tile number t of that list (pgx_nd_gemm.h)
+extern "C" int pgx_nd_sym_tile_count(int nr, int nc, int band) { return nd_sym_tiles(nr, nc, band); }
+extern "C" void pgx_nd_sym_tile_at(int t, int nr, int nc, int band, int* tr, int* tc) {
+  int a = 0, b = 0;
+  nd_sym_tile(t, nr, nc, band, a, b);
+  *tr = a, *tc = b;
+}
 
 extern "C" int pgx_nd_timing(pgx_nd* s, int enable, double* factor_ms, double* solve_ms) {
   if (!s) return PGX_EINVAL;

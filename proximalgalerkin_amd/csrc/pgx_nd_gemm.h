@@ -266,7 +266,7 @@ __host__ __device__ inline int nd_sym_tiles(int nr, int nc, int band) {
   for (int g = 0; 8 * g < nr; ++g) tot += nd_sym_group_count(g, nr, nc, band, rows_g, nfull);
   return tot;
 }
-__device__ __forceinline__ void nd_sym_tile(int t, int nr, int nc, int band, int& tr, int& tc) {
+__host__ __device__ inline void nd_sym_tile(int t, int nr, int nc, int band, int& tr, int& tc) {
   int g = 0, rows_g, nfull;
   for (;; ++g) {
     const int cnt = nd_sym_group_count(g, nr, nc, band, rows_g, nfull);
