@@ -2297,9 +2297,10 @@ extern "C" int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st) {
 
 extern "C" int pgx_nd_set_symmetric(pgx_nd* s, int on) {
   if (!s) return PGX_EINVAL;
-  // eligible: the parent-centric (gather) assembly on ONE rank with the uncut schedule and the MFMA panel kernel - everything the
+  // eligible: the parent-centric (gather) assembly with the uncut schedule and the MFMA panel kernel, on one rank or distributed (the
+  // Schur blocks of the subtree roots travel whole; rank 0 gathers from them through (max, min) like from any child) - everything the
   // configurations of BASELINE.json run; otherwise the request is ignored and the general LU runs (pgx_nd_is_symmetric tells)
-  const bool ok = s->sym_allowed && s->device >= 0 && s->size == 1 && s->kcut < 0 && s->gather && s->d_inv[0] && s->d_inv[1] && s->panel_kind == 0;
+  const bool ok = s->sym_allowed && s->device >= 0 && s->kcut < 0 && s->gather && s->d_inv[0] && s->d_inv[1] && s->panel_kind == 0;
   s->sym = (on && ok) ? 1 : 0;
   s->factored = false;
   return PGX_OK;

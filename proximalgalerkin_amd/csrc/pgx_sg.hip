@@ -681,7 +681,7 @@ static int sg_create_impl(pgx_sg_handle* h, const pgx_sg_mesh* m, const pgx_sg_p
   // PGX_SG_SYM=0 keeps the general LU of the matrix as UFL's derivative gives it (A/B)
   {
     const char* e = pgx_tune("PGX_SG_SYM");
-    if (!(e && atoi(e) == 0) && !comm) {
+    if (!(e && atoi(e) == 0)) {
       pgx_nd_set_symmetric(h->lu, 1);
       if (pgx_nd_is_symmetric(h->lu)) h->lu_flip_from = nu;
     }
