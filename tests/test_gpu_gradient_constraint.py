@@ -272,3 +272,21 @@ def test_quadrilateral_full_run_matches_oracle(require_gpu, N, k):
     assert list(its) == list(its_r), (list(its), list(its_r))
     n2 = prob.n2
     assert np.linalg.norm(x[:n2] - xr[:n2]) <= 1e-9 * np.linalg.norm(xr[:n2])
+
+
+def test_symmetric_factorisation_agrees_with_the_general_lu(require_gpu, monkeypatch):
+    """Round 5: example 06's Newton matrix [[alpha K, G^T], [G, -N(psi)]] is symmetric and its sparse LU runs in symmetric mode (L D L^T
+    in LU clothing, include/pgx_nd.h).  PGX_ND_SYM=0 ignores the request: same Newton counts per proximal step, same primal field."""
+    from proximalgalerkin_amd import fem
+    from proximalgalerkin_amd.gradient_constraint import GradientConstraintProblem, f_default, phi_default, solve_problem
+
+    out = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("PGX_ND_SYM", sym)
+        p = GradientConstraintProblem(fem.create_unit_square(24, 24), phi_default, f_default)
+        assert p.lu_stats()["symmetric"] is (sym == "1")
+        p.close()
+        out[sym] = solve_problem(24, 24, verbose=False, return_solution=True)
+    (ia, _, xa), (ib, _, xb) = out["1"], out["0"]
+    assert list(ia) == list(ib)
+    assert np.linalg.norm(np.asarray(xa) - np.asarray(xb)) <= 1e-10 * np.linalg.norm(np.asarray(xb))

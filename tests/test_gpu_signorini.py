@@ -263,3 +263,27 @@ def test_hexahedra_kernels_and_full_run_match_oracle(require_gpu, n, degree):
     x_ref, it_ref, its_ref = S.solve_contact_problem(prob)
     assert it == it_ref and list(iterations) == list(its_ref), (it, iterations, it_ref, its_ref)
     assert _rel(xs[:3 * prob.nv], x_ref[:3 * prob.nv]) < 1e-10
+
+
+def test_symmetrised_lu_agrees_with_the_general_lu(require_gpu, monkeypatch):
+    """Round 5: the Newton matrix [[alpha A, M_G^T], [-M_G, D]] enters the sparse LU with the rows of its latent block negated - a
+    symmetric matrix, factorised as L D L^T at half the flops (csrc/pgx_mixed.h lu_flip_from, pgx_nd_set_symmetric).  PGX_SG_SYM=0 keeps
+    the general LU of the matrix as assembled: same Newton counts, same solution to the accuracy of the refined solves."""
+    from proximalgalerkin_amd import signorini as G
+
+    mesh = G.create_unit_cube(6, 5, 4)
+    mt, bcs = G.native_tags(mesh)
+    runs = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("PGX_SG_SYM", sym)
+        runs[sym] = G.solve_contact_problem(mesh, mt, bcs, degree=2, verbose=False, return_solution=True)
+    (it1, its1, x1, _), (it0, its0, x0, _) = runs["1"], runs["0"]
+    assert it1 == it0 and list(its1) == list(its0)
+    assert _rel(x1, x0) < 1e-10
+    problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.0, -0.25, degree=2, bc_facets=mt.find(1))
+    assert problem.lu_stats()["symmetric"] is False  # (PGX_SG_SYM=0 is still set)
+    problem.close()
+    monkeypatch.delenv("PGX_SG_SYM")
+    problem = G.SignoriniProblem(mesh, mt.find(2), None, 2.0e4, 0.3, 0.0, -0.25, degree=2, bc_facets=mt.find(1))
+    assert problem.lu_stats()["symmetric"] is True
+    problem.close()
