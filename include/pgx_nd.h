@@ -76,8 +76,8 @@ int pgx_nd_solve(pgx_nd* s, const double* b, double* x, int on_device);
  * caller's values as those of a symmetric matrix (both triangles still passed, the pattern is the general one) and computes
  * L D L^T in LU clothing: half the flops - the U panels are written as scaled transposes of the L panels, the Schur updates run on
  * the tiles on and below the diagonal.  The factors it stores and pgx_nd_solve are those of the general path (same accuracy class:
- * no pivoting across blocks either way).  The request is honoured with the default schedule - on one rank or on a distributed handle - and
- * silently ignored otherwise (pgx_nd_is_symmetric tells); a matrix that is NOT symmetric gets the factorisation of its lower triangle's
+ * no pivoting across blocks either way).  The request is honoured with the default kernels (parent-centric assembly, MFMA panels) - single
+ * rank or distributed, cut schedule or not - and silently ignored otherwise (pgx_nd_is_symmetric tells); a matrix that is NOT symmetric gets the factorisation of its lower triangle's
  * symmetric completion - wrap the solve in refinement on the exact operator, as every caller in this library does.
  * Replaces: -pc_factor_mat_solver_type mumps with -mat_mumps_sym / MatSetOption(A, MAT_SYMMETRIC, PETSC_TRUE). */
 int pgx_nd_set_symmetric(pgx_nd* s, int on);

@@ -812,7 +812,7 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
                                 const int32_t* __restrict__ slot01, const int32_t* __restrict__ parent,
                                 const int32_t* __restrict__ fM, const int64_t* __restrict__ fbase,
                                 const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel,
-                                double* __restrict__ arena) {
+                                double* __restrict__ arena, int sym) {
   const int64_t f = c0 + blockIdx.x;
   if (slot01[f] != pass) return;
   const int b = fb[f];
@@ -826,7 +826,8 @@ __global__ void k_nd_extend_add(int64_t c0, int pass, int Pc, int Mc, const int3
   const unsigned ub = (unsigned)b, total = ub * ub, step = gridDim.y * blockDim.x;
   for (unsigned idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += step) {
     const unsigned c = idx / ub, r = idx - c * ub;
-    dst[(int64_t)R[c] * Mp + R[r]] += src[(int64_t)c * Mc + r];
+    // (symmetric mode: only the lower triangle of the child's block is valid - the parent gets both halves from it)
+    dst[(int64_t)R[c] * Mp + R[r]] += (sym && r < c) ? src[(int64_t)r * Mc + c] : src[(int64_t)c * Mc + r];
   }
 }
 
@@ -2297,10 +2298,11 @@ extern "C" int pgx_nd_get_stats(const pgx_nd* s, pgx_nd_stats* st) {
 
 extern "C" int pgx_nd_set_symmetric(pgx_nd* s, int on) {
   if (!s) return PGX_EINVAL;
-  // eligible: the parent-centric (gather) assembly with the uncut schedule and the MFMA panel kernel, on one rank or distributed (the
+  // eligible: the parent-centric (gather) assembly and the MFMA panel kernel, on one rank or distributed, cut schedule or not (the
+  // extend-add at the cut reads a subtree root's Schur block through (max, min) as well; the
   // Schur blocks of the subtree roots travel whole; rank 0 gathers from them through (max, min) like from any child) - everything the
   // configurations of BASELINE.json run; otherwise the request is ignored and the general LU runs (pgx_nd_is_symmetric tells)
-  const bool ok = s->sym_allowed && s->device >= 0 && s->kcut < 0 && s->gather && s->d_inv[0] && s->d_inv[1] && s->panel_kind == 0;
+  const bool ok = s->sym_allowed && s->device >= 0 && s->gather && s->d_inv[0] && s->d_inv[1] && s->panel_kind == 0;
   s->sym = (on && ok) ? 1 : 0;
   s->factored = false;
   return PGX_OK;
@@ -2488,7 +2490,7 @@ extern "C" int pgx_nd_factor(pgx_nd* s, const double* vals, int on_device) {
       while ((int64_t)gy * C.count > (int64_t)1 << 22 && gy > 1) gy /= 2;  // keep the grid bounded for very wide levels
       for (int pass = 0; pass < 2; ++pass)
         hipLaunchKernelGGL(k_nd_extend_add, dim3((unsigned)C.count, gy), dim3(256), 0, s->st, C.start, pass, C.P, C.P + C.B,
-                           s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel, s->arena);
+                           s->d_fb, s->d_slot01, s->d_parent, s->d_fM, s->d_fbase, s->d_rel_ptr, s->d_rel, s->arena, s->sym);
     }
   };
   auto eliminate = [&](const pgx_nd::Group& G, bool cgather = false) {  // the batches of a group on forked streams

@@ -260,6 +260,15 @@ def test_symmetric_mode_factorises_half_and_agrees_with_the_general_lu(require_g
             assert np.array_equal(ds.solve(b), xs[sym])
             ds.close()
         assert np.linalg.norm(xs[True] - xs[False]) <= 1e-9 * np.linalg.norm(xs[False])
+    # the CUT schedule of large factorisations (subtrees one after the other, extend-add at the cut: PGX_ND_CUT_GB=0 forces it here)
+    monkeypatch.setenv("PGX_ND_CUT_GB", "0")
+    ds = DirectSolver(J.indptr, J.indices, nod, g.dof_coords, device=0)
+    assert ds.set_symmetric(True) is True
+    ds.factor(J.data)
+    xc = ds.solve(b)
+    assert _berr(J, xc, b) <= 1e-13 and np.linalg.norm(xc - xs[False]) <= 1e-9 * np.linalg.norm(xs[False])
+    ds.close()
+    monkeypatch.delenv("PGX_ND_CUT_GB")
     monkeypatch.setenv("PGX_ND_SYM", "0")  # the A/B key: the request is ignored
     ds = DirectSolver(J.indptr, J.indices, nod, g.dof_coords, device=0)
     assert ds.set_symmetric(True) is False
